@@ -1,0 +1,596 @@
+"""CPU restatement (PyTorch-CPU fp32, functional) of StreamVoiceAnon's chunk-by-chunk
+``infer_arvc`` hot path.  TEST INFRASTRUCTURE: the checker for the HIP engine and the
+"port" CPU baseline timed by bench.py.  It is pinned against the real reference by
+tools/make_golden.py (run in the build container, where /root/reference exists), which
+stores the reference's outputs under tests/golden/; tests/test_oracle_golden.py replays
+them.  The reference repository holds no tests or golden vectors of its own
+(SURVEY.md §4), so those captured outputs are the only pin.
+
+Every function cites the reference lines it follows (paths relative to the reference
+root).  Weights are a flat ``dict[str, Tensor]`` keyed by the reference state-dict names
+prefixed with the network: ``arvc.`` (ARVCWrapper), ``tok.`` (speech tokenizer) and
+``voc.`` (Firefly vocoder, weight-norm already folded, evaluations/infer_arvc.py:94).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SAMPLES_PER_FRAME = 2048          # evaluations/infer_arvc.py:28
+NUM_CODEBOOKS = 8                 # evaluations/infer_arvc.py:29
+HOP = 512
+N_FFT = 2048
+N_MELS = 160
+SR = 44100
+
+
+# =========================================================================================
+# shared pieces
+# =========================================================================================
+def rope_table(seq_len: int, n_elem: int, base: float = 10000.0) -> torch.Tensor:
+    """cos/sin table rounded to bf16, as float32 [seq_len, n_elem/2, 2].
+    modules/dual_ar_stream.py:993-1001 and modules/vqgan/windowed_transformer.py:356-365:
+    both return ``cache.to(bfloat16)``; the rounded values are then used in fp32 math."""
+    freqs = 1.0 / (base ** (torch.arange(0, n_elem, 2)[: n_elem // 2].float() / n_elem))
+    ang = torch.outer(torch.arange(seq_len).float(), freqs)
+    tab = torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1)
+    return tab.to(torch.bfloat16).float()
+
+
+def apply_rope(x: torch.Tensor, tab: torch.Tensor) -> torch.Tensor:
+    """x [..., T, H, D]; tab [T, D/2, 2].  Adjacent-pair rotation
+    (modules/dual_ar_stream.py:1004-1016, windowed_transformer.py:368-380)."""
+    xs = x.float().reshape(*x.shape[:-1], -1, 2)
+    c = tab[:, None, :, 0]
+    s = tab[:, None, :, 1]
+    out = torch.stack([xs[..., 0] * c - xs[..., 1] * s, xs[..., 1] * c + xs[..., 0] * s], dim=-1)
+    return out.flatten(-2)
+
+
+def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """modules/dual_ar_stream.py:979-990; windowed_transformer.py:248-259."""
+    return x * torch.rsqrt(torch.mean(x * x, dim=-1, keepdim=True) + eps) * w
+
+
+def layer_norm_c(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """LayerNorm over the channel axis of a channel-first [B, C, T] tensor, biased variance
+    (modules/vqgan/modules/firefly.py:361-371, both data formats normalise over C)."""
+    return F.layer_norm(x.transpose(1, 2), (x.shape[1],), w, b, eps).transpose(1, 2)
+
+
+def causal_conv1d(x, w, b, stride=1, dilation=1, groups=1):
+    """FishConvNet.forward, modules/vqgan/modules/firefly.py:92-103: left-pad
+    (k-1)*dil+1-stride zeros, no right pad."""
+    k_eff = (w.shape[-1] - 1) * dilation + 1
+    x = F.pad(x, (k_eff - stride, 0))
+    return F.conv1d(x, w, b, stride=stride, dilation=dilation, groups=groups)
+
+
+def causal_conv_transpose1d(x, w, b, stride):
+    """FishTransConvNet.forward, modules/vqgan/modules/firefly.py:114-138."""
+    k = w.shape[-1]
+    if stride == k // 2:
+        x = F.pad(x, (1, 0))
+    elif stride == k:
+        x = F.pad(x, (1, 1))
+    return F.conv_transpose1d(x, w, b, stride=stride, padding=stride, output_padding=stride % 2)
+
+
+def convnext_block(x, W, p):
+    """ConvNeXtBlock.forward, modules/vqgan/modules/firefly.py:421-440 (x is [B, C, T])."""
+    y = causal_conv1d(x, W[p + "dwconv.conv.weight"], W[p + "dwconv.conv.bias"], groups=x.shape[1])
+    y = y.transpose(1, 2)
+    y = F.layer_norm(y, (y.shape[-1],), W[p + "norm.weight"], W[p + "norm.bias"], 1e-6)
+    y = F.linear(y, W[p + "pwconv1.weight"], W[p + "pwconv1.bias"])
+    y = F.gelu(y)
+    y = F.linear(y, W[p + "pwconv2.weight"], W[p + "pwconv2.bias"])
+    y = W[p + "gamma"] * y
+    return x + y.transpose(1, 2)
+
+
+# =========================================================================================
+# E: content encoder  (speech_tokenizer.encode, modules/vqgan/modules/firefly_encoder.py:553-566)
+# =========================================================================================
+_FB_CACHE = {}
+
+
+def slaney_mel_fb(n_freqs=1025, f_min=0.0, f_max=22050.0, n_mels=N_MELS, sample_rate=SR) -> torch.Tensor:
+    """torchaudio.functional.melscale_fbanks(norm="slaney", mel_scale="slaney") -- published
+    algorithm of torchaudio==2.4.0 (requirements.txt:7), which is not vendored in the
+    reference; call site modules/vqgan/spectrogram.py:93-101.  Returns [n_freqs, n_mels]."""
+    key = (n_freqs, f_min, f_max, n_mels, sample_rate)
+    if key in _FB_CACHE:
+        return _FB_CACHE[key]
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+
+    def hz2mel(f):
+        return min_log_mel + math.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = torch.linspace(hz2mel(f_min), hz2mel(f_max), n_mels + 2)
+    f_pts = f_sp * m_pts
+    is_log = m_pts >= min_log_mel
+    f_pts[is_log] = min_log_hz * torch.exp(logstep * (m_pts[is_log] - min_log_mel))
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = torch.clamp(torch.min(down, up), min=0.0)
+    fb = fb * (2.0 / (f_pts[2: n_mels + 2] - f_pts[:n_mels])).unsqueeze(0)
+    _FB_CACHE[key] = fb
+    return fb
+
+
+def stft_magnitude(audio: torch.Tensor) -> torch.Tensor:
+    """LinearSpectrogram.forward, modules/vqgan/spectrogram.py:26-65: left zero-pad
+    win-hop = 1536, periodic Hann 2048, hop 512, center=False, sqrt(re^2+im^2+1e-6).
+    audio [B, N] -> [B, 1025, N/512]."""
+    y = F.pad(audio.float(), (N_FFT - HOP, 0))
+    frames = y.unfold(-1, N_FFT, HOP)                         # [B, T, 2048]
+    spec = torch.fft.rfft(frames * torch.hann_window(N_FFT), dim=-1)
+    mag = torch.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-6)
+    return mag.transpose(1, 2)
+
+
+def log_mel(audio: torch.Tensor) -> torch.Tensor:
+    """LogMelSpectrogram.forward, modules/vqgan/spectrogram.py:117-130 -> [B, 160, T]."""
+    mag = stft_magnitude(audio)
+    mel = torch.matmul(mag.transpose(1, 2), slaney_mel_fb()).transpose(1, 2)
+    return torch.log(torch.clamp(mel, min=1e-5))
+
+
+def convnext_encoder(x: torch.Tensor, W: dict, p: str, depths=(3, 3, 9, 3)) -> torch.Tensor:
+    """ConvNeXtEncoder.forward, modules/vqgan/modules/firefly.py:506-517."""
+    for i, depth in enumerate(depths):
+        d = f"{p}downsample_layers.{i}."
+        if i == 0:
+            x = causal_conv1d(x, W[d + "0.conv.weight"], W[d + "0.conv.bias"])
+            x = layer_norm_c(x, W[d + "1.weight"], W[d + "1.bias"])
+        else:
+            x = layer_norm_c(x, W[d + "0.weight"], W[d + "0.bias"])
+            x = F.conv1d(x, W[d + "1.weight"], W[d + "1.bias"])
+        for j in range(depth):
+            x = convnext_block(x, W, f"{p}stages.{i}.{j}.")
+    return layer_norm_c(x, W[p + "norm.weight"], W[p + "norm.bias"])
+
+
+def window_transformer(x: torch.Tensor, W: dict, p: str, n_layer=8, n_head=8) -> torch.Tensor:
+    """WindowLimitedTransformer.forward (causal, window 512 >= T so the mask is plain causal),
+    modules/vqgan/windowed_transformer.py:337-354, 103-120, 134-143, 163-194.
+    x [B, C, T] -> [B, C, T]."""
+    x = x.transpose(1, 2)
+    B, T, C = x.shape
+    hd = C // n_head
+    tab = rope_table(2048, hd)[:T]
+    for l in range(n_layer):
+        q = f"{p}layers.{l}."
+        h = rms_norm(x, W[q + "attention_norm.weight"])
+        qkv = F.linear(h, W[q + "attention.wqkv.weight"])
+        qq, kk, vv = qkv.split([C, C, C], dim=-1)
+        qq = apply_rope(qq.view(B, T, n_head, hd), tab).transpose(1, 2)
+        kk = apply_rope(kk.view(B, T, n_head, hd), tab).transpose(1, 2)
+        vv = vv.view(B, T, n_head, hd).transpose(1, 2)
+        y = F.scaled_dot_product_attention(qq, kk, vv, is_causal=True)
+        y = y.transpose(1, 2).reshape(B, T, C)
+        y = F.linear(y, W[q + "attention.wo.weight"])
+        x = x + y * W[q + "attention_layer_scale.gamma"]
+        h = rms_norm(x, W[q + "ffn_norm.weight"])
+        f = F.linear(F.silu(F.linear(h, W[q + "feed_forward.w1.weight"])) * F.linear(h, W[q + "feed_forward.w3.weight"]),
+                     W[q + "feed_forward.w2.weight"])
+        x = x + f * W[q + "ffn_layer_scale.gamma"]
+    x = rms_norm(x, W[p + "norm.weight"])
+    return x.transpose(1, 2)
+
+
+def bsq_encode(feat: torch.Tensor, W: dict, p: str = "tok.quantizer.", return_u: bool = False):
+    """DownsampleBinarySphericalQuantize.encode, modules/vqgan/modules/bsq_no_upsample.py:103-107
+    + LFQ.forward eval branch, modules/vqgan/modules/bsq.py:330-369: downsample x2, pre_module,
+    Linear 512->13, L2 normalise, sign bits, MSB-first index.  feat [B, 512, T] -> int64 [B, T/4]."""
+    z = feat
+    for i in range(2):
+        d = f"{p}downsample.{i}."
+        z = causal_conv1d(z, W[d + "0.conv.weight"], W[d + "0.conv.bias"], stride=2)
+        z = convnext_block(z, W, d + "1.")
+    z = window_transformer(z, W, p + "pre_module.")
+    u = F.linear(z.transpose(1, 2), W[p + "residual_bsq.rvqs.0.project_in.weight"],
+                 W[p + "residual_bsq.rvqs.0.project_in.bias"])
+    u = F.normalize(u.float(), dim=-1)
+    nbits = u.shape[-1]
+    weights = 2 ** torch.arange(nbits - 1, -1, -1)
+    idx = ((u > 0).long() * weights).sum(-1)
+    return (idx, u) if return_u else idx
+
+
+def encode_window(audio: torch.Tensor, W: dict, lengths: torch.Tensor | None = None, taps: dict | None = None):
+    """FireflyArchitecture.encode of the tokenizer, firefly_encoder.py:553-566.
+    audio [B, N] -> codes int64 [1, B, N // 2048] (the leading 1 is the BSQ group axis)."""
+    mel = log_mel(audio)
+    T = mel.shape[-1]
+    if lengths is None:
+        mask = torch.ones(audio.shape[0], 1, T)
+    else:
+        mask = (torch.arange(T)[None] < (lengths // HOP)[:, None])[:, None, :].float()
+    mel = mel * mask
+    feat = convnext_encoder(mel, W, "tok.backbone.") * mask
+    idx, u = bsq_encode(feat, W, return_u=True)
+    if taps is not None:
+        taps.update(mel=mel, feat=feat, u=u)
+    return idx[None]
+
+
+# =========================================================================================
+# A: dual-AR conversion transformer (modules/dual_ar_stream.py, modules/arvc_wrapper.py)
+# =========================================================================================
+def sample_token(logits: torch.Tensor, noise: torch.Tensor, temperature: float = 0.7, top_p: float = 0.7) -> int:
+    """logits_to_probs + multinomial_sample_one_no_sync, modules/dual_ar_stream.py:1092-1132
+    with previous_tokens=None: nucleus cut on the *sorted inclusive* cumulative softmax (no
+    right shift, rank 0 always kept), then temperature, softmax, argmax(p / Exp(1) noise)."""
+    s, order = torch.sort(logits, descending=True)
+    cum = torch.cumsum(torch.softmax(s, dim=-1), dim=-1)
+    rm_sorted = cum > top_p
+    rm_sorted[0] = False
+    rm = torch.zeros_like(rm_sorted).scatter(0, order, rm_sorted)
+    lg = logits.masked_fill(rm, -float("inf")) / max(temperature, 1e-5)
+    p = torch.softmax(lg, dim=-1)
+    return int(torch.argmax(p / noise))
+
+
+@dataclass
+class ARConfig:
+    dim: int = 768
+    n_head: int = 12
+    n_layer: int = 12
+    n_fast_layer: int = 4
+    inter: int = 2304
+    vocab: int = 8192
+    codebook_size: int = 1000
+    num_codebooks: int = 8
+    max_seq_len: int = 2048
+    n_spk_tokens: int = 33
+
+
+class DualAR:
+    """KV-cached dual-AR decoder state for ONE stream (the reference is batch-1 only,
+    evaluations/infer_arvc.py:56)."""
+
+    def __init__(self, W: dict, cfg: ARConfig = ARConfig(), temperature: float = 0.7, top_p: float = 0.7):
+        self.W, self.cfg = W, cfg
+        self.temperature, self.top_p = temperature, top_p
+        hd = cfg.dim // cfg.n_head
+        self.hd = hd
+        self.tab = rope_table(cfg.max_seq_len, hd)
+        self.fast_tab = rope_table(cfg.num_codebooks, hd)
+        self.k = torch.zeros(cfg.n_layer, cfg.n_head, cfg.max_seq_len, hd)
+        self.v = torch.zeros_like(self.k)
+        self.delay = 0
+        self.last_pos = -1
+        self.cached_ref_emb = None
+        self.cached_new_audio_emb = None
+
+    # ---- embeddings ------------------------------------------------------------------
+    def embed_content(self, codes: torch.Tensor) -> torch.Tensor:
+        """ARVCWrapper.embedding, modules/arvc_wrapper.py:107,118,125."""
+        return self.W["arvc.embedding.weight"][codes]
+
+    def embed_audio(self, codes: torch.Tensor) -> torch.Tensor:
+        """BaseTransformer.embed, modules/dual_ar_stream.py:245-255: codes [8, T] -> [T, dim]."""
+        tabw = self.W["arvc.decoder.model.codebook_embeddings.weight"]
+        off = (torch.arange(self.cfg.num_codebooks) * self.cfg.codebook_size)[:, None]
+        return tabw[codes.long() + off].sum(0)
+
+    def speaker_prefix(self, style: torch.Tensor, timbre: torch.Tensor) -> torch.Tensor:
+        """modules/arvc_wrapper.py:108-109: cat[context_in(timbre) (32), style_in(style) (1)]."""
+        W = self.W
+        c = F.linear(timbre, W["arvc.context_in.weight"], W["arvc.context_in.bias"])
+        s = F.linear(style, W["arvc.style_in.weight"], W["arvc.style_in.bias"])
+        return torch.cat([c, s[None]], dim=0)
+
+    # ---- transformer -----------------------------------------------------------------
+    def _block(self, x, p, tab, kc, vc, pos):
+        """TransformerBlock / Attention / FeedForward, modules/dual_ar_stream.py:839-861,
+        895-936, 967-976.  x [M, dim]; pos LongTensor [M] (KV slots == rope positions)."""
+        W, H, hd = self.W, self.cfg.n_head, self.hd
+        M = x.shape[0]
+        h = rms_norm(x, W[p + "attention_norm.weight"])
+        qkv = F.linear(h, W[p + "attention.wqkv.weight"])
+        q, k, v = qkv.split([H * hd] * 3, dim=-1)
+        q = apply_rope(q.view(M, H, hd), tab[pos]).transpose(0, 1)        # [H, M, hd]
+        k = apply_rope(k.view(M, H, hd), tab[pos]).transpose(0, 1)
+        v = v.view(M, H, hd).transpose(0, 1)
+        kc[:, pos] = k
+        vc[:, pos] = v
+        L = int(pos.max()) + 1
+        att = torch.matmul(q, kc[:, :L].transpose(1, 2)) / math.sqrt(hd)   # [H, M, L]
+        mask = torch.arange(L)[None, :] <= pos[:, None]                     # causal_mask[kv_pos]
+        att = att.masked_fill(~mask[None], -float("inf"))
+        y = torch.matmul(torch.softmax(att, dim=-1), vc[:, :L])            # [H, M, hd]
+        y = y.transpose(0, 1).reshape(M, H * hd)
+        x = x + F.linear(y, W[p + "attention.wo.weight"])
+        h = rms_norm(x, W[p + "ffn_norm.weight"])
+        f = F.linear(F.silu(F.linear(h, W[p + "feed_forward.w1.weight"])) * F.linear(h, W[p + "feed_forward.w3.weight"]),
+                     W[p + "feed_forward.w2.weight"])
+        return x + f
+
+    def slow_forward(self, x: torch.Tensor, pos: torch.Tensor):
+        """BaseTransformer.forward_generate, modules/dual_ar_stream.py:312-356: returns
+        (pre-norm hidden of the last token, logits of the last token)."""
+        for l in range(self.cfg.n_layer):
+            x = self._block(x, f"arvc.decoder.model.layers.{l}.", self.tab, self.k[l], self.v[l], pos)
+        h = x[-1]
+        logits = F.linear(rms_norm(h, self.W["arvc.decoder.model.norm.weight"]), self.W["arvc.decoder.model.output.weight"])
+        return h, logits
+
+    def fast_decode(self, hidden: torch.Tensor, noise: torch.Tensor, forced: torch.Tensor | None = None):
+        """Fast-AR loop of decode_one_token_ar, modules/dual_ar_stream.py:1196-1216 +
+        forward_generate_fast 540-558.  noise [8, codebook_size] Exp(1).  If `forced` is given
+        (teacher forcing) the sampled token is replaced by forced[i] for the next input."""
+        cfg = self.cfg
+        kc = torch.zeros(cfg.n_fast_layer, cfg.n_head, cfg.num_codebooks, self.hd)   # "Cleanup the cache"
+        vc = torch.zeros_like(kc)
+        x = hidden
+        codes, all_logits = [], []
+        for cb in range(cfg.num_codebooks):
+            pos = torch.tensor([cb])
+            h = x[None]
+            for l in range(cfg.n_fast_layer):
+                h = self._block(h, f"arvc.decoder.model.fast_layers.{l}.", self.fast_tab, kc[l], vc[l], pos)
+            lg = F.linear(rms_norm(h[0], self.W["arvc.decoder.model.fast_norm.weight"]),
+                          self.W["arvc.decoder.model.fast_output.weight"])
+            tok = sample_token(lg, noise[cb], self.temperature, self.top_p)
+            all_logits.append(lg)
+            codes.append(tok)
+            nxt = tok if forced is None else int(forced[cb])
+            x = self.W["arvc.decoder.model.fast_embeddings.weight"][nxt]
+        return torch.tensor(codes, dtype=torch.int32), torch.stack(all_logits)
+
+    def decode_tokens(self, x, pos, noise_slow, noise_fast, forced=None):
+        """decode_one_token_ar, modules/dual_ar_stream.py:1168-1219 (the semantic-token sample is
+        drawn and discarded by every caller, :833, but consumes noise)."""
+        hidden, logits = self.slow_forward(x, pos)
+        sem = sample_token(logits, noise_slow, self.temperature, self.top_p)
+        codes, fast_logits = self.fast_decode(hidden, noise_fast, forced)
+        return dict(semantic=sem, codes=codes, hidden=hidden, logits=logits, fast_logits=fast_logits)
+
+    # ---- DualARWrapper streaming protocol ----------------------------------------------
+    def prefill_prompt(self, ref_content_codes, ref_audio_codes, style, timbre, delay: int):
+        """ARVCWrapper.prefill_prompt (arvc_wrapper.py:100-112) + DualARWrapper.prefill_prompt
+        (dual_ar_stream.py:764-796).  ref_content_codes [R], ref_audio_codes [8, R]."""
+        assert delay != 0, "delay=0 breaks at re-prefill in the reference (SURVEY hard part 5.v)"
+        self.delay = delay
+        W = self.W
+        cond = self.embed_content(ref_content_codes)
+        ref_emb = self.embed_audio(ref_audio_codes)
+        self.cached_ref_emb = ref_emb[-delay:].clone()
+        a = torch.cat([W["arvc.decoder.wait4start_embedding.weight"][:delay], ref_emb[:-delay]], dim=0)
+        seq = torch.stack([cond, a], dim=1).reshape(-1, self.cfg.dim)
+        seq = torch.cat([self.speaker_prefix(style, timbre), seq], dim=0)
+        pos = torch.arange(seq.shape[0])
+        hidden, logits = self.slow_forward(seq, pos)
+        self.last_pos = int(pos[-1])
+        return hidden, logits
+
+    def prefill_src_condition4delay(self, src_codes):
+        """dual_ar_stream.py:798-815 (src_codes [delay])."""
+        assert src_codes.shape[0] == self.delay
+        cond = self.embed_content(src_codes)
+        seq = torch.stack([cond, self.cached_ref_emb], dim=1).reshape(-1, self.cfg.dim)
+        self.cached_new_audio_emb = seq[-1:].clone()
+        seq = seq[:-1]
+        pos = torch.arange(seq.shape[0]) + self.last_pos + 1
+        hidden, logits = self.slow_forward(seq, pos)
+        self.last_pos = int(pos[-1])
+        return hidden, logits
+
+    def decode_one(self, src_code: int, noise_slow, noise_fast, forced=None):
+        """dual_ar_stream.py:817-837 -> (codes int32 [8], kv_pos[-1], aux)."""
+        cond = self.embed_content(torch.tensor([src_code]))
+        seq = torch.cat([self.cached_new_audio_emb, cond], dim=0)
+        pos = torch.arange(2) + self.last_pos + 1
+        out = self.decode_tokens(seq, pos, noise_slow, noise_fast, forced)
+        nxt = out["codes"] if forced is None else forced.to(torch.int32)
+        self.cached_new_audio_emb = self.embed_audio(nxt[:, None].long())
+        self.last_pos = int(pos[-1])
+        return out["codes"], self.last_pos, out
+
+    def generate(self, ref_content_codes, ref_audio_codes, src_content_codes, style, timbre, delay, noise_fn):
+        """Offline ARVCWrapper.generate (arvc_wrapper.py:82-98) + DualARWrapper.generate
+        (dual_ar_stream.py:698-762).  noise_fn(step) -> (noise_slow [vocab], noise_fast [8, cb])."""
+        W, d = self.W, delay
+        self.delay = d
+        ref_cond = self.embed_content(ref_content_codes)
+        src_cond = self.embed_content(src_content_codes)
+        ref_emb = torch.cat([W["arvc.decoder.wait4start_embedding.weight"][:d], self.embed_audio(ref_audio_codes)], dim=0)
+        pre_cond = torch.cat([ref_cond, src_cond[:d]], dim=0)
+        seq = torch.stack([pre_cond, ref_emb], dim=1).reshape(-1, self.cfg.dim)
+        seq = torch.cat([self.speaker_prefix(style, timbre), seq], dim=0)
+        remaining = torch.cat([src_cond[d:], W["arvc.decoder.wait4end_embedding.weight"][:d]], dim=0)
+        seq = torch.cat([seq, remaining[:1]], dim=0)
+        pos = torch.arange(seq.shape[0])
+        out = self.decode_tokens(seq, pos, *noise_fn(0))
+        codes = [out["codes"]]
+        last = int(pos[-1])
+        for i in range(remaining.shape[0] - 1):
+            x = torch.cat([self.embed_audio(codes[-1][:, None].long()), remaining[i + 1:i + 2]], dim=0)
+            pos = torch.arange(2) + last + 1
+            out = self.decode_tokens(x, pos, *noise_fn(i + 1))
+            codes.append(out["codes"])
+            last = int(pos[-1])
+        return torch.stack(codes, dim=-1)[None]          # [1, 8, S]
+
+
+# =========================================================================================
+# V: Firefly vocoder (FSQ decode + upsample + HiFiGAN head)
+# =========================================================================================
+FSQ_LEVELS = (8, 5, 5, 5)
+
+
+def fsq_decode(codes: torch.Tensor, W: dict) -> torch.Tensor:
+    """DownsampleFiniteScalarQuantize.decode up to (not including) the upsampler,
+    modules/vqgan/modules/fsq.py:112-114.  The index arithmetic is that of
+    vector_quantize_pytorch==1.14.24 (requirements.txt:26; readable twin vendored at
+    modules/bicodec_speaker_encoder/fsq/finite_scalar_quantization.py:143-162 and
+    residual_fsq.py:112-156): digit_d = (idx // basis_d) % level_d, basis = [1, 8, 40, 200];
+    code_d = (digit_d - half_d) / half_d with half = level // 2 = [4, 2, 2, 2]; one quantizer
+    per group so the residual scale is 1; per-group Linear 4 -> 64; groups concatenated.
+    codes int [B, 8, T] -> [B, 512, T]."""
+    levels = torch.tensor(FSQ_LEVELS)
+    basis = torch.cumprod(torch.tensor((1,) + FSQ_LEVELS[:-1]), 0)
+    half = levels // 2
+    outs = []
+    for g in range(codes.shape[1]):
+        digits = (codes[:, g, :, None].long() // basis) % levels            # [B, T, 4]
+        c = (digits - half).float() / half.float()
+        outs.append(F.linear(c, W[f"voc.quantizer.residual_fsq.rvqs.{g}.project_out.weight"],
+                             W[f"voc.quantizer.residual_fsq.rvqs.{g}.project_out.bias"]))
+    return torch.cat(outs, dim=-1).transpose(1, 2)
+
+
+def fsq_upsample(z: torch.Tensor, W: dict) -> torch.Tensor:
+    """`self.upsample` of DownsampleFiniteScalarQuantize, fsq.py:61-74,115: two x
+    (ConvTranspose k=s=2 + ConvNeXtBlock); built in reversed(enumerate) order so
+    upsample.0 is applied first.  [B, 512, T] -> [B, 512, 4T]."""
+    for i in range(2):
+        p = f"voc.quantizer.upsample.{i}."
+        z = causal_conv_transpose1d(z, W[p + "0.conv.weight"], W[p + "0.conv.bias"], stride=2)
+        z = convnext_block(z, W, p + "1.")
+    return z
+
+
+UPS = ((16, 8), (16, 8), (4, 2), (4, 2), (4, 2))     # configs/hydra_arcs/vocoders/firefly_gan_vq.yaml
+RES_K = (3, 7, 11)
+RES_D = (1, 3, 5)
+
+
+def hifigan(z: torch.Tensor, W: dict) -> torch.Tensor:
+    """HiFiGANGenerator.forward, modules/vqgan/modules/firefly.py:280-293 (+ResBlock1 183-190,
+    ParallelBlock 214-215).  [B, 512, T] -> [B, 1, 512 T]."""
+    p = "voc.head."
+    x = causal_conv1d(z, W[p + "conv_pre.conv.weight"], W[p + "conv_pre.conv.bias"])
+    for i, (k, s) in enumerate(UPS):
+        x = F.silu(x)
+        x = causal_conv_transpose1d(x, W[f"{p}ups.{i}.conv.weight"], W[f"{p}ups.{i}.conv.bias"], stride=s)
+        acc = None
+        for bi, rk in enumerate(RES_K):
+            y = x
+            for j, dil in enumerate(RES_D):
+                q = f"{p}resblocks.{i}.blocks.{bi}."
+                t = causal_conv1d(F.silu(y), W[f"{q}convs1.{j}.conv.weight"], W[f"{q}convs1.{j}.conv.bias"], dilation=dil)
+                # NB: convs2 carry the SAME dilation as convs1 here (firefly.py:168-180), unlike
+                # the original HiFi-GAN where the second conv is undilated.
+                t = causal_conv1d(F.silu(t), W[f"{q}convs2.{j}.conv.weight"], W[f"{q}convs2.{j}.conv.bias"], dilation=dil)
+                y = t + y
+            acc = y if acc is None else acc + y
+        x = acc / len(RES_K)
+    x = F.silu(x)
+    x = causal_conv1d(x, W[p + "conv_post.conv.weight"], W[p + "conv_post.conv.bias"])
+    return torch.tanh(x)
+
+
+def vocode_window(codes: torch.Tensor, W: dict, taps: dict | None = None) -> torch.Tensor:
+    """code2wav_fn, evaluations/infer_arvc.py:173-176: head(quantizer.decode(codes)).
+    codes int [B, 8, T] -> [B, 1, 2048 T]."""
+    z = fsq_upsample(fsq_decode(codes, W), W)
+    if taps is not None:
+        taps["z"] = z
+    return hifigan(z, W)
+
+
+# =========================================================================================
+# streaming driver (InferenceWrapper.process_one_chunk semantics)
+# =========================================================================================
+def apply_noise_mixing(x: torch.Tensor, alpha: float, gauss: torch.Tensor) -> torch.Tensor:
+    """evaluations/infer_arvc.py:228-232 with the Gaussian draw made explicit:
+    alpha*x + (1-alpha)*(gauss*std + mean), global mean / unbiased std of the tensor."""
+    mean, std = x.mean(), x.std()
+    return alpha * x + (1 - alpha) * (gauss * std + mean)
+
+
+class StreamSession:
+    """One stream of InferenceWrapper.{prefill_prompt, setup_stream_caches, process_one_chunk}
+    (evaluations/infer_arvc.py:443-596) with prompt codes/embeddings supplied by the caller
+    (the wav -> prompt path is row N1 of SURVEY.md §8f) and sampler noise supplied per frame
+    by ``noise_fn(frame_idx) -> (noise_slow[8192], noise_fast[8,1000])``."""
+
+    def __init__(self, W, ref_content_codes, ref_audio_codes, style, timbre, noise_fn, delay=2,
+                 encode_window_frames=128, decode_window_frames=64, max_prompt_frames=256,
+                 max_seq_frames=768, buffer_frames=32, decode_chunk_frames=1,
+                 temperature=0.7, top_p=0.7):
+        self.W = W
+        self.noise_fn = noise_fn
+        self.delay = int(delay)
+        # prefill_prompt (:463-489): quirk iv -- the KV prefill uses the UNTRUNCATED prompt,
+        # the stored (re-prefill / vocoder-fill) prompt is truncated to max_prompt_frames.
+        self.ref_audio_codes = ref_audio_codes[:, :max_prompt_frames]
+        self.ref_content_codes = ref_content_codes[:max_prompt_frames]
+        self.style, self.timbre = style, timbre
+        self.ar = DualAR(W, temperature=temperature, top_p=top_p)
+        self.ar.prefill_prompt(ref_content_codes, ref_audio_codes, style, timbre, self.delay)
+        # setup_stream_caches (:443-460)
+        self.We, self.Wd = encode_window_frames, decode_window_frames
+        self.max_seq_frames, self.buffer_frames, self.chunk = max_seq_frames, buffer_frames, decode_chunk_frames
+        self.window = torch.zeros(1, self.We * SAMPLES_PER_FRAME)
+        self.src_content_codes = torch.zeros(0, dtype=torch.long)
+        self.pred_codes = torch.zeros(NUM_CODEBOOKS, 0, dtype=torch.long)
+        self.prefilled = False
+        self.frame_idx = 0
+        self.n_reprefill = 0
+        self.trace = []
+
+    def process_one_chunk(self, chunk: torch.Tensor, forced_codes: torch.Tensor | None = None) -> torch.Tensor:
+        """chunk [1, 2048*c] -> [1, 2048*c] (:492-596).  forced_codes [8, c] teacher-forces the AR."""
+        n = chunk.shape[-1]
+        c = self.chunk
+        self.window = torch.cat([self.window[:, n:], chunk], dim=-1)                      # :495-496
+        codes = encode_window(self.window, self.W)[0, 0]                                  # :505-508
+        new_codes = codes[-c:]
+        self.src_content_codes = torch.cat([self.src_content_codes, new_codes])           # :518
+        rec = dict(content=new_codes.clone(), audio=None)
+        self.trace.append(rec)
+        if self.src_content_codes.shape[0] < self.delay:                                  # :519-520
+            return torch.zeros_like(chunk)
+        if not self.prefilled:                                                            # :521-525
+            self.ar.prefill_src_condition4delay(self.src_content_codes[-self.delay:])
+            self.prefilled = True
+            return torch.zeros_like(chunk)
+        pos = None
+        for i in range(c):                                                                # :534-538
+            ns, nf = self.noise_fn(self.frame_idx)
+            forced = None if forced_codes is None else forced_codes[:, i]
+            out_codes, pos, _ = self.ar.decode_one(int(new_codes[i]), ns, nf, forced)
+            keep = out_codes if forced is None else forced
+            self.pred_codes = torch.cat([self.pred_codes, keep.long()[:, None]], dim=-1)
+            self.frame_idx += 1
+        rec["audio"] = self.pred_codes[:, -c:].clone()
+        if pos // 2 >= self.max_seq_frames:                                               # :547-564
+            d, bf = self.delay, self.buffer_frames
+            ext_audio = torch.cat([self.ref_audio_codes, self.pred_codes[:, -bf:]], dim=-1)
+            ext_content = torch.cat([self.ref_content_codes, self.src_content_codes[-bf - d:-d]])
+            self.ar.prefill_prompt(ext_content, ext_audio, self.style, self.timbre, d)
+            self.ar.prefill_src_condition4delay(self.src_content_codes[-d:])
+            self.n_reprefill += 1
+        win = self.pred_codes[:, -self.Wd:]                                               # :567-571
+        pad = self.Wd - win.shape[-1]
+        if pad > 0:
+            win = torch.cat([self.ref_audio_codes[:, -pad:], win], dim=-1)
+        wav = vocode_window(win.reshape(1, NUM_CODEBOOKS, self.Wd), self.W)               # :581-583
+        self.pred_codes = self.pred_codes[:, -SAMPLES_PER_FRAME:]                         # :593-594
+        self.src_content_codes = self.src_content_codes[-SAMPLES_PER_FRAME:]
+        return wav[..., -SAMPLES_PER_FRAME * c:].squeeze(1)                               # :596
+
+
+def load_synth_weights(seed: int, specs: dict) -> dict:
+    """name -> torch tensor for every (prefixed name, shape) in specs."""
+    from streamvoiceanon_amd import synth_weights as sw
+    out = {}
+    for name, shape in specs.items():
+        arr = sw.generate(seed, name, shape)
+        if arr is not None:
+            out[name] = torch.from_numpy(arr)
+    return out
