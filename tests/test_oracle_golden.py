@@ -1,0 +1,103 @@
+"""The CPU oracle (oracle/sva_oracle.py) replayed against outputs of the REAL reference
+captured by tools/make_golden.py (tests/golden/*.npz).  This is what pins the oracle:
+the reference repository itself holds no tests or golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import sva_oracle as O
+from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+from streamvoiceanon_amd import synth_weights as sw
+
+torch.set_grad_enabled(False)
+
+
+def test_mel_filterbank_matches_reference():
+    g = load_golden("melfb")
+    fb = O.slaney_mel_fb()
+    assert fb.shape == (1025, 160)
+    np.testing.assert_allclose(fb.sum(0).numpy(), g["col_sum"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(fb.sum(1).numpy(), g["row_sum"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(fb.argmax(0).numpy(), g["argpeak"])
+
+
+@pytest.mark.parametrize("wseed", [0, 1])
+def test_encoder_indices_bit_exact(wseed, weights0, weights1):
+    g = load_golden(f"encoder_s{wseed}")
+    W = weights0 if wseed == 0 else weights1
+    x = torch.from_numpy(synth_utterance(int(g["audio_seed"]), int(g["n_samples"])))[None]
+    taps = {}
+    codes = O.encode_window(x, W, taps=taps)
+    assert codes.shape == (1, 1, 128) and codes.dtype == torch.int64
+    np.testing.assert_array_equal(codes[0, 0].numpy(), g["codes"])           # BSQ indices: bit-exact
+    np.testing.assert_allclose(taps["u"][0].numpy(), g["u"], atol=2e-5)
+    np.testing.assert_allclose(taps["mel"].flatten()[g["mel_idx"]].numpy(), g["mel_val"], atol=1e-4)
+    np.testing.assert_allclose(taps["feat"].flatten()[g["feat_idx"]].numpy(), g["feat_val"], atol=1e-4)
+
+
+def test_vocoder_window(weights0):
+    g = load_golden("vocoder_s0")
+    codes = torch.from_numpy(g["codes"])
+    taps = {}
+    wav = O.vocode_window(codes, weights0, taps=taps)
+    assert wav.shape == (1, 1, 131072)
+    np.testing.assert_allclose(taps["z"].flatten()[g["z_idx"]].numpy(), g["z_val"], atol=1e-5)
+    np.testing.assert_allclose(wav[0, 0, -2048:].numpy(), g["pcm_last_frame"], atol=1e-5)   # fp32 path tolerance
+    np.testing.assert_allclose(wav.flatten()[g["pcm_idx"]].numpy(), g["pcm_val"], atol=1e-5)
+
+
+def _run_stream(g, W, forced=False):
+    useed, pseed = int(g["audio_seed"]), int(g["prompt_seed"])
+    ac, cc, style, timbre = synth_prompt(pseed, int(g["prompt_frames"]))
+    chunk, n_chunks = int(g["chunk"]), int(g["n_chunks"])
+    sess = O.StreamSession(
+        W, torch.from_numpy(cc), torch.from_numpy(ac), torch.from_numpy(style), torch.from_numpy(timbre),
+        noise_fn=lambda f: tuple(torch.from_numpy(a) for a in frame_noise(useed, f)),
+        delay=int(g["delay"]), max_seq_frames=int(g["max_seq_frames"]), buffer_frames=int(g["buffer_frames"]),
+        decode_chunk_frames=chunk)
+    n = 2048 * chunk
+    src = torch.from_numpy(synth_utterance(useed, n * n_chunks))[None]
+    outs = []
+    for i in range(n_chunks):
+        outs.append(sess.process_one_chunk(src[:, i * n:(i + 1) * n]))
+    return sess, outs
+
+
+@pytest.mark.parametrize("name", ["stream_s0", "stream_reprefill", "stream_chunk4"])
+def test_stream_matches_reference(name, weights0):
+    g = load_golden(name)
+    sess, outs = _run_stream(g, weights0)
+    content = torch.cat([r["content"] for r in sess.trace]).numpy()
+    np.testing.assert_array_equal(content, g["content_codes"])
+    np.testing.assert_array_equal(sess.pred_codes.numpy(), g["audio_codes"])       # same noise -> same codes
+    assert sess.ar.last_pos == int(g["final_pos"])
+    for k, idx in enumerate(g["pcm_full_idx"]):
+        np.testing.assert_allclose(outs[int(idx)][0].numpy(), g["pcm_full"][k], atol=1e-5)
+    sums = np.array([float(o.double().sum()) for o in outs])
+    np.testing.assert_allclose(sums, g["pcm_sum"], atol=1e-3)
+    if name == "stream_reprefill":
+        assert sess.n_reprefill > 0
+
+
+def test_offline_generate_matches_reference(weights0):
+    g = load_golden("offline_s0")
+    useed = int(g["audio_seed"])
+    ac, cc, style, timbre = synth_prompt(int(g["prompt_seed"]), int(g["prompt_frames"]))
+    ar = O.DualAR(weights0)
+    codes = ar.generate(torch.from_numpy(cc), torch.from_numpy(ac), torch.from_numpy(g["src_codes"]),
+                        torch.from_numpy(style), torch.from_numpy(timbre), int(g["delay"]),
+                        noise_fn=lambda s: tuple(torch.from_numpy(a) for a in frame_noise(useed, s)))
+    np.testing.assert_array_equal(codes.numpy(), g["codes"])
+    wav = O.vocode_window(codes.long(), weights0)
+    np.testing.assert_allclose(wav[0, 0, -2048:].numpy(), g["pcm_last"], atol=1e-5)
+
+
+def test_sampler_rules():
+    # nucleus cut has NO right shift: the entry that crosses top_p is dropped too, rank 0 always kept
+    logits = torch.log(torch.tensor([0.5, 0.3, 0.15, 0.05]))
+    noise = torch.ones(4)
+    assert O.sample_token(logits, noise, 1.0, 0.7) == 0          # cum = .5,.8 -> only rank 0 survives
+    noise = torch.tensor([100.0, 1e-3, 1.0, 1.0])                # would pick 1 if it survived
+    assert O.sample_token(logits, noise, 1.0, 0.7) == 0
+    assert O.sample_token(logits, noise, 1.0, 0.85) == 1         # cum=.5,.8 kept

@@ -1,0 +1,254 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference
+through tools/ref_harness.py) on CPU with the synthetic weights of
+streamvoiceanon_amd.synth_weights.  Runs only in the build container; the fixtures it writes
+are data (inputs are regenerated from seeds; outputs are the reference's tensors).
+
+    python tools/make_golden.py            # writes tests/golden/*.npz   (~3 min on 8 vCPU)
+
+Fixture contents (SURVEY.md §8c "Golden vectors to capture"):
+  encoder_s{0,1}.npz   BSQ indices [128] + pre-sign u [128,13] + sampled mel / backbone values
+  vocoder_s0.npz       windowed vocoder: z samples, last-frame PCM, strided PCM samples
+  stream_s0.npz        24-chunk stream (delay 2, chunk 1): content codes, audio codes, PCM of
+                       3 frames + per-chunk checksums, per-frame top-32 slow/fast logits
+  stream_reprefill.npz stream with max_seq_frames small enough to trigger a re-prefill
+  stream_chunk4.npz    chunk = 4 stream (config-5 shape), delay 2
+  offline_s0.npz       offline ARVCWrapper.generate codes for a short source
+  melfb.npz            mel filterbank checksums
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import ref_harness as rh  # noqa: E402
+from streamvoiceanon_amd import specs, synth_weights as sw  # noqa: E402
+from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+def top32(x: torch.Tensor):
+    v, i = torch.topk(x.flatten().float(), 32)
+    return v.numpy(), i.numpy().astype(np.int32)
+
+
+class NoiseFeed:
+    """Replacement for modules.dual_ar_stream.multinomial_sample_one_no_sync (:1092-1096) that
+    takes the Exp(1) noise from a queue instead of torch's global generator."""
+
+    def __init__(self):
+        self.q, self.live = [], False
+
+    def __call__(self, probs):
+        if self.live and self.q:
+            nz = torch.from_numpy(self.q.pop(0))
+        else:
+            nz = torch.ones_like(probs)
+        assert nz.shape == probs.shape
+        return torch.argmax(probs / nz, dim=-1, keepdim=True).to(dtype=torch.int)
+
+
+def check_specs(w):
+    sp = specs.all_specs(prompt_path=True)
+    for net, pre in ((w.model, "arvc."), (w.speech_tokenizer, "tok."), (w.firefly, "voc.")):
+        sd = net.state_dict()
+        for n, s in sp.items():
+            if n.startswith(pre):
+                assert tuple(sd[n[len(pre):]].shape) == tuple(s), n
+    return len(sp)
+
+
+def encoder_fixture(w, wseed, useed):
+    x = torch.from_numpy(synth_utterance(useed, 262144))[None]
+    tok = w.speech_tokenizer
+    codes, lens = tok.encode(x, torch.LongTensor([262144]))
+    mel = tok.spec_transform(x)
+    feat = tok.backbone(mel)
+    q = tok.quantizer
+    z = q.pre_module(q.downsample(feat))
+    u = torch.nn.functional.normalize(q.residual_bsq.rvqs[0].project_in(z.mT).float(), dim=-1)
+    mel_idx = (np.arange(64) * 1279) % mel.numel()
+    feat_idx = (np.arange(64) * 4093) % feat.numel()
+    np.savez_compressed(
+        os.path.join(OUT, f"encoder_s{wseed}.npz"),
+        weight_seed=wseed, audio_seed=useed, n_samples=262144,
+        codes=codes[0, 0].numpy(), u=u[0].numpy(),
+        mel_idx=mel_idx, mel_val=mel.flatten()[mel_idx].numpy(), mel_sum=float(mel.double().sum()),
+        feat_idx=feat_idx, feat_val=feat.flatten()[feat_idx].numpy(),
+        z_last=z[0, :, -1].numpy(),
+    )
+    print("encoder fixture", wseed, "distinct codes", len(set(codes.flatten().tolist())),
+          "min|u| q01", float(np.quantile(u.abs().min(-1).values.numpy(), 0.01)))
+
+
+def vocoder_fixture(w, wseed):
+    cseed = 77
+    codes = np.floor(sw.uniform01(cseed, "voc.codes", 8 * 64).astype(np.float64) * 1000).astype(np.int64).reshape(1, 8, 64)
+    ct = torch.from_numpy(codes)
+    z = w.firefly.quantizer.decode(ct)
+    wav = w.firefly.head(z)
+    z_idx = (np.arange(64) * 2039) % z.numel()
+    s_idx = (np.arange(512) * 257) % wav.numel()
+    np.savez_compressed(
+        os.path.join(OUT, f"vocoder_s{wseed}.npz"),
+        weight_seed=wseed, code_seed=cseed, codes=codes,
+        z_idx=z_idx, z_val=z.flatten()[z_idx].numpy(),
+        pcm_idx=s_idx, pcm_val=wav.flatten()[s_idx].numpy(),
+        pcm_last_frame=wav[0, 0, -2048:].numpy(), pcm_sum=float(wav.double().sum()),
+    )
+    print("vocoder fixture", float(wav.std()))
+
+
+def stream_fixture(w, feed, name, wseed, useed, pseed, n_chunks, chunk=1, delay=2, max_seq_frames=768,
+                   buffer_frames=32, prompt_frames=107, full_pcm_frames=(2, 3, -1)):
+    import modules.dual_ar_stream as das
+
+    ac, cc, style, timbre = synth_prompt(pseed, prompt_frames)
+    tup = (torch.from_numpy(ac)[None], torch.from_numpy(cc)[None], torch.from_numpy(style)[None],
+           torch.from_numpy(timbre)[None], torch.zeros(1, prompt_frames * 2048))
+    w.calculate_prompt = lambda ref, alpha=1.0, spk_emb_collate_type="concat_mel": tup
+    ar = w.model.decoder.model
+    rec = dict(slow_v=[], slow_i=[], fast_v=[], fast_i=[], hidden=[])
+    state = dict(frame=0, live=False)
+    orig_fg, orig_ff = ar.forward_generate, ar.forward_generate_fast
+
+    def fg(*a, **k):
+        r = orig_fg(*a, **k)
+        if state["live"]:
+            v, i = top32(r.logits)
+            rec["slow_v"].append(v); rec["slow_i"].append(i)
+            rec["hidden"].append(r.hidden_states.flatten()[:16].numpy().copy())
+        return r
+
+    def ff(*a, **k):
+        r = orig_ff(*a, **k)
+        if state["live"]:
+            v, i = top32(r)
+            rec["fast_v"].append(v); rec["fast_i"].append(i)
+        return r
+
+    ar.forward_generate, ar.forward_generate_fast = fg, ff
+    orig_decode_one = w.model.__class__.decode_one
+
+    def decode_one(code):
+        ns, nf = frame_noise(useed, state["frame"])
+        state["frame"] += 1
+        feed.q = [ns] + [nf[i] for i in range(8)]
+        feed.live = state["live"] = True
+        r = orig_decode_one(w.model, code)
+        feed.live = state["live"] = False
+        return r
+
+    w.model.decode_one = decode_one
+    # prompt prefill: capture the last-token logits of the prefill pass
+    pre = {}
+    orig_fg2 = ar.forward_generate
+
+    def fg_pre(*a, **k):
+        r = orig_fg2(*a, **k)
+        pre.setdefault("v", top32(r.logits))
+        return r
+
+    ar.forward_generate = fg_pre
+    w.prefill_prompt([None], max_prompt_frames=256, delay=delay)
+    ar.forward_generate = fg
+    w.setup_stream_caches(encode_window_frames=128, decode_window_frames=64, max_seq_frames=max_seq_frames,
+                          buffer_frames=buffer_frames, decode_chunk_frames=chunk)
+    n = 2048 * chunk
+    src = torch.from_numpy(synth_utterance(useed, n * n_chunks))[None]
+    content, pcm_sum, pcm_abs, pcm_full = [], [], [], {}
+    t0 = time.time()
+    for i in range(n_chunks):
+        out = w.process_one_chunk(src[:, i * n:(i + 1) * n])
+        content.append(w.src_content_codes[0, -chunk:].numpy().copy())
+        pcm_sum.append(float(out.double().sum()))
+        pcm_abs.append(float(out.double().abs().sum()))
+        pcm_full[i] = out[0].numpy().copy()
+    keep = sorted({(f if f >= 0 else n_chunks + f) for f in full_pcm_frames})
+    audio_codes = w.pred_codes[0].numpy().copy()          # [8, frames decoded]
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        weight_seed=wseed, audio_seed=useed, prompt_seed=pseed, prompt_frames=prompt_frames,
+        n_chunks=n_chunks, chunk=chunk, delay=delay, max_seq_frames=max_seq_frames, buffer_frames=buffer_frames,
+        content_codes=np.concatenate(content), audio_codes=audio_codes,
+        pcm_sum=np.array(pcm_sum), pcm_abs=np.array(pcm_abs),
+        pcm_full_idx=np.array(keep), pcm_full=np.stack([pcm_full[k] for k in keep]),
+        slow_top_v=np.stack(rec["slow_v"]), slow_top_i=np.stack(rec["slow_i"]),
+        fast_top_v=np.stack(rec["fast_v"]).reshape(-1, 8, 32), fast_top_i=np.stack(rec["fast_i"]).reshape(-1, 8, 32),
+        hidden16=np.stack(rec["hidden"]),
+        prefill_top_v=pre["v"][0], prefill_top_i=pre["v"][1],
+        final_pos=int(w.model.decoder.cached_kv_pos[-1]),
+    )
+    ar.forward_generate, ar.forward_generate_fast = orig_fg, orig_ff
+    del w.model.decode_one
+    print(name, "frames", audio_codes.shape, "time %.1fs" % (time.time() - t0), "final pos", int(w.model.decoder.cached_kv_pos[-1]))
+
+
+def offline_fixture(w, feed, wseed, useed, pseed, src_frames=12, prompt_frames=40, delay=2):
+    import modules.dual_ar_stream as das
+
+    ac, cc, style, timbre = synth_prompt(pseed, prompt_frames)
+    src_codes = np.floor(sw.uniform01(useed, "offline.src", src_frames).astype(np.float64) * 8192).astype(np.int64)
+    # noise for step s = frame_noise(useed, s); decode_one_token_ar draws 1 + 8 times per step
+    step = dict(i=0)
+    orig = das.decode_one_token_ar
+
+    def patched(*a, **k):
+        ns, nf = frame_noise(useed, step["i"])
+        step["i"] += 1
+        feed.q = [ns] + [nf[j] for j in range(8)]
+        feed.live = True
+        r = orig(*a, **k)
+        feed.live = False
+        return r
+
+    das.decode_one_token_ar = patched
+    w.model.set_delay(delay=delay)
+    codes = w.model.generate(
+        ref_content_codes=torch.from_numpy(cc)[None], ref_audio_codes=torch.from_numpy(ac)[None],
+        src_content_codes=torch.from_numpy(src_codes)[None], style_vectors=torch.from_numpy(style)[None],
+        timbre_latents=torch.from_numpy(timbre)[None])
+    das.decode_one_token_ar = orig
+    wav = w.code2wav_fn(codes)
+    np.savez_compressed(os.path.join(OUT, f"offline_s{wseed}.npz"), weight_seed=wseed, audio_seed=useed,
+                        prompt_seed=pseed, prompt_frames=prompt_frames, delay=delay, src_codes=src_codes,
+                        codes=codes.numpy(), pcm_sum=float(wav.double().sum()), pcm_last=wav[0, 0, -2048:].numpy())
+    print("offline fixture", codes.shape)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rh.install_stubs()
+    import modules.dual_ar_stream as das
+
+    feed = NoiseFeed()
+    das.multinomial_sample_one_no_sync = feed
+    fb = rh.melscale_fbanks(1025, 0.0, 22050.0, 160, 44100, norm="slaney", mel_scale="slaney")
+    np.savez_compressed(os.path.join(OUT, "melfb.npz"), col_sum=fb.sum(0).numpy(), row_sum=fb.sum(1).numpy(),
+                        peak=fb.max(0).values.numpy(), argpeak=fb.argmax(0).numpy())
+    for wseed in (0, 1):
+        w = rh.build_wrapper(seed=wseed)
+        print("spec table entries checked:", check_specs(w))
+        encoder_fixture(w, wseed, 1000 + wseed)
+        if wseed == 0:
+            vocoder_fixture(w, wseed)
+            stream_fixture(w, feed, "stream_s0", 0, useed=1000, pseed=2000, n_chunks=24)
+            stream_fixture(w, feed, "stream_reprefill", 0, useed=1001, pseed=2001, n_chunks=30,
+                           max_seq_frames=136, buffer_frames=32, full_pcm_frames=(-1,))
+            stream_fixture(w, feed, "stream_chunk4", 0, useed=1002, pseed=2002, n_chunks=6, chunk=4,
+                           full_pcm_frames=(-1,))
+            offline_fixture(w, feed, 0, useed=1003, pseed=2003)
+
+
+if __name__ == "__main__":
+    main()
