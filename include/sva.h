@@ -1,0 +1,140 @@
+/*
+ * sva.h -- C ABI of the MI355X-native StreamVoiceAnon streaming voice-conversion engine.
+ *
+ * The reference (Plachtaa/StreamVoiceAnon) is pure Python and has no FFI of its own; this
+ * header is the boundary a maintainer would bind (ctypes stub in INTEGRATION.md) to replace
+ * the four per-chunk seams of evaluations/infer_arvc.py `process_one_chunk` (:492-596):
+ *     speech_tokenizer.encode  (:506-508)   -> sva_encode_window / inside sva_step
+ *     model.decode_one         (:535-537)   -> inside sva_step (sva_prefill_prompt for :484-489)
+ *     firefly.quantizer.decode (:175)       -> sva_vocode_window / inside sva_step
+ *     firefly.head             (:175)       -> sva_vocode_window / inside sva_step
+ *
+ * Conventions: every function returns 0 on success and a negative code on failure (message via
+ * sva_last_error()); nothing throws across the ABI.  The caller owns all I/O buffers; the engine
+ * owns weights and per-stream state.  Handles are not re-entrant (one host thread per handle).
+ * All host pointers are plain C arrays; no torch / C++ types appear in any signature.
+ */
+#ifndef SVA_H
+#define SVA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sva_engine sva_engine;
+typedef struct sva_batch sva_batch;
+
+/* Model dimensions.  sva_config_default() fills the values of the reference's Hydra YAMLs
+ * (configs/hydra_arcs/{vc/firefly_arvc_bsq_8192_delay0_8, speech_tokenizers/causal-encoder-lfq-8192,
+ * vocoders/firefly_gan_vq}.yaml). */
+typedef struct sva_config {
+    int n_mels;            /* 160 */
+    int enc_depths[4];     /* 3,3,9,3 */
+    int enc_dims[4];       /* 128,256,384,512 */
+    int tr_layers;         /* 8   BSQ pre_module transformer */
+    int tr_heads;          /* 8 */
+    int tr_dim;            /* 512 */
+    int tr_inter;          /* 1536 */
+    int bsq_bits;          /* 13 */
+    int ar_dim;            /* 768 */
+    int ar_heads;          /* 12 */
+    int ar_layers;         /* 12 */
+    int ar_fast_layers;    /* 4 */
+    int ar_inter;          /* 2304 */
+    int ar_vocab;          /* 8192 */
+    int codebook_size;     /* 1000 */
+    int num_codebooks;     /* 8 */
+    int max_delay;         /* 8 */
+    int max_seq_len;       /* 2048 */
+    int timbre_dim;        /* 128 */
+    int timbre_tokens;     /* 32 */
+    int style_dim;         /* 192 */
+    int voc_dim;           /* 512 */
+    int ar_dtype;          /* 0: fp32 weights + fp32 KV (parity mode); 1: fp16 weights + fp16 KV */
+} sva_config;
+
+/* evaluations/infer_arvc.py setup_stream_caches (:443-460) + stream_infer defaults (:598-613) */
+typedef struct sva_stream_params {
+    int n_streams;             /* B concurrent streams (the reference is hard-wired to 1) */
+    int encode_window_frames;  /* 128 */
+    int decode_window_frames;  /* 64  (used only to size vocoder priming = window - 1 frames) */
+    int chunk_frames;          /* decode_chunk_frames, 1 */
+    int delay;                 /* 2 */
+    int max_seq_frames;        /* 768 */
+    int buffer_frames;         /* 32 */
+    int max_prompt_frames;     /* 256 */
+    float temperature;         /* 0.7  (modules/dual_ar_stream.py:1103) */
+    float top_p;               /* 0.7  (:1104) */
+    int voc_max_frames;        /* largest T accepted by sva_vocode_window / one streaming call (>= chunk) */
+    int use_graph;             /* capture the steady-state step in a hipGraph */
+    int skip_semantic;         /* skip the semantic-token head whose sample every caller discards (:833) */
+} sva_stream_params;
+
+const char* sva_last_error(void);
+int sva_config_default(sva_config* cfg);
+int sva_stream_params_default(sva_stream_params* p);
+
+/* ---- engine: weights ------------------------------------------------------------------ */
+int sva_engine_create(const sva_config* cfg, int device, sva_engine** out);
+/* name = reference state-dict key prefixed by its network: "arvc." (ARVCWrapper), "tok." (speech
+ * tokenizer), "voc." (Firefly vocoder); data = fp32 host array of the given shape.  Unknown names
+ * are ignored (strict=False, evaluations/infer_arvc.py:79-93,162).  Weight-norm pairs
+ * (...parametrizations.weight.original0/1) are folded as g*v/||v|| (firefly.py:295-301). */
+int sva_engine_load_weight(sva_engine* e, const char* name, int ndim, const int64_t* shape, const float* data);
+/* pack to the compute layout and upload; after this the engine is immutable */
+int sva_engine_finalize(sva_engine* e);
+void sva_engine_destroy(sva_engine* e);
+
+/* ---- batch of streams ------------------------------------------------------------------- */
+int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_batch** out);
+void sva_batch_destroy(sva_batch* b);
+
+/* ARVCWrapper.prefill_prompt (modules/arvc_wrapper.py:100-112) + InferenceWrapper.prefill_prompt
+ * bookkeeping (infer_arvc.py:463-489) for one stream slot: content codes int64[R], audio codes
+ * int32[8][R] (row-major), style float[192], timbre float[32][128].  noise_seed keys the
+ * on-device sampler noise of this utterance.  Call for every slot, then sva_streams_begin(). */
+int sva_prefill_prompt(sva_batch* b, int slot, const int64_t* ref_content_codes, const int32_t* ref_audio_codes,
+                       int R, const float* style, const float* timbre, uint64_t noise_seed);
+/* zero the audio windows / histories and prime the streaming vocoder with the prompt tail */
+int sva_streams_begin(sva_batch* b);
+
+/* InferenceWrapper.process_one_chunk (infer_arvc.py:492-596) for all streams in lock step.
+ *   pcm_in  host float[B][2048*chunk]      pcm_out host float[B][2048*chunk]
+ *   noise   host float[B][chunk][vocab + 8*codebook_size] Exp(1) draws in the reference's RNG
+ *           order (slow head first, then the 8 codebooks), or NULL = on-device counter RNG
+ *   forced_codes host int32[B][8][chunk] teacher-forces the AR (parity tests), or NULL */
+int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const float* noise, const int32_t* forced_codes);
+/* same with device pointers (no host copies); asynchronous on the engine stream */
+int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm_out);
+int sva_sync(sva_batch* b);
+
+/* ---- seam-level entry points (parity tests, drop-in for the module calls) ------------------ */
+/* speech_tokenizer.encode (firefly_encoder.py:553-566) on full windows: audio host float[B][W*2048]
+ * -> codes int64[B][W] (+ optional L2-normalised pre-sign u float[B][W][13]) */
+int sva_encode_window(sva_batch* b, const float* audio, int64_t* codes_out, float* u_out);
+/* code2wav_fn (infer_arvc.py:173-176) with the reference's window semantics (zero history):
+ * codes host int32[B][8][T] -> pcm float[B][2048*T];  T <= voc_max_frames */
+int sva_vocode_window(sva_batch* b, const int32_t* codes, int T, float* pcm_out);
+/* streaming-exact vocoder: continue from the ring-buffer state: codes int32[B][8][T] -> pcm[B][2048*T] */
+int sva_vocode_stream(sva_batch* b, const int32_t* codes, int T, float* pcm_out);
+int sva_vocode_reset(sva_batch* b);
+
+/* taps of the last step: "content_codes" int32[B][chunk], "audio_codes" int32[B][8][chunk] (as int32),
+ * "slow_logits" float[B][vocab], "fast_logits" float[B][8][codebook_size], "hidden" float[B][dim],
+ * "semantic" int32[B], "last_pos" int32[B], "mel" float[B][T][160] ... ; returns #bytes or <0 */
+long sva_get_tap(sva_batch* b, const char* what, void* out, long out_bytes);
+/* per-stage device time of the last sva_step in ms: [encoder, ar, vocoder, total] (hipEvents) */
+int sva_get_timings(sva_batch* b, float ms[4]);
+/* dominant-kernel bookkeeping for bench.py: number of conv-GEMM launches and their summed
+ * algorithmic FLOPs in the last step */
+int sva_get_gemm_stats(sva_batch* b, double* flops, long* launches);
+
+/* kernel unit-test hook: C = A[M,K] * W[N,K]^T (+bias) through the conv-GEMM kernel (host arrays) */
+int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVA_H */

@@ -1,0 +1,205 @@
+// Engine / batch data structures of the sva HIP engine.
+#pragma once
+#include "../../include/sva.h"
+#include "kernels.h"
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace sva {
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    long numel() const {
+        long n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+// [N][K] row-major weight (K = taps * Cin, tap-major) + optional bias [N]
+struct Lin {
+    float* W = nullptr;
+    float* b = nullptr;
+    int N = 0, K = 0;
+};
+
+// ConvNeXtBlock (modules/vqgan/modules/firefly.py:375-440)
+struct CNX {
+    float *dwT = nullptr, *dwb = nullptr, *lnw = nullptr, *lnb = nullptr, *gamma = nullptr;
+    Lin pw1, pw2;
+    int C = 0;
+};
+
+// Llama-style block; w13 = rows of w1/w3 interleaved in groups of 16 (SwiGLU fused in the epilogue).
+// ls_* are the LayerScale gammas of the BSQ pre-transformer (null for the AR).
+struct TrLayer {
+    float* attn_norm = nullptr;
+    float* ffn_norm = nullptr;
+    float* ls_attn = nullptr;
+    float* ls_ffn = nullptr;
+    Lin wqkv, wo, w13, w2;
+};
+
+// activation tensor [B, H + Tmax, C] channel-last with H history / zero-pad rows in front
+struct Act {
+    float* p = nullptr;
+    int H = 0, C = 0;
+    long rows = 0;       // H + Tmax
+    long bstride = 0;    // rows * C
+};
+
+struct ResConv {
+    Lin c1, c2;
+    int k = 0, dil = 1;
+};
+
+}  // namespace sva
+
+struct sva_engine {
+    sva_config cfg;
+    int device = 0;
+    bool finalized = false;
+    std::unordered_map<std::string, sva::HostTensor> host;
+    std::vector<void*> allocs;
+
+    // ---- content encoder ----
+    sva::Lin mel_fb;                       // [160][1040]  (K padded 1025 -> 1040)
+    float2* twiddle = nullptr;             // [1024]
+    float* hann = nullptr;                 // [2048]
+    sva::Lin stem;                         // conv k7 160 -> 128
+    float *stem_lnw = nullptr, *stem_lnb = nullptr;
+    std::vector<std::vector<sva::CNX>> stages;
+    float* trans_lnw[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* trans_lnb[4] = {nullptr, nullptr, nullptr, nullptr};
+    sva::Lin trans[4];
+    float *final_lnw = nullptr, *final_lnb = nullptr;
+    sva::Lin ds_conv[2];
+    sva::CNX ds_cnx[2];
+    std::vector<sva::TrLayer> tr;
+    float* tr_norm = nullptr;
+    float* rope_enc = nullptr;             // [2048][32][2]
+    float *bsq_W = nullptr, *bsq_b = nullptr;
+
+    // ---- dual AR ----
+    float *content_emb = nullptr, *codebook_emb = nullptr, *fast_emb = nullptr, *wait4start = nullptr;
+    std::vector<sva::TrLayer> ar_layers, ar_fast_layers;
+    float *ar_norm = nullptr, *ar_fast_norm = nullptr;
+    sva::Lin ar_output, ar_fast_output, context_in, style_in;
+    float *rope_ar = nullptr, *rope_fast = nullptr;
+
+    // ---- vocoder ----
+    float *fsq_W = nullptr, *fsq_b = nullptr;   // [8][64][4], [8][64]
+    sva::Lin up_conv[2];
+    sva::CNX up_cnx[2];
+    sva::Lin conv_pre;
+    sva::Lin ups[5];
+    int ups_k[5] = {16, 16, 4, 4, 4};
+    int ups_s[5] = {8, 8, 2, 2, 2};
+    sva::ResConv res[5][3][3];
+    float *post_w = nullptr, *post_b = nullptr;  // [13][16], [1]
+    int post_k = 13, pre_k = 13;
+};
+
+struct sva_batch {
+    sva_engine* e = nullptr;
+    sva_stream_params p;
+    int B = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+
+    // ---- device control block ----
+    int* d_step = nullptr;                 // chunks consumed (ring position)
+    int* d_last_pos = nullptr;             // [B] last written slow-AR KV position
+    int* d_nframes = nullptr;              // [B] decoded frames (sampler noise counter)
+    int* d_ncontent = nullptr;             // [B] content codes seen
+    unsigned long long* d_seed = nullptr;  // [B]
+    int* d_use_forced = nullptr;           // [1]
+
+    // ---- encoder workspace ----
+    int We = 0, N = 0, T0 = 0, T2 = 0;
+    float* ring = nullptr;                 // [B][N]
+    float* d_chunk = nullptr;              // [B][2048*c] staged input
+    float* mag = nullptr;                  // [B][T0][1040]
+    sva::Act mel;                          // [B][6+T0][160]
+    sva::Act xs[4];                        // stage activations with 6 pad rows
+    float *h1 = nullptr, *h2 = nullptr;    // [B][T0][512], [B][T0][2048]
+    sva::Act feat;                         // [B][T0][512]
+    sva::Act d1, d2;                       // [B][6+T0/2][512], [B][6+T0/4][512]
+    float *tr_hn = nullptr, *tr_qkv = nullptr, *tr_att = nullptr, *tr_g = nullptr, *tr_z = nullptr;
+    long long* d_codes = nullptr;          // [B][T2]
+    float* d_u = nullptr;                  // [B][T2][13]
+
+    // ---- AR workspace ----
+    int Mmax = 0;
+    float *ax = nullptr, *ahn = nullptr, *aqkv = nullptr, *aatt = nullptr, *ag = nullptr;
+    float *xf = nullptr;                   // [B][dim] fast-AR residual stream
+    float *slow_logits = nullptr, *fast_logits = nullptr, *hidden = nullptr;
+    int *d_slot = nullptr, *d_pos = nullptr;          // [Mmax]
+    int *d_fast_slot = nullptr, *d_fast_pos = nullptr; // [B], [8][B]
+    void* kv_slow = nullptr;               // [L][B][2][H][S][64]
+    void* kv_fast = nullptr;               // [Lf][B][2][H][8][64]
+    long kv_slow_slot = 0, kv_slow_layer = 0, kv_fast_slot = 0, kv_fast_layer = 0;
+    float* cached_audio_emb = nullptr;     // [B][dim]
+    float* cached_ref_emb = nullptr;       // [B][max_delay][dim]
+    float* spk = nullptr;                  // [33][dim] scratch
+    float *d_style = nullptr, *d_timbre = nullptr;     // [B][192], [B][32][128]
+    int* d_sem = nullptr;                  // [B] semantic token (discarded by callers)
+    int* d_tok = nullptr;                  // [B][8] sampled fast tokens of the current frame
+    int* d_tok_raw = nullptr;              // [B][8] sampled (before teacher forcing)
+    int* d_forced = nullptr;               // [B][8][chunk]
+    float* d_noise = nullptr;              // [B][chunk][vocab + 8*cb]
+    bool noise_on_device = false;
+    // histories (per slot, linear with device counters)
+    int hist_cap = 0;
+    int* d_content_hist = nullptr;         // [B][hist_cap]
+    int* d_pred_hist = nullptr;            // [B][8][hist_cap]
+    int* d_step_content = nullptr;         // [B][chunk] content codes of this step (int32)
+    int* d_step_audio = nullptr;           // [B][8][chunk]
+    // prompt (truncated to max_prompt_frames) kept for re-prefill / vocoder priming
+    std::vector<std::vector<int64_t>> ref_content;   // [B][R']
+    std::vector<std::vector<int32_t>> ref_audio;     // [B][8*R']
+    std::vector<int> ref_len;
+    int* d_prompt_cc = nullptr;            // [Pmax] scratch prompt content codes (int32)
+    int* d_prompt_ac = nullptr;            // [8][Pmax]
+    int Pmax = 0;
+
+    // host mirrors of the deterministic per-slot state
+    std::vector<int> h_last_pos, h_nframes;
+    int h_ncontent = 0;                    // content codes seen (lock step)
+    int h_step = 0;
+    bool delay_filled = false;
+    bool begun = false;
+    std::vector<char> prefilled;
+
+    // ---- vocoder workspace ----
+    int Tv = 0;                            // max code frames per call
+    sva::Act zq;                           // [B][Tv][512]
+    sva::Act u0, v0, u1, pin;              // upsample stack, conv_pre input
+    float *vh1 = nullptr, *vh2 = nullptr;  // ConvNeXt scratch
+    sva::Act S[6];                         // S[i] = input of ups.i (i<5); S[5] = conv_post input
+    sva::Act X[5];                         // resblock inputs
+    sva::Act tb[5][3][3];                  // c1 outputs
+    sva::Act yb[5][3][2];                  // y_{b,1}, y_{b,2}
+    float* d_pcm = nullptr;                // [B][2048*Tv]
+    int* d_vcodes = nullptr;               // [B][8][Tv]
+    std::vector<sva::ShiftDesc> shift_host;
+    sva::ShiftDesc* d_shift = nullptr;
+
+    // pinned staging
+    float *hp_in = nullptr, *hp_out = nullptr;
+
+    // timing / stats
+    hipEvent_t ev[5];
+    bool ev_ok = false;
+    float last_ms[4] = {0, 0, 0, 0};
+    double gemm_flops = 0;
+    long gemm_launches = 0;
+
+    // graph
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_ready = false;
+};

@@ -1,0 +1,1348 @@
+// sva engine: weight packing, per-batch state and the per-chunk step of the streaming
+// voice-conversion hot path (content encoder -> dual AR -> Firefly vocoder) on MI355X.
+//
+// Host-side control flow mirrors evaluations/infer_arvc.py InferenceWrapper.{prefill_prompt,
+// setup_stream_caches, process_one_chunk} (:443-596) and modules/dual_ar_stream.py
+// DualARWrapper.{prefill_prompt, prefill_src_condition4delay, decode_one} (:764-837); the
+// arithmetic runs in the HIP kernels of gemm.hip / kernels.hip.
+#include "engine.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace sva {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+#define SVA_TRY(expr)            \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc) return _rc;     \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(std::vector<void*>& pool, T** out, size_t n, bool zero = true) {
+    void* p = nullptr;
+    if (n == 0) n = 1;
+    SVA_HIP(hipMalloc(&p, n * sizeof(T)));
+    if (zero) SVA_HIP(hipMemset(p, 0, n * sizeof(T)));
+    pool.push_back(p);
+    *out = (T*)p;
+    return 0;
+}
+static int upload(std::vector<void*>& pool, float** out, const std::vector<float>& v) {
+    SVA_TRY(dev_alloc(pool, out, v.size(), false));
+    SVA_HIP(hipMemcpy(*out, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+static int alloc_act(std::vector<void*>& pool, Act& a, int B, int H, long Tmax, int C) {
+    a.H = H;
+    a.C = C;
+    a.rows = H + Tmax;
+    a.bstride = a.rows * C;
+    return dev_alloc(pool, &a.p, (size_t)B * a.bstride, true);
+}
+
+}  // namespace sva
+
+using namespace sva;
+
+// ============================================================================================
+// config defaults
+// ============================================================================================
+extern "C" const char* sva_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sva_config_default(sva_config* c) {
+    if (!c) return -1;
+    memset(c, 0, sizeof(*c));
+    c->n_mels = 160;
+    int dep[4] = {3, 3, 9, 3}, dims[4] = {128, 256, 384, 512};
+    for (int i = 0; i < 4; ++i) { c->enc_depths[i] = dep[i]; c->enc_dims[i] = dims[i]; }
+    c->tr_layers = 8; c->tr_heads = 8; c->tr_dim = 512; c->tr_inter = 1536; c->bsq_bits = 13;
+    c->ar_dim = 768; c->ar_heads = 12; c->ar_layers = 12; c->ar_fast_layers = 4; c->ar_inter = 2304;
+    c->ar_vocab = 8192; c->codebook_size = 1000; c->num_codebooks = 8; c->max_delay = 8; c->max_seq_len = 2048;
+    c->timbre_dim = 128; c->timbre_tokens = 32; c->style_dim = 192; c->voc_dim = 512; c->ar_dtype = 0;
+    return 0;
+}
+extern "C" int sva_stream_params_default(sva_stream_params* p) {
+    if (!p) return -1;
+    memset(p, 0, sizeof(*p));
+    p->n_streams = 1; p->encode_window_frames = 128; p->decode_window_frames = 64; p->chunk_frames = 1;
+    p->delay = 2; p->max_seq_frames = 768; p->buffer_frames = 32; p->max_prompt_frames = 256;
+    p->temperature = 0.7f; p->top_p = 0.7f; p->voc_max_frames = 1; p->use_graph = 0; p->skip_semantic = 0;
+    return 0;
+}
+
+// ============================================================================================
+// engine: weights
+// ============================================================================================
+extern "C" int sva_engine_create(const sva_config* cfg, int device, sva_engine** out) {
+    SVA_CHECK(cfg && out, "null argument");
+    SVA_CHECK(cfg->tr_dim == cfg->enc_dims[3] && cfg->voc_dim == 512, "unsupported dims");
+    SVA_CHECK(cfg->ar_dim / cfg->ar_heads == 64 && cfg->tr_dim / cfg->tr_heads == 64, "head_dim must be 64");
+    SVA_CHECK(cfg->ar_dtype == 0, "ar_dtype=1 (fp16 weights) is not built in this round");
+    int ndev = 0;
+    SVA_HIP(hipGetDeviceCount(&ndev));
+    SVA_CHECK(ndev > 0 && device < ndev, "no such HIP device (the product path has no CPU fallback)");
+    SVA_HIP(hipSetDevice(device));
+    sva_engine* e = new sva_engine();
+    e->cfg = *cfg;
+    e->device = device;
+    *out = e;
+    return 0;
+}
+
+extern "C" int sva_engine_load_weight(sva_engine* e, const char* name, int ndim, const int64_t* shape, const float* data) {
+    SVA_CHECK(e && name && data, "null argument");
+    SVA_CHECK(!e->finalized, "engine already finalized");
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    t.data.assign(data, data + t.numel());
+    e->host[name] = std::move(t);
+    return 0;
+}
+
+extern "C" void sva_engine_destroy(sva_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    for (void* p : e->allocs) hipFree(p);
+    delete e;
+}
+
+namespace {
+
+struct Packer {
+    sva_engine* e;
+    std::string err;
+
+    const HostTensor* find(const std::string& n) {
+        auto it = e->host.find(n);
+        if (it != e->host.end()) return &it->second;
+        return nullptr;
+    }
+    // plain weight or folded weight-norm pair (firefly.py:105-111, 295-301: w = g * v / ||v||, norm over dims 1..)
+    bool weight(const std::string& prefix, HostTensor& out) {
+        if (const HostTensor* t = find(prefix + ".weight")) { out = *t; return true; }
+        const HostTensor* g = find(prefix + ".parametrizations.weight.original0");
+        const HostTensor* v = find(prefix + ".parametrizations.weight.original1");
+        if (!g || !v) { err = "missing weight " + prefix + ".weight"; return false; }
+        out = *v;
+        const long rows = v->shape[0], inner = v->numel() / rows;
+        for (long r = 0; r < rows; ++r) {
+            double s = 0;
+            for (long i = 0; i < inner; ++i) s += (double)v->data[r * inner + i] * v->data[r * inner + i];
+            const float sc = (float)(g->data[r] / sqrt(s));
+            for (long i = 0; i < inner; ++i) out.data[r * inner + i] = v->data[r * inner + i] * sc;
+        }
+        return true;
+    }
+    int vec(const std::string& n, float** out, long expect) {
+        const HostTensor* t = find(n);
+        SVA_CHECK(t, ("missing tensor " + n).c_str());
+        SVA_CHECK(t->numel() == expect, ("bad size for " + n).c_str());
+        return upload(e->allocs, out, t->data);
+    }
+    int bias_of(const std::string& prefix, Lin& l) {
+        if (const HostTensor* t = find(prefix + ".bias")) {
+            SVA_CHECK(t->numel() == l.N, ("bad bias size " + prefix).c_str());
+            return upload(e->allocs, &l.b, t->data);
+        }
+        l.b = nullptr;
+        return 0;
+    }
+    // nn.Linear [N, K]
+    int linear(const std::string& prefix, Lin& l, int N, int K) {
+        HostTensor w;
+        SVA_CHECK(weight(prefix, w), err.c_str());
+        SVA_CHECK(w.numel() == (long)N * K, ("bad shape " + prefix).c_str());
+        l.N = N; l.K = K;
+        SVA_TRY(upload(e->allocs, &l.W, w.data));
+        return bias_of(prefix, l);
+    }
+    // nn.Conv1d weight [Cout, Cin, k] -> [Cout][k][Cin]
+    int conv(const std::string& prefix, Lin& l, int Cout, int Cin, int k) {
+        HostTensor w;
+        SVA_CHECK(weight(prefix, w), err.c_str());
+        SVA_CHECK(w.numel() == (long)Cout * Cin * k, ("bad shape " + prefix).c_str());
+        std::vector<float> p((size_t)Cout * k * Cin);
+        for (int o = 0; o < Cout; ++o)
+            for (int i = 0; i < Cin; ++i)
+                for (int j = 0; j < k; ++j) p[((size_t)o * k + j) * Cin + i] = w.data[((size_t)o * Cin + i) * k + j];
+        l.N = Cout; l.K = k * Cin;
+        SVA_TRY(upload(e->allocs, &l.W, p));
+        return bias_of(prefix, l);
+    }
+    // nn.ConvTranspose1d weight [Cin, Cout, k], stride s, k == 2s (FishTransConvNet, firefly.py:114-138):
+    //   y[q*s + r, co] = b[co] + sum_ci x[q, ci] W[ci, co, r] + sum_ci x[q-1, ci] W[ci, co, r + s]
+    // packed as a 2-tap GEMM with N = s*Cout: row n = r*Cout + co, tap 0 (x[q-1]) = W[:, co, r+s], tap 1 (x[q]) = W[:, co, r]
+    // k == s: 1 tap, row n = r*Cout + co = W[:, co, r]
+    int conv_t(const std::string& prefix, Lin& l, int Cin, int Cout, int k, int s) {
+        HostTensor w;
+        SVA_CHECK(weight(prefix, w), err.c_str());
+        SVA_CHECK(w.numel() == (long)Cin * Cout * k, ("bad shape " + prefix).c_str());
+        SVA_CHECK(k == 2 * s || k == s, "conv_t: kernel must be stride or 2*stride");
+        const int taps = k / s;
+        std::vector<float> p((size_t)s * Cout * taps * Cin);
+        for (int r = 0; r < s; ++r)
+            for (int co = 0; co < Cout; ++co)
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const int kk = (taps == 2) ? (tap == 0 ? r + s : r) : r;
+                        p[(((size_t)r * Cout + co) * taps + tap) * Cin + ci] = w.data[((size_t)ci * Cout + co) * k + kk];
+                    }
+        l.N = s * Cout; l.K = taps * Cin;
+        SVA_TRY(upload(e->allocs, &l.W, p));
+        const HostTensor* b = find(prefix + ".bias");
+        SVA_CHECK(b && b->numel() == Cout, ("missing bias " + prefix).c_str());
+        std::vector<float> bb((size_t)s * Cout);
+        for (int r = 0; r < s; ++r)
+            for (int co = 0; co < Cout; ++co) bb[(size_t)r * Cout + co] = b->data[co];
+        return upload(e->allocs, &l.b, bb);
+    }
+    int cnx(const std::string& p, CNX& c, int C) {
+        c.C = C;
+        const HostTensor* dw = find(p + "dwconv.conv.weight");
+        SVA_CHECK(dw && dw->numel() == (long)C * 7, ("missing " + p + "dwconv").c_str());
+        std::vector<float> t((size_t)7 * C);
+        for (int ch = 0; ch < C; ++ch)
+            for (int j = 0; j < 7; ++j) t[(size_t)j * C + ch] = dw->data[(size_t)ch * 7 + j];
+        SVA_TRY(upload(e->allocs, &c.dwT, t));
+        SVA_TRY(vec(p + "dwconv.conv.bias", &c.dwb, C));
+        SVA_TRY(vec(p + "norm.weight", &c.lnw, C));
+        SVA_TRY(vec(p + "norm.bias", &c.lnb, C));
+        SVA_TRY(vec(p + "gamma", &c.gamma, C));
+        SVA_TRY(linear(p + "pwconv1", c.pw1, 4 * C, C));
+        SVA_TRY(linear(p + "pwconv2", c.pw2, C, 4 * C));
+        return 0;
+    }
+    // w1 / w3 rows interleaved in groups of 16 -> [2*I][D]
+    int w13(const std::string& p, Lin& l, int I, int D) {
+        HostTensor w1, w3;
+        SVA_CHECK(weight(p + "feed_forward.w1", w1), err.c_str());
+        SVA_CHECK(weight(p + "feed_forward.w3", w3), err.c_str());
+        SVA_CHECK(w1.numel() == (long)I * D && w3.numel() == (long)I * D && I % 16 == 0, ("bad ffn shape " + p).c_str());
+        std::vector<float> out((size_t)2 * I * D);
+        for (int g = 0; g < I / 16; ++g)
+            for (int r = 0; r < 16; ++r) {
+                memcpy(&out[((size_t)g * 32 + r) * D], &w1.data[((size_t)g * 16 + r) * D], sizeof(float) * D);
+                memcpy(&out[((size_t)g * 32 + 16 + r) * D], &w3.data[((size_t)g * 16 + r) * D], sizeof(float) * D);
+            }
+        l.N = 2 * I; l.K = D; l.b = nullptr;
+        return upload(e->allocs, &l.W, out);
+    }
+    int llama(const std::string& p, TrLayer& L, int D, int I, bool layerscale) {
+        SVA_TRY(vec(p + "attention_norm.weight", &L.attn_norm, D));
+        SVA_TRY(vec(p + "ffn_norm.weight", &L.ffn_norm, D));
+        SVA_TRY(linear(p + "attention.wqkv", L.wqkv, 3 * D, D));
+        SVA_TRY(linear(p + "attention.wo", L.wo, D, D));
+        SVA_TRY(w13(p, L.w13, I, D));
+        SVA_TRY(linear(p + "feed_forward.w2", L.w2, D, I));
+        if (layerscale) {
+            SVA_TRY(vec(p + "attention_layer_scale.gamma", &L.ls_attn, D));
+            SVA_TRY(vec(p + "ffn_layer_scale.gamma", &L.ls_ffn, D));
+        }
+        return 0;
+    }
+    // precompute_freqs_cis (dual_ar_stream.py:993-1001 / windowed_transformer.py:356-365): cos/sin rounded to
+    // bf16.  Normally supplied by the host mirror (computed with torch, bit-identical to the reference); this
+    // fallback evaluates the same formula here.
+    int rope(const std::string& name, float** out, int L, int hd) {
+        if (const HostTensor* t = find(name)) {
+            SVA_CHECK(t->numel() == (long)L * hd, ("bad rope table " + name).c_str());
+            return upload(e->allocs, out, t->data);
+        }
+        std::vector<float> tab((size_t)L * hd);
+        for (int t = 0; t < L; ++t)
+            for (int j = 0; j < hd / 2; ++j) {
+                const float freq = 1.0f / powf(10000.f, (float)(2 * j) / (float)hd);
+                const float ang = (float)t * freq;
+                float cs[2] = {(float)cos((double)ang), (float)sin((double)ang)};
+                for (int q = 0; q < 2; ++q) {           // round-to-nearest-even to bf16
+                    uint32_t u;
+                    memcpy(&u, &cs[q], 4);
+                    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+                    memcpy(&cs[q], &u, 4);
+                    tab[((size_t)t * (hd / 2) + j) * 2 + q] = cs[q];
+                }
+            }
+        return upload(e->allocs, out, tab);
+    }
+};
+
+}  // namespace
+
+extern "C" int sva_engine_finalize(sva_engine* e) {
+    SVA_CHECK(e && !e->finalized, "bad engine");
+    SVA_HIP(hipSetDevice(e->device));
+    const sva_config& c = e->cfg;
+    Packer P{e, ""};
+    // ---- encoder ----
+    {
+        // mel filterbank [1025][160] -> W [160][1040] (K padded with zeros)
+        const HostTensor* fb = P.find("tok.spec_transform.fb");
+        SVA_CHECK(fb && fb->numel() == 1025L * c.n_mels, "missing tok.spec_transform.fb [1025, n_mels] (host mirror supplies it)");
+        std::vector<float> w((size_t)c.n_mels * 1040, 0.f);
+        for (int f = 0; f < 1025; ++f)
+            for (int m = 0; m < c.n_mels; ++m) w[(size_t)m * 1040 + f] = fb->data[(size_t)f * c.n_mels + m];
+        e->mel_fb.N = c.n_mels; e->mel_fb.K = 1040; e->mel_fb.b = nullptr;
+        SVA_TRY(upload(e->allocs, &e->mel_fb.W, w));
+        std::vector<float> hann(2048);
+        for (int i = 0; i < 2048; ++i) hann[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / 2048.0));   // torch.hann_window (periodic)
+        if (const HostTensor* hw = P.find("tok.spec_transform.spectrogram.window")) {
+            SVA_CHECK(hw->numel() == 2048, "bad window");
+            hann = hw->data;
+        }
+        SVA_TRY(upload(e->allocs, &e->hann, hann));
+        std::vector<float> tw(2048);
+        for (int k = 0; k < 1024; ++k) {
+            tw[2 * k] = (float)cos(2.0 * M_PI * k / 2048.0);
+            tw[2 * k + 1] = (float)(-sin(2.0 * M_PI * k / 2048.0));
+        }
+        float* twp;
+        SVA_TRY(upload(e->allocs, &twp, tw));
+        e->twiddle = (float2*)twp;
+        const std::string bb = "tok.backbone.";
+        SVA_TRY(P.conv(bb + "downsample_layers.0.0.conv", e->stem, c.enc_dims[0], c.n_mels, 7));
+        SVA_TRY(P.vec(bb + "downsample_layers.0.1.weight", &e->stem_lnw, c.enc_dims[0]));
+        SVA_TRY(P.vec(bb + "downsample_layers.0.1.bias", &e->stem_lnb, c.enc_dims[0]));
+        e->stages.resize(4);
+        for (int i = 0; i < 4; ++i) {
+            if (i > 0) {
+                const std::string d = bb + "downsample_layers." + std::to_string(i) + ".";
+                SVA_TRY(P.vec(d + "0.weight", &e->trans_lnw[i], c.enc_dims[i - 1]));
+                SVA_TRY(P.vec(d + "0.bias", &e->trans_lnb[i], c.enc_dims[i - 1]));
+                SVA_TRY(P.conv(d + "1", e->trans[i], c.enc_dims[i], c.enc_dims[i - 1], 1));
+            }
+            e->stages[i].resize(c.enc_depths[i]);
+            for (int j = 0; j < c.enc_depths[i]; ++j)
+                SVA_TRY(P.cnx(bb + "stages." + std::to_string(i) + "." + std::to_string(j) + ".", e->stages[i][j], c.enc_dims[i]));
+        }
+        SVA_TRY(P.vec(bb + "norm.weight", &e->final_lnw, c.enc_dims[3]));
+        SVA_TRY(P.vec(bb + "norm.bias", &e->final_lnb, c.enc_dims[3]));
+        const int D = c.tr_dim;
+        for (int i = 0; i < 2; ++i) {
+            const std::string d = "tok.quantizer.downsample." + std::to_string(i) + ".";
+            SVA_TRY(P.conv(d + "0.conv", e->ds_conv[i], D, D, 2));
+            SVA_TRY(P.cnx(d + "1.", e->ds_cnx[i], D));
+        }
+        e->tr.resize(c.tr_layers);
+        for (int l = 0; l < c.tr_layers; ++l)
+            SVA_TRY(P.llama("tok.quantizer.pre_module.layers." + std::to_string(l) + ".", e->tr[l], D, c.tr_inter, true));
+        SVA_TRY(P.vec("tok.quantizer.pre_module.norm.weight", &e->tr_norm, D));
+        SVA_TRY(P.rope("tok.quantizer.pre_module.freqs_cis", &e->rope_enc, 2048, 64));
+        SVA_TRY(P.vec("tok.quantizer.residual_bsq.rvqs.0.project_in.weight", &e->bsq_W, (long)c.bsq_bits * D));
+        SVA_TRY(P.vec("tok.quantizer.residual_bsq.rvqs.0.project_in.bias", &e->bsq_b, c.bsq_bits));
+    }
+    // ---- AR ----
+    {
+        const int D = c.ar_dim;
+        const std::string m = "arvc.decoder.model.";
+        SVA_TRY(P.vec("arvc.embedding.weight", &e->content_emb, (long)c.ar_vocab * D));
+        SVA_TRY(P.vec(m + "codebook_embeddings.weight", &e->codebook_emb, (long)c.codebook_size * c.num_codebooks * D));
+        SVA_TRY(P.vec(m + "fast_embeddings.weight", &e->fast_emb, (long)c.codebook_size * D));
+        SVA_TRY(P.vec("arvc.decoder.wait4start_embedding.weight", &e->wait4start, (long)c.max_delay * D));
+        e->ar_layers.resize(c.ar_layers);
+        for (int l = 0; l < c.ar_layers; ++l) SVA_TRY(P.llama(m + "layers." + std::to_string(l) + ".", e->ar_layers[l], D, c.ar_inter, false));
+        e->ar_fast_layers.resize(c.ar_fast_layers);
+        for (int l = 0; l < c.ar_fast_layers; ++l)
+            SVA_TRY(P.llama(m + "fast_layers." + std::to_string(l) + ".", e->ar_fast_layers[l], D, c.ar_inter, false));
+        SVA_TRY(P.vec(m + "norm.weight", &e->ar_norm, D));
+        SVA_TRY(P.vec(m + "fast_norm.weight", &e->ar_fast_norm, D));
+        SVA_TRY(P.linear(m + "output", e->ar_output, c.ar_vocab, D));
+        SVA_TRY(P.linear(m + "fast_output", e->ar_fast_output, c.codebook_size, D));
+        SVA_TRY(P.linear("arvc.context_in", e->context_in, D, c.timbre_dim));
+        SVA_TRY(P.linear("arvc.style_in", e->style_in, D, c.style_dim));
+        SVA_TRY(P.rope(m + "freqs_cis", &e->rope_ar, c.max_seq_len, 64));
+        SVA_TRY(P.rope(m + "fast_freqs_cis", &e->rope_fast, c.num_codebooks, 64));
+    }
+    // ---- vocoder ----
+    {
+        const int V = c.voc_dim, G = c.num_codebooks, gd = V / G;
+        std::vector<float> fw((size_t)G * gd * 4), fb((size_t)G * gd);
+        for (int g = 0; g < G; ++g) {
+            const std::string p = "voc.quantizer.residual_fsq.rvqs." + std::to_string(g) + ".project_out";
+            const HostTensor* w = P.find(p + ".weight");
+            const HostTensor* b = P.find(p + ".bias");
+            SVA_CHECK(w && b && w->numel() == (long)gd * 4 && b->numel() == gd, ("missing " + p).c_str());
+            memcpy(&fw[(size_t)g * gd * 4], w->data.data(), sizeof(float) * gd * 4);
+            memcpy(&fb[(size_t)g * gd], b->data.data(), sizeof(float) * gd);
+        }
+        SVA_TRY(upload(e->allocs, &e->fsq_W, fw));
+        SVA_TRY(upload(e->allocs, &e->fsq_b, fb));
+        for (int i = 0; i < 2; ++i) {
+            const std::string u = "voc.quantizer.upsample." + std::to_string(i) + ".";
+            SVA_TRY(P.conv_t(u + "0.conv", e->up_conv[i], V, V, 2, 2));
+            SVA_TRY(P.cnx(u + "1.", e->up_cnx[i], V));
+        }
+        const std::string h = "voc.head.";
+        SVA_TRY(P.conv(h + "conv_pre.conv", e->conv_pre, V, V, e->pre_k));
+        int ch = V;
+        const int rk[3] = {3, 7, 11}, rd[3] = {1, 3, 5};
+        for (int i = 0; i < 5; ++i) {
+            SVA_TRY(P.conv_t(h + "ups." + std::to_string(i) + ".conv", e->ups[i], ch, ch / 2, e->ups_k[i], e->ups_s[i]));
+            ch /= 2;
+            for (int b = 0; b < 3; ++b)
+                for (int j = 0; j < 3; ++j) {
+                    const std::string q = h + "resblocks." + std::to_string(i) + ".blocks." + std::to_string(b) + ".";
+                    ResConv& rc = e->res[i][b][j];
+                    rc.k = rk[b];
+                    rc.dil = rd[j];   // convs1 AND convs2 carry dilation d_j (firefly.py:153-180)
+                    SVA_TRY(P.conv(q + "convs1." + std::to_string(j) + ".conv", rc.c1, ch, ch, rk[b]));
+                    SVA_TRY(P.conv(q + "convs2." + std::to_string(j) + ".conv", rc.c2, ch, ch, rk[b]));
+                }
+        }
+        HostTensor pw;
+        SVA_CHECK(P.weight(h + "conv_post.conv", pw), P.err.c_str());
+        SVA_CHECK(pw.numel() == (long)ch * e->post_k, "bad conv_post shape");
+        std::vector<float> pt((size_t)e->post_k * ch);
+        for (int cc = 0; cc < ch; ++cc)
+            for (int j = 0; j < e->post_k; ++j) pt[(size_t)j * ch + cc] = pw.data[(size_t)cc * e->post_k + j];
+        SVA_TRY(upload(e->allocs, &e->post_w, pt));
+        SVA_TRY(P.vec(h + "conv_post.conv.bias", &e->post_b, 1));
+    }
+    e->host.clear();
+    e->finalized = true;
+    SVA_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+// ============================================================================================
+// batch
+// ============================================================================================
+namespace {
+
+const int kResK[3] = {3, 7, 11};
+const int kResD[3] = {1, 3, 5};
+
+int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda, int nb, int T, int stride, int dil,
+              int taps, int Cin, const Lin& w, float* C, long c_bstride, long c_off, int ldc, ConvGemm proto = ConvGemm()) {
+    ConvGemm g = proto;
+    g.A = A; g.a_bstride = a_bstride; g.a_off = a_off; g.lda = lda;
+    g.T = T; g.M = nb * T; g.stride = stride; g.dil = dil; g.taps = taps; g.Cin = Cin;
+    g.W = w.W; g.N = w.N; g.bias = w.b;
+    g.C = C; g.c_bstride = c_bstride; g.c_off = c_off; g.ldc = ldc;
+    SVA_CHECK(w.K == taps * Cin, "gemm_call: weight K mismatch");
+    b->gemm_flops += 2.0 * g.M * (double)g.N * w.K;
+    b->gemm_launches += 1;
+    return launch_conv_gemm(g, b->stream);
+}
+
+// causal conv (FishConvNet) of `in` (history rows in front) into rows [out.H, out.H+T) of `out`
+int conv_act(sva_batch* b, const Act& in, int T_out, int stride, int dil, int taps, const Lin& w, Act& out,
+             ConvGemm proto = ConvGemm()) {
+    const int padL = (taps - 1) * dil + 1 - stride;
+    SVA_CHECK(in.H >= padL, "conv_act: not enough history rows");
+    return gemm_call(b, in.p, in.bstride, (long)(in.H - padL) * in.C, in.C, b->B, T_out, stride, dil, taps, in.C, w, out.p,
+                     out.bstride, (long)out.H * out.C, out.C, proto);
+}
+
+// ConvNeXtBlock in place on x rows [x.H, x.H+T)  (firefly.py:421-440)
+int cnx_block(sva_batch* b, const CNX& c, Act& x, int T, float* h1, float* h2) {
+    const int C = c.C;
+    SVA_CHECK(x.H >= 6 && x.C == C, "cnx_block: bad activation");
+    SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, b->stream));
+    ConvGemm p1;
+    p1.act = ACT_GELU;
+    SVA_TRY(gemm_call(b, h1, (long)T * C, 0, C, b->B, T, 1, 1, 1, C, c.pw1, h2, (long)T * 4 * C, 0, 4 * C, p1));
+    ConvGemm p2;
+    p2.gamma = c.gamma;
+    p2.res = x.p; p2.r_bstride = x.bstride; p2.r_off = (long)x.H * C; p2.ldr = C;
+    SVA_TRY(gemm_call(b, h2, (long)T * 4 * C, 0, 4 * C, b->B, T, 1, 1, 1, 4 * C, c.pw2, x.p, x.bstride, (long)x.H * C, C, p2));
+    return 0;
+}
+
+// ---- E: encode the current window of every stream -> d_codes [B][T2] ---------------------------
+int encode(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int B = b->B, T0 = b->T0;
+    hipStream_t st = b->stream;
+    SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, b->mag, 1040, st));
+    {   // mel = log(clamp(fb^T mag, 1e-5))  (spectrogram.py:110-115, 124-125)
+        ConvGemm p;
+        p.act = ACT_LOGCLAMP;
+        SVA_TRY(gemm_call(b, b->mag, (long)T0 * 1040, 0, 1040, B, T0, 1, 1, 1, 1040, e->mel_fb, b->mel.p, b->mel.bstride,
+                          (long)b->mel.H * c.n_mels, c.n_mels, p));
+    }
+    // stem: causal conv k7 + LayerNorm(channels)  (firefly.py:458-468)
+    SVA_TRY(gemm_call(b, b->mel.p, b->mel.bstride, 0, c.n_mels, B, T0, 1, 1, 7, c.n_mels, e->stem, b->h1, (long)T0 * c.enc_dims[0], 0,
+                      c.enc_dims[0]));
+    SVA_TRY(launch_layernorm_rows(b->h1, (long)T0 * c.enc_dims[0], 0, c.enc_dims[0], B, T0, c.enc_dims[0], e->stem_lnw, e->stem_lnb,
+                                  1e-6f, b->xs[0].p, b->xs[0].bstride, (long)b->xs[0].H * c.enc_dims[0], c.enc_dims[0], st));
+    for (int i = 0; i < 4; ++i) {
+        const int C = c.enc_dims[i];
+        if (i > 0) {   // LayerNorm(channels) + Conv1d k1  (firefly.py:471-476)
+            const int Cp = c.enc_dims[i - 1];
+            SVA_TRY(launch_layernorm_rows(b->xs[i - 1].p, b->xs[i - 1].bstride, (long)b->xs[i - 1].H * Cp, Cp, B, T0, Cp, e->trans_lnw[i],
+                                          e->trans_lnb[i], 1e-6f, b->h1, (long)T0 * Cp, 0, Cp, st));
+            SVA_TRY(gemm_call(b, b->h1, (long)T0 * Cp, 0, Cp, B, T0, 1, 1, 1, Cp, e->trans[i], b->xs[i].p, b->xs[i].bstride,
+                              (long)b->xs[i].H * C, C));
+        }
+        for (auto& blk : e->stages[i]) SVA_TRY(cnx_block(b, blk, b->xs[i], T0, b->h1, b->h2));
+    }
+    const int D = c.tr_dim;
+    SVA_TRY(launch_layernorm_rows(b->xs[3].p, b->xs[3].bstride, (long)b->xs[3].H * D, D, B, T0, D, e->final_lnw, e->final_lnb, 1e-6f,
+                                  b->feat.p, b->feat.bstride, 0, D, st));
+    // BSQ downsample x2: conv k2 s2 + ConvNeXtBlock  (bsq_no_upsample.py:48-61)
+    SVA_TRY(conv_act(b, b->feat, T0 / 2, 2, 1, 2, e->ds_conv[0], b->d1));
+    SVA_TRY(cnx_block(b, e->ds_cnx[0], b->d1, T0 / 2, b->h1, b->h2));
+    {
+        Act in = b->d1;      // read the T0/2 new rows (no left padding needed: padL = 0)
+        in.p = b->d1.p + (long)b->d1.H * D;
+        in.H = 0;
+        SVA_TRY(conv_act(b, in, T0 / 4, 2, 1, 2, e->ds_conv[1], b->d2));
+    }
+    SVA_TRY(cnx_block(b, e->ds_cnx[1], b->d2, T0 / 4, b->h1, b->h2));
+    // pre_module: 8-layer causal transformer on T2 tokens  (windowed_transformer.py:103-143)
+    const int T2 = b->T2, I = c.tr_inter;
+    Act& x = b->d2;
+    const long xoff = (long)x.H * D;
+    for (auto& L : e->tr) {
+        SVA_TRY(launch_rmsnorm_rows(x.p, x.bstride, xoff, D, B, T2, D, L.attn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
+        SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D));
+        SVA_TRY(launch_enc_attention(b->tr_qkv, e->rope_enc, B, T2, c.tr_heads, 64, b->tr_att, st));
+        ConvGemm po;
+        po.gamma = L.ls_attn;
+        po.res = x.p; po.r_bstride = x.bstride; po.r_off = xoff; po.ldr = D;
+        SVA_TRY(gemm_call(b, b->tr_att, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wo, x.p, x.bstride, xoff, D, po));
+        SVA_TRY(launch_rmsnorm_rows(x.p, x.bstride, xoff, D, B, T2, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
+        ConvGemm pg;
+        pg.w13 = 1;
+        SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, 0, I, pg));
+        ConvGemm pd;
+        pd.gamma = L.ls_ffn;
+        pd.res = x.p; pd.r_bstride = x.bstride; pd.r_off = xoff; pd.ldr = D;
+        SVA_TRY(gemm_call(b, b->tr_g, (long)T2 * I, 0, I, B, T2, 1, 1, 1, I, L.w2, x.p, x.bstride, xoff, D, pd));
+    }
+    SVA_TRY(launch_rmsnorm_rows(x.p, x.bstride, xoff, D, B, T2, D, e->tr_norm, 1e-5f, b->tr_z, (long)T2 * D, 0, D, st));
+    SVA_TRY(launch_bsq(b->tr_z, (long)T2 * D, 0, D, B, T2, D, e->bsq_W, e->bsq_b, c.bsq_bits, b->d_codes, b->d_u, st));
+    return 0;
+}
+
+// ---- A: slow / fast transformer passes ------------------------------------------------------------
+// rows [M, dim] in b->ax, slot/pos arrays on device; KV written at pos, attention over 0..pos
+int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int* d_slot, const int* d_pos, const float* rope,
+                   float* kv, long kv_layer, long kv_slot, int S, float* x) {
+    const sva_config& c = b->e->cfg;
+    const int D = c.ar_dim, I = c.ar_inter, H = c.ar_heads;
+    hipStream_t st = b->stream;
+    for (size_t l = 0; l < layers.size(); ++l) {
+        TrLayer& L = layers[l];
+        float* cache = kv + (long)l * kv_layer;
+        SVA_TRY(launch_rmsnorm_rows(x, (long)M * D, 0, D, 1, M, D, L.attn_norm, 1e-5f, b->ahn, (long)M * D, 0, D, st));
+        SVA_TRY(gemm_call(b, b->ahn, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.wqkv, b->aqkv, (long)M * 3 * D, 0, 3 * D));
+        SVA_TRY(launch_rope_kvwrite<float>(b->aqkv, M, H, 64, d_slot, d_pos, rope, cache, kv_slot, S, st));
+        SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
+        ConvGemm po;
+        po.res = x; po.r_bstride = (long)M * D; po.r_off = 0; po.ldr = D;
+        SVA_TRY(gemm_call(b, b->aatt, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.wo, x, (long)M * D, 0, D, po));
+        SVA_TRY(launch_rmsnorm_rows(x, (long)M * D, 0, D, 1, M, D, L.ffn_norm, 1e-5f, b->ahn, (long)M * D, 0, D, st));
+        ConvGemm pg;
+        pg.w13 = 1;
+        SVA_TRY(gemm_call(b, b->ahn, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.w13, b->ag, (long)M * I, 0, I, pg));
+        ConvGemm pd;
+        pd.res = x; pd.r_bstride = (long)M * D; pd.r_off = 0; pd.ldr = D;
+        SVA_TRY(gemm_call(b, b->ag, (long)M * I, 0, I, 1, M, 1, 1, 1, I, L.w2, x, (long)M * D, 0, D, pd));
+    }
+    return 0;
+}
+
+}  // namespace
+
+// small device helpers that live here because they touch the batch control block -------------------------
+__global__ void ar_prepare_step_kernel(const float* __restrict__ cached_audio_emb, const float* __restrict__ content_emb,
+                                       const long long* __restrict__ codes, int T2, int code_off, const int* __restrict__ last_pos,
+                                       int D, float* __restrict__ x, int* __restrict__ slot, int* __restrict__ pos,
+                                       int* __restrict__ step_content, int chunk, int ci) {
+    // decode_one (dual_ar_stream.py:817-837): tokens [cached_new_audio_emb, src_cond] at (last+1, last+2)
+    const int b = blockIdx.x;
+    const int code = (int)codes[(long)b * T2 + code_off];
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        x[((long)b * 2) * D + i] = cached_audio_emb[(long)b * D + i];
+        x[((long)b * 2 + 1) * D + i] = content_emb[(long)code * D + i];
+    }
+    if (threadIdx.x == 0) {
+        slot[2 * b] = b; slot[2 * b + 1] = b;
+        pos[2 * b] = last_pos[b] + 1; pos[2 * b + 1] = last_pos[b] + 2;
+        step_content[b * chunk + ci] = code;
+    }
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, long src_stride, long src_off, float* __restrict__ dst, int D) {
+    const int r = blockIdx.x;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) dst[(long)r * D + i] = src[(long)r * src_stride + src_off + i];
+}
+
+__global__ void apply_forced_kernel(const int* __restrict__ raw, const int* __restrict__ forced, const int* __restrict__ use_forced,
+                                    int chunk, int ci, int cb, int ncb, int* __restrict__ tok, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int t = raw[b * ncb + cb];
+    if (*use_forced) t = forced[((long)b * ncb + cb) * chunk + ci];
+    tok[b * ncb + cb] = t;
+}
+
+__global__ void ar_finish_frame_kernel(const int* __restrict__ tok, int ncb, int* __restrict__ last_pos, int* __restrict__ nframes,
+                                       int* __restrict__ pred_hist, int hist_cap, int* __restrict__ step_audio, int chunk, int ci,
+                                       const long long* __restrict__ codes, int T2, int code_off, int* __restrict__ content_hist,
+                                       int* __restrict__ ncontent, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int f = nframes[b];
+    for (int i = 0; i < ncb; ++i) {
+        const int t = tok[b * ncb + i];
+        if (f < hist_cap) pred_hist[((long)b * ncb + i) * hist_cap + f] = t;
+        step_audio[((long)b * ncb + i) * chunk + ci] = t;
+    }
+    nframes[b] = f + 1;
+    last_pos[b] += 2;
+}
+
+__global__ void append_content_kernel(const long long* __restrict__ codes, int T2, int chunk, int* __restrict__ content_hist,
+                                      int hist_cap, int* __restrict__ ncontent, int* __restrict__ step_content, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n = ncontent[b];
+    for (int i = 0; i < chunk; ++i) {
+        const int code = (int)codes[(long)b * T2 + T2 - chunk + i];
+        if (n + i < hist_cap) content_hist[(long)b * hist_cap + n + i] = code;
+        step_content[b * chunk + i] = code;
+    }
+    ncontent[b] = n + chunk;
+}
+
+__global__ void inc_kernel(int* p, int v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *p += v;
+}
+
+// prompt sequence builder (DualARWrapper.prefill_prompt, dual_ar_stream.py:764-796, layout in SURVEY.md A.1):
+//   rows 0..32 = speaker prefix; then for i < R: row 33+2i = content_emb[cc[i]],
+//   row 34+2i = (i < d ? wait4start[i] : audio_embed(ac[:, i-d]))
+__global__ void build_prompt_kernel(const float* __restrict__ spk, int nspk, const float* __restrict__ content_emb,
+                                    const float* __restrict__ codebook_emb, const float* __restrict__ wait4start,
+                                    const int* __restrict__ cc, const int* __restrict__ ac, int Pmax, int R, int d, int ncb,
+                                    int cbsize, int D, float* __restrict__ x) {
+    const int r = blockIdx.x;
+    float* o = x + (long)r * D;
+    if (r < nspk) {
+        for (int i = threadIdx.x; i < D; i += blockDim.x) o[i] = spk[(long)r * D + i];
+        return;
+    }
+    const int i = (r - nspk) >> 1;
+    if (((r - nspk) & 1) == 0) {
+        const float* s = content_emb + (long)cc[i] * D;
+        for (int k = threadIdx.x; k < D; k += blockDim.x) o[k] = s[k];
+    } else if (i < d) {
+        const float* s = wait4start + (long)i * D;
+        for (int k = threadIdx.x; k < D; k += blockDim.x) o[k] = s[k];
+    } else {
+        for (int k = threadIdx.x; k < D; k += blockDim.x) {
+            float acc = 0.f;
+            for (int q = 0; q < ncb; ++q) acc += codebook_emb[((long)ac[(long)q * Pmax + i - d] + (long)q * cbsize) * D + k];
+            o[k] = acc;
+        }
+    }
+}
+
+// delay fill (prefill_src_condition4delay, dual_ar_stream.py:798-815): per slot the interleave
+// [c_0, r_0, c_1, r_1, ..., c_{d-1}] (2d-1 rows; the dropped last row r_{d-1} becomes cached_new_audio_emb)
+__global__ void build_delayfill_kernel(const float* __restrict__ content_emb, const int* __restrict__ content_hist, int hist_cap,
+                                       const int* __restrict__ ncontent, const float* __restrict__ cached_ref_emb, int max_delay,
+                                       const int* __restrict__ last_pos, int d, int D, float* __restrict__ x, int* __restrict__ slot,
+                                       int* __restrict__ pos, float* __restrict__ cached_audio_emb) {
+    const int rows = 2 * d - 1;
+    const int b = blockIdx.x / rows, r = blockIdx.x % rows;
+    const int i = r >> 1;
+    float* o = x + ((long)b * rows + r) * D;
+    if ((r & 1) == 0) {
+        const int code = content_hist[(long)b * hist_cap + ncontent[b] - d + i];
+        for (int k = threadIdx.x; k < D; k += blockDim.x) o[k] = content_emb[(long)code * D + k];
+    } else {
+        for (int k = threadIdx.x; k < D; k += blockDim.x) o[k] = cached_ref_emb[((long)b * max_delay + i) * D + k];
+    }
+    if (r == 0)
+        for (int k = threadIdx.x; k < D; k += blockDim.x)
+            cached_audio_emb[(long)b * D + k] = cached_ref_emb[((long)b * max_delay + d - 1) * D + k];
+    if (threadIdx.x == 0) {
+        slot[b * rows + r] = b;
+        pos[b * rows + r] = last_pos[b] + 1 + r;
+    }
+}
+__global__ void add_vec_kernel(int* p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += v;
+}
+
+namespace {
+
+// one decoded frame for every stream (decode_one_token_ar, dual_ar_stream.py:1168-1219)
+int ar_decode_frame(sva_batch* b, int ci) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int B = b->B, D = c.ar_dim, chunk = b->p.chunk_frames, ncb = c.num_codebooks, cbs = c.codebook_size;
+    hipStream_t st = b->stream;
+    const int code_off = b->T2 - chunk + ci;
+    hipLaunchKernelGGL(ar_prepare_step_kernel, dim3(B), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, b->d_codes, b->T2,
+                       code_off, b->d_last_pos, D, b->ax, b->d_slot, b->d_pos, b->d_step_content, chunk, ci);
+    SVA_TRY(ar_layers_pass(b, e->ar_layers, 2 * B, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
+                           b->kv_slow_slot, c.max_seq_len, b->ax));
+    // hidden = pre-norm state of the content token (forward_generate :340-341)
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(B), dim3(256), 0, st, b->ax, (long)2 * D, (long)D, b->hidden, D);
+    const int nstride = c.ar_vocab + ncb * cbs;
+    const float* noise = b->noise_on_device ? nullptr : b->d_noise + (long)ci * nstride;
+    const int ldn = chunk * nstride;
+    if (!b->p.skip_semantic) {
+        SVA_TRY(launch_rmsnorm_rows(b->hidden, (long)B * D, 0, D, 1, B, D, e->ar_norm, 1e-5f, b->ahn, (long)B * D, 0, D, st));
+        SVA_TRY(gemm_call(b, b->ahn, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_output, b->slow_logits, (long)B * c.ar_vocab, 0, c.ar_vocab));
+        SVA_TRY(launch_sampler(b->slow_logits, B, c.ar_vocab, c.ar_vocab, noise, ldn, b->d_seed, b->d_nframes, 0, 0, b->p.temperature,
+                               b->p.top_p, b->d_sem, 1, st));
+    }
+    SVA_HIP(hipMemcpyAsync(b->xf, b->hidden, sizeof(float) * (size_t)B * D, hipMemcpyDeviceToDevice, st));
+    for (int cb = 0; cb < ncb; ++cb) {
+        SVA_TRY(ar_layers_pass(b, e->ar_fast_layers, B, b->d_fast_slot, b->d_fast_pos + cb * B, e->rope_fast, (float*)b->kv_fast,
+                               b->kv_fast_layer, b->kv_fast_slot, ncb, b->xf));
+        SVA_TRY(launch_rmsnorm_rows(b->xf, (long)B * D, 0, D, 1, B, D, e->ar_fast_norm, 1e-5f, b->ahn, (long)B * D, 0, D, st));
+        float* lg = b->fast_logits + (long)cb * cbs;     // [B][8][cbs]
+        SVA_TRY(gemm_call(b, b->ahn, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_fast_output, lg, (long)B * ncb * cbs, 0, ncb * cbs));
+        SVA_TRY(launch_sampler(lg, B, cbs, ncb * cbs, noise ? noise + c.ar_vocab + (long)cb * cbs : nullptr, ldn, b->d_seed, b->d_nframes,
+                               1, cb * cbs, b->p.temperature, b->p.top_p, b->d_tok_raw + cb, ncb, st));
+        hipLaunchKernelGGL(apply_forced_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_tok_raw, b->d_forced, b->d_use_forced, chunk, ci,
+                           cb, ncb, b->d_tok, B);
+        if (cb + 1 < ncb) SVA_TRY(launch_gather_rows(e->fast_emb, b->d_tok + cb, ncb, 0, B, D, b->xf, D, st));
+    }
+    // cached_new_audio_emb = embed(codes) (:834); positions advance by 2 (:835-836)
+    SVA_TRY(launch_audio_embed(e->codebook_emb, b->d_tok, ncb, 1, B, ncb, cbs, D, b->cached_audio_emb, D, st));
+    hipLaunchKernelGGL(ar_finish_frame_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_tok, ncb, b->d_last_pos, b->d_nframes,
+                       b->d_pred_hist, b->hist_cap, b->d_step_audio, chunk, ci, b->d_codes, b->T2, code_off, b->d_content_hist,
+                       b->d_ncontent, B);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// prefill of ONE slot from prompt codes already staged in d_prompt_cc / d_prompt_ac (R frames)
+int ar_prefill_slot(sva_batch* b, int slot, int R) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int D = c.ar_dim, d = b->p.delay, nspk = c.timbre_tokens + 1;
+    hipStream_t st = b->stream;
+    const int M = nspk + 2 * R;
+    SVA_CHECK(M <= b->Mmax && M <= c.max_seq_len, "prompt too long for the KV cache");
+    SVA_CHECK(R > d, "prompt must be longer than the delay");
+    // speaker prefix: cat[context_in(timbre) (32 tok), style_in(style) (1 tok)]  (arvc_wrapper.py:108-109)
+    SVA_TRY(gemm_call(b, b->d_timbre + (long)slot * c.timbre_tokens * c.timbre_dim, (long)c.timbre_tokens * c.timbre_dim, 0, c.timbre_dim, 1,
+                      c.timbre_tokens, 1, 1, 1, c.timbre_dim, e->context_in, b->spk, (long)nspk * D, 0, D));
+    SVA_TRY(gemm_call(b, b->d_style + (long)slot * c.style_dim, c.style_dim, 0, c.style_dim, 1, 1, 1, 1, 1, c.style_dim, e->style_in,
+                      b->spk + (long)c.timbre_tokens * D, D, 0, D));
+    hipLaunchKernelGGL(build_prompt_kernel, dim3(M), dim3(256), 0, st, b->spk, nspk, e->content_emb, e->codebook_emb, e->wait4start,
+                       b->d_prompt_cc, b->d_prompt_ac, b->Pmax, R, d, c.num_codebooks, c.codebook_size, D, b->ax);
+    // positions 0..M-1, all rows in this slot
+    std::vector<int> hs(M, slot), hp(M);
+    for (int i = 0; i < M; ++i) hp[i] = i;
+    SVA_HIP(hipMemcpyAsync(b->d_slot, hs.data(), sizeof(int) * M, hipMemcpyHostToDevice, st));
+    SVA_HIP(hipMemcpyAsync(b->d_pos, hp.data(), sizeof(int) * M, hipMemcpyHostToDevice, st));
+    SVA_HIP(hipStreamSynchronize(st));       // hs/hp are stack-lifetime host buffers
+    SVA_TRY(ar_layers_pass(b, e->ar_layers, M, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer, b->kv_slow_slot,
+                           c.max_seq_len, b->ax));
+    // cached_ref_emb = embed(ref_audio_codes)[-d:]  (:775)
+    SVA_TRY(launch_audio_embed(e->codebook_emb, b->d_prompt_ac + (R - d), 1, b->Pmax, d, c.num_codebooks, c.codebook_size, D,
+                               b->cached_ref_emb + (long)slot * c.max_delay * D, D, st));
+    const int lp = M - 1;
+    SVA_HIP(hipMemcpyAsync(b->d_last_pos + slot, &lp, sizeof(int), hipMemcpyHostToDevice, st));
+    SVA_HIP(hipStreamSynchronize(st));
+    b->h_last_pos[slot] = lp;
+    return 0;
+}
+
+int ar_delay_fill(sva_batch* b) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int B = b->B, D = c.ar_dim, d = b->p.delay, rows = 2 * d - 1;
+    hipStream_t st = b->stream;
+    hipLaunchKernelGGL(build_delayfill_kernel, dim3(B * rows), dim3(256), 0, st, e->content_emb, b->d_content_hist, b->hist_cap,
+                       b->d_ncontent, b->cached_ref_emb, c.max_delay, b->d_last_pos, d, D, b->ax, b->d_slot, b->d_pos, b->cached_audio_emb);
+    SVA_TRY(ar_layers_pass(b, e->ar_layers, B * rows, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
+                           b->kv_slow_slot, c.max_seq_len, b->ax));
+    hipLaunchKernelGGL(add_vec_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_last_pos, B, rows);
+    for (int i = 0; i < B; ++i) b->h_last_pos[i] += rows;
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- V: streaming vocoder on T new code frames held in d_vcodes [B][8][Tv] -------------------------------
+int vocode(sva_batch* b, int T, bool shift) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int B = b->B, V = c.voc_dim, G = c.num_codebooks;
+    hipStream_t st = b->stream;
+    SVA_CHECK(T >= 1 && T <= b->Tv, "vocode: T out of range");
+    SVA_TRY(launch_fsq_decode(b->d_vcodes, (long)G * b->Tv, b->Tv, B, T, G, V / G, e->fsq_W, e->fsq_b, b->zq.p, b->zq.bstride, 0, V, st));
+    // upsample.0: ConvTranspose k=s=2 (stateless) + ConvNeXtBlock  (fsq.py:61-74)
+    SVA_TRY(gemm_call(b, b->zq.p, b->zq.bstride, 0, V, B, T, 1, 1, 1, V, e->up_conv[0], b->u0.p, b->u0.bstride, (long)b->u0.H * V, 2 * V));
+    SVA_TRY(cnx_block(b, e->up_cnx[0], b->u0, 2 * T, b->vh1, b->vh2));
+    SVA_TRY(gemm_call(b, b->u0.p, b->u0.bstride, (long)b->u0.H * V, V, B, 2 * T, 1, 1, 1, V, e->up_conv[1], b->u1.p, b->u1.bstride,
+                      (long)b->u1.H * V, 2 * V));
+    SVA_TRY(cnx_block(b, e->up_cnx[1], b->u1, 4 * T, b->vh1, b->vh2));
+    // conv_pre k13 (reads u1 with 12 history rows) -> S[0]
+    SVA_TRY(conv_act(b, b->u1, 4 * T, 1, 1, e->pre_k, e->conv_pre, b->S[0]));
+    long Tl = 4L * T;
+    for (int i = 0; i < 5; ++i) {
+        const int s = e->ups_s[i];
+        const int Cout = b->X[i].C;
+        // SiLU -> ConvTranspose (k = 2s): 2-tap GEMM over rows q-1, q with N = s*Cout  (firefly.py:284-285, 131-138)
+        {
+            ConvGemm p;
+            p.a_silu = 1;
+            SVA_CHECK(b->S[i].H >= 1, "ups: history");
+            SVA_TRY(gemm_call(b, b->S[i].p, b->S[i].bstride, (long)(b->S[i].H - 1) * b->S[i].C, b->S[i].C, B, (int)Tl, 1, 1, 2, b->S[i].C,
+                              e->ups[i], b->X[i].p, b->X[i].bstride, (long)b->X[i].H * Cout, s * Cout, p));
+        }
+        Tl *= s;
+        // ParallelBlock = mean of three ResBlock1 (firefly.py:183-190, 214-215)
+        Act& out = b->S[i + 1];
+        for (int br = 0; br < 3; ++br) {
+            Act* y = &b->X[i];
+            for (int j = 0; j < 3; ++j) {
+                const ResConv& rc = e->res[i][br][j];
+                ConvGemm p1;
+                p1.a_silu = 1;
+                SVA_TRY(conv_act(b, *y, (int)Tl, 1, rc.dil, rc.k, rc.c1, b->tb[i][br][j], p1));
+                ConvGemm p2;
+                p2.a_silu = 1;
+                p2.res = y->p; p2.r_bstride = y->bstride; p2.r_off = (long)y->H * Cout; p2.ldr = Cout;
+                if (j < 2) {
+                    SVA_TRY(conv_act(b, b->tb[i][br][j], (int)Tl, 1, rc.dil, rc.k, rc.c2, b->yb[i][br][j], p2));
+                    y = &b->yb[i][br][j];
+                } else {
+                    p2.scale = 1.0f / 3.0f;
+                    p2.accumulate = br > 0;
+                    SVA_TRY(conv_act(b, b->tb[i][br][j], (int)Tl, 1, rc.dil, rc.k, rc.c2, out, p2));
+                }
+            }
+        }
+    }
+    SVA_TRY(launch_conv_post_tanh(b->S[5].p, b->S[5].bstride, (long)(b->S[5].H - (e->post_k - 1)) * b->S[5].C, B, (int)Tl, b->S[5].C, e->post_k,
+                                  e->post_w, e->post_b, b->d_pcm, 2048L * b->Tv, 0, st));
+    if (shift) {
+        // update T in the descriptors if it changed (host table re-uploaded; rare)
+        bool dirty = false;
+        for (auto& d : b->shift_host) {
+            const int t = (int)((long)T * d.pad);      // pad holds rows-per-code-frame of this tensor
+            if (d.T != t) { d.T = t; dirty = true; }
+        }
+        if (dirty) {
+            SVA_HIP(hipMemcpyAsync(b->d_shift, b->shift_host.data(), sizeof(ShiftDesc) * b->shift_host.size(), hipMemcpyHostToDevice, st));
+            SVA_HIP(hipStreamSynchronize(st));
+        }
+        SVA_TRY(launch_shift_history(b->d_shift, (int)b->shift_host.size(), B, st));
+    }
+    return 0;
+}
+
+int register_shift(sva_batch* b, Act& a, int rows_per_frame) {
+    if (a.H == 0) return 0;
+    ShiftDesc d;
+    d.ptr = a.p; d.bstride = a.bstride; d.H = a.H; d.T = 0; d.C = a.C; d.pad = rows_per_frame;
+    b->shift_host.push_back(d);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_batch** out) {
+    SVA_CHECK(e && p && out && e->finalized, "engine not finalized");
+    SVA_HIP(hipSetDevice(e->device));
+    const sva_config& c = e->cfg;
+    sva_batch* b = new sva_batch();
+    b->e = e;
+    b->p = *p;
+    const int B = b->B = p->n_streams;
+    SVA_CHECK(B >= 1 && p->chunk_frames >= 1 && p->delay >= 1 && p->delay <= c.max_delay, "bad stream params (delay 0 is broken upstream too)");
+    SVA_CHECK(p->encode_window_frames % 1 == 0 && p->encode_window_frames >= p->chunk_frames, "bad encode window");
+    if (b->p.voc_max_frames < p->chunk_frames) b->p.voc_max_frames = p->chunk_frames;
+    SVA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    auto& A = b->allocs;
+    const int chunk = p->chunk_frames;
+    // control block
+    SVA_TRY(dev_alloc(A, &b->d_step, 1));
+    SVA_TRY(dev_alloc(A, &b->d_last_pos, B));
+    SVA_TRY(dev_alloc(A, &b->d_nframes, B));
+    SVA_TRY(dev_alloc(A, &b->d_ncontent, B));
+    SVA_TRY(dev_alloc(A, &b->d_seed, B));
+    SVA_TRY(dev_alloc(A, &b->d_use_forced, 1));
+    // encoder
+    b->We = p->encode_window_frames;
+    b->N = b->We * 2048;
+    b->T0 = b->N / 512;
+    b->T2 = b->T0 / 4;
+    SVA_CHECK(b->T2 % 4 == 0 && b->T2 <= 256, "encode_window_frames must be a multiple of 4 and <= 256");
+    const int T0 = b->T0;
+    SVA_TRY(dev_alloc(A, &b->ring, (size_t)B * b->N));
+    SVA_TRY(dev_alloc(A, &b->d_chunk, (size_t)B * 2048 * chunk));
+    SVA_TRY(dev_alloc(A, &b->mag, (size_t)B * T0 * 1040));
+    SVA_TRY(alloc_act(A, b->mel, B, 6, T0, c.n_mels));
+    for (int i = 0; i < 4; ++i) SVA_TRY(alloc_act(A, b->xs[i], B, 6, T0, c.enc_dims[i]));
+    const int Dm = c.tr_dim;
+    SVA_TRY(dev_alloc(A, &b->h1, (size_t)B * T0 * Dm));
+    SVA_TRY(dev_alloc(A, &b->h2, (size_t)B * T0 * 4 * Dm));
+    SVA_TRY(alloc_act(A, b->feat, B, 0, T0, Dm));
+    SVA_TRY(alloc_act(A, b->d1, B, 6, T0 / 2, Dm));
+    SVA_TRY(alloc_act(A, b->d2, B, 6, T0 / 4, Dm));
+    const int T2 = b->T2;
+    SVA_TRY(dev_alloc(A, &b->tr_hn, (size_t)B * T2 * Dm));
+    SVA_TRY(dev_alloc(A, &b->tr_qkv, (size_t)B * T2 * 3 * Dm));
+    SVA_TRY(dev_alloc(A, &b->tr_att, (size_t)B * T2 * Dm));
+    SVA_TRY(dev_alloc(A, &b->tr_g, (size_t)B * T2 * c.tr_inter));
+    SVA_TRY(dev_alloc(A, &b->tr_z, (size_t)B * T2 * Dm));
+    SVA_TRY(dev_alloc(A, &b->d_codes, (size_t)B * T2));
+    SVA_TRY(dev_alloc(A, &b->d_u, (size_t)B * T2 * c.bsq_bits));
+    // AR
+    const int D = c.ar_dim, S = c.max_seq_len, H = c.ar_heads, ncb = c.num_codebooks;
+    b->Mmax = std::max(std::max(2 * B, B * (2 * c.max_delay - 1)), S);
+    SVA_TRY(dev_alloc(A, &b->ax, (size_t)b->Mmax * D));
+    SVA_TRY(dev_alloc(A, &b->ahn, (size_t)b->Mmax * D));
+    SVA_TRY(dev_alloc(A, &b->aqkv, (size_t)b->Mmax * 3 * D));
+    SVA_TRY(dev_alloc(A, &b->aatt, (size_t)b->Mmax * D));
+    SVA_TRY(dev_alloc(A, &b->ag, (size_t)b->Mmax * c.ar_inter));
+    SVA_TRY(dev_alloc(A, &b->xf, (size_t)B * D));
+    SVA_TRY(dev_alloc(A, &b->hidden, (size_t)B * D));
+    SVA_TRY(dev_alloc(A, &b->slow_logits, (size_t)B * c.ar_vocab));
+    SVA_TRY(dev_alloc(A, &b->fast_logits, (size_t)B * ncb * c.codebook_size));
+    SVA_TRY(dev_alloc(A, &b->d_slot, b->Mmax));
+    SVA_TRY(dev_alloc(A, &b->d_pos, b->Mmax));
+    SVA_TRY(dev_alloc(A, &b->d_fast_slot, B));
+    SVA_TRY(dev_alloc(A, &b->d_fast_pos, ncb * B));
+    {
+        std::vector<int> fs(B), fp((size_t)ncb * B);
+        for (int i = 0; i < B; ++i) fs[i] = i;
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int i = 0; i < B; ++i) fp[(size_t)cb * B + i] = cb;
+        SVA_HIP(hipMemcpy(b->d_fast_slot, fs.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+        SVA_HIP(hipMemcpy(b->d_fast_pos, fp.data(), sizeof(int) * fp.size(), hipMemcpyHostToDevice));
+    }
+    b->kv_slow_slot = 2L * H * S * 64;
+    b->kv_slow_layer = b->kv_slow_slot * B;
+    b->kv_fast_slot = 2L * H * ncb * 64;
+    b->kv_fast_layer = b->kv_fast_slot * B;
+    {
+        float* p1; float* p2;
+        SVA_TRY(dev_alloc(A, &p1, (size_t)c.ar_layers * b->kv_slow_layer));
+        SVA_TRY(dev_alloc(A, &p2, (size_t)c.ar_fast_layers * b->kv_fast_layer));
+        b->kv_slow = p1; b->kv_fast = p2;
+    }
+    SVA_TRY(dev_alloc(A, &b->cached_audio_emb, (size_t)B * D));
+    SVA_TRY(dev_alloc(A, &b->cached_ref_emb, (size_t)B * c.max_delay * D));
+    SVA_TRY(dev_alloc(A, &b->spk, (size_t)(c.timbre_tokens + 1) * D));
+    SVA_TRY(dev_alloc(A, &b->d_style, (size_t)B * c.style_dim));
+    SVA_TRY(dev_alloc(A, &b->d_timbre, (size_t)B * c.timbre_tokens * c.timbre_dim));
+    SVA_TRY(dev_alloc(A, &b->d_sem, B));
+    SVA_TRY(dev_alloc(A, &b->d_tok, B * ncb));
+    SVA_TRY(dev_alloc(A, &b->d_tok_raw, B * ncb));
+    SVA_TRY(dev_alloc(A, &b->d_forced, (size_t)B * ncb * chunk));
+    SVA_TRY(dev_alloc(A, &b->d_noise, (size_t)B * chunk * (c.ar_vocab + ncb * c.codebook_size)));
+    b->hist_cap = 4096;
+    SVA_TRY(dev_alloc(A, &b->d_content_hist, (size_t)B * b->hist_cap));
+    SVA_TRY(dev_alloc(A, &b->d_pred_hist, (size_t)B * ncb * b->hist_cap));
+    SVA_TRY(dev_alloc(A, &b->d_step_content, (size_t)B * chunk));
+    SVA_TRY(dev_alloc(A, &b->d_step_audio, (size_t)B * ncb * chunk));
+    b->Pmax = S;
+    SVA_TRY(dev_alloc(A, &b->d_prompt_cc, b->Pmax));
+    SVA_TRY(dev_alloc(A, &b->d_prompt_ac, (size_t)ncb * b->Pmax));
+    b->ref_content.resize(B); b->ref_audio.resize(B); b->ref_len.assign(B, 0);
+    b->h_last_pos.assign(B, -1); b->h_nframes.assign(B, 0); b->prefilled.assign(B, 0);
+    // vocoder
+    const int Tv = b->Tv = b->p.voc_max_frames;
+    const int V = c.voc_dim;
+    SVA_TRY(alloc_act(A, b->zq, B, 0, Tv, V));
+    SVA_TRY(alloc_act(A, b->u0, B, 6, 2L * Tv, V));
+    SVA_TRY(alloc_act(A, b->u1, B, 12, 4L * Tv, V));      // history 12 >= 6 (dwconv) and = conv_pre k13 - 1
+    SVA_TRY(dev_alloc(A, &b->vh1, (size_t)B * 4 * Tv * V));
+    SVA_TRY(dev_alloc(A, &b->vh2, (size_t)B * 4 * Tv * 4 * V));
+    SVA_TRY(alloc_act(A, b->S[0], B, 1, 4L * Tv, V));
+    SVA_TRY(register_shift(b, b->u0, 2));
+    SVA_TRY(register_shift(b, b->u1, 4));
+    SVA_TRY(register_shift(b, b->S[0], 4));
+    long rows = 4L * Tv;
+    int rpf = 4;
+    int ch = V;
+    for (int i = 0; i < 5; ++i) {
+        rows *= e->ups_s[i];
+        rpf *= e->ups_s[i];
+        ch /= 2;
+        SVA_TRY(alloc_act(A, b->X[i], B, (kResK[2] - 1) * kResD[0], rows, ch));
+        SVA_TRY(register_shift(b, b->X[i], rpf));
+        for (int br = 0; br < 3; ++br)
+            for (int j = 0; j < 3; ++j) {
+                SVA_TRY(alloc_act(A, b->tb[i][br][j], B, (kResK[br] - 1) * kResD[j], rows, ch));
+                SVA_TRY(register_shift(b, b->tb[i][br][j], rpf));
+                if (j < 2) {
+                    SVA_TRY(alloc_act(A, b->yb[i][br][j], B, (kResK[br] - 1) * kResD[j + 1], rows, ch));
+                    SVA_TRY(register_shift(b, b->yb[i][br][j], rpf));
+                }
+            }
+        SVA_TRY(alloc_act(A, b->S[i + 1], B, i < 4 ? 1 : e->post_k - 1, rows, ch));
+        SVA_TRY(register_shift(b, b->S[i + 1], rpf));
+    }
+    SVA_TRY(dev_alloc(A, &b->d_pcm, (size_t)B * 2048 * Tv));
+    SVA_TRY(dev_alloc(A, &b->d_vcodes, (size_t)B * ncb * Tv));
+    SVA_TRY(dev_alloc(A, &b->d_shift, b->shift_host.size()));
+    SVA_HIP(hipHostMalloc((void**)&b->hp_in, sizeof(float) * (size_t)B * 2048 * chunk));
+    SVA_HIP(hipHostMalloc((void**)&b->hp_out, sizeof(float) * (size_t)B * 2048 * chunk));
+    for (int i = 0; i < 5; ++i) SVA_HIP(hipEventCreate(&b->ev[i]));
+    b->ev_ok = true;
+    SVA_HIP(hipDeviceSynchronize());
+    *out = b;
+    return 0;
+}
+
+extern "C" void sva_batch_destroy(sva_batch* b) {
+    if (!b) return;
+    hipSetDevice(b->e->device);
+    hipStreamSynchronize(b->stream);
+    if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
+    for (void* p : b->allocs) hipFree(p);
+    if (b->hp_in) hipHostFree(b->hp_in);
+    if (b->hp_out) hipHostFree(b->hp_out);
+    if (b->ev_ok)
+        for (int i = 0; i < 5; ++i) hipEventDestroy(b->ev[i]);
+    hipStreamDestroy(b->stream);
+    delete b;
+}
+
+// ============================================================================================
+// prompt / begin
+// ============================================================================================
+namespace {
+int stage_prompt(sva_batch* b, const std::vector<int64_t>& cc, const std::vector<int32_t>& ac, int R) {
+    // cc [R] int64 -> d_prompt_cc int32; ac [8][R] -> d_prompt_ac [8][Pmax]
+    const int ncb = b->e->cfg.num_codebooks;
+    SVA_CHECK(R <= b->Pmax, "prompt longer than the staging buffer");
+    std::vector<int> c32(R);
+    for (int i = 0; i < R; ++i) c32[i] = (int)cc[i];
+    SVA_HIP(hipMemcpy(b->d_prompt_cc, c32.data(), sizeof(int) * R, hipMemcpyHostToDevice));
+    for (int q = 0; q < ncb; ++q)
+        SVA_HIP(hipMemcpy(b->d_prompt_ac + (long)q * b->Pmax, ac.data() + (long)q * R, sizeof(int) * R, hipMemcpyHostToDevice));
+    return 0;
+}
+}  // namespace
+
+extern "C" int sva_prefill_prompt(sva_batch* b, int slot, const int64_t* ref_content_codes, const int32_t* ref_audio_codes, int R,
+                                  const float* style, const float* timbre, uint64_t noise_seed) {
+    SVA_CHECK(b && slot >= 0 && slot < b->B && ref_content_codes && ref_audio_codes && style && timbre, "bad argument");
+    SVA_HIP(hipSetDevice(b->e->device));
+    const sva_config& c = b->e->cfg;
+    const int ncb = c.num_codebooks;
+    std::vector<int64_t> cc(ref_content_codes, ref_content_codes + R);
+    std::vector<int32_t> ac(ref_audio_codes, ref_audio_codes + (size_t)ncb * R);
+    SVA_HIP(hipMemcpy(b->d_style + (long)slot * c.style_dim, style, sizeof(float) * c.style_dim, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(b->d_timbre + (long)slot * c.timbre_tokens * c.timbre_dim, timbre, sizeof(float) * c.timbre_tokens * c.timbre_dim,
+                      hipMemcpyHostToDevice));
+    unsigned long long sd = noise_seed;
+    SVA_HIP(hipMemcpy(b->d_seed + slot, &sd, sizeof(sd), hipMemcpyHostToDevice));
+    // quirk (iv): the KV prefill uses the UNTRUNCATED prompt (infer_arvc.py:484-489) ...
+    SVA_TRY(stage_prompt(b, cc, ac, R));
+    SVA_TRY(ar_prefill_slot(b, slot, R));
+    // ... while the stored prompt (re-prefill, vocoder fill) is truncated to max_prompt_frames (:469-470)
+    const int Rt = std::min(R, b->p.max_prompt_frames);
+    b->ref_content[slot].assign(cc.begin(), cc.begin() + Rt);
+    b->ref_audio[slot].resize((size_t)ncb * Rt);
+    for (int q = 0; q < ncb; ++q)
+        for (int i = 0; i < Rt; ++i) b->ref_audio[slot][(size_t)q * Rt + i] = ac[(size_t)q * R + i];
+    b->ref_len[slot] = Rt;
+    b->prefilled[slot] = 1;
+    return 0;
+}
+
+extern "C" int sva_vocode_reset(sva_batch* b) {
+    SVA_CHECK(b, "null batch");
+    SVA_HIP(hipSetDevice(b->e->device));
+    auto zero = [&](Act& a) -> int {
+        SVA_HIP(hipMemsetAsync(a.p, 0, sizeof(float) * (size_t)b->B * a.bstride, b->stream));
+        return 0;
+    };
+    SVA_TRY(zero(b->u0)); SVA_TRY(zero(b->u1));
+    for (int i = 0; i < 6; ++i) SVA_TRY(zero(b->S[i]));
+    for (int i = 0; i < 5; ++i) {
+        SVA_TRY(zero(b->X[i]));
+        for (int br = 0; br < 3; ++br)
+            for (int j = 0; j < 3; ++j) {
+                SVA_TRY(zero(b->tb[i][br][j]));
+                if (j < 2) SVA_TRY(zero(b->yb[i][br][j]));
+            }
+    }
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+namespace {
+int upload_vcodes(sva_batch* b, const int32_t* codes, int T) {
+    // host codes [B][8][T] -> d_vcodes [B][8][Tv]
+    const int ncb = b->e->cfg.num_codebooks;
+    SVA_HIP(hipMemcpy2DAsync(b->d_vcodes, sizeof(int) * b->Tv, codes, sizeof(int) * T, sizeof(int) * T, (size_t)b->B * ncb,
+                             hipMemcpyHostToDevice, b->stream));
+    return 0;
+}
+int download_pcm(sva_batch* b, int T, float* pcm_out) {
+    SVA_HIP(hipMemcpy2DAsync(pcm_out, sizeof(float) * 2048 * T, b->d_pcm, sizeof(float) * 2048 * b->Tv, sizeof(float) * 2048 * T, b->B,
+                             hipMemcpyDeviceToHost, b->stream));
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+}  // namespace
+
+extern "C" int sva_vocode_stream(sva_batch* b, const int32_t* codes, int T, float* pcm_out) {
+    SVA_CHECK(b && codes && pcm_out, "null argument");
+    SVA_HIP(hipSetDevice(b->e->device));
+    SVA_TRY(upload_vcodes(b, codes, T));
+    SVA_TRY(vocode(b, T, true));
+    return download_pcm(b, T, pcm_out);
+}
+
+extern "C" int sva_vocode_window(sva_batch* b, const int32_t* codes, int T, float* pcm_out) {
+    SVA_TRY(sva_vocode_reset(b));
+    SVA_TRY(sva_vocode_stream(b, codes, T, pcm_out));
+    return sva_vocode_reset(b);
+}
+
+extern "C" int sva_streams_begin(sva_batch* b) {
+    SVA_CHECK(b, "null batch");
+    SVA_HIP(hipSetDevice(b->e->device));
+    const int B = b->B, ncb = b->e->cfg.num_codebooks, c = b->p.chunk_frames;
+    for (int i = 0; i < B; ++i) SVA_CHECK(b->prefilled[i], "every slot needs sva_prefill_prompt before sva_streams_begin");
+    // setup_stream_caches (infer_arvc.py:443-460)
+    SVA_HIP(hipMemsetAsync(b->ring, 0, sizeof(float) * (size_t)B * b->N, b->stream));
+    SVA_HIP(hipMemsetAsync(b->d_step, 0, sizeof(int), b->stream));
+    SVA_HIP(hipMemsetAsync(b->d_nframes, 0, sizeof(int) * B, b->stream));
+    SVA_HIP(hipMemsetAsync(b->d_ncontent, 0, sizeof(int) * B, b->stream));
+    b->h_step = 0; b->h_ncontent = 0; b->delay_filled = false;
+    std::fill(b->h_nframes.begin(), b->h_nframes.end(), 0);
+    // prime the streaming vocoder with the tail of the (truncated) prompt: the reference left-fills its
+    // 64-frame vocoder window with the prompt's last frames (:567-571, quirk ix), and the newest frame only
+    // depends on the newest 16 code frames, so running the last (window-1) prompt frames through the
+    // ring-buffer vocoder reproduces the windowed output.
+    SVA_TRY(sva_vocode_reset(b));
+    int P = b->p.decode_window_frames - 1;
+    for (int i = 0; i < B; ++i) P = std::min(P, b->ref_len[i]);
+    P = (P / c) * c;
+    SVA_CHECK(P >= 16 || P == b->p.decode_window_frames - 1, "prompt shorter than the vocoder receptive field (16 frames)");
+    std::vector<int32_t> codes((size_t)B * ncb * c);
+    std::vector<float> sink((size_t)B * 2048 * c);
+    for (int f = 0; f < P; f += c) {
+        for (int i = 0; i < B; ++i) {
+            const int R = b->ref_len[i];
+            for (int q = 0; q < ncb; ++q)
+                for (int k = 0; k < c; ++k) codes[((size_t)i * ncb + q) * c + k] = b->ref_audio[i][(size_t)q * R + (R - P + f + k)];
+        }
+        SVA_TRY(sva_vocode_stream(b, codes.data(), c, sink.data()));
+    }
+    b->begun = true;
+    b->graph_ready = false;
+    return 0;
+}
+
+// ============================================================================================
+// the per-chunk step
+// ============================================================================================
+namespace {
+
+int reprefill_slot(sva_batch* b, int slot) {
+    // infer_arvc.py:547-564: prompt <- [ref (truncated), last buffer_frames predicted frames] /
+    // [ref content, src content[-buffer-d:-d]]; then delay fill with src content[-d:]
+    const sva_config& c = b->e->cfg;
+    const int ncb = c.num_codebooks, d = b->p.delay, bf = b->p.buffer_frames;
+    const int R = b->ref_len[slot];
+    const int nf = b->h_nframes[slot], ncon = b->h_ncontent;
+    const int na = std::min(bf, nf);                   // pred_codes[..., -bf:]
+    const int c_hi = ncon - d, c_lo = std::max(0, ncon - bf - d);
+    const int nc = std::max(0, c_hi - c_lo);
+    SVA_CHECK(na == nc, "re-prefill: content/audio history length mismatch");
+    std::vector<int> hc(nc), ha((size_t)ncb * na);
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    if (nc) SVA_HIP(hipMemcpy(hc.data(), b->d_content_hist + (long)slot * b->hist_cap + c_lo, sizeof(int) * nc, hipMemcpyDeviceToHost));
+    for (int q = 0; q < ncb; ++q)
+        if (na) SVA_HIP(hipMemcpy(ha.data() + (size_t)q * na, b->d_pred_hist + ((long)slot * ncb + q) * b->hist_cap + (nf - na), sizeof(int) * na,
+                                 hipMemcpyDeviceToHost));
+    std::vector<int64_t> cc(b->ref_content[slot]);
+    for (int i = 0; i < nc; ++i) cc.push_back(hc[i]);
+    const int Rn = R + na;
+    std::vector<int32_t> ac((size_t)ncb * Rn);
+    for (int q = 0; q < ncb; ++q) {
+        for (int i = 0; i < R; ++i) ac[(size_t)q * Rn + i] = b->ref_audio[slot][(size_t)q * R + i];
+        for (int i = 0; i < na; ++i) ac[(size_t)q * Rn + R + i] = ha[(size_t)q * na + i];
+    }
+    SVA_TRY(stage_prompt(b, cc, ac, Rn));
+    SVA_TRY(ar_prefill_slot(b, slot, Rn));
+    return 0;
+}
+
+int step_body(sva_batch* b) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int B = b->B, chunk = b->p.chunk_frames, d = b->p.delay, n = 2048 * chunk, ncb = c.num_codebooks;
+    hipStream_t st = b->stream;
+    SVA_HIP(hipEventRecord(b->ev[0], st));
+    // E0: shift window / append chunk (:495-496), then E1..E8
+    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->d_chunk, n, st));
+    SVA_TRY(encode(b, b->d_step, n, 1));
+    hipLaunchKernelGGL(inc_kernel, dim3(1), dim3(64), 0, st, b->d_step, 1);
+    hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
+                       b->d_ncontent, b->d_step_content, B);
+    b->h_step += 1;
+    b->h_ncontent += chunk;
+    SVA_HIP(hipEventRecord(b->ev[1], st));
+    bool produced = false;
+    if (b->h_ncontent < d) {
+        // :519-520 -> zeros
+    } else if (!b->delay_filled) {
+        SVA_TRY(ar_delay_fill(b));                      // :521-525 -> zeros
+        b->delay_filled = true;
+    } else {
+        for (int ci = 0; ci < chunk; ++ci) {            // :534-538
+            SVA_TRY(ar_decode_frame(b, ci));
+            for (int i = 0; i < B; ++i) { b->h_last_pos[i] += 2; b->h_nframes[i] += 1; }
+        }
+        produced = true;
+    }
+    SVA_HIP(hipEventRecord(b->ev[2], st));
+    if (produced) {
+        // re-prefill when current_pos // 2 >= max_seq_frames (:547-564); positions are deterministic, so the
+        // host mirror decides without a device round trip
+        bool any = false;
+        for (int i = 0; i < B; ++i)
+            if (b->h_last_pos[i] / 2 >= b->p.max_seq_frames) { SVA_TRY(reprefill_slot(b, i)); any = true; }
+        if (any) {
+            // prefill_src_condition4delay(src_content_codes[-d:]) for the re-prefilled slots: the delay-fill kernel
+            // works on all slots in lock step, so slots that did NOT re-prefill must be excluded -> run it per slot
+            // through a one-slot view is not possible with the lock-step kernel; the reference is batch-1 and in the
+            // lock-step batch every slot with equal prompt length re-prefills at the same step.
+            for (int i = 0; i < B; ++i) SVA_CHECK(b->h_last_pos[i] == b->h_last_pos[0], "re-prefill needs equal positions across slots in this round");
+            SVA_TRY(ar_delay_fill(b));
+        }
+        // vocoder: streaming-exact (ring state) on the c new frames
+        SVA_HIP(hipMemcpy2DAsync(b->d_vcodes, sizeof(int) * b->Tv, b->d_step_audio, sizeof(int) * chunk, sizeof(int) * chunk, (size_t)B * ncb,
+                                 hipMemcpyDeviceToDevice, st));
+        SVA_TRY(vocode(b, chunk, true));
+    } else {
+        SVA_HIP(hipMemsetAsync(b->d_pcm, 0, sizeof(float) * (size_t)B * 2048 * b->Tv, st));
+    }
+    SVA_HIP(hipEventRecord(b->ev[3], st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const float* noise, const int32_t* forced_codes) {
+    SVA_CHECK(b && pcm_in && pcm_out && b->begun, "sva_step: bad argument or sva_streams_begin not called");
+    SVA_HIP(hipSetDevice(b->e->device));
+    const sva_config& c = b->e->cfg;
+    const int B = b->B, chunk = b->p.chunk_frames, n = 2048 * chunk, ncb = c.num_codebooks;
+    hipStream_t st = b->stream;
+    memcpy(b->hp_in, pcm_in, sizeof(float) * (size_t)B * n);
+    SVA_HIP(hipMemcpyAsync(b->d_chunk, b->hp_in, sizeof(float) * (size_t)B * n, hipMemcpyHostToDevice, st));
+    b->noise_on_device = (noise == nullptr);
+    if (noise)
+        SVA_HIP(hipMemcpyAsync(b->d_noise, noise, sizeof(float) * (size_t)B * chunk * (c.ar_vocab + ncb * c.codebook_size), hipMemcpyHostToDevice, st));
+    const int uf = forced_codes ? 1 : 0;
+    SVA_HIP(hipMemcpyAsync(b->d_use_forced, &uf, sizeof(int), hipMemcpyHostToDevice, st));
+    if (forced_codes) SVA_HIP(hipMemcpyAsync(b->d_forced, forced_codes, sizeof(int) * (size_t)B * ncb * chunk, hipMemcpyHostToDevice, st));
+    SVA_HIP(hipStreamSynchronize(st));
+    b->gemm_flops = 0; b->gemm_launches = 0;
+    SVA_TRY(step_body(b));
+    SVA_HIP(hipMemcpy2DAsync(b->hp_out, sizeof(float) * n, b->d_pcm, sizeof(float) * 2048 * b->Tv, sizeof(float) * n, B, hipMemcpyDeviceToHost, st));
+    SVA_HIP(hipStreamSynchronize(st));
+    memcpy(pcm_out, b->hp_out, sizeof(float) * (size_t)B * n);
+    float t;
+    for (int i = 0; i < 3; ++i) {
+        if (hipEventElapsedTime(&t, b->ev[i], b->ev[i + 1]) == hipSuccess) b->last_ms[i] = t;
+    }
+    if (hipEventElapsedTime(&t, b->ev[0], b->ev[3]) == hipSuccess) b->last_ms[3] = t;
+    return 0;
+}
+
+extern "C" int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm_out) {
+    SVA_CHECK(b && d_pcm_in && d_pcm_out && b->begun, "sva_step_device: bad argument");
+    SVA_HIP(hipSetDevice(b->e->device));
+    const int B = b->B, n = 2048 * b->p.chunk_frames;
+    hipStream_t st = b->stream;
+    SVA_HIP(hipMemcpyAsync(b->d_chunk, d_pcm_in, sizeof(float) * (size_t)B * n, hipMemcpyDeviceToDevice, st));
+    b->noise_on_device = true;
+    SVA_HIP(hipMemsetAsync(b->d_use_forced, 0, sizeof(int), st));
+    b->gemm_flops = 0; b->gemm_launches = 0;
+    SVA_TRY(step_body(b));
+    SVA_HIP(hipMemcpy2DAsync(d_pcm_out, sizeof(float) * n, b->d_pcm, sizeof(float) * 2048 * b->Tv, sizeof(float) * n, B, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int sva_sync(sva_batch* b) {
+    SVA_CHECK(b, "null batch");
+    SVA_HIP(hipSetDevice(b->e->device));
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    float t;
+    for (int i = 0; i < 3; ++i)
+        if (hipEventElapsedTime(&t, b->ev[i], b->ev[i + 1]) == hipSuccess) b->last_ms[i] = t;
+    if (hipEventElapsedTime(&t, b->ev[0], b->ev[3]) == hipSuccess) b->last_ms[3] = t;
+    return 0;
+}
+
+extern "C" int sva_encode_window(sva_batch* b, const float* audio, int64_t* codes_out, float* u_out) {
+    SVA_CHECK(b && audio && codes_out, "null argument");
+    SVA_HIP(hipSetDevice(b->e->device));
+    hipStream_t st = b->stream;
+    SVA_HIP(hipMemcpyAsync(b->ring, audio, sizeof(float) * (size_t)b->B * b->N, hipMemcpyHostToDevice, st));
+    b->gemm_flops = 0; b->gemm_launches = 0;
+    SVA_HIP(hipEventRecord(b->ev[0], st));
+    SVA_TRY(encode(b, nullptr, 0, 0));
+    SVA_HIP(hipEventRecord(b->ev[1], st));
+    SVA_HIP(hipMemcpyAsync(codes_out, b->d_codes, sizeof(int64_t) * (size_t)b->B * b->T2, hipMemcpyDeviceToHost, st));
+    if (u_out) SVA_HIP(hipMemcpyAsync(u_out, b->d_u, sizeof(float) * (size_t)b->B * b->T2 * b->e->cfg.bsq_bits, hipMemcpyDeviceToHost, st));
+    SVA_HIP(hipStreamSynchronize(st));
+    float t;
+    if (hipEventElapsedTime(&t, b->ev[0], b->ev[1]) == hipSuccess) b->last_ms[0] = t;
+    return 0;
+}
+
+extern "C" long sva_get_tap(sva_batch* b, const char* what, void* out, long out_bytes) {
+    if (!b || !what || !out) { set_error("null argument"); return -1; }
+    hipSetDevice(b->e->device);
+    const sva_config& c = b->e->cfg;
+    const std::string w(what);
+    const void* src = nullptr;
+    long bytes = 0;
+    const int B = b->B, chunk = b->p.chunk_frames;
+    if (w == "content_codes") { src = b->d_step_content; bytes = sizeof(int) * (long)B * chunk; }
+    else if (w == "audio_codes") { src = b->d_step_audio; bytes = sizeof(int) * (long)B * c.num_codebooks * chunk; }
+    else if (w == "sampled_codes") { src = b->d_tok_raw; bytes = sizeof(int) * (long)B * c.num_codebooks; }
+    else if (w == "slow_logits") { src = b->slow_logits; bytes = sizeof(float) * (long)B * c.ar_vocab; }
+    else if (w == "fast_logits") { src = b->fast_logits; bytes = sizeof(float) * (long)B * c.num_codebooks * c.codebook_size; }
+    else if (w == "hidden") { src = b->hidden; bytes = sizeof(float) * (long)B * c.ar_dim; }
+    else if (w == "semantic") { src = b->d_sem; bytes = sizeof(int) * (long)B; }
+    else if (w == "last_pos") { src = b->d_last_pos; bytes = sizeof(int) * (long)B; }
+    else if (w == "window_codes") { src = b->d_codes; bytes = sizeof(long long) * (long)B * b->T2; }
+    else if (w == "u") { src = b->d_u; bytes = sizeof(float) * (long)B * b->T2 * c.bsq_bits; }
+    else if (w == "mel") { src = b->mel.p; bytes = sizeof(float) * (long)B * b->mel.bstride; }
+    else if (w == "feat") { src = b->feat.p; bytes = sizeof(float) * (long)B * b->feat.bstride; }
+    else if (w == "mag") { src = b->mag; bytes = sizeof(float) * (long)B * b->T0 * 1040; }
+    else if (w == "z") { src = b->tr_z; bytes = sizeof(float) * (long)B * b->T2 * c.tr_dim; }
+    else if (w == "voc_z") { src = b->u1.p; bytes = sizeof(float) * (long)B * b->u1.bstride; }
+    else { set_error("unknown tap " + w); return -1; }
+    if (out_bytes < bytes) { set_error("tap buffer too small"); return -1; }
+    if (hipStreamSynchronize(b->stream) != hipSuccess || hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("tap copy failed");
+        return -2;
+    }
+    return bytes;
+}
+
+extern "C" int sva_get_timings(sva_batch* b, float ms[4]) {
+    SVA_CHECK(b && ms, "null argument");
+    for (int i = 0; i < 4; ++i) ms[i] = b->last_ms[i];
+    return 0;
+}
+extern "C" int sva_get_gemm_stats(sva_batch* b, double* flops, long* launches) {
+    SVA_CHECK(b && flops && launches, "null argument");
+    *flops = b->gemm_flops;
+    *launches = b->gemm_launches;
+    return 0;
+}

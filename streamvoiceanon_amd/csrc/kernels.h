@@ -1,0 +1,85 @@
+// Launchers of the non-GEMM kernels (kernels.hip).  All activations are fp32 channel-last.
+#pragma once
+#include "sva_common.h"
+
+namespace sva {
+
+// ---- content encoder -------------------------------------------------------------------
+// E0/E1: causal STFT magnitude of the sliding audio window kept as a ring.
+//   ring  [B, N] (N = window samples); oldest sample at ((*step + add) * n_chunk) % N
+//   (step == nullptr -> 0);  mag [B, T, ldm], T = N/512, bins 0..1024 written, pad zeroed
+int launch_stft_mag_ring(const float* ring, const int* step, int n_chunk, int add, int B, int N, const float2* twiddle,
+                         const float* hann, float* mag, int ldm, hipStream_t st);
+
+// depthwise causal k=7 conv + LayerNorm(eps) over channels (ConvNeXtBlock prologue).
+//   x element (b, r, c): x[b*x_bstride + x_off + r*C + c]; output row t reads rows t..t+6.
+//   wT [7][C] (tap-major), out [B, T, C] dense.
+int launch_dwconv7_ln(const float* x, long x_bstride, long x_off, int B, int T, int C, const float* wT,
+                      const float* bias, const float* ln_w, const float* ln_b, float eps, float* out,
+                      hipStream_t st);
+
+// row LayerNorm / RMSNorm with strided in/out (rows = B*T).
+int launch_layernorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C,
+                          const float* w, const float* b, float eps, float* out, long o_bstride, long o_off,
+                          int ldo, hipStream_t st);
+int launch_rmsnorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
+                        float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st);
+
+// causal self-attention of the BSQ pre-transformer: qkv [B, T, 3*D] -> out [B, T, D]; RoPE
+// (adjacent pairs, bf16-rounded table rope[T][hd/2][2]) applied to q and k on load.
+int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out,
+                         hipStream_t st);
+
+// BSQ: u = W z + b (nbits x C), index = sum_d (u_d > 0) << (nbits-1-d); optional L2-normalised u out.
+int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T, int C, const float* W,
+               const float* bias, int nbits, long long* idx_out, float* u_out, hipStream_t st);
+
+// ---- dual AR ------------------------------------------------------------------------------
+// RoPE on q,k of qkv rows [M, 3*D] (in place) + KV-cache write at (slot[m], pos[m]).
+//   cache layout per layer: [slot][2][H][S][hd]; KV = float or __half
+template <typename KV>
+int launch_rope_kvwrite(float* qkv, int M, int H, int hd, const int* slot, const int* pos, const float* rope,
+                        KV* cache, long slot_stride, int S, hipStream_t st);
+// attention of M query rows against their slot's cache, keys 0..pos[m] inclusive.
+template <typename KV>
+int launch_ar_attention(const float* qkv, int M, int H, int hd, const int* slot, const int* pos, const KV* cache,
+                        long slot_stride, int S, float* out, hipStream_t st);
+
+// nucleus + temperature + Exp(1)-argmax sampler (modules/dual_ar_stream.py:1092-1132), one
+// workgroup per row.  noise: [rows, ldn] or nullptr -> on-device counter RNG keyed by
+// (seed[row], frame[row], kind) at element offset noise_elem_off.
+int launch_sampler(const float* logits, int rows, int V, int ldl, const float* noise, int ldn,
+                   const unsigned long long* seed, const int* frame, int kind, int noise_elem_off,
+                   float temperature, float top_p, int* tok_out, int tok_stride, hipStream_t st);
+
+// out[r, :] = table[idx[r*idx_stride] + idx_offset, :]
+int launch_gather_rows(const float* table, const int* idx, int idx_stride, int idx_offset, int rows, int D,
+                       float* out, int ldo, hipStream_t st);
+// audio embedding: out[r, :] = sum_i table[codes[r*code_stride + i*cb_stride] + i*codebook_size, :]
+int launch_audio_embed(const float* table, const int* codes, int code_stride, int cb_stride, int rows, int ncb,
+                       int codebook_size, int D, float* out, int ldo, hipStream_t st);
+
+// ---- vocoder ------------------------------------------------------------------------------
+// FSQ index -> latent: codes element (b,g,t) at codes[b*c_bstride + g*c_gstride + t] ->
+// out (b, t, g*gdim + j) at out[b*o_bstride + o_off + t*ldo + g*gdim + j]
+int launch_fsq_decode(const int* codes, long c_bstride, long c_gstride, int B, int T, int G, int gdim,
+                      const float* Wout /*[G][gdim][4]*/, const float* bout /*[G][gdim]*/, float* out,
+                      long o_bstride, long o_off, int ldo, hipStream_t st);
+// conv_post (C -> 1, k taps) on silu(x) + tanh: x (b, r, c) at x[b*x_bstride + x_off + r*C + c]; row t reads t..t+k-1
+int launch_conv_post_tanh(const float* x, long x_bstride, long x_off, int B, int T, int C, int k,
+                          const float* w /*[k][C]*/, const float* bias, float* pcm, long p_bstride, long p_off,
+                          hipStream_t st);
+
+struct ShiftDesc {      // one history buffer: rows [T, T+H) move to [0, H) after a step
+    float* ptr;
+    long bstride;
+    int H, T, C;
+    int pad;
+};
+int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStream_t st);
+
+// small helpers
+int launch_fill_i32(int* p, int n, int v, hipStream_t st);
+int launch_ring_write(float* ring, int* step, int B, int N, const float* chunk, int n, hipStream_t st);
+
+}  // namespace sva

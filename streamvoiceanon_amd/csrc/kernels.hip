@@ -1,0 +1,761 @@
+// Non-GEMM kernels of the sva engine (gfx950).  wave = 64 lanes everywhere.
+//
+// Reference behaviour restated by each kernel is cited next to it (paths relative to the
+// StreamVoiceAnon repository); the CPU oracle (oracle/sva_oracle.py) is the checker.
+#include "kernels.h"
+
+namespace sva {
+
+// ------------------------------------------------------------------------------------------
+// wave / block reductions
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float silu_acc(float x) { return x / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------
+// E0: audio ring write.  The reference shifts a [1, W*2048] window left by one chunk and
+// appends the new chunk (evaluations/infer_arvc.py:495-496); here the window is a ring whose
+// oldest sample sits at ((step + add) * n) % N, `step` being the device-side chunk counter.
+// ------------------------------------------------------------------------------------------
+__global__ void ring_write_kernel(float* ring, const int* step, int N, const float* chunk, int n) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int start = (int)(((long)(*step) * n) % N);
+    int idx = start + i;
+    if (idx >= N) idx -= N;
+    ring[(long)b * N + idx] = chunk[(long)b * n + i];
+}
+int launch_ring_write(float* ring, int* step, int B, int N, const float* chunk, int n, hipStream_t st) {
+    dim3 grid((n + 255) / 256, B);
+    hipLaunchKernelGGL(ring_write_kernel, grid, dim3(256), 0, st, ring, step, N, chunk, n);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void fill_i32_kernel(int* p, int n, int v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+int launch_fill_i32(int* p, int n, int v, hipStream_t st) {
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, n, v);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// E1: causal STFT magnitude (modules/vqgan/spectrogram.py:26-65): frame m = samples
+// [512 m - 1536, 512 m + 512) of the window (zeros before the window start), periodic Hann,
+// 2048-point DFT, sqrt(re^2 + im^2 + 1e-6).  One workgroup per frame; radix-2 DIT in LDS.
+// `step_info` = {step pointer, chunk n, add}: oldest sample at ((step+add)*n) % N.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ ring, const int* step, int n_chunk,
+                                                       int add, int N, const float2* __restrict__ tw,
+                                                       const float* __restrict__ hann, float* __restrict__ mag,
+                                                       int ldm, int T) {
+    __shared__ float re[2048];
+    __shared__ float im[2048];
+    const int m = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int start = step ? (int)(((long)(*step + add) * n_chunk) % N) : 0;
+    const float* rb = ring + (long)b * N;
+    for (int i = tid; i < 2048; i += 256) {
+        const int j = 512 * m - 1536 + i;
+        float v = 0.f;
+        if (j >= 0) {
+            int idx = start + j;
+            if (idx >= N) idx -= N;
+            v = rb[idx] * hann[i];
+        }
+        const int r = (int)(__brev((unsigned)i) >> 21);
+        re[r] = v;
+        im[r] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 1; s <= 11; ++s) {
+        const int half = 1 << (s - 1);
+        for (int jb = tid; jb < 1024; jb += 256) {
+            const int pos = jb & (half - 1);
+            const int i0 = ((jb >> (s - 1)) << s) + pos;
+            const int i1 = i0 + half;
+            const float2 w = tw[pos << (11 - s)];
+            const float xr = re[i1], xi = im[i1];
+            const float tr = w.x * xr - w.y * xi, ti = w.x * xi + w.y * xr;
+            const float ur = re[i0], ui = im[i0];
+            re[i0] = ur + tr;
+            im[i0] = ui + ti;
+            re[i1] = ur - tr;
+            im[i1] = ui - ti;
+        }
+        __syncthreads();
+    }
+    float* out = mag + ((long)b * T + m) * ldm;
+    for (int k = tid; k < ldm; k += 256) out[k] = k <= 1024 ? sqrtf(re[k] * re[k] + im[k] * im[k] + 1e-6f) : 0.f;
+}
+int launch_stft_mag_ring(const float* ring, const int* step, int n_chunk, int add, int B, int N, const float2* tw,
+                         const float* hann, float* mag, int ldm, hipStream_t st) {
+    SVA_CHECK(N % 512 == 0 && ldm >= 1025, "stft: bad shape");
+    const int T = N / 512;
+    hipLaunchKernelGGL(stft_mag_kernel, dim3(T, B), dim3(256), 0, st, ring, step, n_chunk, add, N, tw, hann, mag, ldm, T);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// ConvNeXtBlock prologue: depthwise causal k=7 conv + LayerNorm(eps 1e-6, biased variance)
+// (modules/vqgan/modules/firefly.py:421-427, 92-103, 361-365).  One wave per output row.
+// ------------------------------------------------------------------------------------------
+template <int NPL>
+__global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, long x_bstride, long x_off, int T,
+                                                         int C, int rows, const float* __restrict__ wT,
+                                                         const float* __restrict__ bias, const float* __restrict__ lw,
+                                                         const float* __restrict__ lb, float eps, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int b = row / T, t = row - b * T;
+    const float* xr = x + (long)b * x_bstride + x_off + (long)t * C;
+    float v[NPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = lane + 64 * i;
+        float acc = bias[c];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc = fmaf(wT[j * C + c], xr[(long)j * C + c], acc);
+        v[i] = acc;
+        s += acc;
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const float d = v[i] - mean;
+        q = fmaf(d, d, q);
+    }
+    const float inv = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+    float* o = out + (long)row * C;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = lane + 64 * i;
+        o[c] = (v[i] - mean) * inv * lw[c] + lb[c];
+    }
+}
+int launch_dwconv7_ln(const float* x, long x_bstride, long x_off, int B, int T, int C, const float* wT,
+                      const float* bias, const float* ln_w, const float* ln_b, float eps, float* out, hipStream_t st) {
+    SVA_CHECK(C % 64 == 0 && C <= 512, "dwconv7_ln: C must be a multiple of 64, <= 512");
+    const int rows = B * T;
+    dim3 grid((rows + 3) / 4);
+#define SVA_DW(N_) hipLaunchKernelGGL((dwconv7_ln_kernel<N_>), grid, dim3(256), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out)
+    switch (C / 64) {
+        case 1: SVA_DW(1); break;
+        case 2: SVA_DW(2); break;
+        case 3: SVA_DW(3); break;
+        case 4: SVA_DW(4); break;
+        case 5: SVA_DW(5); break;
+        case 6: SVA_DW(6); break;
+        case 7: SVA_DW(7); break;
+        default: SVA_DW(8); break;
+    }
+#undef SVA_DW
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// row LayerNorm (firefly.py:361-371) / RMSNorm (dual_ar_stream.py:979-990,
+// windowed_transformer.py:248-259: x * rsqrt(mean(x^2) + eps) * w), one wave per row.
+// ------------------------------------------------------------------------------------------
+template <int NPL, bool RMS>
+__global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ x, long x_bstride, long x_off, int ldx,
+                                                        int T, int C, int rows, const float* __restrict__ w,
+                                                        const float* __restrict__ bvec, float eps,
+                                                        float* __restrict__ out, long o_bstride, long o_off, int ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int b = row / T, t = row - b * T;
+    const float* xr = x + (long)b * x_bstride + x_off + (long)t * ldx;
+    float* o = out + (long)b * o_bstride + o_off + (long)t * ldo;
+    float v[NPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        v[i] = xr[lane + 64 * i];
+        s += RMS ? v[i] * v[i] : v[i];
+    }
+    if (RMS) {
+        const float inv = 1.f / sqrtf(wave_sum(s) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) o[lane + 64 * i] = v[i] * inv * w[lane + 64 * i];
+    } else {
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const float d = v[i] - mean;
+            q = fmaf(d, d, q);
+        }
+        const float inv = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int c = lane + 64 * i;
+            o[c] = (v[i] - mean) * inv * w[c] + bvec[c];
+        }
+    }
+}
+template <bool RMS>
+static int launch_norm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
+                            const float* b, float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st) {
+    SVA_CHECK(C % 64 == 0 && C <= 1024, "norm_rows: C must be a multiple of 64, <= 1024");
+    const int rows = B * T;
+    dim3 grid((rows + 3) / 4);
+#define SVA_NR(N_) hipLaunchKernelGGL((norm_rows_kernel<N_, RMS>), grid, dim3(256), 0, st, x, x_bstride, x_off, ldx, T, C, rows, w, b, eps, out, o_bstride, o_off, ldo)
+    switch (C / 64) {
+        case 1: SVA_NR(1); break;
+        case 2: SVA_NR(2); break;
+        case 3: SVA_NR(3); break;
+        case 4: SVA_NR(4); break;
+        case 6: SVA_NR(6); break;
+        case 8: SVA_NR(8); break;
+        case 12: SVA_NR(12); break;
+        case 16: SVA_NR(16); break;
+        default: set_error("norm_rows: unsupported C"); return -1;
+    }
+#undef SVA_NR
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+int launch_layernorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
+                          const float* b, float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st) {
+    return launch_norm_rows<false>(x, x_bstride, x_off, ldx, B, T, C, w, b, eps, out, o_bstride, o_off, ldo, st);
+}
+int launch_rmsnorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
+                        float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st) {
+    return launch_norm_rows<true>(x, x_bstride, x_off, ldx, B, T, C, w, nullptr, eps, out, o_bstride, o_off, ldo, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// E7 attention (modules/vqgan/windowed_transformer.py:163-194, mask 298-303 = plain causal
+// because window 512 >= T): one workgroup per (head, stream); K (RoPE'd) and V in LDS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ rope,
+                                                            int T, int H, float* __restrict__ out) {
+    constexpr int HD = 64, LDK = HD + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                    // [T][65]
+    float* Vs = Ks + (long)T * LDK;      // [T][65]
+    float* qs = Vs + (long)T * LDK;      // [4][64]
+    float* ps = qs + 4 * HD;             // [4][T]
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int D = H * HD;
+    const float* base = qkv + (long)b * T * 3 * D;
+    for (int idx = tid; idx < T * (HD / 2); idx += 256) {
+        const int t = idx / (HD / 2), p = idx - t * (HD / 2);
+        const float* row = base + (long)t * 3 * D;
+        const float k0 = row[D + h * HD + 2 * p], k1 = row[D + h * HD + 2 * p + 1];
+        const float c = rope[(t * (HD / 2) + p) * 2], s = rope[(t * (HD / 2) + p) * 2 + 1];
+        Ks[t * LDK + 2 * p] = k0 * c - k1 * s;
+        Ks[t * LDK + 2 * p + 1] = k1 * c + k0 * s;
+        Vs[t * LDK + 2 * p] = row[2 * D + h * HD + 2 * p];
+        Vs[t * LDK + 2 * p + 1] = row[2 * D + h * HD + 2 * p + 1];
+    }
+    __syncthreads();
+    const float scale = 0.125f;          // 1/sqrt(64)
+    for (int r = wave; r < T; r += 4) {  // T % 4 == 0: uniform trip count, barriers are legal
+        if (lane < HD / 2) {
+            const float* row = base + (long)r * 3 * D + h * HD;
+            const float q0 = row[2 * lane], q1 = row[2 * lane + 1];
+            const float c = rope[(r * (HD / 2) + lane) * 2], s = rope[(r * (HD / 2) + lane) * 2 + 1];
+            qs[wave * HD + 2 * lane] = q0 * c - q1 * s;
+            qs[wave * HD + 2 * lane + 1] = q1 * c + q0 * s;
+        }
+        __syncthreads();
+        float mx = -INFINITY;
+        for (int j = lane; j <= r; j += 64) {
+            float acc = 0.f;
+#pragma unroll 16
+            for (int d = 0; d < HD; ++d) acc = fmaf(qs[wave * HD + d], Ks[j * LDK + d], acc);
+            acc *= scale;
+            ps[wave * T + j] = acc;
+            mx = fmaxf(mx, acc);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j <= r; j += 64) {
+            const float e = expf(ps[wave * T + j] - mx);
+            ps[wave * T + j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        __syncthreads();
+        float acc = 0.f;
+        for (int j = 0; j <= r; ++j) acc = fmaf(ps[wave * T + j], Vs[j * LDK + lane], acc);
+        out[((long)b * T + r) * D + h * HD + lane] = acc / sum;
+        __syncthreads();
+    }
+}
+int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out, hipStream_t st) {
+    SVA_CHECK(hd == 64 && T % 4 == 0, "enc_attention: head_dim must be 64 and T a multiple of 4");
+    const size_t smem = ((size_t)T * 65 * 2 + 4 * 64 + 4 * (size_t)T) * sizeof(float);
+    SVA_CHECK(smem <= 160 * 1024, "enc_attention: window too long for the LDS-resident kernel");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SVA_HIP(hipFuncSetAttribute((const void*)enc_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(enc_attention_kernel, dim3(H, B), dim3(256), smem, st, qkv, rope, T, H, out);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// E8 BSQ (modules/vqgan/modules/bsq.py:330-369): Linear C->nbits (+bias), L2-normalise,
+// bit_d = u_d > 0, index = sum bit_d << (nbits-1-d) (MSB first, mask buffer :230).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bsq_kernel(const float* __restrict__ z, long z_bstride, long z_off, int ldz, int T,
+                                                  int C, int rows, const float* __restrict__ W, const float* __restrict__ bias,
+                                                  int nbits, long long* __restrict__ idx_out, float* __restrict__ u_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int b = row / T, t = row - b * T;
+    const float* zr = z + (long)b * z_bstride + z_off + (long)t * ldz;
+    float u[16];
+    float nrm = 0.f;
+    for (int d = 0; d < nbits; ++d) {
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc = fmaf(W[d * C + c], zr[c], acc);
+        acc = wave_sum(acc) + bias[d];
+        u[d] = acc;
+        nrm = fmaf(acc, acc, nrm);
+    }
+    if (lane == 0) {
+        long long idx = 0;
+        const float inv = 1.f / fmaxf(sqrtf(nrm), 1e-12f);      // F.normalize eps
+        for (int d = 0; d < nbits; ++d) {
+            if (u[d] > 0.f) idx |= 1ll << (nbits - 1 - d);
+            if (u_out) u_out[(long)row * nbits + d] = u[d] * inv;
+        }
+        idx_out[row] = idx;
+    }
+}
+int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T, int C, const float* W,
+               const float* bias, int nbits, long long* idx_out, float* u_out, hipStream_t st) {
+    SVA_CHECK(nbits <= 16, "bsq: nbits <= 16");
+    const int rows = B * T;
+    hipLaunchKernelGGL(bsq_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, z, z_bstride, z_off, ldz, T, C, rows, W, bias,
+                       nbits, idx_out, u_out);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// A2: RoPE (adjacent pairs, bf16-rounded table; modules/dual_ar_stream.py:1004-1016) on q,k
+// and KV-cache write at kv_pos (KVCache.update :141-150).  One workgroup per row.
+// ------------------------------------------------------------------------------------------
+template <typename KV> __device__ __forceinline__ KV to_kv(float v);
+template <> __device__ __forceinline__ float to_kv<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half to_kv<__half>(float v) { return __float2half(v); }
+__device__ __forceinline__ float from_kv(float v) { return v; }
+__device__ __forceinline__ float from_kv(__half v) { return __half2float(v); }
+
+template <typename KV>
+__global__ __launch_bounds__(256) void rope_kvwrite_kernel(float* __restrict__ qkv, int H, int hd, const int* __restrict__ slot,
+                                                           const int* __restrict__ pos, const float* __restrict__ rope,
+                                                           KV* __restrict__ cache, long slot_stride, int S) {
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int D = H * hd, hp = hd / 2;
+    float* row = qkv + (long)m * 3 * D;
+    const int p = pos[m];
+    KV* kc = cache + (long)slot[m] * slot_stride;
+    KV* vc = kc + (long)H * S * hd;
+    for (int i = tid; i < D / 2; i += 256) {
+        const int h = i / hp, j = i - h * hp;
+        const float c = rope[((long)p * hp + j) * 2], s = rope[((long)p * hp + j) * 2 + 1];
+        const float q0 = row[2 * i], q1 = row[2 * i + 1];
+        row[2 * i] = q0 * c - q1 * s;
+        row[2 * i + 1] = q1 * c + q0 * s;
+        const float k0 = row[D + 2 * i], k1 = row[D + 2 * i + 1];
+        const long o = ((long)h * S + p) * hd + 2 * j;
+        kc[o] = to_kv<KV>(k0 * c - k1 * s);
+        kc[o + 1] = to_kv<KV>(k1 * c + k0 * s);
+        vc[o] = to_kv<KV>(row[2 * D + 2 * i]);
+        vc[o + 1] = to_kv<KV>(row[2 * D + 2 * i + 1]);
+    }
+}
+template <typename KV>
+int launch_rope_kvwrite(float* qkv, int M, int H, int hd, const int* slot, const int* pos, const float* rope, KV* cache,
+                        long slot_stride, int S, hipStream_t st) {
+    hipLaunchKernelGGL((rope_kvwrite_kernel<KV>), dim3(M), dim3(256), 0, st, qkv, H, hd, slot, pos, rope, cache, slot_stride, S);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+template int launch_rope_kvwrite<float>(float*, int, int, int, const int*, const int*, const float*, float*, long, int, hipStream_t);
+template int launch_rope_kvwrite<__half>(float*, int, int, int, const int*, const int*, const float*, __half*, long, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// A2 decode attention (Attention.forward, modules/dual_ar_stream.py:895-936 with the mask
+// causal_mask[kv_pos, :max_seq_len] of :333): query row m attends cache slots 0..pos[m].
+// One workgroup per (head, row): scores in LDS, block softmax, V reduction split over waves.
+// ------------------------------------------------------------------------------------------
+template <typename KV>
+__global__ __launch_bounds__(256) void ar_attention_kernel(const float* __restrict__ qkv, int H, const int* __restrict__ slot,
+                                                           const int* __restrict__ pos, const KV* __restrict__ cache,
+                                                           long slot_stride, int S, float* __restrict__ out) {
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sc = smem;                 // [S]
+    float* qs = sc + S;               // [64]
+    float* red = qs + HD;             // [8]
+    float* part = red + 8;            // [4][64]
+    const int h = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int D = H * HD;
+    const int L = pos[m] + 1;
+    const KV* kc = cache + (long)slot[m] * slot_stride + (long)h * S * HD;
+    const KV* vc = kc + (long)H * S * HD;
+    if (tid < HD) qs[tid] = qkv[(long)m * 3 * D + h * HD + tid];
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < L; j += 256) {
+        const KV* kr = kc + (long)j * HD;
+        float acc = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < HD; ++d) acc = fmaf(qs[d], from_kv(kr[d]), acc);
+        acc *= 0.125f;
+        sc[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < L; j += 256) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = red[4] + red[5] + red[6] + red[7];
+    float acc = 0.f;
+    for (int j = wave; j < L; j += 4) acc = fmaf(sc[j], from_kv(vc[(long)j * HD + lane]), acc);
+    part[wave * HD + lane] = acc;
+    __syncthreads();
+    if (tid < HD) out[(long)m * D + h * HD + tid] = (part[tid] + part[HD + tid] + part[2 * HD + tid] + part[3 * HD + tid]) / sum;
+}
+template <typename KV>
+int launch_ar_attention(const float* qkv, int M, int H, int hd, const int* slot, const int* pos, const KV* cache,
+                        long slot_stride, int S, float* out, hipStream_t st) {
+    SVA_CHECK(hd == 64, "ar_attention: head_dim must be 64");
+    const size_t smem = ((size_t)S + 64 + 8 + 256) * sizeof(float);
+    hipLaunchKernelGGL((ar_attention_kernel<KV>), dim3(H, M), dim3(256), smem, st, qkv, H, slot, pos, cache, slot_stride, S, out);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+template int launch_ar_attention<float>(const float*, int, int, int, const int*, const int*, const float*, long, int, float*, hipStream_t);
+template int launch_ar_attention<__half>(const float*, int, int, int, const int*, const int*, const __half*, long, int, float*, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// A5 sampler (modules/dual_ar_stream.py:1092-1132, defaults T = 0.7, top_p = 0.7, no repetition
+// penalty): sort descending, inclusive cumsum of softmax, drop every sorted entry with
+// cum > top_p except rank 0 (no right shift), divide by max(T, 1e-5), softmax, argmax(p / q),
+// q ~ Exp(1).  One 1024-thread workgroup per row; bitonic sort in LDS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float exp1_noise_dev(unsigned long long seed, int frame, int kind, unsigned elem) {
+    // streamvoiceanon_amd/synth_weights.py: noise_key() + u24_from_key() + exp1_noise()
+    unsigned long long z = (seed + 1ull) * 0xD6E8FEB86659FD93ull;
+    z ^= ((unsigned long long)frame + 1ull) * 0x9E3779B97F4A7C15ull;
+    z ^= ((unsigned long long)kind + 1ull) * 0xC2B2AE3D27D4EB4Full;
+    const unsigned long long key = mix64(z);
+    const unsigned long long hsh = mix64(key + ((unsigned long long)elem + 1ull) * 0x9E3779B97F4A7C15ull);
+    const float k = (float)(unsigned)(hsh >> 40);
+    return -logf(fmaxf(k, 0.5f) * (1.0f / 16777216.0f));
+}
+
+__global__ __launch_bounds__(1024) void sampler_kernel(const float* __restrict__ logits, int V, int ldl, int P,
+                                                       const float* __restrict__ noise, int ldn,
+                                                       const unsigned long long* __restrict__ seed, const int* __restrict__ frame,
+                                                       int kind, int noise_elem_off, float inv_temp, float top_p,
+                                                       int* __restrict__ tok_out, int tok_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* val = smem;                                  // [P]
+    unsigned short* ids = (unsigned short*)(val + P);   // [P]
+    double* dred = (double*)(ids + P);                  // [16] wave partials (P*6 bytes is 8-aligned: P % 4 == 0)
+    float* fred = (float*)(dred + 16);                  // [16]
+    int* ired = (int*)(fred + 16);                      // [16]
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lg = logits + (long)row * ldl;
+    for (int i = tid; i < P; i += 1024) {
+        val[i] = i < V ? lg[i] : -INFINITY;
+        ids[i] = (unsigned short)i;
+    }
+    __syncthreads();
+    // bitonic sort, descending (ties: smaller id first)
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < P / 2; t += 1024) {
+                const int i = ((t / j) * 2 * j) + (t % j);
+                const int l = i + j;
+                const bool desc = (i & k) == 0;
+                const float a = val[i], b = val[l];
+                const unsigned short ia = ids[i], ib = ids[l];
+                const bool a_first = (a > b) || (a == b && ia < ib);   // a should precede b in descending order
+                if (desc ? !a_first : a_first) {
+                    val[i] = b; val[l] = a;
+                    ids[i] = ib; ids[l] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const float mx = val[0];
+    // softmax denominator
+    float s = 0.f;
+    for (int i = tid; i < V; i += 1024) s += expf(val[i] - mx);
+    s = wave_sum(s);
+    if (lane == 0) fred[wave] = s;
+    __syncthreads();
+    float denom = 0.f;
+    for (int w = 0; w < 16; ++w) denom += fred[w];
+    __syncthreads();
+    // inclusive cumulative sum in sorted order (double accumulation: torch's CPU cumsum uses a
+    // double accumulator for float inputs), each thread owns PER consecutive entries
+    const int PER = P / 1024;
+    double local = 0.0;
+    for (int e = 0; e < PER; ++e) {
+        const int i = tid * PER + e;
+        if (i < V) local += (double)(expf(val[i] - mx) / denom);
+    }
+    double incl = local;                                 // wave inclusive scan
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) dred[wave] = incl;
+    __syncthreads();
+    double base = 0.0;
+    for (int w = 0; w < wave; ++w) base += dred[w];
+    double run = base + incl - local;                    // exclusive prefix of this thread
+    int first_rm = P;                                    // first sorted rank (>= 1) with cum > top_p
+    for (int e = 0; e < PER; ++e) {
+        const int i = tid * PER + e;
+        if (i < V) {
+            run += (double)(expf(val[i] - mx) / denom);
+            if (i >= 1 && (float)run > top_p && i < first_rm) first_rm = i;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first_rm = min(first_rm, __shfl_xor(first_rm, o, 64));
+    if (lane == 0) ired[wave] = first_rm;
+    __syncthreads();
+    int ncut = P;
+    for (int w = 0; w < 16; ++w) ncut = min(ncut, ired[w]);
+    if (ncut > V) ncut = V;
+    __syncthreads();
+    // temperature softmax over the kept prefix, then argmax(p / q)
+    const float m2 = mx * inv_temp;
+    float s2 = 0.f;
+    for (int i = tid; i < ncut; i += 1024) s2 += expf(val[i] * inv_temp - m2);
+    s2 = wave_sum(s2);
+    if (lane == 0) fred[wave] = s2;
+    __syncthreads();
+    float denom2 = 0.f;
+    for (int w = 0; w < 16; ++w) denom2 += fred[w];
+    __syncthreads();
+    float best = -1.f;
+    int best_id = 0x7fffffff;
+    for (int i = tid; i < ncut; i += 1024) {
+        const int id = ids[i];
+        const float p = expf(val[i] * inv_temp - m2) / denom2;
+        const float q = noise ? noise[(long)row * ldn + id]
+                              : exp1_noise_dev(seed[row], frame[row], kind, (unsigned)(noise_elem_off + id));
+        const float r = p / q;
+        if (r > best || (r == best && id < best_id)) { best = r; best_id = id; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_id, o, 64);
+        if (ob > best || (ob == best && oi < best_id)) { best = ob; best_id = oi; }
+    }
+    if (lane == 0) { fred[wave] = best; ired[wave] = best_id; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (fred[w] > best || (fred[w] == best && ired[w] < best_id)) { best = fred[w]; best_id = ired[w]; }
+        tok_out[(long)row * tok_stride] = best_id;
+    }
+}
+int launch_sampler(const float* logits, int rows, int V, int ldl, const float* noise, int ldn,
+                   const unsigned long long* seed, const int* frame, int kind, int noise_elem_off, float temperature,
+                   float top_p, int* tok_out, int tok_stride, hipStream_t st) {
+    int P = 1024;
+    while (P < V) P <<= 1;
+    SVA_CHECK(P <= 16384, "sampler: vocabulary too large");
+    const size_t smem = (size_t)P * 6 + 16 * 8 + 16 * 4 + 16 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SVA_HIP(hipFuncSetAttribute((const void*)sampler_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    const float tclamp = temperature > 1e-5f ? temperature : 1e-5f;
+    hipLaunchKernelGGL(sampler_kernel, dim3(rows), dim3(1024), smem, st, logits, V, ldl, P, noise, ldn, seed, frame, kind,
+                       noise_elem_off, 1.0f / tclamp, top_p, tok_out, tok_stride);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// embeddings
+// ------------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int* __restrict__ idx, int idx_stride,
+                                   int idx_offset, int D, float* __restrict__ out, int ldo) {
+    const int r = blockIdx.x;
+    const long src = (long)(idx[(long)r * idx_stride] + idx_offset) * D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) out[(long)r * ldo + c] = table[src + c];
+}
+int launch_gather_rows(const float* table, const int* idx, int idx_stride, int idx_offset, int rows, int D, float* out,
+                       int ldo, hipStream_t st) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, st, table, idx, idx_stride, idx_offset, D, out, ldo);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+// BaseTransformer.embed (modules/dual_ar_stream.py:245-255): sum over codebooks of
+// codebook_embeddings[code_i + i * codebook_size]
+__global__ void audio_embed_kernel(const float* __restrict__ table, const int* __restrict__ codes, int code_stride,
+                                   int cb_stride, int ncb, int codebook_size, int D, float* __restrict__ out, int ldo) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float acc = 0.f;
+        for (int i = 0; i < ncb; ++i) {
+            const int code = codes[(long)r * code_stride + (long)i * cb_stride];
+            acc += table[((long)code + (long)i * codebook_size) * D + c];
+        }
+        out[(long)r * ldo + c] = acc;
+    }
+}
+int launch_audio_embed(const float* table, const int* codes, int code_stride, int cb_stride, int rows, int ncb,
+                       int codebook_size, int D, float* out, int ldo, hipStream_t st) {
+    hipLaunchKernelGGL(audio_embed_kernel, dim3(rows), dim3(256), 0, st, table, codes, code_stride, cb_stride, ncb,
+                       codebook_size, D, out, ldo);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// V1 FSQ decode (modules/vqgan/modules/fsq.py:112-114; arithmetic of vector_quantize_pytorch
+// 1.14.24, twin at modules/bicodec_speaker_encoder/fsq/finite_scalar_quantization.py:143-162):
+// digits = (idx // [1,8,40,200]) % [8,5,5,5]; code = (digit - half) / half, half = [4,2,2,2];
+// per-group Linear 4 -> gdim.
+// ------------------------------------------------------------------------------------------
+__global__ void fsq_decode_kernel(const int* __restrict__ codes, long c_bstride, long c_gstride, int T, int G, int gdim,
+                                  const float* __restrict__ Wout, const float* __restrict__ bout, float* __restrict__ out,
+                                  long o_bstride, long o_off, int ldo) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    for (int e = threadIdx.x; e < G * gdim; e += blockDim.x) {
+        const int g = e / gdim, j = e - g * gdim;
+        const int idx = codes[(long)b * c_bstride + (long)g * c_gstride + t];
+        const float c0 = (float)((idx % 8) - 4) / 4.f;
+        const float c1 = (float)(((idx / 8) % 5) - 2) / 2.f;
+        const float c2 = (float)(((idx / 40) % 5) - 2) / 2.f;
+        const float c3 = (float)(((idx / 200) % 5) - 2) / 2.f;
+        const float* w = Wout + ((long)g * gdim + j) * 4;
+        out[(long)b * o_bstride + o_off + (long)t * ldo + e] = bout[g * gdim + j] + w[0] * c0 + w[1] * c1 + w[2] * c2 + w[3] * c3;
+    }
+}
+int launch_fsq_decode(const int* codes, long c_bstride, long c_gstride, int B, int T, int G, int gdim, const float* Wout,
+                      const float* bout, float* out, long o_bstride, long o_off, int ldo, hipStream_t st) {
+    hipLaunchKernelGGL(fsq_decode_kernel, dim3(T, B), dim3(256), 0, st, codes, c_bstride, c_gstride, T, G, gdim, Wout, bout,
+                       out, o_bstride, o_off, ldo);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// V3 tail: SiLU -> conv_post (C -> 1, k taps, causal) -> tanh (firefly.py:289-291).
+// 256 outputs per workgroup, silu'd input rows staged once in LDS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __restrict__ x, long x_bstride, long x_off, int T,
+                                                             int C, int k, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ pcm,
+                                                             long p_bstride, long p_off) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+    const int nrows = min(256, T - t0) + k - 1;
+    const float* xb = x + (long)b * x_bstride + x_off + (long)t0 * C;
+    for (int i = tid; i < nrows * C; i += 256) smem[i] = silu_acc(xb[i]);
+    float* ws = smem + (256 + k - 1) * C;
+    for (int i = tid; i < k * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t < T) {
+        float acc = bias[0];
+        const float* r = smem + tid * C;
+        for (int i = 0; i < k * C; ++i) acc = fmaf(ws[i], r[i], acc);
+        pcm[(long)b * p_bstride + p_off + t] = tanhf(acc);
+    }
+}
+int launch_conv_post_tanh(const float* x, long x_bstride, long x_off, int B, int T, int C, int k, const float* w,
+                          const float* bias, float* pcm, long p_bstride, long p_off, hipStream_t st) {
+    const size_t smem = ((size_t)(256 + k - 1) * C + (size_t)k * C) * sizeof(float);
+    SVA_CHECK(smem <= 64 * 1024, "conv_post: tile too large");
+    hipLaunchKernelGGL(conv_post_tanh_kernel, dim3((T + 255) / 256, B), dim3(256), smem, st, x, x_bstride, x_off, T, C, k, w,
+                       bias, pcm, p_bstride, p_off);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// streaming state: every conv input tensor keeps H history rows in front of its T new rows;
+// after a step rows [T, T+H) become the next step's history [0, H).  One workgroup per
+// (tensor, stream) walks the rows in increasing address order (dst < src always), staging
+// each 256-element chunk in registers across a barrier so overlapping ranges are safe.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shift_history_kernel(const ShiftDesc* __restrict__ descs) {
+    const ShiftDesc d = descs[blockIdx.x];
+    float* base = d.ptr + (long)blockIdx.y * d.bstride;
+    const long n = (long)d.H * d.C, delta = (long)d.T * d.C;
+    for (long i0 = 0; i0 < n; i0 += 1024) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long i = i0 + threadIdx.x + e * 256;
+            v[e] = i < n ? base[i + delta] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long i = i0 + threadIdx.x + e * 256;
+            if (i < n) base[i] = v[e];
+        }
+        __syncthreads();
+    }
+}
+int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStream_t st) {
+    if (n_desc == 0) return 0;
+    hipLaunchKernelGGL(shift_history_kernel, dim3(n_desc, B), dim3(256), 0, st, descs_dev);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace sva

@@ -1,0 +1,70 @@
+// Common declarations of the sva HIP engine (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string>
+
+namespace sva {
+
+void set_error(const std::string& msg);
+
+#define SVA_HIP(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ::sva::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + \
+                             __FILE__ + ":" + std::to_string(__LINE__) + ")");               \
+            return -2;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+#define SVA_CHECK(cond, msg)                                                       \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            ::sva::set_error(std::string(msg) + " [" #cond "] (" + __FILE__ + ":" + \
+                             std::to_string(__LINE__) + ")");                      \
+            return -1;                                                             \
+        }                                                                          \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// conv-GEMM: the one matrix kernel of the encoder / vocoder (and the f32 AR mode).
+//   C[b, t, n] = epi( sum_{tap, k} A[b, t*stride + tap*dil, k] * W[n, tap*Cin + k] )
+// Activations are channel-last [B, rows, C] with a few history / zero-pad rows in front of
+// every tensor, so a causal Conv1d is a GEMM whose K axis is split into taps that read
+// shifted rows (no im2col, no bounds checks).  ConvTranspose1d (k = 2*stride or k = stride)
+// is the same GEMM with N = stride*Cout and 2 (or 1) taps -- see DESIGN.md.
+// ---------------------------------------------------------------------------------------
+enum ActKind : int { ACT_NONE = 0, ACT_GELU = 1, ACT_LOGCLAMP = 2 };
+
+struct ConvGemm {
+    const float* A = nullptr;   // element (b, r, k): A[b*a_bstride + a_off + r*lda + k]
+    long a_bstride = 0;
+    long a_off = 0;
+    int lda = 0;
+    int T = 0;                  // output rows per batch item
+    int M = 0;                  // B * T
+    int stride = 1, dil = 1, taps = 1, Cin = 0;
+    const float* W = nullptr;   // [N][taps*Cin], K contiguous
+    int N = 0;
+    const float* bias = nullptr;    // [N]
+    const float* gamma = nullptr;   // [N]  (ConvNeXt gamma / LayerScale)
+    const float* res = nullptr;     // residual, element (b, t, n): res[b*r_bstride + r_off + t*ldr + n]
+    long r_bstride = 0;
+    long r_off = 0;
+    int ldr = 0;
+    float* C = nullptr;         // element (b, t, n): C[b*c_bstride + c_off + t*ldc + n]
+    long c_bstride = 0;
+    long c_off = 0;
+    int ldc = 0;
+    float scale = 1.f;
+    int act = ACT_NONE;
+    int accumulate = 0;         // C += value   (ParallelBlock mean of three ResBlock branches)
+    int a_silu = 0;             // apply SiLU to A on load (HiFiGAN: silu precedes every conv)
+    int w13 = 0;                // SwiGLU: W rows interleave w1/w3 in groups of 16; C[., n/2] = silu(a)*b
+};
+
+int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
+
+}  // namespace sva

@@ -1,0 +1,297 @@
+"""ctypes binding of the C ABI in include/sva.h (libsva_hip.so, built by csrc/Makefile).
+
+This is the ONLY compute path of the package: if the HIP library is missing or no MI355X is
+visible the constructors raise -- there is no CPU fallback (the CPU oracle under oracle/ is
+test infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsva_hip.so")
+
+
+class SvaConfig(C.Structure):
+    _fields_ = [
+        ("n_mels", C.c_int), ("enc_depths", C.c_int * 4), ("enc_dims", C.c_int * 4),
+        ("tr_layers", C.c_int), ("tr_heads", C.c_int), ("tr_dim", C.c_int), ("tr_inter", C.c_int), ("bsq_bits", C.c_int),
+        ("ar_dim", C.c_int), ("ar_heads", C.c_int), ("ar_layers", C.c_int), ("ar_fast_layers", C.c_int), ("ar_inter", C.c_int),
+        ("ar_vocab", C.c_int), ("codebook_size", C.c_int), ("num_codebooks", C.c_int), ("max_delay", C.c_int),
+        ("max_seq_len", C.c_int), ("timbre_dim", C.c_int), ("timbre_tokens", C.c_int), ("style_dim", C.c_int),
+        ("voc_dim", C.c_int), ("ar_dtype", C.c_int),
+    ]
+
+
+class SvaStreamParams(C.Structure):
+    _fields_ = [
+        ("n_streams", C.c_int), ("encode_window_frames", C.c_int), ("decode_window_frames", C.c_int),
+        ("chunk_frames", C.c_int), ("delay", C.c_int), ("max_seq_frames", C.c_int), ("buffer_frames", C.c_int),
+        ("max_prompt_frames", C.c_int), ("temperature", C.c_float), ("top_p", C.c_float),
+        ("voc_max_frames", C.c_int), ("use_graph", C.c_int), ("skip_semantic", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libsva_hip.so; raises RuntimeError (never falls back) if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The engine has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    lib.sva_last_error.restype = C.c_char_p
+    lib.sva_config_default.argtypes = [C.POINTER(SvaConfig)]
+    lib.sva_stream_params_default.argtypes = [C.POINTER(SvaStreamParams)]
+    lib.sva_engine_create.argtypes = [C.POINTER(SvaConfig), i32, C.POINTER(vp)]
+    lib.sva_engine_load_weight.argtypes = [vp, C.c_char_p, i32, C.POINTER(C.c_int64), vp]
+    lib.sva_engine_finalize.argtypes = [vp]
+    lib.sva_engine_destroy.argtypes = [vp]
+    lib.sva_engine_destroy.restype = None
+    lib.sva_batch_create.argtypes = [vp, C.POINTER(SvaStreamParams), C.POINTER(vp)]
+    lib.sva_batch_destroy.argtypes = [vp]
+    lib.sva_batch_destroy.restype = None
+    lib.sva_prefill_prompt.argtypes = [vp, i32, vp, vp, i32, vp, vp, C.c_uint64]
+    lib.sva_streams_begin.argtypes = [vp]
+    lib.sva_step.argtypes = [vp, vp, vp, vp, vp]
+    lib.sva_step_device.argtypes = [vp, vp, vp]
+    lib.sva_sync.argtypes = [vp]
+    lib.sva_encode_window.argtypes = [vp, vp, vp, vp]
+    lib.sva_vocode_window.argtypes = [vp, vp, i32, vp]
+    lib.sva_vocode_stream.argtypes = [vp, vp, i32, vp]
+    lib.sva_vocode_reset.argtypes = [vp]
+    lib.sva_get_tap.argtypes = [vp, C.c_char_p, vp, C.c_long]
+    lib.sva_get_tap.restype = C.c_long
+    lib.sva_get_timings.argtypes = [vp, f32p]
+    lib.sva_get_gemm_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "sva_last_error", "sva_config_default", "sva_stream_params_default", "sva_engine_create",
+    "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
+    "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_encode_window",
+    "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_get_tap", "sva_get_timings",
+    "sva_get_gemm_stats", "sva_test_gemm",
+]
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().sva_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# --------------------------------------------------------------------------------------------
+# derived (non-persistent) buffers of the reference modules, computed exactly as the reference does
+# --------------------------------------------------------------------------------------------
+def slaney_mel_fb(n_freqs=1025, f_min=0.0, f_max=22050.0, n_mels=160, sample_rate=44100) -> np.ndarray:
+    """LogMelSpectrogram.fb (modules/vqgan/spectrogram.py:93-101) = torchaudio.functional.
+    melscale_fbanks(norm="slaney", mel_scale="slaney") of torchaudio==2.4.0, restated with torch fp32
+    ops in the same order (torchaudio is not a dependency of this package).  [n_freqs, n_mels]."""
+    import torch
+
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+
+    def hz2mel(f):
+        return min_log_mel + math.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = torch.linspace(hz2mel(f_min), hz2mel(f_max), n_mels + 2)
+    f_pts = f_sp * m_pts
+    is_log = m_pts >= min_log_mel
+    f_pts[is_log] = min_log_hz * torch.exp(logstep * (m_pts[is_log] - min_log_mel))
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = torch.clamp(torch.min(down, up), min=0.0)
+    fb = fb * (2.0 / (f_pts[2: n_mels + 2] - f_pts[:n_mels])).unsqueeze(0)
+    return fb.numpy().astype(np.float32)
+
+
+def rope_table(seq_len: int, n_elem: int = 64, base: float = 10000.0) -> np.ndarray:
+    """precompute_freqs_cis (modules/dual_ar_stream.py:993-1001): cos/sin rounded to bf16, returned as
+    float32 [seq_len, n_elem/2, 2].  Computed with torch so the bf16 rounding matches the reference bit
+    for bit on the same host."""
+    import torch
+
+    freqs = 1.0 / (base ** (torch.arange(0, n_elem, 2)[: n_elem // 2].float() / n_elem))
+    ang = torch.outer(torch.arange(seq_len).float(), freqs)
+    tab = torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1)
+    return tab.to(torch.bfloat16).float().numpy()
+
+
+def derived_buffers(cfg: SvaConfig | None = None) -> dict:
+    import torch
+
+    out = {
+        "tok.spec_transform.fb": slaney_mel_fb(),
+        "tok.spec_transform.spectrogram.window": torch.hann_window(2048).numpy(),
+        "tok.quantizer.pre_module.freqs_cis": rope_table(2048),
+        "arvc.decoder.model.freqs_cis": rope_table(2048 if cfg is None else cfg.max_seq_len),
+        "arvc.decoder.model.fast_freqs_cis": rope_table(8 if cfg is None else cfg.num_codebooks),
+    }
+    return out
+
+
+class Engine:
+    """Weights on one MI355X.  `weights`: dict name -> array-like (numpy / torch CPU tensor) keyed by the
+    reference state-dict names prefixed with 'arvc.' / 'tok.' / 'voc.'."""
+
+    def __init__(self, weights: dict, device: int = 0, ar_dtype: int = 0):
+        self.lib = load_library()
+        self.cfg = SvaConfig()
+        _check(self.lib.sva_config_default(C.byref(self.cfg)), "sva_config_default")
+        self.cfg.ar_dtype = ar_dtype
+        self.h = C.c_void_p()
+        _check(self.lib.sva_engine_create(C.byref(self.cfg), device, C.byref(self.h)), "sva_engine_create")
+        self.device = device
+        allw = dict(derived_buffers(self.cfg))
+        allw.update(weights)
+        for name, arr in allw.items():
+            a = np.ascontiguousarray(arr.detach().cpu().numpy() if hasattr(arr, "detach") else arr, dtype=np.float32)
+            shape = (C.c_int64 * max(a.ndim, 1))(*(a.shape if a.ndim else (1,)))
+            _check(self.lib.sva_engine_load_weight(self.h, name.encode(), max(a.ndim, 1), shape, _ptr(a)),
+                   f"sva_engine_load_weight({name})")
+        _check(self.lib.sva_engine_finalize(self.h), "sva_engine_finalize")
+
+    def close(self):
+        if self.h:
+            self.lib.sva_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """B lock-step streams on one engine (InferenceWrapper.setup_stream_caches for B streams)."""
+
+    def __init__(self, engine: Engine, n_streams=1, encode_window_frames=128, decode_window_frames=64, chunk_frames=1,
+                 delay=2, max_seq_frames=768, buffer_frames=32, max_prompt_frames=256, temperature=0.7, top_p=0.7,
+                 voc_max_frames=None, use_graph=False, skip_semantic=False):
+        self.engine = engine
+        self.lib = engine.lib
+        p = SvaStreamParams()
+        _check(self.lib.sva_stream_params_default(C.byref(p)), "sva_stream_params_default")
+        p.n_streams, p.encode_window_frames, p.decode_window_frames = n_streams, encode_window_frames, decode_window_frames
+        p.chunk_frames, p.delay, p.max_seq_frames, p.buffer_frames = chunk_frames, delay, max_seq_frames, buffer_frames
+        p.max_prompt_frames, p.temperature, p.top_p = max_prompt_frames, temperature, top_p
+        p.voc_max_frames = voc_max_frames or chunk_frames
+        p.use_graph, p.skip_semantic = int(use_graph), int(skip_semantic)
+        self.p = p
+        self.B, self.chunk = n_streams, chunk_frames
+        self.h = C.c_void_p()
+        _check(self.lib.sva_batch_create(engine.h, C.byref(p), C.byref(self.h)), "sva_batch_create")
+        cfg = engine.cfg
+        self.noise_stride = cfg.ar_vocab + cfg.num_codebooks * cfg.codebook_size
+
+    def close(self):
+        if self.h:
+            self.lib.sva_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prefill_prompt(self, slot, ref_content_codes, ref_audio_codes, style, timbre, noise_seed=0):
+        cc = np.ascontiguousarray(ref_content_codes, dtype=np.int64).reshape(-1)
+        ac = np.ascontiguousarray(ref_audio_codes, dtype=np.int32).reshape(8, -1)
+        assert ac.shape[1] == cc.shape[0]
+        st = np.ascontiguousarray(style, dtype=np.float32).reshape(-1)
+        tm = np.ascontiguousarray(timbre, dtype=np.float32)
+        _check(self.lib.sva_prefill_prompt(self.h, slot, _ptr(cc), _ptr(ac), cc.shape[0], _ptr(st), _ptr(tm), int(noise_seed)),
+               "sva_prefill_prompt")
+
+    def begin(self):
+        _check(self.lib.sva_streams_begin(self.h), "sva_streams_begin")
+
+    def step(self, pcm_in, noise=None, forced_codes=None):
+        x = np.ascontiguousarray(pcm_in, dtype=np.float32).reshape(self.B, 2048 * self.chunk)
+        out = np.empty_like(x)
+        nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float32).reshape(self.B, self.chunk, self.noise_stride)
+        fc = None if forced_codes is None else np.ascontiguousarray(forced_codes, dtype=np.int32).reshape(self.B, 8, self.chunk)
+        _check(self.lib.sva_step(self.h, _ptr(x), _ptr(out), _ptr(nz), _ptr(fc)), "sva_step")
+        return out
+
+    def encode_window(self, audio, return_u=False):
+        a = np.ascontiguousarray(audio, dtype=np.float32).reshape(self.B, -1)
+        W = self.p.encode_window_frames
+        assert a.shape[1] == W * 2048
+        codes = np.empty((self.B, W), dtype=np.int64)
+        u = np.empty((self.B, W, self.engine.cfg.bsq_bits), dtype=np.float32) if return_u else None
+        _check(self.lib.sva_encode_window(self.h, _ptr(a), _ptr(codes), _ptr(u)), "sva_encode_window")
+        return (codes, u) if return_u else codes
+
+    def vocode_window(self, codes):
+        c = np.ascontiguousarray(codes, dtype=np.int32).reshape(self.B, 8, -1)
+        T = c.shape[2]
+        out = np.empty((self.B, 2048 * T), dtype=np.float32)
+        _check(self.lib.sva_vocode_window(self.h, _ptr(c), T, _ptr(out)), "sva_vocode_window")
+        return out
+
+    def vocode_stream(self, codes):
+        c = np.ascontiguousarray(codes, dtype=np.int32).reshape(self.B, 8, -1)
+        T = c.shape[2]
+        out = np.empty((self.B, 2048 * T), dtype=np.float32)
+        _check(self.lib.sva_vocode_stream(self.h, _ptr(c), T, _ptr(out)), "sva_vocode_stream")
+        return out
+
+    def vocode_reset(self):
+        _check(self.lib.sva_vocode_reset(self.h), "sva_vocode_reset")
+
+    def tap(self, what, shape, dtype=np.float32):
+        out = np.empty(shape, dtype=dtype)
+        n = self.lib.sva_get_tap(self.h, what.encode(), _ptr(out), out.nbytes)
+        if n < 0:
+            raise RuntimeError(f"sva_get_tap({what}): " + self.lib.sva_last_error().decode())
+        assert n == out.nbytes, (what, n, out.nbytes)
+        return out
+
+    def timings(self):
+        ms = (C.c_float * 4)()
+        _check(self.lib.sva_get_timings(self.h, ms), "sva_get_timings")
+        return dict(encoder=ms[0], ar=ms[1], vocoder=ms[2], total=ms[3])
+
+    def gemm_stats(self):
+        f, n = C.c_double(), C.c_long()
+        _check(self.lib.sva_get_gemm_stats(self.h, C.byref(f), C.byref(n)), "sva_get_gemm_stats")
+        return f.value, n.value
+
+
+def test_gemm(A, W, bias=None, device=0):
+    lib = load_library()
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    M, K = A.shape
+    N = W.shape[0]
+    out = np.empty((M, N), dtype=np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    _check(lib.sva_test_gemm(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out)), "sva_test_gemm")
+    return out

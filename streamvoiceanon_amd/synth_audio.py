@@ -115,6 +115,6 @@ def frame_noise(seed: int, frame: int, vocab: int = 8192, codebook_size: int = 1
     (modules/dual_ar_stream.py:1183-1216).  Keyed by utterance and frame, never by rank/slot."""
     from . import synth_weights as sw
 
-    slow = sw.exp1_noise(seed, f"slow.{frame}", vocab)
-    fast = sw.exp1_noise(seed, f"fast.{frame}", num_codebooks * codebook_size).reshape(num_codebooks, codebook_size)
+    slow = sw.exp1_noise(seed, frame, 0, vocab)
+    fast = sw.exp1_noise(seed, frame, 1, num_codebooks * codebook_size).reshape(num_codebooks, codebook_size)
     return slow, fast

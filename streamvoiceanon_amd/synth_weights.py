@@ -131,9 +131,40 @@ def generate(seed: int, name: str, shape) -> np.ndarray | None:
     return _sym(seed, name, shape, amp)
 
 
-def exp1_noise(seed: int, tag: str, n: int) -> np.ndarray:
+def _mix64(z: int) -> int:
+    z &= 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def noise_key(utt_seed: int, frame: int, kind: int) -> int:
+    """64-bit key of the sampler-noise stream for (utterance, decoded frame, kind) with
+    kind 0 = semantic/slow head, 1 = fast codebooks.  Pure integer arithmetic: the HIP
+    engine's on-device generator (csrc/kernels.hip: sampler noise) evaluates the same formula."""
+    z = ((int(utt_seed) + 1) * 0xD6E8FEB86659FD93) & 0xFFFFFFFFFFFFFFFF
+    z ^= ((int(frame) + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z ^= ((int(kind) + 1) * 0xC2B2AE3D27D4EB4F) & 0xFFFFFFFFFFFFFFFF
+    return _mix64(z)
+
+
+def u24_from_key(key: int, n: int) -> np.ndarray:
+    """top 24 bits of mix64(key + (i+1)*GOLD), i < n, as uint32."""
+    out = np.empty(n, dtype=np.uint32)
+    k = np.uint64(key)
+    with np.errstate(over="ignore"):
+        z = k + np.arange(1, n + 1, dtype=np.uint64) * _GOLD
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    out[:] = (z >> np.uint64(40)).astype(np.uint32)
+    return out
+
+
+def exp1_noise(utt_seed: int, frame: int, kind: int, n: int) -> np.ndarray:
     """Deterministic Exp(1) noise for the sampler (the reference draws it from torch's global
-    generator, modules/dual_ar_stream.py:1095; parity is defined given the same noise)."""
-    u = uniform01(seed, "noise." + tag, n).astype(np.float64)
-    u = np.maximum(u, 2.0 ** -25)
+    generator, modules/dual_ar_stream.py:1095; parity is defined given the same noise).
+    u = max(k, 0.5) / 2^24 with k the 24-bit hash; noise = -log(u) (float64 log, cast to f32)."""
+    k = u24_from_key(noise_key(utt_seed, frame, kind), n).astype(np.float64)
+    u = np.maximum(k, 0.5) * (1.0 / 16777216.0)
     return (-np.log(u)).astype(np.float32)
