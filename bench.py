@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- StreamVoiceAnon chunk-by-chunk infer_arvc hot path on MI355X.
+
+A "step" is one pass of the hot path (content encoder -> dual AR -> vocoder) over one batch of
+synthetic 44.1 kHz audio chunks: every stream of every rank consumes one 2048*chunk-sample chunk
+and emits one converted chunk (InferenceWrapper.process_one_chunk, evaluations/infer_arvc.py:492-596).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5 [--streams 1] [--chunk 1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload at N=1: BASELINE.json configs[1] -- `infer_arvc --simulate_streaming --decode_chunk_frames 1`,
+delay 2, a single stream (B=1) on one MI355X.  `--streams 64` gives configs[2].  With N>1 every
+rank runs the same number of independent streams (utterance-parallel, weak scaling) and the only
+collective is the gather of per-utterance results + a MAX of the wall time.
+
+Prints ONE JSON line (rank 0).  `value` = frames/s aggregated over all streams of all ranks with
+inputs already resident in HBM; `rtf` = per-stream real-time factor = step time / chunk duration.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAME_S = 2048 / 44100.0
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (B)")
+    ap.add_argument("--chunk", type=int, default=1, help="decode_chunk_frames")
+    ap.add_argument("--prompt-frames", type=int, default=107)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=24, help="CPU-baseline sample size (chunk-steps)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, W):
+    """The oracle ("port": build-owned CPU restatement in the reference's formulation -- sliding-window
+    recompute of encoder AND vocoder, fp32 PyTorch-CPU) timed on this box's host cores, B=1."""
+    import torch
+
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    torch.set_grad_enabled(False)
+    threads = torch.get_num_threads()
+    useed = 1000
+    ac, cc, style, timbre = synth_prompt(2000, args.prompt_frames)
+    sess = O.StreamSession(W, torch.from_numpy(cc), torch.from_numpy(ac), torch.from_numpy(style), torch.from_numpy(timbre),
+                           noise_fn=lambda f: tuple(torch.from_numpy(a) for a in frame_noise(useed, f)), delay=2,
+                           decode_chunk_frames=args.chunk)
+    n = 2048 * args.chunk
+    warm = 3                        # delay warm-up chunks + one steady step (not timed)
+    src = torch.from_numpy(synth_utterance(useed, n * (warm + args.cpu_steps)))[None]
+    for i in range(warm):
+        sess.process_one_chunk(src[:, i * n:(i + 1) * n])
+    t0 = time.perf_counter()
+    for i in range(warm, warm + args.cpu_steps):
+        sess.process_one_chunk(src[:, i * n:(i + 1) * n])
+    dt = time.perf_counter() - t0
+    fps = args.cpu_steps * args.chunk / dt
+    return {
+        "value": round(fps, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": f"{args.cpu_steps} steady-state chunk-steps of one stream (B=1, chunk={args.chunk}, window recompute as in the reference), "
+                  f"{dt:.1f} s wall, torch {torch.__version__} CPU fp32, host cpu_count={os.cpu_count()}",
+        "rtf": round(dt / args.cpu_steps / (args.chunk * FRAME_S), 3),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+
+    torch.set_grad_enabled(False)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from oracle import sva_oracle as O            # only to regenerate the synthetic weights + cpu_baseline leg
+    from streamvoiceanon_amd import engine as E, specs
+    from streamvoiceanon_amd.sharding import gather_results, shard_utterances
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    B, c = args.streams, args.chunk
+    n = 2048 * c
+    W = O.load_synth_weights(0, specs.all_specs())
+    eng = E.Engine(W, device=local_rank)
+    batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2)
+    # utterances are global ids sharded over ranks (weak scaling: B per rank)
+    my_utts = shard_utterances(list(range(world * B)), world)[rank]
+    for s, u in enumerate(my_utts):
+        ac, cc, style, timbre = synth_prompt(2000 + u, args.prompt_frames)
+        batch.prefill_prompt(s, cc, ac, style, timbre, noise_seed=1000 + u)
+    batch.begin()
+    n_delay = (2 + c - 1) // c              # chunks that only fill the delay (return zeros)
+    total_chunks = n_delay + args.warmup + args.steps + 2
+    audio = np.stack([synth_utterance(1000 + u, n * total_chunks) for u in my_utts])     # [B, n*total]
+    d_audio = torch.from_numpy(audio).cuda().reshape(B, total_chunks, n).transpose(0, 1).contiguous()   # [chunks, B, n]
+    d_out = torch.empty(B, n, device="cuda")
+    torch.cuda.synchronize()
+
+    def run(i):
+        batch.step_device(d_audio[i].data_ptr(), d_out.data_ptr())
+
+    k = 0
+    for _ in range(n_delay + args.warmup):
+        run(k); k += 1
+    batch.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run(k); k += 1
+    batch.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tm = batch.timings()
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the trivial gather of per-utterance results (codes of the last step) to rank 0
+    codes = batch.tap("audio_codes", (B, 8, c), np.int32)
+    gathered = gather_results(torch.from_numpy(codes).cuda(), world, rank)
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel = conv_gemm_kernel (f32 MFMA): algorithmic FLOPs of all its launches in one step /
+        # their summed duration, measured with hipEvents on the engine stream (2 profiled steps)
+        batch.profile_gemm(True)
+        run(k); k += 1
+        batch.sync()
+        flops, launches = batch.gemm_stats()
+        tot_ms, nl = batch.gemm_profile()
+        batch.profile_gemm(False)
+        ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "conv_gemm_kernel (v_mfma_f32_16x16x4_f32)", "achieved": round(ach, 3),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
+                "traffic": None, "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
+                "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4)}
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms = dt / args.steps * 1e3
+    fps = world * B * c * args.steps / dt
+    out = {
+        "metric": "aggregate converted frames/s (2048-sample frames @44.1 kHz), chunk-by-chunk streaming infer_arvc",
+        "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"infer_arvc --simulate_streaming --decode_chunk_frames {c}, delay=2, {B} stream(s) per GPU, "
+                               f"encode window 128 / vocoder window 64 frames, synthetic 44.1 kHz speech-like audio, "
+                               f"synthetic prompt R={args.prompt_frames}, random-init weights of the reference architecture",
+                   "streams_per_gpu": B, "chunk_frames": c, "parallelism": f"utterance-parallel x{world}"},
+        "rtf": round(ms * 1e-3 / (c * FRAME_S), 5), "x_realtime": round(fps * FRAME_S, 2),
+        "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm.items()},
+        "gathered_utterances": int(gathered.shape[0]) if gathered is not None else B,
+    }
+    if roof:
+        out["roofline"] = roof
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, W)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

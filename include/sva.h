@@ -131,6 +131,11 @@ int sva_get_timings(sva_batch* b, float ms[4]);
  * algorithmic FLOPs in the last step */
 int sva_get_gemm_stats(sva_batch* b, double* flops, long* launches);
 
+/* roofline leg of bench.py: bracket every conv-GEMM launch of the following steps with hipEvents on the
+ * engine stream; sva_get_gemm_profile returns the summed kernel time and the launch count since enabling */
+int sva_profile_gemm(sva_batch* b, int enable);
+int sva_get_gemm_profile(sva_batch* b, double* total_ms, long* launches);
+
 /* kernel unit-test hook: C = A[M,K] * W[N,K]^T (+bias) through the conv-GEMM kernel (host arrays) */
 int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C);
 

@@ -198,6 +198,9 @@ struct sva_batch {
     float last_ms[4] = {0, 0, 0, 0};
     double gemm_flops = 0;
     long gemm_launches = 0;
+    bool prof_on = false;
+    int prof_n = 0;
+    std::vector<hipEvent_t> prof_ev;
 
     // graph
     hipGraphExec_t graph_exec = nullptr;

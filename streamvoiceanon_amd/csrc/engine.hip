@@ -427,6 +427,18 @@ int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda,
     SVA_CHECK(w.K == taps * Cin, "gemm_call: weight K mismatch");
     b->gemm_flops += 2.0 * g.M * (double)g.N * w.K;
     b->gemm_launches += 1;
+    if (b->prof_on) {        // bench.py roofline leg: bracket every conv-GEMM launch with hipEvents on the launch stream
+        if (b->prof_n + 2 > (int)b->prof_ev.size()) {
+            const size_t old = b->prof_ev.size();
+            b->prof_ev.resize(old + 512);
+            for (size_t i = old; i < b->prof_ev.size(); ++i) SVA_HIP(hipEventCreate(&b->prof_ev[i]));
+        }
+        SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n], b->stream));
+        int rc = launch_conv_gemm(g, b->stream);
+        SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n + 1], b->stream));
+        b->prof_n += 2;
+        return rc;
+    }
     return launch_conv_gemm(g, b->stream);
 }
 
@@ -439,10 +451,14 @@ int conv_act(sva_batch* b, const Act& in, int T_out, int stride, int dil, int ta
                      out.bstride, (long)out.H * out.C, out.C, proto);
 }
 
-// ConvNeXtBlock in place on x rows [x.H, x.H+T)  (firefly.py:421-440)
-int cnx_block(sva_batch* b, const CNX& c, Act& x, int T, float* h1, float* h2) {
+// ConvNeXtBlock (firefly.py:421-440) on x rows [x.H, x.H+T); result into `out` rows [out.H, out.H+T)
+// (out == nullptr: in place).  The streaming vocoder must NOT run in place: the dwconv history of the next
+// step is the block INPUT, while downstream convs need history of the block OUTPUT.
+int cnx_block(sva_batch* b, const CNX& c, Act& x, int T, float* h1, float* h2, Act* out = nullptr) {
     const int C = c.C;
     SVA_CHECK(x.H >= 6 && x.C == C, "cnx_block: bad activation");
+    Act& o = out ? *out : x;
+    SVA_CHECK(o.C == C, "cnx_block: bad output activation");
     SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, b->stream));
     ConvGemm p1;
     p1.act = ACT_GELU;
@@ -450,7 +466,7 @@ int cnx_block(sva_batch* b, const CNX& c, Act& x, int T, float* h1, float* h2) {
     ConvGemm p2;
     p2.gamma = c.gamma;
     p2.res = x.p; p2.r_bstride = x.bstride; p2.r_off = (long)x.H * C; p2.ldr = C;
-    SVA_TRY(gemm_call(b, h2, (long)T * 4 * C, 0, 4 * C, b->B, T, 1, 1, 1, 4 * C, c.pw2, x.p, x.bstride, (long)x.H * C, C, p2));
+    SVA_TRY(gemm_call(b, h2, (long)T * 4 * C, 0, 4 * C, b->B, T, 1, 1, 1, 4 * C, c.pw2, o.p, o.bstride, (long)o.H * C, C, p2));
     return 0;
 }
 
@@ -779,14 +795,14 @@ int vocode(sva_batch* b, int T, bool shift) {
     hipStream_t st = b->stream;
     SVA_CHECK(T >= 1 && T <= b->Tv, "vocode: T out of range");
     SVA_TRY(launch_fsq_decode(b->d_vcodes, (long)G * b->Tv, b->Tv, B, T, G, V / G, e->fsq_W, e->fsq_b, b->zq.p, b->zq.bstride, 0, V, st));
-    // upsample.0: ConvTranspose k=s=2 (stateless) + ConvNeXtBlock  (fsq.py:61-74)
+    // upsample.0/1: ConvTranspose k=s=2 (stateless) + ConvNeXtBlock  (fsq.py:61-74)
     SVA_TRY(gemm_call(b, b->zq.p, b->zq.bstride, 0, V, B, T, 1, 1, 1, V, e->up_conv[0], b->u0.p, b->u0.bstride, (long)b->u0.H * V, 2 * V));
-    SVA_TRY(cnx_block(b, e->up_cnx[0], b->u0, 2 * T, b->vh1, b->vh2));
-    SVA_TRY(gemm_call(b, b->u0.p, b->u0.bstride, (long)b->u0.H * V, V, B, 2 * T, 1, 1, 1, V, e->up_conv[1], b->u1.p, b->u1.bstride,
+    SVA_TRY(cnx_block(b, e->up_cnx[0], b->u0, 2 * T, b->vh1, b->vh2, &b->v0));
+    SVA_TRY(gemm_call(b, b->v0.p, b->v0.bstride, 0, V, B, 2 * T, 1, 1, 1, V, e->up_conv[1], b->u1.p, b->u1.bstride,
                       (long)b->u1.H * V, 2 * V));
-    SVA_TRY(cnx_block(b, e->up_cnx[1], b->u1, 4 * T, b->vh1, b->vh2));
-    // conv_pre k13 (reads u1 with 12 history rows) -> S[0]
-    SVA_TRY(conv_act(b, b->u1, 4 * T, 1, 1, e->pre_k, e->conv_pre, b->S[0]));
+    SVA_TRY(cnx_block(b, e->up_cnx[1], b->u1, 4 * T, b->vh1, b->vh2, &b->pin));
+    // conv_pre k13 (reads the upsampler output with 12 history rows) -> S[0]
+    SVA_TRY(conv_act(b, b->pin, 4 * T, 1, 1, e->pre_k, e->conv_pre, b->S[0]));
     long Tl = 4L * T;
     for (int i = 0; i < 5; ++i) {
         const int s = e->ups_s[i];
@@ -957,12 +973,15 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     const int V = c.voc_dim;
     SVA_TRY(alloc_act(A, b->zq, B, 0, Tv, V));
     SVA_TRY(alloc_act(A, b->u0, B, 6, 2L * Tv, V));
-    SVA_TRY(alloc_act(A, b->u1, B, 12, 4L * Tv, V));      // history 12 >= 6 (dwconv) and = conv_pre k13 - 1
+    SVA_TRY(alloc_act(A, b->v0, B, 0, 2L * Tv, V));
+    SVA_TRY(alloc_act(A, b->u1, B, 6, 4L * Tv, V));
+    SVA_TRY(alloc_act(A, b->pin, B, e->pre_k - 1, 4L * Tv, V));
     SVA_TRY(dev_alloc(A, &b->vh1, (size_t)B * 4 * Tv * V));
     SVA_TRY(dev_alloc(A, &b->vh2, (size_t)B * 4 * Tv * 4 * V));
     SVA_TRY(alloc_act(A, b->S[0], B, 1, 4L * Tv, V));
     SVA_TRY(register_shift(b, b->u0, 2));
     SVA_TRY(register_shift(b, b->u1, 4));
+    SVA_TRY(register_shift(b, b->pin, 4));
     SVA_TRY(register_shift(b, b->S[0], 4));
     long rows = 4L * Tv;
     int rpf = 4;
@@ -1007,6 +1026,7 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     if (b->hp_out) hipHostFree(b->hp_out);
     if (b->ev_ok)
         for (int i = 0; i < 5; ++i) hipEventDestroy(b->ev[i]);
+    for (auto& ev : b->prof_ev) hipEventDestroy(ev);
     hipStreamDestroy(b->stream);
     delete b;
 }
@@ -1015,15 +1035,23 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
 // prompt / begin
 // ============================================================================================
 namespace {
+// All engine copies are ordered on the engine's (non-blocking) stream: a null-stream hipMemcpy from pageable
+// memory may return before its DMA lands and is NOT ordered against kernels on a non-blocking stream.
+int h2d(sva_batch* b, void* dst, const void* src, size_t bytes) {
+    SVA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream));
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
 int stage_prompt(sva_batch* b, const std::vector<int64_t>& cc, const std::vector<int32_t>& ac, int R) {
     // cc [R] int64 -> d_prompt_cc int32; ac [8][R] -> d_prompt_ac [8][Pmax]
     const int ncb = b->e->cfg.num_codebooks;
     SVA_CHECK(R <= b->Pmax, "prompt longer than the staging buffer");
     std::vector<int> c32(R);
     for (int i = 0; i < R; ++i) c32[i] = (int)cc[i];
-    SVA_HIP(hipMemcpy(b->d_prompt_cc, c32.data(), sizeof(int) * R, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpyAsync(b->d_prompt_cc, c32.data(), sizeof(int) * R, hipMemcpyHostToDevice, b->stream));
     for (int q = 0; q < ncb; ++q)
-        SVA_HIP(hipMemcpy(b->d_prompt_ac + (long)q * b->Pmax, ac.data() + (long)q * R, sizeof(int) * R, hipMemcpyHostToDevice));
+        SVA_HIP(hipMemcpyAsync(b->d_prompt_ac + (long)q * b->Pmax, ac.data() + (long)q * R, sizeof(int) * R, hipMemcpyHostToDevice, b->stream));
+    SVA_HIP(hipStreamSynchronize(b->stream));
     return 0;
 }
 }  // namespace
@@ -1036,11 +1064,10 @@ extern "C" int sva_prefill_prompt(sva_batch* b, int slot, const int64_t* ref_con
     const int ncb = c.num_codebooks;
     std::vector<int64_t> cc(ref_content_codes, ref_content_codes + R);
     std::vector<int32_t> ac(ref_audio_codes, ref_audio_codes + (size_t)ncb * R);
-    SVA_HIP(hipMemcpy(b->d_style + (long)slot * c.style_dim, style, sizeof(float) * c.style_dim, hipMemcpyHostToDevice));
-    SVA_HIP(hipMemcpy(b->d_timbre + (long)slot * c.timbre_tokens * c.timbre_dim, timbre, sizeof(float) * c.timbre_tokens * c.timbre_dim,
-                      hipMemcpyHostToDevice));
+    SVA_TRY(h2d(b, b->d_style + (long)slot * c.style_dim, style, sizeof(float) * c.style_dim));
+    SVA_TRY(h2d(b, b->d_timbre + (long)slot * c.timbre_tokens * c.timbre_dim, timbre, sizeof(float) * c.timbre_tokens * c.timbre_dim));
     unsigned long long sd = noise_seed;
-    SVA_HIP(hipMemcpy(b->d_seed + slot, &sd, sizeof(sd), hipMemcpyHostToDevice));
+    SVA_TRY(h2d(b, b->d_seed + slot, &sd, sizeof(sd)));
     // quirk (iv): the KV prefill uses the UNTRUNCATED prompt (infer_arvc.py:484-489) ...
     SVA_TRY(stage_prompt(b, cc, ac, R));
     SVA_TRY(ar_prefill_slot(b, slot, R));
@@ -1062,7 +1089,7 @@ extern "C" int sva_vocode_reset(sva_batch* b) {
         SVA_HIP(hipMemsetAsync(a.p, 0, sizeof(float) * (size_t)b->B * a.bstride, b->stream));
         return 0;
     };
-    SVA_TRY(zero(b->u0)); SVA_TRY(zero(b->u1));
+    SVA_TRY(zero(b->u0)); SVA_TRY(zero(b->u1)); SVA_TRY(zero(b->pin));
     for (int i = 0; i < 6; ++i) SVA_TRY(zero(b->S[i]));
     for (int i = 0; i < 5; ++i) {
         SVA_TRY(zero(b->X[i]));
@@ -1325,7 +1352,7 @@ extern "C" long sva_get_tap(sva_batch* b, const char* what, void* out, long out_
     else if (w == "feat") { src = b->feat.p; bytes = sizeof(float) * (long)B * b->feat.bstride; }
     else if (w == "mag") { src = b->mag; bytes = sizeof(float) * (long)B * b->T0 * 1040; }
     else if (w == "z") { src = b->tr_z; bytes = sizeof(float) * (long)B * b->T2 * c.tr_dim; }
-    else if (w == "voc_z") { src = b->u1.p; bytes = sizeof(float) * (long)B * b->u1.bstride; }
+    else if (w == "voc_z") { src = b->pin.p; bytes = sizeof(float) * (long)B * b->pin.bstride; }
     else { set_error("unknown tap " + w); return -1; }
     if (out_bytes < bytes) { set_error("tap buffer too small"); return -1; }
     if (hipStreamSynchronize(b->stream) != hipSuccess || hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
@@ -1338,6 +1365,26 @@ extern "C" long sva_get_tap(sva_batch* b, const char* what, void* out, long out_
 extern "C" int sva_get_timings(sva_batch* b, float ms[4]) {
     SVA_CHECK(b && ms, "null argument");
     for (int i = 0; i < 4; ++i) ms[i] = b->last_ms[i];
+    return 0;
+}
+extern "C" int sva_profile_gemm(sva_batch* b, int enable) {
+    SVA_CHECK(b, "null batch");
+    b->prof_on = enable != 0;
+    b->prof_n = 0;
+    return 0;
+}
+extern "C" int sva_get_gemm_profile(sva_batch* b, double* total_ms, long* launches) {
+    SVA_CHECK(b && total_ms && launches, "null argument");
+    SVA_HIP(hipSetDevice(b->e->device));
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    double tot = 0;
+    for (int i = 0; i + 1 < b->prof_n; i += 2) {
+        float t = 0;
+        SVA_HIP(hipEventElapsedTime(&t, b->prof_ev[i], b->prof_ev[i + 1]));
+        tot += t;
+    }
+    *total_ms = tot;
+    *launches = b->prof_n / 2;
     return 0;
 }
 extern "C" int sva_get_gemm_stats(sva_batch* b, double* flops, long* launches) {

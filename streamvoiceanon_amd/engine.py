@@ -74,6 +74,8 @@ def load_library():
     lib.sva_get_tap.restype = C.c_long
     lib.sva_get_timings.argtypes = [vp, f32p]
     lib.sva_get_gemm_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    lib.sva_profile_gemm.argtypes = [vp, i32]
+    lib.sva_get_gemm_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -84,7 +86,7 @@ EXPORTED_SYMBOLS = [
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
     "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_encode_window",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_get_tap", "sva_get_timings",
-    "sva_get_gemm_stats", "sva_test_gemm",
+    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_test_gemm",
 ]
 
 
@@ -278,6 +280,20 @@ class Batch:
         ms = (C.c_float * 4)()
         _check(self.lib.sva_get_timings(self.h, ms), "sva_get_timings")
         return dict(encoder=ms[0], ar=ms[1], vocoder=ms[2], total=ms[3])
+
+    def profile_gemm(self, enable=True):
+        _check(self.lib.sva_profile_gemm(self.h, int(enable)), "sva_profile_gemm")
+
+    def gemm_profile(self):
+        t, n = C.c_double(), C.c_long()
+        _check(self.lib.sva_get_gemm_profile(self.h, C.byref(t), C.byref(n)), "sva_get_gemm_profile")
+        return t.value, n.value
+
+    def step_device(self, d_in_ptr, d_out_ptr):
+        _check(self.lib.sva_step_device(self.h, C.c_void_p(d_in_ptr), C.c_void_p(d_out_ptr)), "sva_step_device")
+
+    def sync(self):
+        _check(self.lib.sva_sync(self.h), "sva_sync")
 
     def gemm_stats(self):
         f, n = C.c_double(), C.c_long()
