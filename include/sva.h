@@ -139,6 +139,10 @@ int sva_get_gemm_profile(sva_batch* b, double* total_ms, long* launches);
 /* kernel unit-test hook: C = A[M,K] * W[N,K]^T (+bias) through the conv-GEMM kernel (host arrays) */
 int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C);
 
+/* microbenchmark of the conv-GEMM dispatcher: conv over [B][(taps-1)*dil + T][Cin] -> [B][T][N]; mode bits:
+ * 1 GELU, 2 gamma+residual, 4 SiLU-on-load, 8 SwiGLU (w13); returns avg microseconds per launch in out_us[0] */
+int sva_bench_gemm(int device, int B, int T, int N, int Cin, int taps, int dil, int mode, int iters, float* out_us);
+
 #ifdef __cplusplus
 }
 #endif

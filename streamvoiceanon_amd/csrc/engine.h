@@ -67,7 +67,7 @@ struct sva_engine {
     std::vector<void*> allocs;
 
     // ---- content encoder ----
-    sva::Lin mel_fb;                       // [160][1040]  (K padded 1025 -> 1040)
+    sva::Lin mel_fb;                       // [160][1088]  (K padded 1025 -> 1088)
     float2* twiddle = nullptr;             // [1024]
     float* hann = nullptr;                 // [2048]
     sva::Lin stem;                         // conv k7 160 -> 128
@@ -123,7 +123,7 @@ struct sva_batch {
     int We = 0, N = 0, T0 = 0, T2 = 0;
     float* ring = nullptr;                 // [B][N]
     float* d_chunk = nullptr;              // [B][2048*c] staged input
-    float* mag = nullptr;                  // [B][T0][1040]
+    float* mag = nullptr;                  // [B][T0][1088]
     sva::Act mel;                          // [B][6+T0][160]
     sva::Act xs[4];                        // stage activations with 6 pad rows
     float *h1 = nullptr, *h2 = nullptr;    // [B][T0][512], [B][T0][2048]

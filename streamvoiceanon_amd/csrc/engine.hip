@@ -281,13 +281,13 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
     Packer P{e, ""};
     // ---- encoder ----
     {
-        // mel filterbank [1025][160] -> W [160][1040] (K padded with zeros)
+        // mel filterbank [1025][160] -> W [160][1088] (K padded with zeros)
         const HostTensor* fb = P.find("tok.spec_transform.fb");
         SVA_CHECK(fb && fb->numel() == 1025L * c.n_mels, "missing tok.spec_transform.fb [1025, n_mels] (host mirror supplies it)");
-        std::vector<float> w((size_t)c.n_mels * 1040, 0.f);
+        std::vector<float> w((size_t)c.n_mels * 1088, 0.f);
         for (int f = 0; f < 1025; ++f)
-            for (int m = 0; m < c.n_mels; ++m) w[(size_t)m * 1040 + f] = fb->data[(size_t)f * c.n_mels + m];
-        e->mel_fb.N = c.n_mels; e->mel_fb.K = 1040; e->mel_fb.b = nullptr;
+            for (int m = 0; m < c.n_mels; ++m) w[(size_t)m * 1088 + f] = fb->data[(size_t)f * c.n_mels + m];
+        e->mel_fb.N = c.n_mels; e->mel_fb.K = 1088; e->mel_fb.b = nullptr;
         SVA_TRY(upload(e->allocs, &e->mel_fb.W, w));
         std::vector<float> hann(2048);
         for (int i = 0; i < 2048; ++i) hann[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / 2048.0));   // torch.hann_window (periodic)
@@ -476,11 +476,11 @@ int encode(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
     const sva_config& c = e->cfg;
     const int B = b->B, T0 = b->T0;
     hipStream_t st = b->stream;
-    SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, b->mag, 1040, st));
+    SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, b->mag, 1088, st));
     {   // mel = log(clamp(fb^T mag, 1e-5))  (spectrogram.py:110-115, 124-125)
         ConvGemm p;
         p.act = ACT_LOGCLAMP;
-        SVA_TRY(gemm_call(b, b->mag, (long)T0 * 1040, 0, 1040, B, T0, 1, 1, 1, 1040, e->mel_fb, b->mel.p, b->mel.bstride,
+        SVA_TRY(gemm_call(b, b->mag, (long)T0 * 1088, 0, 1088, B, T0, 1, 1, 1, 1088, e->mel_fb, b->mel.p, b->mel.bstride,
                           (long)b->mel.H * c.n_mels, c.n_mels, p));
     }
     // stem: causal conv k7 + LayerNorm(channels)  (firefly.py:458-468)
@@ -897,7 +897,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     const int T0 = b->T0;
     SVA_TRY(dev_alloc(A, &b->ring, (size_t)B * b->N));
     SVA_TRY(dev_alloc(A, &b->d_chunk, (size_t)B * 2048 * chunk));
-    SVA_TRY(dev_alloc(A, &b->mag, (size_t)B * T0 * 1040));
+    SVA_TRY(dev_alloc(A, &b->mag, (size_t)B * T0 * 1088));
     SVA_TRY(alloc_act(A, b->mel, B, 6, T0, c.n_mels));
     for (int i = 0; i < 4; ++i) SVA_TRY(alloc_act(A, b->xs[i], B, 6, T0, c.enc_dims[i]));
     const int Dm = c.tr_dim;
@@ -1350,7 +1350,7 @@ extern "C" long sva_get_tap(sva_batch* b, const char* what, void* out, long out_
     else if (w == "u") { src = b->d_u; bytes = sizeof(float) * (long)B * b->T2 * c.bsq_bits; }
     else if (w == "mel") { src = b->mel.p; bytes = sizeof(float) * (long)B * b->mel.bstride; }
     else if (w == "feat") { src = b->feat.p; bytes = sizeof(float) * (long)B * b->feat.bstride; }
-    else if (w == "mag") { src = b->mag; bytes = sizeof(float) * (long)B * b->T0 * 1040; }
+    else if (w == "mag") { src = b->mag; bytes = sizeof(float) * (long)B * b->T0 * 1088; }
     else if (w == "z") { src = b->tr_z; bytes = sizeof(float) * (long)B * b->T2 * c.tr_dim; }
     else if (w == "voc_z") { src = b->pin.p; bytes = sizeof(float) * (long)B * b->pin.bstride; }
     else { set_error("unknown tap " + w); return -1; }

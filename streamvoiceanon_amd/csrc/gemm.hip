@@ -13,35 +13,43 @@
 
 namespace sva {
 
+#define SVA_TRY_RC(expr)     \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
-    constexpr int BK = 16;
     constexpr int TM = BM / WM, TN = BN / WN;     // wave tile
     constexpr int MI = TM / 16, NI = TN / 16;
-    constexpr int LDA_S = BM + 16, LDB_S = BN + 16;
-    constexpr int A_LD = (BM * 4 + 255) / 256;    // float4 loads per thread per tile
-    constexpr int B_LD = (BN * 4 + 255) / 256;
+    constexpr int LS = BK + 2;                    // LDS row stride: (2*row + k) % 32 is conflict-free for ds_read_b32
+    constexpr int F4R = BK / 4;                   // float4 per tile row
+    constexpr int RPP = 256 / F4R;                // rows covered per pass of the 256 threads
+    constexpr int A_LD = (BM + RPP - 1) / RPP;
+    constexpr int B_LD = (BN + RPP - 1) / RPP;
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ float As[2][BK][LDA_S];
-    __shared__ float Bs[2][BK][LDB_S];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                             // [2][BM][LS]
+    float* Bs = smem + 2 * BM * LS;               // [2][BN][LS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
-    const int kq = tid & 3;                       // which float4 of the 16-wide k tile
-    const int lrow = tid >> 2;                    // 0..63
+    const int kq = tid % F4R;                     // which float4 of the BK-wide k tile
+    const int lrow = tid / F4R;
 
     const float* a_ptr[A_LD];
     bool a_on[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        int r = lrow + i * 64;
+        int r = lrow + i * RPP;
         a_on[i] = r < BM;
         int m = bm0 + r;
         if (m > g.M - 1) m = g.M - 1;
@@ -53,7 +61,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
     const long Kt = (long)g.taps * g.Cin;
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-        int r = lrow + i * 64;
+        int r = lrow + i * RPP;
         b_on[i] = r < BN;
         int n = bn0 + r;
         if (n > g.N - 1) n = g.N - 1;
@@ -88,21 +96,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
             if (a_on[i]) {
                 float4 v = ra[i];
                 if (g.a_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                int r = lrow + i * 64;
-                As[buf][kq * 4 + 0][r] = v.x;
-                As[buf][kq * 4 + 1][r] = v.y;
-                As[buf][kq * 4 + 2][r] = v.z;
-                As[buf][kq * 4 + 3][r] = v.w;
+                float* d = As + ((buf * BM + lrow + i * RPP) * LS + kq * 4);     // 8-byte aligned (LS even)
+                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
             }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i)
             if (b_on[i]) {
                 float4 v = rb[i];
-                int r = lrow + i * 64;
-                Bs[buf][kq * 4 + 0][r] = v.x;
-                Bs[buf][kq * 4 + 1][r] = v.y;
-                Bs[buf][kq * 4 + 2][r] = v.z;
-                Bs[buf][kq * 4 + 3][r] = v.w;
+                float* d = Bs + ((buf * BN + lrow + i * RPP) * LS + kq * 4);
+                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
             }
     };
 
@@ -113,13 +117,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
+        const float* Ab = As + (buf * BM + wm * TM + fr) * LS + fk;
+        const float* Bb = Bs + (buf * BN + wn * TN + fr) * LS + fk;
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 4) {
             float af[MI], bf[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = As[buf][ks + fk][wm * TM + i * 16 + fr];
+            for (int i = 0; i < MI; ++i) af[i] = Ab[i * 16 * LS + ks];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = Bs[buf][ks + fk][wn * TN + j * 16 + fr];
+            for (int j = 0; j < NI; ++j) bf[j] = Bb[j * 16 * LS + ks];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
 #pragma unroll
                     for (int j = 0; j < NI; j += 2) {
                         const int n = bn0 + wn * TN + j * 16 + col;       // w1 column (even 16-group)
-                        if (n + 16 < g.N + 16 && n < g.N) {
+                        if (n < g.N) {
                             float a = acc[i][j][r], bb = acc[i][j + 1][r];
                             const int no = ((bn0 + wn * TN + j * 16) >> 1) + col;
                             crow[no] = silu_f(a) * bb;
@@ -173,10 +179,161 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-static void launch_t(const ConvGemm& g, hipStream_t st) {
+// ------------------------------------------------------------------------------------------
+// small-M ("skinny") path: M <= 64 rows -- the AR decode GEMMs (M = 2B / B tokens) and the streaming
+// vocoder's first levels.  These are weight-streaming problems: the tiled kernel above would run a
+// handful of workgroups through a long serial K loop (one 16-wide tile in flight per barrier) and sit on
+// HBM/L2 latency.  Here a workgroup owns 16*NT output columns and ALL rows; its KW waves split the K axis
+// (interleaved 16-wide blocks), every lane streams one float4 of W and one float4 of A per block straight
+// from global memory into the MFMA operands (no LDS, no barrier in the loop, loads software-pipelined by
+// unrolling), and the KW partial accumulators are reduced through LDS once at the end.
+// Operand mapping: lane l supplies, for MFMA step j of a block, W[n0 + (l&15)][k0 + 4*(l>>4) + j] and
+// A[m0 + (l&15)][k0 + 4*(l>>4) + j] -- a permutation of k inside the block, identical on both operands.
+// ------------------------------------------------------------------------------------------
+template <int MT, int NT, int KW>
+__global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [KW][MT*NT][64][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * (16 * NT);
+    const int m_base = blockIdx.y * (16 * MT);
+    const int fr = lane & 15, fg = lane >> 4;
+    const long Kt = (long)g.taps * g.Cin;
+    const float* wp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int n = n0 + j * 16 + fr;
+        if (n > g.N - 1) n = g.N - 1;
+        wp[j] = g.W + (long)n * Kt + 4 * fg;
+    }
+    const float* ap[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = m_base + i * 16 + fr;
+        if (m > g.M - 1) m = g.M - 1;
+        const int b = m / g.T, t = m - b * g.T;
+        ap[i] = g.A + (long)b * g.a_bstride + g.a_off + (long)t * g.stride * g.lda + 4 * fg;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int kc_tiles = g.Cin / 16;
+    const int nk = g.taps * kc_tiles;
+#pragma unroll 4
+    for (int kb = wave; kb < nk; kb += KW) {
+        const int tap = kb / kc_tiles;
+        const int kc = (kb - tap * kc_tiles) * 16;
+        const long aoff = (long)tap * g.dil * g.lda + kc;
+        const long woff = (long)tap * g.Cin + kc;
+        float4 wv[NT], av[MT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wv[j] = *reinterpret_cast<const float4*>(wp[j] + woff);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            av[i] = *reinterpret_cast<const float4*>(ap[i] + aoff);
+            if (g.a_silu) { av[i].x = silu_f(av[i].x); av[i].y = silu_f(av[i].y); av[i].z = silu_f(av[i].z); av[i].w = silu_f(av[i].w); }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, wv[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, wv[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, wv[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, wv[j].w, acc[i][j], 0, 0, 0);
+            }
+    }
+    // cross-wave reduction of the K slices
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            *reinterpret_cast<f32x4*>(&red[((wave * (MT * NT) + i * NT + j) * 64 + lane) * 4]) = acc[i][j];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4 s = acc[i][j];
+            for (int w = 1; w < KW; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * (MT * NT) + i * NT + j) * 64 + lane) * 4]);
+            acc[i][j] = s;
+        }
+    const int col = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m_base + i * 16 + rq + r;
+            if (m >= g.M) continue;
+            const int b = m / g.T, t = m - b * g.T;
+            float* crow = g.C + (long)b * g.c_bstride + g.c_off + (long)t * g.ldc;
+            const float* rrow = g.res ? g.res + (long)b * g.r_bstride + g.r_off + (long)t * g.ldr : nullptr;
+            if (g.w13) {
+                if constexpr (NT == 2) {
+                    const int n = n0 + col;
+                    if (n < g.N) crow[(n0 >> 1) + col] = silu_f(acc[i][0][r]) * acc[i][1][r];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = n0 + j * 16 + col;
+                    if (n >= g.N) continue;
+                    float v = acc[i][j][r];
+                    if (g.bias) v += g.bias[n];
+                    if (g.act == ACT_GELU) v = gelu_erf(v);
+                    else if (g.act == ACT_LOGCLAMP) v = __logf(fmaxf(v, 1e-5f));
+                    if (g.gamma) v *= g.gamma[n];
+                    if (rrow) v += rrow[n];
+                    v *= g.scale;
+                    if (g.accumulate) v += crow[n];
+                    crow[n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int MT, int NT, int KW>
+static int launch_skinny(const ConvGemm& g, hipStream_t st) {
+    const size_t smem = (size_t)KW * MT * NT * 256 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && smem > 48 * 1024) {
+        SVA_HIP(hipFuncSetAttribute((const void*)skinny_gemm_kernel<MT, NT, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((g.N + 16 * NT - 1) / (16 * NT), (g.M + 16 * MT - 1) / (16 * MT));
+    hipLaunchKernelGGL((skinny_gemm_kernel<MT, NT, KW>), grid, dim3(64 * KW), smem, st, g);
+    return 0;
+}
+
+template <int NT>
+static int dispatch_skinny(const ConvGemm& g, hipStream_t st) {
+    const int mt = g.M > 64 ? 4 : (g.M + 15) / 16;
+    const long nk = (long)g.taps * g.Cin / 16;
+    const long cols = (long)((g.N + 16 * NT - 1) / (16 * NT)) * ((g.M + 16 * mt - 1) / (16 * mt));
+    // many K blocks and few workgroups -> spread K over 8/16 waves, else 4
+    const bool wide = nk >= 64 && cols < 256;
+    switch (mt) {
+        case 1: return wide ? launch_skinny<1, NT, 16>(g, st) : launch_skinny<1, NT, 4>(g, st);
+        case 2: return wide ? launch_skinny<2, NT, 8>(g, st) : launch_skinny<2, NT, 4>(g, st);
+        case 3: return wide ? launch_skinny<3, NT, 8>(g, st) : launch_skinny<3, NT, 4>(g, st);
+        default: return wide ? launch_skinny<4, NT, 8>(g, st) : launch_skinny<4, NT, 4>(g, st);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int BK>
+static int launch_t(const ConvGemm& g, hipStream_t st) {
+    constexpr size_t smem = (size_t)2 * (BM + BN) * (BK + 2) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && smem > 48 * 1024) {
+        SVA_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK>), grid, dim3(256), smem, st, g);
+    return 0;
 }
 
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
@@ -184,20 +341,27 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
     SVA_CHECK(g.lda % 4 == 0 && (g.a_off % 4) == 0 && (g.a_bstride % 4) == 0, "conv_gemm: A must be float4-aligned");
     SVA_CHECK(g.M > 0 && g.N > 0 && g.T > 0, "conv_gemm: empty problem");
     if (g.w13) SVA_CHECK(g.N % 32 == 0, "conv_gemm: w13 needs N % 32 == 0");
-    // tile selection: fill >= ~256 workgroups where the problem allows it
+    // tile selection: the K tile is as deep as Cin allows (bytes in flight per workgroup hide the L2/HBM
+    // latency of the register-staged pipeline); 128x128 tiles only when they still fill the 256 CUs
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (g.N <= 16 && !g.w13) {
-        launch_t<256, 16, 4, 1>(g, st);
+    const int bk = g.Cin % 64 == 0 ? 64 : (g.Cin % 32 == 0 ? 32 : 16);
+    // under-filled grids (fewer than ~1 tiled workgroup per CU): the barrier-free K-split kernel keeps far more
+    // loads in flight per CU than the LDS-staged one and pays for it with extra L2 reads, which are cheap there
+    const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+    if (g.M <= 64 || (tiles64 < 256 && g.N >= 64)) {
+        SVA_TRY_RC(g.w13 ? dispatch_skinny<2>(g, st) : dispatch_skinny<1>(g, st));
+    } else if (g.N <= 16 && !g.w13) {
+        SVA_TRY_RC((launch_t<256, 16, 4, 1, 16>(g, st)));
     } else if (g.N <= 32) {
-        launch_t<128, 32, 4, 1>(g, st);
-    } else if (g.M <= 16) {
-        launch_t<16, 128, 1, 4>(g, st);
-    } else if (g.M <= 32) {
-        launch_t<32, 128, 1, 4>(g, st);
+        if (bk >= 32) SVA_TRY_RC((launch_t<128, 32, 4, 1, 32>(g, st)));
+        else SVA_TRY_RC((launch_t<128, 32, 4, 1, 16>(g, st)));
     } else if (big >= 256) {
-        launch_t<128, 128, 2, 2>(g, st);
+        if (bk >= 32) SVA_TRY_RC((launch_t<128, 128, 2, 2, 32>(g, st)));
+        else SVA_TRY_RC((launch_t<128, 128, 2, 2, 16>(g, st)));
     } else {
-        launch_t<64, 64, 2, 2>(g, st);
+        if (bk == 64) SVA_TRY_RC((launch_t<64, 64, 2, 2, 64>(g, st)));
+        else if (bk == 32) SVA_TRY_RC((launch_t<64, 64, 2, 2, 32>(g, st)));
+        else SVA_TRY_RC((launch_t<64, 64, 2, 2, 16>(g, st)));
     }
     SVA_HIP(hipGetLastError());
     return 0;

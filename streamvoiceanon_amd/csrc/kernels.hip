@@ -272,7 +272,9 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float* __restr
     }
     __syncthreads();
     const float scale = 0.125f;          // 1/sqrt(64)
-    for (int r = wave; r < T; r += 4) {  // T % 4 == 0: uniform trip count, barriers are legal
+    // query rows interleaved over (blockIdx.z, wave) so the causal work is balanced; T % (4*gridDim.z) == 0
+    // keeps the trip count uniform across the workgroup's waves (barriers inside the loop)
+    for (int r = blockIdx.z * 4 + wave; r < T; r += 4 * gridDim.z) {
         if (lane < HD / 2) {
             const float* row = base + (long)r * 3 * D + h * HD;
             const float q0 = row[2 * lane], q1 = row[2 * lane + 1];
@@ -314,7 +316,9 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
         SVA_HIP(hipFuncSetAttribute((const void*)enc_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(enc_attention_kernel, dim3(H, B), dim3(256), smem, st, qkv, rope, T, H, out);
+    int qs = 1;
+    while (qs < 8 && T % (8 * qs) == 0 && (long)H * B * qs < 256) qs *= 2;
+    hipLaunchKernelGGL(enc_attention_kernel, dim3(H, B, qs), dim3(256), smem, st, qkv, rope, T, H, out);
     SVA_HIP(hipGetLastError());
     return 0;
 }

@@ -1,6 +1,7 @@
 // Kernel unit-test hooks exported through the C ABI (include/sva.h: sva_test_*).
 #include "../../include/sva.h"
 #include "kernels.h"
+#include <algorithm>
 #include <vector>
 
 using namespace sva;
@@ -24,6 +25,54 @@ extern "C" int sva_test_gemm(int device, int M, int N, int K, const float* A, co
     if (rc) return rc;
     SVA_HIP(hipDeviceSynchronize());
     SVA_HIP(hipMemcpy(C, dC, sizeof(float) * (size_t)M * N, hipMemcpyDeviceToHost));
-    hipFree(dA); hipFree(dW); hipFree(dC); if (dB) hipFree(dB);
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); if (dB) (void)hipFree(dB);
+    return 0;
+}
+
+// microbenchmark of the conv-GEMM dispatcher on device-resident random data:
+//   out_us[0] = average microseconds per launch over `iters` back-to-back launches (hipEvents)
+// mode bits: 1 = GELU epilogue, 2 = residual + gamma, 4 = silu-on-load, 8 = w13
+extern "C" int sva_bench_gemm(int device, int B, int T, int N, int Cin, int taps, int dil, int mode, int iters, float* out_us) {
+    SVA_HIP(hipSetDevice(device));
+    const int H = (taps - 1) * dil;
+    const long rows = H + T;
+    float *dA, *dW, *dB, *dC, *dR;
+    const long K = (long)taps * Cin;
+    const int Nout = (mode & 8) ? N / 2 : N;
+    SVA_HIP(hipMalloc(&dA, sizeof(float) * (size_t)B * rows * Cin));
+    SVA_HIP(hipMalloc(&dW, sizeof(float) * (size_t)N * K));
+    SVA_HIP(hipMalloc(&dB, sizeof(float) * N));
+    SVA_HIP(hipMalloc(&dC, sizeof(float) * (size_t)B * T * Nout));
+    SVA_HIP(hipMalloc(&dR, sizeof(float) * (size_t)B * T * Nout));
+    std::vector<float> h((size_t)std::max<long>((long)B * rows * Cin, (long)N * K));
+    unsigned s = 12345;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+    SVA_HIP(hipMemcpy(dA, h.data(), sizeof(float) * (size_t)B * rows * Cin, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(dW, h.data(), sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemset(dB, 0, sizeof(float) * N));
+    SVA_HIP(hipMemset(dR, 0, sizeof(float) * (size_t)B * T * Nout));
+    ConvGemm g;
+    g.A = dA; g.a_bstride = rows * Cin; g.a_off = 0; g.lda = Cin; g.T = T; g.M = B * T; g.Cin = Cin; g.taps = taps; g.dil = dil;
+    g.W = dW; g.N = N; g.bias = (mode & 8) ? nullptr : dB; g.C = dC; g.c_bstride = (long)T * Nout; g.ldc = Nout;
+    if (mode & 1) g.act = ACT_GELU;
+    if (mode & 2) { g.res = dR; g.r_bstride = (long)T * Nout; g.ldr = Nout; g.gamma = dB; }
+    if (mode & 4) g.a_silu = 1;
+    if (mode & 8) g.w13 = 1;
+    hipStream_t st;
+    SVA_HIP(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    SVA_HIP(hipEventCreate(&e0));
+    SVA_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) { int rc = launch_conv_gemm(g, st); if (rc) return rc; }
+    SVA_HIP(hipStreamSynchronize(st));
+    SVA_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) { int rc = launch_conv_gemm(g, st); if (rc) return rc; }
+    SVA_HIP(hipEventRecord(e1, st));
+    SVA_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    SVA_HIP(hipEventElapsedTime(&ms, e0, e1));
+    out_us[0] = ms * 1e3f / iters;
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dR);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
     return 0;
 }

@@ -76,6 +76,7 @@ def load_library():
     lib.sva_get_gemm_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.sva_profile_gemm.argtypes = [vp, i32]
     lib.sva_get_gemm_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    lib.sva_bench_gemm.argtypes = [i32] * 9 + [f32p]
     lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -86,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
     "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_encode_window",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_get_tap", "sva_get_timings",
-    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_test_gemm",
+    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_test_gemm", "sva_bench_gemm",
 ]
 
 
@@ -311,3 +312,11 @@ def test_gemm(A, W, bias=None, device=0):
     b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
     _check(lib.sva_test_gemm(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out)), "sva_test_gemm")
     return out
+
+
+def bench_gemm(B, T, N, Cin, taps=1, dil=1, mode=0, iters=50, device=0):
+    """average microseconds per conv-GEMM launch (device-resident random data)"""
+    lib = load_library()
+    out = (C.c_float * 1)()
+    _check(lib.sva_bench_gemm(device, B, T, N, Cin, taps, dil, mode, iters, out), "sva_bench_gemm")
+    return float(out[0])

@@ -43,7 +43,8 @@ def test_conv_gemm_kernel_vs_fp64():
     rng = np.random.RandomState(0)
     # asymmetric operands (a transposed C write would be caught), ragged M / N edges, every tile config
     for (M, N, K) in [(512, 512, 128), (1024, 2048, 512), (100, 13, 512), (2, 2304, 768), (7, 8192, 768), (3000, 16, 48),
-                      (64, 1000, 768), (2048, 32, 96), (33, 768, 128), (1, 768, 192)]:
+                      (64, 1000, 768), (2048, 32, 96), (33, 768, 128), (1, 768, 192), (17, 2304, 2304), (48, 256, 2816),
+                      (4, 2048, 1024), (65, 768, 768), (16, 4608, 768)]:
         A = rng.randn(M, K).astype(np.float32)
         W = rng.randn(N, K).astype(np.float32)
         b = rng.randn(N).astype(np.float32)

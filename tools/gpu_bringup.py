@@ -38,7 +38,7 @@ def run(name, fn):
 def t_gemm():
     rng = np.random.RandomState(0)
     for (M, N, K) in [(512, 512, 128), (512, 2048, 512), (100, 13, 512), (2, 2304, 768), (7, 8192, 768), (3000, 16, 48),
-                      (64, 1000, 768), (2048, 32, 96), (33, 768, 128), (512, 160, 1040)]:
+                      (64, 1000, 768), (2048, 32, 96), (33, 768, 128), (512, 160, 1088)]:
         A = rng.randn(M, K).astype(np.float32)
         W = rng.randn(N, K).astype(np.float32)
         b = rng.randn(N).astype(np.float32)
@@ -75,7 +75,7 @@ def t_enc():
     print("codes equal:", np.array_equal(codes, ref[0].numpy()), "mismatches", int((codes != ref[0].numpy()).sum()))
     mel = b.tap("mel", (2, 6 + 512, 160))[:, 6:]
     print("mel maxdiff", np.abs(mel - taps["mel"].transpose(1, 2).numpy()).max())
-    mag = b.tap("mag", (2, 512, 1040))[:, :, :1025]
+    mag = b.tap("mag", (2, 512, 1088))[:, :, :1025]
     print("mag maxdiff", np.abs(mag - O.stft_magnitude(torch.from_numpy(x)).transpose(1, 2).numpy()).max(), "mag max", mag.max())
     feat = b.tap("feat", (2, 512, 512))
     print("feat maxdiff", np.abs(feat - taps["feat"].transpose(1, 2).numpy()).max())
