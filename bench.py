@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24, help="CPU-baseline sample size (chunk-steps)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying the captured hipGraph")
     return ap.parse_args()
 
 
@@ -106,7 +107,7 @@ def main():
     n = 2048 * c
     W = O.load_synth_weights(0, specs.all_specs())
     eng = E.Engine(W, device=local_rank)
-    batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2)
+    batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=not args.no_graph)
     # utterances are global ids sharded over ranks (weak scaling: B per rank)
     my_utts = shard_utterances(list(range(world * B)), world)[rank]
     for s, u in enumerate(my_utts):
@@ -176,7 +177,8 @@ def main():
         "config": {"workload": f"infer_arvc --simulate_streaming --decode_chunk_frames {c}, delay=2, {B} stream(s) per GPU, "
                                f"encode window 128 / vocoder window 64 frames, synthetic 44.1 kHz speech-like audio, "
                                f"synthetic prompt R={args.prompt_frames}, random-init weights of the reference architecture",
-                   "streams_per_gpu": B, "chunk_frames": c, "parallelism": f"utterance-parallel x{world}"},
+                   "streams_per_gpu": B, "chunk_frames": c, "parallelism": f"utterance-parallel x{world}",
+                   "hipgraph": not args.no_graph},
         "rtf": round(ms * 1e-3 / (c * FRAME_S), 5), "x_realtime": round(fps * FRAME_S, 2),
         "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm.items()},
         "gathered_utterances": int(gathered.shape[0]) if gathered is not None else B,

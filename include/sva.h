@@ -121,6 +121,14 @@ int sva_vocode_window(sva_batch* b, const int32_t* codes, int T, float* pcm_out)
 int sva_vocode_stream(sva_batch* b, const int32_t* codes, int T, float* pcm_out);
 int sva_vocode_reset(sva_batch* b);
 
+/* AR seams with caller-supplied content codes (chunk_frames == 1):
+ *   ARVCWrapper.prefill_src_condition4delay (modules/arvc_wrapper.py:114-119): codes int64[B][delay]
+ *   ARVCWrapper.decode_one (:121-126 -> dual_ar_stream.py:817-837): code int64[B] -> codes_out int32[B][8],
+ *   pos_out int32[B] (kv_pos[-1]); noise float[B][vocab + 8*codebook_size] or NULL; forced int32[B][8] or NULL */
+int sva_ar_delay_fill(sva_batch* b, const int64_t* codes);
+int sva_ar_decode_one(sva_batch* b, const int64_t* code, const float* noise, const int32_t* forced, int32_t* codes_out,
+                      int32_t* pos_out);
+
 /* taps of the last step: "content_codes" int32[B][chunk], "audio_codes" int32[B][8][chunk] (as int32),
  * "slow_logits" float[B][vocab], "fast_logits" float[B][8][codebook_size], "hidden" float[B][dim],
  * "semantic" int32[B], "last_pos" int32[B], "mel" float[B][T][160] ... ; returns #bytes or <0 */

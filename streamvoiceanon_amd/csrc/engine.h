@@ -205,4 +205,7 @@ struct sva_batch {
     // graph
     hipGraphExec_t graph_exec = nullptr;
     bool graph_ready = false;
+    bool graph_step = false;       // last step ran through the graph (no per-stage events)
+    bool forced_now = false;
+    int steady_eager_steps = 0;
 };

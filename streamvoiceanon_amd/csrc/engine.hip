@@ -1165,7 +1165,7 @@ extern "C" int sva_streams_begin(sva_batch* b) {
         SVA_TRY(sva_vocode_stream(b, codes.data(), c, sink.data()));
     }
     b->begun = true;
-    b->graph_ready = false;
+    b->steady_eager_steps = 0;     // (a captured graph stays valid: every pointer / constant in it is unchanged)
     return 0;
 }
 
@@ -1204,11 +1204,75 @@ int reprefill_slot(sva_batch* b, int slot) {
     return 0;
 }
 
+// device work of one steady-state chunk: E0..E8, c AR frames, streaming vocoder, history shift.  Only launches
+// on b->stream with device-resident control state, so the sequence can be captured in a hipGraph.
+int steady_launches(sva_batch* b, bool timing_events) {
+    const sva_config& c = b->e->cfg;
+    const int B = b->B, chunk = b->p.chunk_frames, n = 2048 * chunk, ncb = c.num_codebooks;
+    hipStream_t st = b->stream;
+    if (timing_events) SVA_HIP(hipEventRecord(b->ev[0], st));
+    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->d_chunk, n, st));
+    SVA_TRY(encode(b, b->d_step, n, 1));
+    hipLaunchKernelGGL(inc_kernel, dim3(1), dim3(64), 0, st, b->d_step, 1);
+    hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
+                       b->d_ncontent, b->d_step_content, B);
+    if (timing_events) SVA_HIP(hipEventRecord(b->ev[1], st));
+    for (int ci = 0; ci < chunk; ++ci) SVA_TRY(ar_decode_frame(b, ci));          // :534-538
+    if (timing_events) SVA_HIP(hipEventRecord(b->ev[2], st));
+    SVA_HIP(hipMemcpy2DAsync(b->d_vcodes, sizeof(int) * b->Tv, b->d_step_audio, sizeof(int) * chunk, sizeof(int) * chunk, (size_t)B * ncb,
+                             hipMemcpyDeviceToDevice, st));
+    SVA_TRY(vocode(b, chunk, true));
+    if (timing_events) SVA_HIP(hipEventRecord(b->ev[3], st));
+    return 0;
+}
+
 int step_body(sva_batch* b) {
     sva_engine* e = b->e;
-    const sva_config& c = e->cfg;
-    const int B = b->B, chunk = b->p.chunk_frames, d = b->p.delay, n = 2048 * chunk, ncb = c.num_codebooks;
+    (void)e;
+    const int B = b->B, chunk = b->p.chunk_frames, d = b->p.delay, n = 2048 * chunk;
     hipStream_t st = b->stream;
+    const bool steady = b->delay_filled && (b->h_ncontent + chunk >= d);
+    if (steady) {
+        const bool graph_ok = b->p.use_graph && b->noise_on_device && !b->forced_now && !b->prof_on;
+        if (graph_ok && b->steady_eager_steps >= 2) {
+            if (!b->graph_ready) {
+                // capture once: every launch argument is a fixed device pointer or a constant; per-step variation
+                // (ring position, KV positions, frame counters, sampler noise keys) lives in device memory
+                hipGraph_t graph = nullptr;
+                SVA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                int rc = steady_launches(b, false);
+                hipError_t ce = hipStreamEndCapture(st, &graph);
+                if (rc) return rc;
+                SVA_HIP(ce);
+                SVA_HIP(hipGraphInstantiate(&b->graph_exec, graph, nullptr, nullptr, 0));
+                SVA_HIP(hipGraphDestroy(graph));
+                b->graph_ready = true;
+            }
+            SVA_HIP(hipEventRecord(b->ev[0], st));
+            SVA_HIP(hipGraphLaunch(b->graph_exec, st));
+            SVA_HIP(hipEventRecord(b->ev[3], st));
+            b->graph_step = true;
+        } else {
+            SVA_TRY(steady_launches(b, true));
+            b->steady_eager_steps += 1;
+            b->graph_step = false;
+        }
+        b->h_step += 1;
+        b->h_ncontent += chunk;
+        for (int i = 0; i < B; ++i) { b->h_last_pos[i] += 2 * chunk; b->h_nframes[i] += chunk; }
+        // re-prefill when current_pos // 2 >= max_seq_frames (:547-564).  Positions are deterministic, so the host
+        // mirror decides without a device round trip; doing it after the vocoder instead of before (as the reference
+        // does) changes nothing: the vocoder consumes the codes just decoded, the re-prefill only rewrites KV state.
+        bool any = false;
+        for (int i = 0; i < B; ++i)
+            if (b->h_last_pos[i] / 2 >= b->p.max_seq_frames) { SVA_TRY(reprefill_slot(b, i)); any = true; }
+        if (any) {
+            for (int i = 0; i < B; ++i) SVA_CHECK(b->h_last_pos[i] == b->h_last_pos[0], "re-prefill needs equal positions across slots in this round");
+            SVA_TRY(ar_delay_fill(b));
+        }
+        return 0;
+    }
+    b->graph_step = false;
     SVA_HIP(hipEventRecord(b->ev[0], st));
     // E0: shift window / append chunk (:495-496), then E1..E8
     SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->d_chunk, n, st));
@@ -1219,41 +1283,12 @@ int step_body(sva_batch* b) {
     b->h_step += 1;
     b->h_ncontent += chunk;
     SVA_HIP(hipEventRecord(b->ev[1], st));
-    bool produced = false;
-    if (b->h_ncontent < d) {
-        // :519-520 -> zeros
-    } else if (!b->delay_filled) {
+    if (b->h_ncontent >= d && !b->delay_filled) {
         SVA_TRY(ar_delay_fill(b));                      // :521-525 -> zeros
         b->delay_filled = true;
-    } else {
-        for (int ci = 0; ci < chunk; ++ci) {            // :534-538
-            SVA_TRY(ar_decode_frame(b, ci));
-            for (int i = 0; i < B; ++i) { b->h_last_pos[i] += 2; b->h_nframes[i] += 1; }
-        }
-        produced = true;
-    }
+    }                                                   // else :519-520 -> zeros
     SVA_HIP(hipEventRecord(b->ev[2], st));
-    if (produced) {
-        // re-prefill when current_pos // 2 >= max_seq_frames (:547-564); positions are deterministic, so the
-        // host mirror decides without a device round trip
-        bool any = false;
-        for (int i = 0; i < B; ++i)
-            if (b->h_last_pos[i] / 2 >= b->p.max_seq_frames) { SVA_TRY(reprefill_slot(b, i)); any = true; }
-        if (any) {
-            // prefill_src_condition4delay(src_content_codes[-d:]) for the re-prefilled slots: the delay-fill kernel
-            // works on all slots in lock step, so slots that did NOT re-prefill must be excluded -> run it per slot
-            // through a one-slot view is not possible with the lock-step kernel; the reference is batch-1 and in the
-            // lock-step batch every slot with equal prompt length re-prefills at the same step.
-            for (int i = 0; i < B; ++i) SVA_CHECK(b->h_last_pos[i] == b->h_last_pos[0], "re-prefill needs equal positions across slots in this round");
-            SVA_TRY(ar_delay_fill(b));
-        }
-        // vocoder: streaming-exact (ring state) on the c new frames
-        SVA_HIP(hipMemcpy2DAsync(b->d_vcodes, sizeof(int) * b->Tv, b->d_step_audio, sizeof(int) * chunk, sizeof(int) * chunk, (size_t)B * ncb,
-                                 hipMemcpyDeviceToDevice, st));
-        SVA_TRY(vocode(b, chunk, true));
-    } else {
-        SVA_HIP(hipMemsetAsync(b->d_pcm, 0, sizeof(float) * (size_t)B * 2048 * b->Tv, st));
-    }
+    SVA_HIP(hipMemsetAsync(b->d_pcm, 0, sizeof(float) * (size_t)B * 2048 * b->Tv, st));
     SVA_HIP(hipEventRecord(b->ev[3], st));
     return 0;
 }
@@ -1271,6 +1306,7 @@ extern "C" int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const
     b->noise_on_device = (noise == nullptr);
     if (noise)
         SVA_HIP(hipMemcpyAsync(b->d_noise, noise, sizeof(float) * (size_t)B * chunk * (c.ar_vocab + ncb * c.codebook_size), hipMemcpyHostToDevice, st));
+    b->forced_now = forced_codes != nullptr;
     const int uf = forced_codes ? 1 : 0;
     SVA_HIP(hipMemcpyAsync(b->d_use_forced, &uf, sizeof(int), hipMemcpyHostToDevice, st));
     if (forced_codes) SVA_HIP(hipMemcpyAsync(b->d_forced, forced_codes, sizeof(int) * (size_t)B * ncb * chunk, hipMemcpyHostToDevice, st));
@@ -1281,9 +1317,10 @@ extern "C" int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const
     SVA_HIP(hipStreamSynchronize(st));
     memcpy(pcm_out, b->hp_out, sizeof(float) * (size_t)B * n);
     float t;
-    for (int i = 0; i < 3; ++i) {
-        if (hipEventElapsedTime(&t, b->ev[i], b->ev[i + 1]) == hipSuccess) b->last_ms[i] = t;
-    }
+    if (!b->graph_step)
+        for (int i = 0; i < 3; ++i) {
+            if (hipEventElapsedTime(&t, b->ev[i], b->ev[i + 1]) == hipSuccess) b->last_ms[i] = t;
+        }
     if (hipEventElapsedTime(&t, b->ev[0], b->ev[3]) == hipSuccess) b->last_ms[3] = t;
     return 0;
 }
@@ -1295,6 +1332,7 @@ extern "C" int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm
     hipStream_t st = b->stream;
     SVA_HIP(hipMemcpyAsync(b->d_chunk, d_pcm_in, sizeof(float) * (size_t)B * n, hipMemcpyDeviceToDevice, st));
     b->noise_on_device = true;
+    b->forced_now = false;
     SVA_HIP(hipMemsetAsync(b->d_use_forced, 0, sizeof(int), st));
     b->gemm_flops = 0; b->gemm_launches = 0;
     SVA_TRY(step_body(b));
@@ -1307,9 +1345,64 @@ extern "C" int sva_sync(sva_batch* b) {
     SVA_HIP(hipSetDevice(b->e->device));
     SVA_HIP(hipStreamSynchronize(b->stream));
     float t;
-    for (int i = 0; i < 3; ++i)
-        if (hipEventElapsedTime(&t, b->ev[i], b->ev[i + 1]) == hipSuccess) b->last_ms[i] = t;
+    if (!b->graph_step)
+        for (int i = 0; i < 3; ++i)
+            if (hipEventElapsedTime(&t, b->ev[i], b->ev[i + 1]) == hipSuccess) b->last_ms[i] = t;
     if (hipEventElapsedTime(&t, b->ev[0], b->ev[3]) == hipSuccess) b->last_ms[3] = t;
+    return 0;
+}
+
+// ---- AR seams: DualARWrapper.prefill_src_condition4delay / decode_one driven with caller-supplied content codes ----
+__global__ void put_codes_kernel(const long long* __restrict__ src, int n_per, long long* __restrict__ codes, int T2, int* __restrict__ content_hist,
+                                 int hist_cap, int* __restrict__ ncontent, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n = ncontent[b];
+    for (int i = 0; i < n_per; ++i) {
+        const long long c = src[(long)b * n_per + i];
+        codes[(long)b * T2 + T2 - n_per + i] = c;
+        if (n + i < hist_cap) content_hist[(long)b * hist_cap + n + i] = (int)c;
+    }
+    ncontent[b] = n + n_per;
+}
+
+extern "C" int sva_ar_delay_fill(sva_batch* b, const int64_t* codes) {
+    SVA_CHECK(b && codes && b->begun, "sva_ar_delay_fill: bad argument");
+    SVA_HIP(hipSetDevice(b->e->device));
+    const int B = b->B, d = b->p.delay;
+    long long* tmp = (long long*)b->d_noise;       // scratch (>= B*d*8 bytes)
+    SVA_TRY(h2d(b, tmp, codes, sizeof(int64_t) * (size_t)B * d));
+    hipLaunchKernelGGL(put_codes_kernel, dim3((B + 63) / 64), dim3(64), 0, b->stream, tmp, d, b->d_codes, b->T2, b->d_content_hist, b->hist_cap,
+                       b->d_ncontent, B);
+    b->h_ncontent += d;
+    SVA_TRY(ar_delay_fill(b));
+    b->delay_filled = true;
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+extern "C" int sva_ar_decode_one(sva_batch* b, const int64_t* code, const float* noise, const int32_t* forced, int32_t* codes_out, int32_t* pos_out) {
+    SVA_CHECK(b && code && codes_out && b->begun && b->delay_filled, "sva_ar_decode_one: bad argument / delay not filled");
+    SVA_CHECK(b->p.chunk_frames == 1, "sva_ar_decode_one needs chunk_frames == 1");
+    SVA_HIP(hipSetDevice(b->e->device));
+    const sva_config& c = b->e->cfg;
+    const int B = b->B, ncb = c.num_codebooks;
+    hipStream_t st = b->stream;
+    long long* tmp = (long long*)b->d_tok_raw;     // scratch: B*8 ints >= B int64
+    SVA_TRY(h2d(b, tmp, code, sizeof(int64_t) * (size_t)B));
+    hipLaunchKernelGGL(put_codes_kernel, dim3((B + 63) / 64), dim3(64), 0, st, tmp, 1, b->d_codes, b->T2, b->d_content_hist, b->hist_cap,
+                       b->d_ncontent, B);
+    b->h_ncontent += 1;
+    b->noise_on_device = (noise == nullptr);
+    if (noise) SVA_TRY(h2d(b, b->d_noise, noise, sizeof(float) * (size_t)B * (c.ar_vocab + ncb * c.codebook_size)));
+    const int uf = forced ? 1 : 0;
+    SVA_TRY(h2d(b, b->d_use_forced, &uf, sizeof(int)));
+    if (forced) SVA_TRY(h2d(b, b->d_forced, forced, sizeof(int) * (size_t)B * ncb));
+    SVA_TRY(ar_decode_frame(b, 0));
+    for (int i = 0; i < B; ++i) { b->h_last_pos[i] += 2; b->h_nframes[i] += 1; }
+    SVA_HIP(hipMemcpyAsync(codes_out, b->d_step_audio, sizeof(int) * (size_t)B * ncb, hipMemcpyDeviceToHost, st));
+    if (pos_out) SVA_HIP(hipMemcpyAsync(pos_out, b->d_last_pos, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, st));
+    SVA_HIP(hipStreamSynchronize(st));
     return 0;
 }
 

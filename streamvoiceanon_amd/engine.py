@@ -70,6 +70,8 @@ def load_library():
     lib.sva_vocode_window.argtypes = [vp, vp, i32, vp]
     lib.sva_vocode_stream.argtypes = [vp, vp, i32, vp]
     lib.sva_vocode_reset.argtypes = [vp]
+    lib.sva_ar_delay_fill.argtypes = [vp, vp]
+    lib.sva_ar_decode_one.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.sva_get_tap.argtypes = [vp, C.c_char_p, vp, C.c_long]
     lib.sva_get_tap.restype = C.c_long
     lib.sva_get_timings.argtypes = [vp, f32p]
@@ -86,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "sva_last_error", "sva_config_default", "sva_stream_params_default", "sva_engine_create",
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
     "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_encode_window",
-    "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_get_tap", "sva_get_timings",
+    "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_get_tap", "sva_get_timings",
     "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_test_gemm", "sva_bench_gemm",
 ]
 
@@ -265,6 +267,19 @@ class Batch:
         out = np.empty((self.B, 2048 * T), dtype=np.float32)
         _check(self.lib.sva_vocode_stream(self.h, _ptr(c), T, _ptr(out)), "sva_vocode_stream")
         return out
+
+    def ar_delay_fill(self, codes):
+        c = np.ascontiguousarray(codes, dtype=np.int64).reshape(self.B, self.p.delay)
+        _check(self.lib.sva_ar_delay_fill(self.h, _ptr(c)), "sva_ar_delay_fill")
+
+    def ar_decode_one(self, code, noise=None, forced=None):
+        c = np.ascontiguousarray(code, dtype=np.int64).reshape(self.B)
+        nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float32).reshape(self.B, self.noise_stride)
+        fc = None if forced is None else np.ascontiguousarray(forced, dtype=np.int32).reshape(self.B, 8)
+        out = np.empty((self.B, 8), dtype=np.int32)
+        pos = np.empty((self.B,), dtype=np.int32)
+        _check(self.lib.sva_ar_decode_one(self.h, _ptr(c), _ptr(nz), _ptr(fc), _ptr(out), _ptr(pos)), "sva_ar_decode_one")
+        return out, pos
 
     def vocode_reset(self):
         _check(self.lib.sva_vocode_reset(self.h), "sva_vocode_reset")

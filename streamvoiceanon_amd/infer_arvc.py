@@ -1,0 +1,124 @@
+"""Host-side mirror of ``InferenceWrapper`` (evaluations/infer_arvc.py:26-689) on top of the HIP engine:
+the chunk-by-chunk streaming surface -- ``prefill_prompt`` / ``setup_stream_caches`` /
+``process_one_chunk`` / ``stream_infer`` -- with the reference's names, defaults and quirks, so callers
+such as the CLI (__main__, :691-743) or the GUI's ``custom_infer`` (real-time-gui.py:32-49) can switch
+by changing one import.
+
+Not built in this round: the wav -> prompt encoders (CAM++ style vector,
+SparkTTS timbre latents, ``firefly.encode`` audio codes).  ``prefill_prompt`` therefore also accepts
+the prompt as codes/embeddings via ``prompt=`` (what ``calculate_prompt`` returns, :382-441); calling it
+with raw reference audio raises NotImplementedError naming the missing rows.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import engine as E
+
+
+class InferenceWrapper:
+    SAMPLES_PER_FRAME = 2048       # evaluations/infer_arvc.py:28
+    NUM_CODEBOOKS = 8
+    RESAMPLE_FREQ = 16000
+    MEL_BINS = 80
+
+    def __init__(self, config_path=None, checkpoint_path=None, compile_encoder=False, compile_decoder=False, compile_ar=False,
+                 fp16=False, weights: dict | None = None, device: int = 0):
+        """Same signature as the reference (:33) plus ``weights``: a dict of state-dict tensors keyed
+        'arvc.*' / 'tok.*' / 'voc.*' (real checkpoints are loaded with load_checkpoints())."""
+        if weights is None:
+            weights = self.load_checkpoints(config_path, checkpoint_path)
+        self.sr = 44100
+        self.device = f"cuda:{device}"
+        self.engine = E.Engine(weights, device=device, ar_dtype=0)
+        self.use_graph = bool(compile_ar or compile_decoder or compile_encoder)   # the reference's --compile
+        self.batch = None
+        self._prompt = None
+
+    @staticmethod
+    def load_checkpoints(config_path, checkpoint_path):
+        """Reads the five `.pth` files named by the reference YAML (config_firefly_arvcasr_8192_delay0_8.yaml:43-57)
+        into the prefixed key space, unwrapping 'net' / 'module.' like infer_arvc.py:70-78 does."""
+        import torch
+        import yaml
+
+        cfg = yaml.safe_load(open(config_path))
+        out = {}
+        sd = torch.load(checkpoint_path, map_location="cpu")
+        out.update({"arvc." + k: v for k, v in sd.items()})
+        tok = torch.load(cfg["speech_tokenizer"]["checkpoint_path"], map_location="cpu")
+        tok = tok.get("net", tok)
+        out.update({"tok." + (k[7:] if k.startswith("module.") else k): v for k, v in tok.items()})
+        voc = torch.load(cfg["firefly"]["checkpoint_path"], map_location="cpu")
+        out.update({"voc." + k: v for k, v in voc.items()})     # weight-norm pairs are folded by the engine
+        return {k: v for k, v in out.items() if hasattr(v, "dtype") and v.dtype.is_floating_point}
+
+    # ---- prompt ------------------------------------------------------------------------------------------
+    def calculate_prompt(self, ref_wav_tensors, alpha=1.0, spk_emb_collate_type="concat_mel"):
+        raise NotImplementedError(
+            "wav -> prompt (CAM++ style vector, SparkTTS timbre latents, firefly.encode audio codes) is row N1 of "
+            "SURVEY.md §8f and not built yet; pass prompt=(ref_audio_codes, ref_content_codes, style_vectors, timbre_latents) "
+            "to prefill_prompt instead")
+
+    def apply_noise_mixing(self, tensor, alpha, gauss=None):
+        """:228-232 -- alpha*x + (1-alpha)*(randn*std + mean), global mean / unbiased std."""
+        import torch
+
+        mean, std = tensor.mean(), tensor.std()
+        noise = (torch.randn_like(tensor) if gauss is None else gauss) * std + mean
+        return alpha * tensor + (1 - alpha) * noise
+
+    def prefill_prompt(self, ref_wav_tensors=None, max_prompt_frames=256, delay=4, alpha=1.0, spk_emb_collate_type="concat_mel",
+                       prompt=None, noise_seed=0):
+        if prompt is None:
+            prompt = self.calculate_prompt(ref_wav_tensors, alpha=alpha, spk_emb_collate_type=spk_emb_collate_type)
+        ref_audio_codes, ref_content_codes, style_vectors, timbre_latents = prompt[:4]
+        self._prompt = tuple(np.asarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x) for x in
+                             (ref_audio_codes, ref_content_codes, style_vectors, timbre_latents))
+        self.max_prompt_frames = max_prompt_frames
+        self.delay = int(delay)
+        self._noise_seed = noise_seed
+        print(f"Setting delay to {self.delay} frames")
+
+    def setup_stream_caches(self, encode_window_frames=96, decode_window_frames=64, max_seq_frames=768, buffer_frames=32,
+                            decode_chunk_frames=1, delay=None):
+        assert self._prompt is not None, "call prefill_prompt first (as stream_infer does, :631-645)"
+        if delay is not None:
+            self.delay = int(delay)
+        if self.batch is not None:
+            self.batch.close()
+        self.decode_chunk_frames = decode_chunk_frames
+        self.batch = E.Batch(self.engine, n_streams=1, encode_window_frames=encode_window_frames,
+                             decode_window_frames=decode_window_frames, chunk_frames=decode_chunk_frames, delay=self.delay,
+                             max_seq_frames=max_seq_frames, buffer_frames=buffer_frames, max_prompt_frames=self.max_prompt_frames,
+                             use_graph=self.use_graph)
+        ac, cc, st, tm = self._prompt
+        self.batch.prefill_prompt(0, cc.reshape(-1), ac.reshape(8, -1), st.reshape(-1), tm.reshape(32, -1), noise_seed=self._noise_seed)
+        self.batch.begin()
+
+    # ---- per chunk ---------------------------------------------------------------------------------------
+    def process_one_chunk(self, src_wav_chunk, pitch_shift=0.0):
+        """src_wav_chunk [1, 2048*c] (torch or numpy) -> same type/shape (:492-596): zeros for the first `delay` chunks."""
+        is_torch = hasattr(src_wav_chunk, "detach")
+        x = src_wav_chunk.detach().cpu().numpy() if is_torch else np.asarray(src_wav_chunk)
+        out = self.batch.step(x.reshape(1, -1).astype(np.float32))
+        if is_torch:
+            import torch
+
+            return torch.from_numpy(out).to(src_wav_chunk.device)
+        return out
+
+    def stream_infer(self, src, ref_path=None, out_dir=None, encode_window_frames=128, decode_window_frames=64, max_prompt_frames=256,
+                     max_seq_frames=768, buffer_frames=32, decode_chunk_frames=1, delay=None, ref_crop_lengths=None, alpha=1.0,
+                     spk_emb_collate_type="concat_mel", save_result=False, prompt=None, noise_seed=0):
+        """:598-689.  `src` is a 44.1 kHz mono float array (file I/O + resampling are row N2)."""
+        src = np.asarray(src, dtype=np.float32).reshape(-1)
+        self.prefill_prompt(None if prompt is not None else ref_path, max_prompt_frames=max_prompt_frames,
+                            delay=2 if delay is None else delay, alpha=alpha, spk_emb_collate_type=spk_emb_collate_type,
+                            prompt=prompt, noise_seed=noise_seed)
+        self.setup_stream_caches(encode_window_frames, decode_window_frames, max_seq_frames, buffer_frames, decode_chunk_frames)
+        n = self.SAMPLES_PER_FRAME * decode_chunk_frames
+        pad = n - (src.shape[0] % n)              # :648-649 pads a FULL extra chunk when already aligned
+        src = np.concatenate([np.zeros(pad, np.float32), src])
+        outs = [self.process_one_chunk(src[i:i + n][None]) for i in range(0, src.shape[0], n)]
+        return np.concatenate(outs, axis=1).reshape(-1)

@@ -112,7 +112,7 @@ def test_vocoder_window_and_stream(eng, weights0):
     b.close()
 
 
-def _stream_vs_golden(eng, W, name, forced=False, device_rng=False, n_limit=None):
+def _stream_vs_golden(eng, W, name, forced=False, device_rng=False, n_limit=None, use_graph=False):
     from oracle import sva_oracle as O
     from streamvoiceanon_amd import engine as E
     from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
@@ -124,7 +124,7 @@ def _stream_vs_golden(eng, W, name, forced=False, device_rng=False, n_limit=None
         n_chunks = min(n_chunks, n_limit)
     ac, cc, style, timbre = synth_prompt(pseed, int(g["prompt_frames"]))
     b = E.Batch(eng, n_streams=1, chunk_frames=chunk, delay=delay, max_seq_frames=int(g["max_seq_frames"]),
-                buffer_frames=int(g["buffer_frames"]))
+                buffer_frames=int(g["buffer_frames"]), use_graph=use_graph)
     b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=useed)
     b.begin()
     n = 2048 * chunk
@@ -189,6 +189,19 @@ def test_device_rng_equals_host_noise(eng, weights0):
     np.testing.assert_array_equal(audio, g["audio_codes"][:, :audio.shape[1]])
 
 
+@pytest.mark.parametrize("name", ["stream_s0", "stream_reprefill", "stream_chunk4"])
+def test_hipgraph_step_equals_eager(eng, weights0, name):
+    """The captured steady-state step (hipGraph replay, device-side counters) reproduces the eager run and
+    the reference fixture, including across re-prefills (which run eagerly between replays)."""
+    g, outs_g, content_g, audio_g, *_ = _stream_vs_golden(eng, weights0, name, device_rng=True, use_graph=True)
+    _, outs_e, content_e, audio_e, *_ = _stream_vs_golden(eng, weights0, name, device_rng=True, use_graph=False)
+    np.testing.assert_array_equal(content_g, g["content_codes"])
+    np.testing.assert_array_equal(audio_g, audio_e)
+    np.testing.assert_array_equal(audio_g, g["audio_codes"])
+    for a, c in zip(outs_g, outs_e):
+        np.testing.assert_array_equal(a, c)
+
+
 def test_batched_streams_independent(eng, weights0):
     """Size-independent property at batch scale: a slot's output depends only on its own utterance
     (noise keyed by utterance id, never by slot): B=16 with 4 distinct utterances x 4 copies."""
@@ -218,3 +231,52 @@ def test_batched_streams_independent(eng, weights0):
     # and slot 0 equals the single-stream fixture run (utterance 1000 / prompt 2000 = stream_s0)
     g = load_golden("stream_s0")
     np.testing.assert_array_equal(codes[0][:, 2:], g["audio_codes"][:, :n_chunks - 2])
+
+
+def test_arvc_wrapper_seams(weights0, eng):
+    """ARVCWrapper mirror: prefill_prompt -> prefill_src_condition4delay -> decode_one with the fixture's
+    content codes and the shared Exp(1) noise reproduces the reference's audio codes and KV positions."""
+    from streamvoiceanon_amd.arvc_wrapper import ARVCWrapper
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt
+
+    g = load_golden("stream_s0")
+    ac, cc, style, timbre = synth_prompt(int(g["prompt_seed"]), int(g["prompt_frames"]))
+    m = ARVCWrapper(eng, delay=2)
+    m.setup_caches(max_batch_size=1, max_seq_len=2048)
+    m.prefill_prompt(torch.from_numpy(cc)[None], torch.from_numpy(ac)[None], torch.from_numpy(style)[None], torch.from_numpy(timbre)[None])
+    content = g["content_codes"]
+    m.prefill_src_condition4delay(torch.from_numpy(content[:2])[None])
+    pos = None
+    for f in range(g["audio_codes"].shape[1]):
+        ns, nf = frame_noise(int(g["audio_seed"]), f)
+        codes, pos = m.decode_one(torch.tensor([[int(content[2 + f])]]), noise=np.concatenate([ns, nf.reshape(-1)]))
+        assert codes.shape == (8, 1) and codes.dtype == torch.int32
+        np.testing.assert_array_equal(codes[:, 0].numpy(), g["audio_codes"][:, f])
+    assert pos == int(g["final_pos"])
+    m.batch.close()
+
+
+def test_inference_wrapper_stream_infer(weights0):
+    """InferenceWrapper mirror end to end: stream_infer() = left-pad rule (:648-649, a FULL extra chunk when the
+    length is already aligned) + prefill + per-chunk loop; equals driving the C-ABI batch by hand."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.synth_audio import pad_to_chunks, synth_prompt, synth_utterance
+
+    ac, cc, style, timbre = synth_prompt(2000, 107)
+    w = InferenceWrapper(weights=weights0, compile_ar=True)
+    src = synth_utterance(1000, 2048 * 9)                     # aligned -> one full chunk of left padding
+    out = w.stream_infer(src, prompt=(ac, cc, style, timbre), delay=2, noise_seed=1000)
+    assert out.shape == (2048 * 10,)
+    assert np.all(out[:2048 * 2] == 0) and np.abs(out[2048 * 2:]).max() > 0.01     # delay gating: 2 silent chunks
+    b = E.Batch(w.engine, n_streams=1, delay=2)
+    b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=1000)
+    b.begin()
+    padded = pad_to_chunks(src, 1)
+    ref = np.concatenate([b.step(padded[i:i + 2048][None])[0] for i in range(0, padded.shape[0], 2048)])
+    np.testing.assert_array_equal(out, ref)
+    x = w.process_one_chunk(torch.zeros(1, 2048))
+    assert isinstance(x, torch.Tensor) and x.shape == (1, 2048)
+    b.close()
+    w.batch.close()
+    w.engine.close()
