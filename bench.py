@@ -159,9 +159,16 @@ def main():
         tot_ms, nl = batch.gemm_profile()
         batch.profile_gemm(False)
         ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        # HBM bytes per conv-GEMM launch from the committed PMC passes of the same command (tools/pmc.sh ->
+        # profiles/rNN_pmc_b<B>.json; rocprofv3 cannot run inside bench.py): reads per the guide's gfx950 correction
+        import glob
+        traffic = None
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_b{B}.json")))
+        if cands and c == 1:
+            traffic = round(json.load(open(cands[-1]))["hbm_bytes_per_launch"], 1)
         roof = {"bound": "mfma", "kernel": "conv_gemm_kernel (v_mfma_f32_16x16x4_f32)", "achieved": round(ach, 3),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
-                "traffic": None, "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
+                "traffic": traffic, "traffic_source": os.path.basename(cands[-1]) if traffic is not None else None, "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
                 "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4)}
     if rank != 0:
         if world > 1:

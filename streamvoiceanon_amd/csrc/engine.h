@@ -52,6 +52,20 @@ struct Act {
     long bstride = 0;    // rows * C
 };
 
+// per-layer streaming state of the exact-incremental encoder (newest 4c mel frames per step)
+struct EncStream {
+    float* mag = nullptr;                  // [B][nm][1088]
+    Act mel;                               // [B][6+nm][160]
+    Act tmp0;                              // stem conv output [B][nm][128]
+    std::vector<std::vector<Act>> x;       // x[i][j] = input of block j of stage i  [B][6+nm][C_i]
+    Act xout[4];                           // output of the last block of stage i    [B][nm][C_i]
+    Act feat;                              // [B][nm][512]
+    Act d1, d1o, d2;                       // [B][6+nm/2][512], [B][nm/2][512], [B][6+nm/4][512]
+    float *h1 = nullptr, *h2 = nullptr;    // ConvNeXt scratch
+    ShiftDesc* d_shift = nullptr;
+    int n_shift = 0;
+};
+
 struct ResConv {
     Lin c1, c2;
     int k = 0, dil = 1;
@@ -108,7 +122,12 @@ struct sva_batch {
     sva_engine* e = nullptr;
     sva_stream_params p;
     int B = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // current launch stream (== main except inside a forked branch)
+    hipStream_t main_stream = nullptr;
+    hipStream_t aux[2] = {nullptr, nullptr};   // side streams for independent sub-chains (fork / join by events)
+    hipEvent_t evpool[64];
+    int evi = 0;
+    bool concurrency = true;
     std::vector<void*> allocs;
 
     // ---- device control block ----
@@ -130,6 +149,12 @@ struct sva_batch {
     sva::Act feat;                         // [B][T0][512]
     sva::Act d1, d2;                       // [B][6+T0/2][512], [B][6+T0/4][512]
     float *tr_hn = nullptr, *tr_qkv = nullptr, *tr_att = nullptr, *tr_g = nullptr, *tr_z = nullptr;
+    float* tr_x = nullptr;                 // [B][T2][512] transformer work copy
+    sva::Act d2c;                          // [B][T2][512] steady token cache of the exact-incremental encoder
+    sva::EncStream es;
+    sva::ShiftDesc* d_shift_d2c = nullptr;
+    int Ht = 40;                           // head tokens recomputed every chunk (receptive field 38.25 tokens)
+    bool enc_incremental = true;
     long long* d_codes = nullptr;          // [B][T2]
     float* d_u = nullptr;                  // [B][T2][13]
 

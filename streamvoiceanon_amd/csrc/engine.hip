@@ -8,6 +8,7 @@
 #include "engine.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -442,6 +443,15 @@ int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda,
     return launch_conv_gemm(g, b->stream);
 }
 
+// fork / join of independent sub-chains on side streams (captured into the hipGraph as parallel branches)
+hipEvent_t next_event(sva_batch* b) { return b->evpool[(b->evi++) & 63]; }
+int stream_fork(sva_batch* b, hipStream_t from, hipStream_t to) {
+    hipEvent_t ev = next_event(b);
+    SVA_HIP(hipEventRecord(ev, from));
+    SVA_HIP(hipStreamWaitEvent(to, ev, 0));
+    return 0;
+}
+
 // causal conv (FishConvNet) of `in` (history rows in front) into rows [out.H, out.H+T) of `out`
 int conv_act(sva_batch* b, const Act& in, int T_out, int stride, int dil, int taps, const Lin& w, Act& out,
              ConvGemm proto = ConvGemm()) {
@@ -452,90 +462,186 @@ int conv_act(sva_batch* b, const Act& in, int T_out, int stride, int dil, int ta
 }
 
 // ConvNeXtBlock (firefly.py:421-440) on x rows [x.H, x.H+T); result into `out` rows [out.H, out.H+T)
-// (out == nullptr: in place).  The streaming vocoder must NOT run in place: the dwconv history of the next
-// step is the block INPUT, while downstream convs need history of the block OUTPUT.
-int cnx_block(sva_batch* b, const CNX& c, Act& x, int T, float* h1, float* h2, Act* out = nullptr) {
+// (out == nullptr: in place).  Streaming users must NOT run in place: the dwconv history of the next step is the
+// block INPUT, while downstream convs need history of the block OUTPUT.  h1 / h2 = scratch with batch strides.
+int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs, float* h2, long h2_bs, Act* out = nullptr) {
     const int C = c.C;
     SVA_CHECK(x.H >= 6 && x.C == C, "cnx_block: bad activation");
     Act& o = out ? *out : x;
     SVA_CHECK(o.C == C, "cnx_block: bad output activation");
-    SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, b->stream));
+    SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, h1_bs, b->stream));
     ConvGemm p1;
     p1.act = ACT_GELU;
-    SVA_TRY(gemm_call(b, h1, (long)T * C, 0, C, b->B, T, 1, 1, 1, C, c.pw1, h2, (long)T * 4 * C, 0, 4 * C, p1));
+    SVA_TRY(gemm_call(b, h1, h1_bs, 0, C, b->B, T, 1, 1, 1, C, c.pw1, h2, h2_bs, 0, 4 * C, p1));
     ConvGemm p2;
     p2.gamma = c.gamma;
     p2.res = x.p; p2.r_bstride = x.bstride; p2.r_off = (long)x.H * C; p2.ldr = C;
-    SVA_TRY(gemm_call(b, h2, (long)T * 4 * C, 0, 4 * C, b->B, T, 1, 1, 1, 4 * C, c.pw2, o.p, o.bstride, (long)o.H * C, C, p2));
+    SVA_TRY(gemm_call(b, h2, h2_bs, 0, 4 * C, b->B, T, 1, 1, 1, 4 * C, c.pw2, o.p, o.bstride, (long)o.H * C, C, p2));
     return 0;
 }
+int cnx_block(sva_batch* b, const CNX& c, Act& x, int T, float* h1, float* h2, Act* out = nullptr) {
+    return cnx_block_t(b, c, x, T, h1, (long)T * c.C, h2, (long)T * 4 * c.C, out);
+}
 
-// ---- E: encode the current window of every stream -> d_codes [B][T2] ---------------------------
-int encode(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
+// ---- E: content encoder ------------------------------------------------------------------------------
+// Conv front-end (mel -> stem -> 18 ConvNeXt -> 2x (conv k2 s2 + ConvNeXt)) on the FIRST `Tm` mel frames of the
+// current window, zero left padding exactly as the reference's window pass (causal net: row j depends on rows <= j).
+// Tm = T0: the full-window formulation; Tm = head rows: the head pass of the exact-incremental formulation.
+int enc_frontend_window(sva_batch* b, const int* step_ptr, int n_chunk, int add, int Tm) {
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
     const int B = b->B, T0 = b->T0;
     hipStream_t st = b->stream;
-    SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, b->mag, 1088, st));
+    SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, b->mag, 1088, (long)T0 * 1088, 0, Tm, st));
     {   // mel = log(clamp(fb^T mag, 1e-5))  (spectrogram.py:110-115, 124-125)
         ConvGemm p;
         p.act = ACT_LOGCLAMP;
-        SVA_TRY(gemm_call(b, b->mag, (long)T0 * 1088, 0, 1088, B, T0, 1, 1, 1, 1088, e->mel_fb, b->mel.p, b->mel.bstride,
+        SVA_TRY(gemm_call(b, b->mag, (long)T0 * 1088, 0, 1088, B, Tm, 1, 1, 1, 1088, e->mel_fb, b->mel.p, b->mel.bstride,
                           (long)b->mel.H * c.n_mels, c.n_mels, p));
     }
     // stem: causal conv k7 + LayerNorm(channels)  (firefly.py:458-468)
-    SVA_TRY(gemm_call(b, b->mel.p, b->mel.bstride, 0, c.n_mels, B, T0, 1, 1, 7, c.n_mels, e->stem, b->h1, (long)T0 * c.enc_dims[0], 0,
+    SVA_TRY(gemm_call(b, b->mel.p, b->mel.bstride, 0, c.n_mels, B, Tm, 1, 1, 7, c.n_mels, e->stem, b->h1, (long)Tm * c.enc_dims[0], 0,
                       c.enc_dims[0]));
-    SVA_TRY(launch_layernorm_rows(b->h1, (long)T0 * c.enc_dims[0], 0, c.enc_dims[0], B, T0, c.enc_dims[0], e->stem_lnw, e->stem_lnb,
+    SVA_TRY(launch_layernorm_rows(b->h1, (long)Tm * c.enc_dims[0], 0, c.enc_dims[0], B, Tm, c.enc_dims[0], e->stem_lnw, e->stem_lnb,
                                   1e-6f, b->xs[0].p, b->xs[0].bstride, (long)b->xs[0].H * c.enc_dims[0], c.enc_dims[0], st));
     for (int i = 0; i < 4; ++i) {
         const int C = c.enc_dims[i];
         if (i > 0) {   // LayerNorm(channels) + Conv1d k1  (firefly.py:471-476)
             const int Cp = c.enc_dims[i - 1];
-            SVA_TRY(launch_layernorm_rows(b->xs[i - 1].p, b->xs[i - 1].bstride, (long)b->xs[i - 1].H * Cp, Cp, B, T0, Cp, e->trans_lnw[i],
-                                          e->trans_lnb[i], 1e-6f, b->h1, (long)T0 * Cp, 0, Cp, st));
-            SVA_TRY(gemm_call(b, b->h1, (long)T0 * Cp, 0, Cp, B, T0, 1, 1, 1, Cp, e->trans[i], b->xs[i].p, b->xs[i].bstride,
+            SVA_TRY(launch_layernorm_rows(b->xs[i - 1].p, b->xs[i - 1].bstride, (long)b->xs[i - 1].H * Cp, Cp, B, Tm, Cp, e->trans_lnw[i],
+                                          e->trans_lnb[i], 1e-6f, b->h1, (long)Tm * Cp, 0, Cp, st));
+            SVA_TRY(gemm_call(b, b->h1, (long)Tm * Cp, 0, Cp, B, Tm, 1, 1, 1, Cp, e->trans[i], b->xs[i].p, b->xs[i].bstride,
                               (long)b->xs[i].H * C, C));
         }
-        for (auto& blk : e->stages[i]) SVA_TRY(cnx_block(b, blk, b->xs[i], T0, b->h1, b->h2));
+        for (auto& blk : e->stages[i]) SVA_TRY(cnx_block(b, blk, b->xs[i], Tm, b->h1, b->h2));
     }
     const int D = c.tr_dim;
-    SVA_TRY(launch_layernorm_rows(b->xs[3].p, b->xs[3].bstride, (long)b->xs[3].H * D, D, B, T0, D, e->final_lnw, e->final_lnb, 1e-6f,
+    SVA_TRY(launch_layernorm_rows(b->xs[3].p, b->xs[3].bstride, (long)b->xs[3].H * D, D, B, Tm, D, e->final_lnw, e->final_lnb, 1e-6f,
                                   b->feat.p, b->feat.bstride, 0, D, st));
     // BSQ downsample x2: conv k2 s2 + ConvNeXtBlock  (bsq_no_upsample.py:48-61)
-    SVA_TRY(conv_act(b, b->feat, T0 / 2, 2, 1, 2, e->ds_conv[0], b->d1));
-    SVA_TRY(cnx_block(b, e->ds_cnx[0], b->d1, T0 / 2, b->h1, b->h2));
+    SVA_TRY(conv_act(b, b->feat, Tm / 2, 2, 1, 2, e->ds_conv[0], b->d1));
+    SVA_TRY(cnx_block(b, e->ds_cnx[0], b->d1, Tm / 2, b->h1, b->h2));
     {
-        Act in = b->d1;      // read the T0/2 new rows (no left padding needed: padL = 0)
+        Act in = b->d1;      // read the new rows (no left padding needed: padL = 0)
         in.p = b->d1.p + (long)b->d1.H * D;
         in.H = 0;
-        SVA_TRY(conv_act(b, in, T0 / 4, 2, 1, 2, e->ds_conv[1], b->d2));
+        SVA_TRY(conv_act(b, in, Tm / 4, 2, 1, 2, e->ds_conv[1], b->d2));
     }
-    SVA_TRY(cnx_block(b, e->ds_cnx[1], b->d2, T0 / 4, b->h1, b->h2));
-    // pre_module: 8-layer causal transformer on T2 tokens  (windowed_transformer.py:103-143)
-    const int T2 = b->T2, I = c.tr_inter;
-    Act& x = b->d2;
-    const long xoff = (long)x.H * D;
+    SVA_TRY(cnx_block(b, e->ds_cnx[1], b->d2, Tm / 4, b->h1, b->h2));
+    return 0;
+}
+
+// Streaming pass of the exact-incremental formulation: the nm = 4c NEWEST mel frames of the window through the same
+// conv front-end on per-layer 6-row histories (every tensor that feeds a k7 conv keeps its own history; ConvNeXt
+// blocks are therefore out-of-place).  The resulting c token rows land in d2c[T2-c, T2).
+int enc_frontend_stream(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int B = b->B, nm = 4 * b->p.chunk_frames;
+    hipStream_t st = b->stream;
+    EncStream& S = b->es;
+    SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, S.mag, 1088, (long)nm * 1088, b->T0 - nm, nm, st));
+    {
+        ConvGemm p;
+        p.act = ACT_LOGCLAMP;
+        SVA_TRY(gemm_call(b, S.mag, (long)nm * 1088, 0, 1088, B, nm, 1, 1, 1, 1088, e->mel_fb, S.mel.p, S.mel.bstride, (long)S.mel.H * c.n_mels,
+                          c.n_mels, p));
+    }
+    SVA_TRY(conv_act(b, S.mel, nm, 1, 1, 7, e->stem, S.tmp0));
+    SVA_TRY(launch_layernorm_rows(S.tmp0.p, S.tmp0.bstride, 0, c.enc_dims[0], B, nm, c.enc_dims[0], e->stem_lnw, e->stem_lnb, 1e-6f,
+                                  S.x[0][0].p, S.x[0][0].bstride, (long)S.x[0][0].H * c.enc_dims[0], c.enc_dims[0], st));
+    for (int i = 0; i < 4; ++i) {
+        const int C = c.enc_dims[i];
+        const int nb = (int)e->stages[i].size();
+        for (int j = 0; j < nb; ++j) {
+            Act& out = j + 1 < nb ? S.x[i][j + 1] : S.xout[i];
+            SVA_TRY(cnx_block_t(b, e->stages[i][j], S.x[i][j], nm, S.h1, (long)nm * C, S.h2, (long)nm * 4 * C, &out));
+        }
+        if (i < 3) {
+            const int Cn = c.enc_dims[i + 1];
+            SVA_TRY(launch_layernorm_rows(S.xout[i].p, S.xout[i].bstride, 0, C, B, nm, C, e->trans_lnw[i + 1], e->trans_lnb[i + 1], 1e-6f,
+                                          S.h1, (long)nm * C, 0, C, st));
+            SVA_TRY(gemm_call(b, S.h1, (long)nm * C, 0, C, B, nm, 1, 1, 1, C, e->trans[i + 1], S.x[i + 1][0].p, S.x[i + 1][0].bstride,
+                              (long)S.x[i + 1][0].H * Cn, Cn));
+        }
+    }
+    const int D = c.tr_dim;
+    SVA_TRY(launch_layernorm_rows(S.xout[3].p, S.xout[3].bstride, 0, D, B, nm, D, e->final_lnw, e->final_lnb, 1e-6f, S.feat.p, S.feat.bstride, 0, D, st));
+    SVA_TRY(conv_act(b, S.feat, nm / 2, 2, 1, 2, e->ds_conv[0], S.d1));
+    SVA_TRY(cnx_block_t(b, e->ds_cnx[0], S.d1, nm / 2, S.h1, (long)(nm / 2) * D, S.h2, (long)(nm / 2) * 4 * D, &S.d1o));
+    SVA_TRY(conv_act(b, S.d1o, nm / 4, 2, 1, 2, e->ds_conv[1], S.d2));
+    Act tail = b->d2c;                       // rows [T2 - c, T2) of the steady token cache
+    tail.p = b->d2c.p + (long)(b->T2 - nm / 4) * D;
+    tail.H = 0;
+    SVA_TRY(cnx_block_t(b, e->ds_cnx[1], S.d2, nm / 4, S.h1, (long)(nm / 4) * D, S.h2, (long)(nm / 4) * 4 * D, &tail));
+    SVA_TRY(launch_shift_history(S.d_shift, S.n_shift, B, st));
+    return 0;
+}
+
+// pre_module (8-layer causal transformer on T2 tokens, windowed_transformer.py:103-143) + BSQ.  Reads the token
+// features from `xin` without modifying them (the exact-incremental path keeps them as its steady cache).
+int enc_transformer(sva_batch* b, const Act& xin) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int B = b->B, T2 = b->T2, D = c.tr_dim, I = c.tr_inter;
+    hipStream_t st = b->stream;
+    const float* xr = xin.p;                 // residual source of the current sub-layer
+    long xr_bs = xin.bstride, xr_off = (long)xin.H * D;
+    float* xw = b->tr_x;                     // work copy [B][T2][D]
+    const long xw_bs = (long)T2 * D;
     for (auto& L : e->tr) {
-        SVA_TRY(launch_rmsnorm_rows(x.p, x.bstride, xoff, D, B, T2, D, L.attn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
+        SVA_TRY(launch_rmsnorm_rows(xr, xr_bs, xr_off, D, B, T2, D, L.attn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
         SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D));
         SVA_TRY(launch_enc_attention(b->tr_qkv, e->rope_enc, B, T2, c.tr_heads, 64, b->tr_att, st));
         ConvGemm po;
         po.gamma = L.ls_attn;
-        po.res = x.p; po.r_bstride = x.bstride; po.r_off = xoff; po.ldr = D;
-        SVA_TRY(gemm_call(b, b->tr_att, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wo, x.p, x.bstride, xoff, D, po));
-        SVA_TRY(launch_rmsnorm_rows(x.p, x.bstride, xoff, D, B, T2, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
+        po.res = xr; po.r_bstride = xr_bs; po.r_off = xr_off; po.ldr = D;
+        SVA_TRY(gemm_call(b, b->tr_att, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wo, xw, xw_bs, 0, D, po));
+        xr = xw; xr_bs = xw_bs; xr_off = 0;
+        SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, 0, D, B, T2, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
         ConvGemm pg;
         pg.w13 = 1;
         SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, 0, I, pg));
         ConvGemm pd;
         pd.gamma = L.ls_ffn;
-        pd.res = x.p; pd.r_bstride = x.bstride; pd.r_off = xoff; pd.ldr = D;
-        SVA_TRY(gemm_call(b, b->tr_g, (long)T2 * I, 0, I, B, T2, 1, 1, 1, I, L.w2, x.p, x.bstride, xoff, D, pd));
+        pd.res = xw; pd.r_bstride = xw_bs; pd.r_off = 0; pd.ldr = D;
+        SVA_TRY(gemm_call(b, b->tr_g, (long)T2 * I, 0, I, B, T2, 1, 1, 1, I, L.w2, xw, xw_bs, 0, D, pd));
     }
-    SVA_TRY(launch_rmsnorm_rows(x.p, x.bstride, xoff, D, B, T2, D, e->tr_norm, 1e-5f, b->tr_z, (long)T2 * D, 0, D, st));
+    SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, 0, D, B, T2, D, e->tr_norm, 1e-5f, b->tr_z, (long)T2 * D, 0, D, st));
     SVA_TRY(launch_bsq(b->tr_z, (long)T2 * D, 0, D, B, T2, D, e->bsq_W, e->bsq_b, c.bsq_bits, b->d_codes, b->d_u, st));
     return 0;
+}
+
+// full-window formulation (reference: the whole 128-frame window is re-encoded every chunk, infer_arvc.py:505-508)
+int encode(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
+    SVA_TRY(enc_frontend_window(b, step_ptr, n_chunk, add, b->T0));
+    return enc_transformer(b, b->d2);
+}
+
+// exact-incremental formulation (SURVEY.md §7 hard part 1): window rows whose causal receptive field still touches
+// the zero left padding -- mel frames 0..116, tokens 0..38 -- are recomputed every chunk ("head pass" on the first
+// 160 mel frames = 40 tokens); every later token is the true causal feature of its absolute time, computed once by
+// the streaming pass when it entered the window and kept in d2c, which slides by c tokens per chunk.  The 8-layer
+// transformer + BSQ always run on all T2 tokens.  Same values as the window pass up to fp32 summation order.
+int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
+    const int D = b->e->cfg.tr_dim, c = b->p.chunk_frames;
+    hipStream_t st = b->stream;
+    SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, b->B, st));                   // steady tokens slide down by c
+    // the head pass and the streaming pass are independent chains: run the short one on a side stream
+    const bool par = b->concurrency;
+    if (par) {
+        SVA_TRY(stream_fork(b, st, b->aux[0]));
+        b->stream = b->aux[0];
+    }
+    int rc = enc_frontend_stream(b, step_ptr, n_chunk, add);                     // c newest tokens -> d2c tail
+    b->stream = st;
+    if (rc) return rc;
+    SVA_TRY(enc_frontend_window(b, step_ptr, n_chunk, add, 4 * b->Ht));            // head pass -> d2 rows [0, Ht)
+    SVA_HIP(hipMemcpy2DAsync(b->d2c.p, sizeof(float) * b->d2c.bstride, b->d2.p + (long)b->d2.H * D, sizeof(float) * b->d2.bstride,
+                             sizeof(float) * (size_t)b->Ht * D, b->B, hipMemcpyDeviceToDevice, st));
+    if (par) SVA_TRY(stream_fork(b, b->aux[0], st));                             // join
+    (void)c;
+    return enc_transformer(b, b->d2c);
 }
 
 // ---- A: slow / fast transformer passes ------------------------------------------------------------
@@ -628,6 +734,14 @@ __global__ void append_content_kernel(const long long* __restrict__ codes, int T
         step_content[b * chunk + i] = code;
     }
     ncontent[b] = n + chunk;
+}
+
+// dst rows [lo, hi) of every batch item <- row `src_row`
+__global__ void broadcast_row_kernel(float* p, long bstride, int src_row, int lo, int hi, int C) {
+    float* base = p + (long)blockIdx.y * bstride;
+    const int r = lo + blockIdx.x;
+    if (r >= hi || r == src_row) return;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) base[(long)r * C + i] = base[(long)src_row * C + i];
 }
 
 __global__ void inc_kernel(int* p, int v) {
@@ -816,28 +930,51 @@ int vocode(sva_batch* b, int T, bool shift) {
                               e->ups[i], b->X[i].p, b->X[i].bstride, (long)b->X[i].H * Cout, s * Cout, p));
         }
         Tl *= s;
-        // ParallelBlock = mean of three ResBlock1 (firefly.py:183-190, 214-215)
+        // ParallelBlock = mean of three ResBlock1 (firefly.py:183-190, 214-215).  The three branches are independent
+        // chains of 6 convs: branch 0 stays on the main stream, branches 1/2 run on side streams; the last conv of each
+        // branch accumulates (x 1/3) into the level output in the fixed order 0, 1, 2 (event chain => deterministic sum).
         Act& out = b->S[i + 1];
+        const bool par = b->concurrency;
+        if (par) {
+            SVA_TRY(stream_fork(b, st, b->aux[0]));
+            SVA_TRY(stream_fork(b, st, b->aux[1]));
+        }
+        hipStream_t prev_last = nullptr;
         for (int br = 0; br < 3; ++br) {
+            hipStream_t sbr = (par && br > 0) ? b->aux[br - 1] : st;
+            b->stream = sbr;
             Act* y = &b->X[i];
-            for (int j = 0; j < 3; ++j) {
-                const ResConv& rc = e->res[i][br][j];
+            int rc = 0;
+            for (int j = 0; j < 3 && !rc; ++j) {
+                const ResConv& rcv = e->res[i][br][j];
                 ConvGemm p1;
                 p1.a_silu = 1;
-                SVA_TRY(conv_act(b, *y, (int)Tl, 1, rc.dil, rc.k, rc.c1, b->tb[i][br][j], p1));
+                rc = conv_act(b, *y, (int)Tl, 1, rcv.dil, rcv.k, rcv.c1, b->tb[i][br][j], p1);
+                if (rc) break;
                 ConvGemm p2;
                 p2.a_silu = 1;
                 p2.res = y->p; p2.r_bstride = y->bstride; p2.r_off = (long)y->H * Cout; p2.ldr = Cout;
                 if (j < 2) {
-                    SVA_TRY(conv_act(b, b->tb[i][br][j], (int)Tl, 1, rc.dil, rc.k, rc.c2, b->yb[i][br][j], p2));
+                    rc = conv_act(b, b->tb[i][br][j], (int)Tl, 1, rcv.dil, rcv.k, rcv.c2, b->yb[i][br][j], p2);
                     y = &b->yb[i][br][j];
                 } else {
                     p2.scale = 1.0f / 3.0f;
                     p2.accumulate = br > 0;
-                    SVA_TRY(conv_act(b, b->tb[i][br][j], (int)Tl, 1, rc.dil, rc.k, rc.c2, out, p2));
+                    if (par && br > 0) {
+                        hipError_t he = hipSuccess;
+                        hipEvent_t ev = next_event(b);
+                        he = hipEventRecord(ev, prev_last);
+                        if (he == hipSuccess) he = hipStreamWaitEvent(sbr, ev, 0);
+                        if (he != hipSuccess) { b->stream = st; SVA_HIP(he); }
+                    }
+                    rc = conv_act(b, b->tb[i][br][j], (int)Tl, 1, rcv.dil, rcv.k, rcv.c2, out, p2);
                 }
             }
+            b->stream = st;
+            if (rc) return rc;
+            prev_last = sbr;
         }
+        if (par) SVA_TRY(stream_fork(b, b->aux[1], st));      // join: branch 2's last conv is ordered after 0 and 1
     }
     SVA_TRY(launch_conv_post_tanh(b->S[5].p, b->S[5].bstride, (long)(b->S[5].H - (e->post_k - 1)) * b->S[5].C, B, (int)Tl, b->S[5].C, e->post_k,
                                   e->post_w, e->post_b, b->d_pcm, 2048L * b->Tv, 0, st));
@@ -879,6 +1016,10 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     SVA_CHECK(p->encode_window_frames % 1 == 0 && p->encode_window_frames >= p->chunk_frames, "bad encode window");
     if (b->p.voc_max_frames < p->chunk_frames) b->p.voc_max_frames = p->chunk_frames;
     SVA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    b->main_stream = b->stream;
+    for (int i = 0; i < 2; ++i) SVA_HIP(hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking));
+    for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
+    if (const char* ev = getenv("SVA_CONCURRENCY")) b->concurrency = atoi(ev) != 0;      // 0: single stream (PMC profiling)
     auto& A = b->allocs;
     const int chunk = p->chunk_frames;
     // control block
@@ -912,6 +1053,50 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     SVA_TRY(dev_alloc(A, &b->tr_att, (size_t)B * T2 * Dm));
     SVA_TRY(dev_alloc(A, &b->tr_g, (size_t)B * T2 * c.tr_inter));
     SVA_TRY(dev_alloc(A, &b->tr_z, (size_t)B * T2 * Dm));
+    SVA_TRY(dev_alloc(A, &b->tr_x, (size_t)B * T2 * Dm));
+    SVA_TRY(alloc_act(A, b->d2c, B, 0, T2, Dm));
+    b->Ht = 40;
+    b->enc_incremental = T2 > b->Ht + p->chunk_frames;
+    {   // streaming state of the exact-incremental encoder
+        EncStream& S = b->es;
+        const int nm = 4 * chunk;
+        std::vector<ShiftDesc> sd;
+        auto reg = [&](Act& a, int rows_per_step) {
+            if (a.H == 0) return;
+            ShiftDesc d;
+            d.ptr = a.p; d.bstride = a.bstride; d.H = a.H; d.T = rows_per_step; d.C = a.C; d.pad = 0;
+            sd.push_back(d);
+        };
+        SVA_TRY(dev_alloc(A, &S.mag, (size_t)B * nm * 1088));
+        SVA_TRY(alloc_act(A, S.mel, B, 6, nm, c.n_mels));
+        reg(S.mel, nm);
+        SVA_TRY(alloc_act(A, S.tmp0, B, 0, nm, c.enc_dims[0]));
+        S.x.resize(4);
+        for (int i = 0; i < 4; ++i) {
+            S.x[i].resize(c.enc_depths[i]);
+            for (int j = 0; j < c.enc_depths[i]; ++j) {
+                SVA_TRY(alloc_act(A, S.x[i][j], B, 6, nm, c.enc_dims[i]));
+                reg(S.x[i][j], nm);
+            }
+            SVA_TRY(alloc_act(A, S.xout[i], B, 0, nm, c.enc_dims[i]));
+        }
+        SVA_TRY(alloc_act(A, S.feat, B, 0, nm, Dm));
+        SVA_TRY(alloc_act(A, S.d1, B, 6, nm / 2, Dm));
+        reg(S.d1, nm / 2);
+        SVA_TRY(alloc_act(A, S.d1o, B, 0, nm / 2, Dm));
+        SVA_TRY(alloc_act(A, S.d2, B, 6, nm / 4, Dm));
+        reg(S.d2, nm / 4);
+        SVA_TRY(dev_alloc(A, &S.h1, (size_t)B * nm * Dm));
+        SVA_TRY(dev_alloc(A, &S.h2, (size_t)B * nm * 4 * Dm));
+        S.n_shift = (int)sd.size();
+        SVA_TRY(dev_alloc(A, &S.d_shift, sd.size()));
+        SVA_HIP(hipMemcpy(S.d_shift, sd.data(), sizeof(ShiftDesc) * sd.size(), hipMemcpyHostToDevice));
+        // steady token cache: rows [Ht + c, T2) slide to [Ht, T2 - c) every step
+        ShiftDesc dc;
+        dc.ptr = b->d2c.p + (long)b->Ht * Dm; dc.bstride = b->d2c.bstride; dc.H = std::max(0, T2 - b->Ht - chunk); dc.T = chunk; dc.C = Dm; dc.pad = 0;
+        SVA_TRY(dev_alloc(A, &b->d_shift_d2c, 1));
+        SVA_HIP(hipMemcpy(b->d_shift_d2c, &dc, sizeof(ShiftDesc), hipMemcpyHostToDevice));
+    }
     SVA_TRY(dev_alloc(A, &b->d_codes, (size_t)B * T2));
     SVA_TRY(dev_alloc(A, &b->d_u, (size_t)B * T2 * c.bsq_bits));
     // AR
@@ -1027,7 +1212,9 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     if (b->ev_ok)
         for (int i = 0; i < 5; ++i) hipEventDestroy(b->ev[i]);
     for (auto& ev : b->prof_ev) hipEventDestroy(ev);
-    hipStreamDestroy(b->stream);
+    for (int i = 0; i < 2; ++i) if (b->aux[i]) { hipStreamSynchronize(b->aux[i]); hipStreamDestroy(b->aux[i]); }
+    for (int i = 0; i < 64; ++i) hipEventDestroy(b->evpool[i]);
+    hipStreamDestroy(b->main_stream);
     delete b;
 }
 
@@ -1145,6 +1332,24 @@ extern "C" int sva_streams_begin(sva_batch* b) {
     SVA_HIP(hipMemsetAsync(b->d_ncontent, 0, sizeof(int) * B, b->stream));
     b->h_step = 0; b->h_ncontent = 0; b->delay_filled = false;
     std::fill(b->h_nframes.begin(), b->h_nframes.end(), 0);
+    if (b->enc_incremental) {
+        // The reference's window starts as all-zero audio (:451): initialise the per-layer histories and the steady
+        // token cache with the network's response to silence by streaming zero frames until every history row and
+        // every cached token is that steady response (receptive field 117 mel frames; T2 tokens in the cache).
+        auto zero = [&](Act& a) -> int {
+            SVA_HIP(hipMemsetAsync(a.p, 0, sizeof(float) * (size_t)B * a.bstride, b->stream));
+            return 0;
+        };
+        EncStream& S = b->es;
+        SVA_TRY(zero(S.mel)); SVA_TRY(zero(S.d1)); SVA_TRY(zero(S.d2)); SVA_TRY(zero(b->d2c));
+        for (auto& st_ : S.x) for (auto& a : st_) SVA_TRY(zero(a));
+        const int warm = 48 / c + 2;             // > receptive field (117 mel frames = 30 tokens) -> histories are steady
+        for (int i = 0; i < warm; ++i) SVA_TRY(enc_frontend_stream(b, nullptr, 0, 0));
+        // every cached token of a silent window is that same steady response
+        hipLaunchKernelGGL(broadcast_row_kernel, dim3(b->T2, B), dim3(256), 0, b->stream, b->d2c.p, b->d2c.bstride, b->T2 - 1, 0, b->T2,
+                           b->e->cfg.tr_dim);
+        SVA_HIP(hipStreamSynchronize(b->stream));
+    }
     // prime the streaming vocoder with the tail of the (truncated) prompt: the reference left-fills its
     // 64-frame vocoder window with the prompt's last frames (:567-571, quirk ix), and the newest frame only
     // depends on the newest 16 code frames, so running the last (window-1) prompt frames through the
@@ -1212,7 +1417,7 @@ int steady_launches(sva_batch* b, bool timing_events) {
     hipStream_t st = b->stream;
     if (timing_events) SVA_HIP(hipEventRecord(b->ev[0], st));
     SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->d_chunk, n, st));
-    SVA_TRY(encode(b, b->d_step, n, 1));
+    SVA_TRY(b->enc_incremental ? encode_incremental(b, b->d_step, n, 1) : encode(b, b->d_step, n, 1));
     hipLaunchKernelGGL(inc_kernel, dim3(1), dim3(64), 0, st, b->d_step, 1);
     hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
                        b->d_ncontent, b->d_step_content, B);
@@ -1276,7 +1481,7 @@ int step_body(sva_batch* b) {
     SVA_HIP(hipEventRecord(b->ev[0], st));
     // E0: shift window / append chunk (:495-496), then E1..E8
     SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->d_chunk, n, st));
-    SVA_TRY(encode(b, b->d_step, n, 1));
+    SVA_TRY(b->enc_incremental ? encode_incremental(b, b->d_step, n, 1) : encode(b, b->d_step, n, 1));
     hipLaunchKernelGGL(inc_kernel, dim3(1), dim3(64), 0, st, b->d_step, 1);
     hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
                        b->d_ncontent, b->d_step_content, B);

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
 // Operand mapping: lane l supplies, for MFMA step j of a block, W[n0 + (l&15)][k0 + 4*(l>>4) + j] and
 // A[m0 + (l&15)][k0 + 4*(l>>4) + j] -- a permutation of k inside the block, identical on both operands.
 // ------------------------------------------------------------------------------------------
-template <int MT, int NT, int KW>
+template <int MT, int NT, int KW, int D, bool SILU>
 __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [KW][MT*NT][64][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -220,29 +220,56 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) 
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int kc_tiles = g.Cin / 16;
     const int nk = g.taps * kc_tiles;
-#pragma unroll 4
-    for (int kb = wave; kb < nk; kb += KW) {
+    // software pipeline, D K-blocks in flight per wave.  No branch around any load (a conditional load makes
+    // hipcc drain vmcnt(0) at the join): out-of-range blocks re-load the wave's last valid block and are masked.
+    const int my_n = nk > wave ? (nk - wave + KW - 1) / KW : 0;          // K blocks owned by this wave
+    const int last_kb = my_n > 0 ? wave + (my_n - 1) * KW : 0;
+    float4 wv[D][NT], av[D][MT];
+    auto issue = [&](float4 (&w)[NT], float4 (&a)[MT], int kb) {
+        kb = kb < nk ? kb : last_kb;
         const int tap = kb / kc_tiles;
         const int kc = (kb - tap * kc_tiles) * 16;
         const long aoff = (long)tap * g.dil * g.lda + kc;
         const long woff = (long)tap * g.Cin + kc;
-        float4 wv[NT], av[MT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wv[j] = *reinterpret_cast<const float4*>(wp[j] + woff);
+        for (int j = 0; j < NT; ++j) w[j] = *reinterpret_cast<const float4*>(wp[j] + woff);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            av[i] = *reinterpret_cast<const float4*>(ap[i] + aoff);
-            if (g.a_silu) { av[i].x = silu_f(av[i].x); av[i].y = silu_f(av[i].y); av[i].z = silu_f(av[i].z); av[i].w = silu_f(av[i].w); }
-        }
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(ap[i] + aoff);
+    };
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int d = 0; d < D; ++d) issue(wv[d], av[d], wave + d * KW);
+    for (int it = 0; it < my_n; it += D) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, wv[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, wv[j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, wv[j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, wv[j].w, acc[i][j], 0, 0, 0);
+        for (int d = 0; d < D; ++d) {
+            const int kb = wave + (it + d) * KW;
+            const float keep = kb < nk ? 1.f : 0.f;
+            float4 w[NT], a[MT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) w[j] = wv[d][j];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                a[i] = av[d][i];
+                if (SILU) { a[i].x = silu_f(a[i].x); a[i].y = silu_f(a[i].y); a[i].z = silu_f(a[i].z); a[i].w = silu_f(a[i].w); }
+                a[i].x *= keep; a[i].y *= keep; a[i].z *= keep; a[i].w *= keep;
             }
+            issue(wv[d], av[d], kb + D * KW);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, w[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, w[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, w[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, w[j].w, acc[i][j], 0, 0, 0);
+        }
     }
     // cross-wave reduction of the K slices
 #pragma unroll
@@ -295,16 +322,25 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) 
     }
 }
 
-template <int MT, int NT, int KW>
+template <int MT, int NT, int KW, int D>
 static int launch_skinny(const ConvGemm& g, hipStream_t st) {
     const size_t smem = (size_t)KW * MT * NT * 256 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
-        SVA_HIP(hipFuncSetAttribute((const void*)skinny_gemm_kernel<MT, NT, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
     dim3 grid((g.N + 16 * NT - 1) / (16 * NT), (g.M + 16 * MT - 1) / (16 * MT));
-    hipLaunchKernelGGL((skinny_gemm_kernel<MT, NT, KW>), grid, dim3(64 * KW), smem, st, g);
+    if (g.a_silu) {
+        static bool attr_a = false;
+        if (!attr_a && smem > 48 * 1024) {
+            SVA_HIP(hipFuncSetAttribute((const void*)skinny_gemm_kernel<MT, NT, KW, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_a = true;
+        }
+        hipLaunchKernelGGL((skinny_gemm_kernel<MT, NT, KW, D, true>), grid, dim3(64 * KW), smem, st, g);
+    } else {
+        static bool attr_b = false;
+        if (!attr_b && smem > 48 * 1024) {
+            SVA_HIP(hipFuncSetAttribute((const void*)skinny_gemm_kernel<MT, NT, KW, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_b = true;
+        }
+        hipLaunchKernelGGL((skinny_gemm_kernel<MT, NT, KW, D, false>), grid, dim3(64 * KW), smem, st, g);
+    }
     return 0;
 }
 
@@ -313,13 +349,13 @@ static int dispatch_skinny(const ConvGemm& g, hipStream_t st) {
     const int mt = g.M > 64 ? 4 : (g.M + 15) / 16;
     const long nk = (long)g.taps * g.Cin / 16;
     const long cols = (long)((g.N + 16 * NT - 1) / (16 * NT)) * ((g.M + 16 * mt - 1) / (16 * mt));
-    // many K blocks and few workgroups -> spread K over 8/16 waves, else 4
+    // many K blocks and few workgroups -> spread K over 8/16 waves, else 4; pipeline depth by register budget
     const bool wide = nk >= 64 && cols < 256;
     switch (mt) {
-        case 1: return wide ? launch_skinny<1, NT, 16>(g, st) : launch_skinny<1, NT, 4>(g, st);
-        case 2: return wide ? launch_skinny<2, NT, 8>(g, st) : launch_skinny<2, NT, 4>(g, st);
-        case 3: return wide ? launch_skinny<3, NT, 8>(g, st) : launch_skinny<3, NT, 4>(g, st);
-        default: return wide ? launch_skinny<4, NT, 8>(g, st) : launch_skinny<4, NT, 4>(g, st);
+        case 1: return wide ? launch_skinny<1, NT, 16, 4>(g, st) : launch_skinny<1, NT, 4, 8>(g, st);
+        case 2: return wide ? launch_skinny<2, NT, 8, 4>(g, st) : launch_skinny<2, NT, 4, 6>(g, st);
+        case 3: return wide ? launch_skinny<3, NT, 8, 4>(g, st) : launch_skinny<3, NT, 4, 4>(g, st);
+        default: return wide ? launch_skinny<4, NT, 8, 3>(g, st) : launch_skinny<4, NT, 4, 4>(g, st);
     }
 }
 

@@ -7,15 +7,16 @@ namespace sva {
 // ---- content encoder -------------------------------------------------------------------
 // E0/E1: causal STFT magnitude of the sliding audio window kept as a ring.
 //   ring  [B, N] (N = window samples); oldest sample at ((*step + add) * n_chunk) % N
-//   (step == nullptr -> 0);  mag [B, T, ldm], T = N/512, bins 0..1024 written, pad zeroed
+//   (step == nullptr -> 0);  frames m0 .. m0+nfr-1 of the window -> mag[b*mag_bstride + i*ldm], bins 0..1024
+//   written, pad columns zeroed
 int launch_stft_mag_ring(const float* ring, const int* step, int n_chunk, int add, int B, int N, const float2* twiddle,
-                         const float* hann, float* mag, int ldm, hipStream_t st);
+                         const float* hann, float* mag, int ldm, long mag_bstride, int m0, int nfr, hipStream_t st);
 
 // depthwise causal k=7 conv + LayerNorm(eps) over channels (ConvNeXtBlock prologue).
 //   x element (b, r, c): x[b*x_bstride + x_off + r*C + c]; output row t reads rows t..t+6.
-//   wT [7][C] (tap-major), out [B, T, C] dense.
+//   wT [7][C] (tap-major), out element (b, t, c) at out[b*o_bstride + t*C + c].
 int launch_dwconv7_ln(const float* x, long x_bstride, long x_off, int B, int T, int C, const float* wT,
-                      const float* bias, const float* ln_w, const float* ln_b, float eps, float* out,
+                      const float* bias, const float* ln_w, const float* ln_b, float eps, float* out, long o_bstride,
                       hipStream_t st);
 
 // row LayerNorm / RMSNorm with strided in/out (rows = B*T).

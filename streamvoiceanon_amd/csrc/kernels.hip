@@ -61,10 +61,10 @@ int launch_fill_i32(int* p, int n, int v, hipStream_t st) {
 __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ ring, const int* step, int n_chunk,
                                                        int add, int N, const float2* __restrict__ tw,
                                                        const float* __restrict__ hann, float* __restrict__ mag,
-                                                       int ldm, int T) {
+                                                       int ldm, long mag_bstride, int m0) {
     __shared__ float re[2048];
     __shared__ float im[2048];
-    const int m = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int m = m0 + blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int start = step ? (int)(((long)(*step + add) * n_chunk) % N) : 0;
     const float* rb = ring + (long)b * N;
     for (int i = tid; i < 2048; i += 256) {
@@ -98,14 +98,13 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
         }
         __syncthreads();
     }
-    float* out = mag + ((long)b * T + m) * ldm;
+    float* out = mag + (long)b * mag_bstride + (long)blockIdx.x * ldm;
     for (int k = tid; k < ldm; k += 256) out[k] = k <= 1024 ? sqrtf(re[k] * re[k] + im[k] * im[k] + 1e-6f) : 0.f;
 }
 int launch_stft_mag_ring(const float* ring, const int* step, int n_chunk, int add, int B, int N, const float2* tw,
-                         const float* hann, float* mag, int ldm, hipStream_t st) {
-    SVA_CHECK(N % 512 == 0 && ldm >= 1025, "stft: bad shape");
-    const int T = N / 512;
-    hipLaunchKernelGGL(stft_mag_kernel, dim3(T, B), dim3(256), 0, st, ring, step, n_chunk, add, N, tw, hann, mag, ldm, T);
+                         const float* hann, float* mag, int ldm, long mag_bstride, int m0, int nfr, hipStream_t st) {
+    SVA_CHECK(N % 512 == 0 && ldm >= 1025 && m0 >= 0 && m0 + nfr <= N / 512, "stft: bad shape");
+    hipLaunchKernelGGL(stft_mag_kernel, dim3(nfr, B), dim3(256), 0, st, ring, step, n_chunk, add, N, tw, hann, mag, ldm, mag_bstride, m0);
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -118,7 +117,8 @@ template <int NPL>
 __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, long x_bstride, long x_off, int T,
                                                          int C, int rows, const float* __restrict__ wT,
                                                          const float* __restrict__ bias, const float* __restrict__ lw,
-                                                         const float* __restrict__ lb, float eps, float* __restrict__ out) {
+                                                         const float* __restrict__ lb, float eps, float* __restrict__ out,
+                                                         long o_bstride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
         q = fmaf(d, d, q);
     }
     const float inv = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
-    float* o = out + (long)row * C;
+    float* o = out + (long)b * o_bstride + (long)t * C;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int c = lane + 64 * i;
@@ -151,11 +151,12 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     }
 }
 int launch_dwconv7_ln(const float* x, long x_bstride, long x_off, int B, int T, int C, const float* wT,
-                      const float* bias, const float* ln_w, const float* ln_b, float eps, float* out, hipStream_t st) {
+                      const float* bias, const float* ln_w, const float* ln_b, float eps, float* out, long o_bstride,
+                      hipStream_t st) {
     SVA_CHECK(C % 64 == 0 && C <= 512, "dwconv7_ln: C must be a multiple of 64, <= 512");
     const int rows = B * T;
     dim3 grid((rows + 3) / 4);
-#define SVA_DW(N_) hipLaunchKernelGGL((dwconv7_ln_kernel<N_>), grid, dim3(256), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out)
+#define SVA_DW(N_) hipLaunchKernelGGL((dwconv7_ln_kernel<N_>), grid, dim3(256), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out, o_bstride)
     switch (C / 64) {
         case 1: SVA_DW(1); break;
         case 2: SVA_DW(2); break;
