@@ -157,6 +157,18 @@ def main():
         batch.sync()
         flops, launches = batch.gemm_stats()
         tot_ms, nl = batch.gemm_profile()
+        if os.environ.get("SVA_GEMM_TABLE"):
+            tab = batch.gemm_profile_table()
+            agg = {}
+            for M_, N_, K_, taps_, mode_, us in tab:
+                key = (int(M_), int(N_), int(K_), int(taps_), int(mode_))
+                a = agg.setdefault(key, [0, 0.0])
+                a[0] += 1; a[1] += us
+            with open(os.environ["SVA_GEMM_TABLE"], "w") as f:
+                f.write("M,N,K,taps,mode,calls,total_us,avg_us,TFLOPs\n")
+                for key, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    fl = 2.0 * key[0] * key[1] * key[2] * cnt
+                    f.write(",".join(map(str, key)) + f",{cnt},{us:.1f},{us / cnt:.2f},{fl / us / 1e6:.2f}\n")
         batch.profile_gemm(False)
         ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         # HBM bytes per conv-GEMM launch from the committed PMC passes of the same command (tools/pmc.sh ->

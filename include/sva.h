@@ -143,6 +143,8 @@ int sva_get_gemm_stats(sva_batch* b, double* flops, long* launches);
  * engine stream; sva_get_gemm_profile returns the summed kernel time and the launch count since enabling */
 int sva_profile_gemm(sva_batch* b, int enable);
 int sva_get_gemm_profile(sva_batch* b, double* total_ms, long* launches);
+/* per-launch rows (M, N, K, taps, mode bits, microseconds) of the profiled steps; returns the number of rows */
+long sva_get_gemm_profile_table(sva_batch* b, double* out, long max_rows);
 
 /* kernel unit-test hook: C = A[M,K] * W[N,K]^T (+bias) through the conv-GEMM kernel (host arrays) */
 int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C);

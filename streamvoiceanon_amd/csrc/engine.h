@@ -3,6 +3,7 @@
 #include "../../include/sva.h"
 #include "kernels.h"
 
+#include <array>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -128,6 +129,7 @@ struct sva_batch {
     hipEvent_t evpool[64];
     int evi = 0;
     bool concurrency = true;
+    bool fused_decode = true;              // B <= 2: GEMV path with fused norm / RoPE / KV-write / SwiGLU
     std::vector<void*> allocs;
 
     // ---- device control block ----
@@ -226,6 +228,7 @@ struct sva_batch {
     bool prof_on = false;
     int prof_n = 0;
     std::vector<hipEvent_t> prof_ev;
+    std::vector<std::array<int, 5>> prof_shapes;
 
     // graph
     hipGraphExec_t graph_exec = nullptr;

@@ -434,6 +434,7 @@ int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda,
             b->prof_ev.resize(old + 512);
             for (size_t i = old; i < b->prof_ev.size(); ++i) SVA_HIP(hipEventCreate(&b->prof_ev[i]));
         }
+        b->prof_shapes.push_back({g.M, g.N, w.K, taps, g.w13 * 8 + g.a_silu * 4 + (g.res ? 2 : 0) + (g.act == ACT_GELU ? 1 : 0)});
         SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n], b->stream));
         int rc = launch_conv_gemm(g, b->stream);
         SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n + 1], b->stream));
@@ -651,6 +652,31 @@ int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int*
     const sva_config& c = b->e->cfg;
     const int D = c.ar_dim, I = c.ar_inter, H = c.ar_heads;
     hipStream_t st = b->stream;
+    if (M <= 4 && b->fused_decode) {
+        // decode at B <= 2: 5 launches per layer -- QKV GEMV (+RMSNorm, +RoPE, +KV write), attention, wo GEMV (+residual),
+        // w1|w3 GEMV (+RMSNorm, +SwiGLU), w2 GEMV (+residual)
+        for (size_t l = 0; l < layers.size(); ++l) {
+            TrLayer& L = layers[l];
+            float* cache = kv + (long)l * kv_layer;
+            Gemv q;
+            q.X = x; q.ldx = D; q.M = M; q.W = L.wqkv.W; q.N = 3 * D; q.K = D; q.norm_w = L.attn_norm; q.eps = 1e-5f;
+            q.Y = b->aqkv; q.ldy = 3 * D; q.mode = 2; q.slot = d_slot; q.pos = d_pos; q.rope = rope; q.kv = cache;
+            q.kv_slot_stride = kv_slot; q.S = S; q.H = H;
+            SVA_TRY(launch_gemv(q, st));
+            SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
+            Gemv o;
+            o.X = b->aatt; o.ldx = D; o.M = M; o.W = L.wo.W; o.N = D; o.K = D; o.res = x; o.ldr = D; o.Y = x; o.ldy = D;
+            SVA_TRY(launch_gemv(o, st));
+            Gemv u;
+            u.X = x; u.ldx = D; u.M = M; u.W = L.w13.W; u.N = 2 * I; u.K = D; u.norm_w = L.ffn_norm; u.eps = 1e-5f;
+            u.Y = b->ag; u.ldy = I; u.mode = 1;
+            SVA_TRY(launch_gemv(u, st));
+            Gemv dn;
+            dn.X = b->ag; dn.ldx = I; dn.M = M; dn.W = L.w2.W; dn.N = D; dn.K = I; dn.res = x; dn.ldr = D; dn.Y = x; dn.ldy = D;
+            SVA_TRY(launch_gemv(dn, st));
+        }
+        return 0;
+    }
     for (size_t l = 0; l < layers.size(); ++l) {
         TrLayer& L = layers[l];
         float* cache = kv + (long)l * kv_layer;
@@ -696,6 +722,16 @@ __global__ void ar_prepare_step_kernel(const float* __restrict__ cached_audio_em
 __global__ void copy_rows_kernel(const float* __restrict__ src, long src_stride, long src_off, float* __restrict__ dst, int D) {
     const int r = blockIdx.x;
     for (int i = threadIdx.x; i < D; i += blockDim.x) dst[(long)r * D + i] = src[(long)r * src_stride + src_off + i];
+}
+
+__global__ void copy_rows2_kernel(const float* __restrict__ src, long src_stride, long src_off, float* __restrict__ dst1,
+                                  float* __restrict__ dst2, int D) {
+    const int r = blockIdx.x;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        const float v = src[(long)r * src_stride + src_off + i];
+        dst1[(long)r * D + i] = v;
+        dst2[(long)r * D + i] = v;
+    }
 }
 
 __global__ void apply_forced_kernel(const int* __restrict__ raw, const int* __restrict__ forced, const int* __restrict__ use_forced,
@@ -819,29 +855,51 @@ int ar_decode_frame(sva_batch* b, int ci) {
                        code_off, b->d_last_pos, D, b->ax, b->d_slot, b->d_pos, b->d_step_content, chunk, ci);
     SVA_TRY(ar_layers_pass(b, e->ar_layers, 2 * B, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
                            b->kv_slow_slot, c.max_seq_len, b->ax));
-    // hidden = pre-norm state of the content token (forward_generate :340-341)
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(B), dim3(256), 0, st, b->ax, (long)2 * D, (long)D, b->hidden, D);
+    // hidden = pre-norm state of the content token (forward_generate :340-341); it also seeds the fast AR
+    hipLaunchKernelGGL(copy_rows2_kernel, dim3(B), dim3(256), 0, st, b->ax, (long)2 * D, (long)D, b->hidden, b->xf, D);
     const int nstride = c.ar_vocab + ncb * cbs;
     const float* noise = b->noise_on_device ? nullptr : b->d_noise + (long)ci * nstride;
     const int ldn = chunk * nstride;
+    const bool fused = B <= 4 && b->fused_decode;
     if (!b->p.skip_semantic) {
-        SVA_TRY(launch_rmsnorm_rows(b->hidden, (long)B * D, 0, D, 1, B, D, e->ar_norm, 1e-5f, b->ahn, (long)B * D, 0, D, st));
-        SVA_TRY(gemm_call(b, b->ahn, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_output, b->slow_logits, (long)B * c.ar_vocab, 0, c.ar_vocab));
+        if (fused) {
+            Gemv hg;
+            hg.X = b->hidden; hg.ldx = D; hg.M = B; hg.W = e->ar_output.W; hg.N = c.ar_vocab; hg.K = D; hg.norm_w = e->ar_norm;
+            hg.eps = 1e-5f; hg.Y = b->slow_logits; hg.ldy = c.ar_vocab;
+            SVA_TRY(launch_gemv(hg, st));
+        } else {
+            SVA_TRY(launch_rmsnorm_rows(b->hidden, (long)B * D, 0, D, 1, B, D, e->ar_norm, 1e-5f, b->ahn, (long)B * D, 0, D, st));
+            SVA_TRY(gemm_call(b, b->ahn, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_output, b->slow_logits, (long)B * c.ar_vocab, 0, c.ar_vocab));
+        }
         SVA_TRY(launch_sampler(b->slow_logits, B, c.ar_vocab, c.ar_vocab, noise, ldn, b->d_seed, b->d_nframes, 0, 0, b->p.temperature,
                                b->p.top_p, b->d_sem, 1, st));
     }
-    SVA_HIP(hipMemcpyAsync(b->xf, b->hidden, sizeof(float) * (size_t)B * D, hipMemcpyDeviceToDevice, st));
     for (int cb = 0; cb < ncb; ++cb) {
         SVA_TRY(ar_layers_pass(b, e->ar_fast_layers, B, b->d_fast_slot, b->d_fast_pos + cb * B, e->rope_fast, (float*)b->kv_fast,
                                b->kv_fast_layer, b->kv_fast_slot, ncb, b->xf));
-        SVA_TRY(launch_rmsnorm_rows(b->xf, (long)B * D, 0, D, 1, B, D, e->ar_fast_norm, 1e-5f, b->ahn, (long)B * D, 0, D, st));
         float* lg = b->fast_logits + (long)cb * cbs;     // [B][8][cbs]
-        SVA_TRY(gemm_call(b, b->ahn, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_fast_output, lg, (long)B * ncb * cbs, 0, ncb * cbs));
-        SVA_TRY(launch_sampler(lg, B, cbs, ncb * cbs, noise ? noise + c.ar_vocab + (long)cb * cbs : nullptr, ldn, b->d_seed, b->d_nframes,
-                               1, cb * cbs, b->p.temperature, b->p.top_p, b->d_tok_raw + cb, ncb, st));
-        hipLaunchKernelGGL(apply_forced_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_tok_raw, b->d_forced, b->d_use_forced, chunk, ci,
-                           cb, ncb, b->d_tok, B);
-        if (cb + 1 < ncb) SVA_TRY(launch_gather_rows(e->fast_emb, b->d_tok + cb, ncb, 0, B, D, b->xf, D, st));
+        if (fused) {
+            Gemv fg;
+            fg.X = b->xf; fg.ldx = D; fg.M = B; fg.W = e->ar_fast_output.W; fg.N = cbs; fg.K = D; fg.norm_w = e->ar_fast_norm; fg.eps = 1e-5f;
+            fg.Y = lg; fg.ldy = ncb * cbs;
+            SVA_TRY(launch_gemv(fg, st));
+        } else {
+            SVA_TRY(launch_rmsnorm_rows(b->xf, (long)B * D, 0, D, 1, B, D, e->ar_fast_norm, 1e-5f, b->ahn, (long)B * D, 0, D, st));
+            SVA_TRY(gemm_call(b, b->ahn, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_fast_output, lg, (long)B * ncb * cbs, 0, ncb * cbs));
+        }
+        // sample (+ teacher forcing) and gather the next fast-AR input embedding in the same launch
+        const float* nz = noise ? noise + c.ar_vocab + (long)cb * cbs : nullptr;
+        if (cbs <= 1024) {
+            SVA_TRY(launch_sampler_small(lg, B, cbs, ncb * cbs, nz, ldn, b->d_seed, b->d_nframes, 1, cb * cbs, b->p.temperature, b->p.top_p,
+                                         b->d_tok_raw + cb, b->d_tok + cb, ncb, b->d_forced + (long)cb * chunk + ci, ncb * chunk, b->d_use_forced,
+                                         cb + 1 < ncb ? e->fast_emb : nullptr, D, b->xf, D, st));
+        } else {
+            SVA_TRY(launch_sampler(lg, B, cbs, ncb * cbs, nz, ldn, b->d_seed, b->d_nframes, 1, cb * cbs, b->p.temperature, b->p.top_p,
+                                   b->d_tok_raw + cb, ncb, st));
+            hipLaunchKernelGGL(apply_forced_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_tok_raw, b->d_forced, b->d_use_forced, chunk, ci,
+                               cb, ncb, b->d_tok, B);
+            if (cb + 1 < ncb) SVA_TRY(launch_gather_rows(e->fast_emb, b->d_tok + cb, ncb, 0, B, D, b->xf, D, st));
+        }
     }
     // cached_new_audio_emb = embed(codes) (:834); positions advance by 2 (:835-836)
     SVA_TRY(launch_audio_embed(e->codebook_emb, b->d_tok, ncb, 1, B, ncb, cbs, D, b->cached_audio_emb, D, st));
@@ -1019,7 +1077,8 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     b->main_stream = b->stream;
     for (int i = 0; i < 2; ++i) SVA_HIP(hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking));
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
-    if (const char* ev = getenv("SVA_CONCURRENCY")) b->concurrency = atoi(ev) != 0;      // 0: single stream (PMC profiling)
+    if (const char* ev = getenv("SVA_CONCURRENCY")) b->concurrency = atoi(ev) != 0;
+    if (const char* ev = getenv("SVA_FUSED_DECODE")) b->fused_decode = atoi(ev) != 0;      // 0: single stream (PMC profiling)
     auto& A = b->allocs;
     const int chunk = p->chunk_frames;
     // control block
@@ -1669,6 +1728,11 @@ extern "C" int sva_profile_gemm(sva_batch* b, int enable) {
     SVA_CHECK(b, "null batch");
     b->prof_on = enable != 0;
     b->prof_n = 0;
+    if (enable) b->prof_shapes.clear();
+    // per-launch durations are only meaningful when launches do not overlap: single stream while profiling
+    static bool saved = true;
+    if (enable) { saved = b->concurrency; b->concurrency = false; }
+    else b->concurrency = saved;
     return 0;
 }
 extern "C" int sva_get_gemm_profile(sva_batch* b, double* total_ms, long* launches) {
@@ -1684,6 +1748,22 @@ extern "C" int sva_get_gemm_profile(sva_batch* b, double* total_ms, long* launch
     *total_ms = tot;
     *launches = b->prof_n / 2;
     return 0;
+}
+// per-launch table of the profiled steps: rows of (M, N, K, taps, mode, microseconds) as doubles; returns #rows
+extern "C" long sva_get_gemm_profile_table(sva_batch* b, double* out, long max_rows) {
+    if (!b || !out) return -1;
+    hipSetDevice(b->e->device);
+    hipStreamSynchronize(b->stream);
+    long n = std::min<long>(max_rows, (long)b->prof_shapes.size());
+    n = std::min<long>(n, b->prof_n / 2);
+    for (long i = 0; i < n; ++i) {
+        float t = 0;
+        hipEventElapsedTime(&t, b->prof_ev[2 * i], b->prof_ev[2 * i + 1]);
+        const auto& sh = b->prof_shapes[i];
+        out[i * 6 + 0] = sh[0]; out[i * 6 + 1] = sh[1]; out[i * 6 + 2] = sh[2]; out[i * 6 + 3] = sh[3]; out[i * 6 + 4] = sh[4];
+        out[i * 6 + 5] = t * 1e3;
+    }
+    return n;
 }
 extern "C" int sva_get_gemm_stats(sva_batch* b, double* flops, long* launches) {
     SVA_CHECK(b && flops && launches, "null argument");

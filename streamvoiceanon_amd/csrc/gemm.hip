@@ -136,46 +136,68 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----
+    // ---- epilogue ----
+    // The accumulators (C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg) are staged
+    // through LDS so that bias / residual reads and the C stores are whole 16-byte, row-contiguous accesses
+    // (a lane-per-element epilogue touches a 64-byte segment per row per instruction and costs up to 30 % of a
+    // K = 512 GEMM).  The last loop iteration ended with a barrier, so the A/B buffers are free to reuse.
+    constexpr int CS = BN + 4;
+    float* Cs = smem;                              // [BM][CS]
     const int col = lane & 15, rq = (lane >> 4) * 4;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = bm0 + wm * TM + i * 16 + rq + r;
-            if (m >= g.M) continue;
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(wm * TM + i * 16 + rq + r) * CS + wn * TN + j * 16 + col] = acc[i][j][r];
+    __syncthreads();
+    if (g.w13) {
+        // SwiGLU: tile columns alternate 16 x w1 | 16 x w3; output column (n0 >> 1) + c
+        constexpr int OC4 = BN / 8;                // float4 chunks of output per row
+        for (int idx = tid; idx < BM * OC4; idx += 256) {
+            const int row = idx / OC4, q = idx - row * OC4;
+            const int m = bm0 + row;
+            const int grp = q >> 2, c4 = (q & 3) * 4;       // 16-wide group, offset inside it
+            const int n = bn0 + grp * 32 + c4;              // w1 column
+            if (m >= g.M || n >= g.N) continue;
             const int b = m / g.T, t = m - b * g.T;
+            const float4 a = *reinterpret_cast<const float4*>(&Cs[row * CS + grp * 32 + c4]);
+            const float4 w = *reinterpret_cast<const float4*>(&Cs[row * CS + grp * 32 + 16 + c4]);
+            float4 o;
+            o.x = silu_f(a.x) * w.x; o.y = silu_f(a.y) * w.y; o.z = silu_f(a.z) * w.z; o.w = silu_f(a.w) * w.w;
             float* crow = g.C + (long)b * g.c_bstride + g.c_off + (long)t * g.ldc;
-            const float* rrow = g.res ? g.res + (long)b * g.r_bstride + g.r_off + (long)t * g.ldr : nullptr;
-            if (g.w13) {
-                if constexpr (NI >= 2) {
-#pragma unroll
-                    for (int j = 0; j < NI; j += 2) {
-                        const int n = bn0 + wn * TN + j * 16 + col;       // w1 column (even 16-group)
-                        if (n < g.N) {
-                            float a = acc[i][j][r], bb = acc[i][j + 1][r];
-                            const int no = ((bn0 + wn * TN + j * 16) >> 1) + col;
-                            crow[no] = silu_f(a) * bb;
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int n = bn0 + wn * TN + j * 16 + col;
-                    if (n >= g.N) continue;
-                    float v = acc[i][j][r];
-                    if (g.bias) v += g.bias[n];
-                    if (g.act == ACT_GELU) v = gelu_erf(v);
-                    else if (g.act == ACT_LOGCLAMP) v = __logf(fmaxf(v, 1e-5f));
-                    if (g.gamma) v *= g.gamma[n];
-                    if (rrow) v += rrow[n];
-                    v *= g.scale;
-                    if (g.accumulate) v += crow[n];
-                    crow[n] = v;
-                }
-            }
+            *reinterpret_cast<float4*>(crow + ((bn0 + grp * 32) >> 1) + c4) = o;
         }
+        return;
+    }
+    constexpr int C4 = BN / 4;
+    for (int idx = tid; idx < BM * C4; idx += 256) {
+        const int row = idx / C4, c4 = (idx - row * C4) * 4;
+        const int m = bm0 + row, n = bn0 + c4;
+        if (m >= g.M || n >= g.N) continue;
+        const int b = m / g.T, t = m - b * g.T;
+        float4 v = *reinterpret_cast<const float4*>(&Cs[row * CS + c4]);
+        if (g.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (g.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        else if (g.act == ACT_LOGCLAMP) { v.x = __logf(fmaxf(v.x, 1e-5f)); v.y = __logf(fmaxf(v.y, 1e-5f)); v.z = __logf(fmaxf(v.z, 1e-5f)); v.w = __logf(fmaxf(v.w, 1e-5f)); }
+        if (g.gamma) {
+            const float4 gg = *reinterpret_cast<const float4*>(g.gamma + n);
+            v.x *= gg.x; v.y *= gg.y; v.z *= gg.z; v.w *= gg.w;
+        }
+        if (g.res) {
+            const float4 rr = *reinterpret_cast<const float4*>(g.res + (long)b * g.r_bstride + g.r_off + (long)t * g.ldr + n);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        v.x *= g.scale; v.y *= g.scale; v.z *= g.scale; v.w *= g.scale;
+        float* cp = g.C + (long)b * g.c_bstride + g.c_off + (long)t * g.ldc + n;
+        if (g.accumulate) {
+            const float4 cc = *reinterpret_cast<const float4*>(cp);
+            v.x += cc.x; v.y += cc.y; v.z += cc.z; v.w += cc.w;
+        }
+        *reinterpret_cast<float4*>(cp) = v;
     }
 }
 
@@ -344,24 +366,42 @@ static int launch_skinny(const ConvGemm& g, hipStream_t st) {
     return 0;
 }
 
+// Choice of (rows per workgroup = 16*MT, K-split waves KW) for the skinny kernel: enough waves to occupy the 256 CUs
+// (>= ~1024 when the problem allows), K slices of at least 2 blocks per wave.
 template <int NT>
 static int dispatch_skinny(const ConvGemm& g, hipStream_t st) {
-    const int mt = g.M > 64 ? 4 : (g.M + 15) / 16;
+    const int mt_total = (g.M + 15) / 16;
     const long nk = (long)g.taps * g.Cin / 16;
-    const long cols = (long)((g.N + 16 * NT - 1) / (16 * NT)) * ((g.M + 16 * mt - 1) / (16 * mt));
-    // many K blocks and few workgroups -> spread K over 8/16 waves, else 4; pipeline depth by register budget
-    const bool wide = nk >= 64 && cols < 256;
+    const long cols = (g.N + 16 * NT - 1) / (16 * NT);
+    int mt = mt_total < 4 ? mt_total : 4;
+    if (mt == 3 && mt_total == 3) mt = 3;
+    auto blocks = [&](int m) { return cols * ((mt_total + m - 1) / m); };
+    while (mt > 1 && blocks(mt) * 4 < 512) mt = mt > 2 ? 2 : 1;
+    int kw = 4;
+    while (kw < 16 && blocks(mt) * kw < 1024 && nk / (2 * kw) >= 2) kw *= 2;
+    if (mt >= 2 && kw == 16) kw = 8;              // register budget of 1024-thread workgroups
     switch (mt) {
-        case 1: return wide ? launch_skinny<1, NT, 16, 4>(g, st) : launch_skinny<1, NT, 4, 8>(g, st);
-        case 2: return wide ? launch_skinny<2, NT, 8, 4>(g, st) : launch_skinny<2, NT, 4, 6>(g, st);
-        case 3: return wide ? launch_skinny<3, NT, 8, 4>(g, st) : launch_skinny<3, NT, 4, 4>(g, st);
-        default: return wide ? launch_skinny<4, NT, 8, 3>(g, st) : launch_skinny<4, NT, 4, 4>(g, st);
+        case 1:
+            if (kw == 16) return launch_skinny<1, NT, 16, 4>(g, st);
+            if (kw == 8) return launch_skinny<1, NT, 8, 6>(g, st);
+            return launch_skinny<1, NT, 4, 8>(g, st);
+        case 2:
+            if (kw == 8) return launch_skinny<2, NT, 8, 4>(g, st);
+            return launch_skinny<2, NT, 4, 6>(g, st);
+        case 3:
+            if (kw == 8) return launch_skinny<3, NT, 8, 4>(g, st);
+            return launch_skinny<3, NT, 4, 4>(g, st);
+        default:
+            if (kw == 8) return launch_skinny<4, NT, 8, 3>(g, st);
+            return launch_skinny<4, NT, 4, 4>(g, st);
     }
 }
 
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_t(const ConvGemm& g, hipStream_t st) {
-    constexpr size_t smem = (size_t)2 * (BM + BN) * (BK + 2) * sizeof(float);
+    constexpr size_t smem_ab = (size_t)2 * (BM + BN) * (BK + 2) * sizeof(float);
+    constexpr size_t smem_c = (size_t)BM * (BN + 4) * sizeof(float);          // epilogue staging tile reuses the buffers
+    constexpr size_t smem = smem_ab > smem_c ? smem_ab : smem_c;
     static bool attr_set = false;
     if (!attr_set && smem > 48 * 1024) {
         SVA_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -375,6 +415,8 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
     SVA_CHECK(g.Cin % 16 == 0 && g.Cin > 0, "conv_gemm: Cin must be a multiple of 16");
     SVA_CHECK(g.lda % 4 == 0 && (g.a_off % 4) == 0 && (g.a_bstride % 4) == 0, "conv_gemm: A must be float4-aligned");
+    const bool c_vec = g.N % 4 == 0 && g.ldc % 4 == 0 && g.c_off % 4 == 0 && g.c_bstride % 4 == 0 &&
+                       (!g.res || (g.ldr % 4 == 0 && g.r_off % 4 == 0 && g.r_bstride % 4 == 0));
     SVA_CHECK(g.M > 0 && g.N > 0 && g.T > 0, "conv_gemm: empty problem");
     if (g.w13) SVA_CHECK(g.N % 32 == 0, "conv_gemm: w13 needs N % 32 == 0");
     // tile selection: the K tile is as deep as Cin allows (bytes in flight per workgroup hide the L2/HBM
@@ -384,14 +426,18 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
     // under-filled grids (fewer than ~1 tiled workgroup per CU): the barrier-free K-split kernel keeps far more
     // loads in flight per CU than the LDS-staged one and pays for it with extra L2 reads, which are cheap there
     const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-    if (g.M <= 64 || (tiles64 < 256 && g.N >= 64)) {
-        SVA_TRY_RC(g.w13 ? dispatch_skinny<2>(g, st) : dispatch_skinny<1>(g, st));
+    if (g.M <= 64 || (tiles64 < 256 && g.N >= 64) || !c_vec) {      // (the tiled epilogue needs 16-byte aligned C rows)
+        // two 16-column tiles per wave halve the A re-reads; worth it once the A panel dominates the L2 traffic
+        const bool nt2 = g.w13 || (g.N % 32 == 0 && g.M >= 512 && (long)g.M * g.N >= 256L * 1024);
+        SVA_TRY_RC(nt2 ? dispatch_skinny<2>(g, st) : dispatch_skinny<1>(g, st));
     } else if (g.N <= 16 && !g.w13) {
         SVA_TRY_RC((launch_t<256, 16, 4, 1, 16>(g, st)));
     } else if (g.N <= 32) {
         if (bk >= 32) SVA_TRY_RC((launch_t<128, 32, 4, 1, 32>(g, st)));
         else SVA_TRY_RC((launch_t<128, 32, 4, 1, 16>(g, st)));
-    } else if (big >= 256) {
+    } else if (big >= 256 && ((big + 255) / 256) * 4.0 <= ((tiles64 + 255) / 256) * 1.25) {
+        // 128x128 tiles only when their last (partial) round over the 256 CUs does not cost more than the lower
+        // operand reuse of 64x64 tiles (e.g. 320 big tiles = 2 rounds for 1.25 rounds of work)
         if (bk >= 32) SVA_TRY_RC((launch_t<128, 128, 2, 2, 32>(g, st)));
         else SVA_TRY_RC((launch_t<128, 128, 2, 2, 16>(g, st)));
     } else {

@@ -84,3 +84,28 @@ int launch_fill_i32(int* p, int n, int v, hipStream_t st);
 int launch_ring_write(float* ring, int* step, int B, int N, const float* chunk, int n, hipStream_t st);
 
 }  // namespace sva
+
+namespace sva {
+// ---- decode GEMV (M <= 4 rows): one wave per pair of output columns, W rows streamed fully coalesced, the x rows
+// held in registers; optional fused RMSNorm prologue and SwiGLU / RoPE+KV-write epilogues (kernels.hip) ----
+struct Gemv {
+    const float* X = nullptr; int ldx = 0; int M = 0;
+    const float* W = nullptr; int N = 0, K = 0;
+    const float* norm_w = nullptr; float eps = 1e-5f;     // RMSNorm(x) * norm_w fused on load
+    const float* bias = nullptr;
+    const float* res = nullptr; int ldr = 0;
+    float* Y = nullptr; int ldy = 0;
+    int mode = 0;                                         // 0 plain, 1 SwiGLU (w13 interleave), 2 q/k RoPE + KV write
+    const int* slot = nullptr; const int* pos = nullptr; const float* rope = nullptr;
+    float* kv = nullptr; long kv_slot_stride = 0; int S = 0, H = 0;
+};
+int launch_gemv(const Gemv& g, hipStream_t st);
+
+// sampler for vocabularies <= 1024 without a sort (rank by counting), fused with teacher forcing and the embedding
+// gather of the sampled token:  tok_raw[row*tok_stride] = sample;  tok[...] = forced ? forced : sample;
+// emb_out[row, :] = emb_table[tok, :]  (emb_table may be null)
+int launch_sampler_small(const float* logits, int rows, int V, int ldl, const float* noise, int ldn,
+                         const unsigned long long* seed, const int* frame, int kind, int noise_elem_off, float temperature,
+                         float top_p, int* tok_raw, int* tok, int tok_stride, const int* forced, int forced_stride,
+                         const int* use_forced, const float* emb_table, int D, float* emb_out, int ldo, hipStream_t st);
+}  // namespace sva

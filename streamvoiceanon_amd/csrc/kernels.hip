@@ -763,4 +763,270 @@ int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStrea
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Decode GEMV for M <= 4 token rows (B = 1..2 streams): the AR's Linear layers at batch 1 are pure weight
+// streaming.  One wave owns two adjacent output columns (a RoPE pair); it reads their W rows as whole contiguous
+// 1-KiB wave loads (lane l takes float4 #l, #l+64, ...), keeps the M input rows in registers, and reduces with
+// wave shuffles -- no LDS, no barrier, every load issued before the first FMA.  Fusions (each one removes a
+// dependent launch from a ~350-kernel chain): RMSNorm of the input rows (the wave sees the whole row, so the
+// statistics cost one extra FMA per element), SwiGLU on the interleaved w1|w3 weight, and for the QKV projection
+// the adjacent-pair RoPE plus the KV-cache write (modules/dual_ar_stream.py:985-990, 967-976, 1004-1016, 141-150).
+// ------------------------------------------------------------------------------------------
+template <int MR, int KI>
+__global__ __launch_bounds__(256) void gemv_kernel(const Gemv g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = blockIdx.x * 4 + wave;                 // pair index
+    const int n_units = g.mode == 1 ? g.N / 4 : g.N / 2;
+    if (unit >= n_units) return;
+    // W rows of this wave: plain / rope: rows 2u, 2u+1; SwiGLU: features f = 2u, 2u+1 -> rows r1(f), r1(f)+16
+    int rows[4];
+    int nrows = 2;
+    if (g.mode == 1) {
+        nrows = 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = 2 * unit + q;
+            const int r1 = (f >> 4) * 32 + (f & 15);
+            rows[2 * q] = r1;
+            rows[2 * q + 1] = r1 + 16;
+        }
+    } else {
+        rows[0] = 2 * unit; rows[1] = 2 * unit + 1; rows[2] = rows[3] = 0;
+    }
+    float4 w[4][KI];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (r < nrows) {
+            const float4* wr = reinterpret_cast<const float4*>(g.W + (long)rows[r] * g.K);
+#pragma unroll
+            for (int i = 0; i < KI; ++i) w[r][i] = wr[lane + 64 * i];
+        }
+    float4 x[MR][KI];
+    float ss[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const float4* xr = reinterpret_cast<const float4*>(g.X + (long)(m < g.M ? m : 0) * g.ldx);
+        ss[m] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            float4 v = xr[lane + 64 * i];
+            ss[m] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            if (g.norm_w) {
+                const float4 nw = reinterpret_cast<const float4*>(g.norm_w)[lane + 64 * i];
+                v.x *= nw.x; v.y *= nw.y; v.z *= nw.z; v.w *= nw.w;
+            }
+            x[m][i] = v;
+        }
+    }
+    float acc[MR][4];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = 0.f;
+            if (r < nrows) {
+#pragma unroll
+                for (int i = 0; i < KI; ++i) {
+                    a = fmaf(x[m][i].x, w[r][i].x, a);
+                    a = fmaf(x[m][i].y, w[r][i].y, a);
+                    a = fmaf(x[m][i].z, w[r][i].z, a);
+                    a = fmaf(x[m][i].w, w[r][i].w, a);
+                }
+            }
+            acc[m][r] = a;
+        }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nrows) acc[m][r] = wave_sum(acc[m][r]);
+        if (g.norm_w) {
+            const float inv = 1.f / sqrtf(wave_sum(ss[m]) / (float)g.K + g.eps);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][r] *= inv;
+        }
+    }
+    if (lane != 0) return;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        if (m >= g.M) break;
+        if (g.mode == 1) {
+            const float o0 = (acc[m][0] / (1.f + expf(-acc[m][0]))) * acc[m][1];
+            const float o1 = (acc[m][2] / (1.f + expf(-acc[m][2]))) * acc[m][3];
+            g.Y[(long)m * g.ldy + 2 * unit] = o0;
+            g.Y[(long)m * g.ldy + 2 * unit + 1] = o1;
+        } else if (g.mode == 2) {
+            const int n = 2 * unit, D = g.H * 64;
+            float a = acc[m][0], b2 = acc[m][1];
+            if (n < 2 * D) {                       // q or k: rotate the adjacent pair
+                const int d = n & 63;
+                const int p = g.pos[m];
+                const float c = g.rope[((long)p * 32 + (d >> 1)) * 2], sn = g.rope[((long)p * 32 + (d >> 1)) * 2 + 1];
+                const float ra = a * c - b2 * sn, rb = b2 * c + a * sn;
+                a = ra; b2 = rb;
+            }
+            if (n < D) {
+                g.Y[(long)m * g.ldy + n] = a;
+                g.Y[(long)m * g.ldy + n + 1] = b2;
+            } else {
+                const int kvsel = n < 2 * D ? 0 : 1;
+                const int nn = n - (kvsel ? 2 * D : D);
+                const int h = nn >> 6, d = nn & 63;
+                float* dst = g.kv + (long)g.slot[m] * g.kv_slot_stride + ((long)kvsel * g.H + h) * (long)g.S * 64 + (long)g.pos[m] * 64 + d;
+                dst[0] = a;
+                dst[1] = b2;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int n = 2 * unit + r;
+                float v = acc[m][r];
+                if (g.bias) v += g.bias[n];
+                if (g.res) v += g.res[(long)m * g.ldr + n];
+                g.Y[(long)m * g.ldy + n] = v;
+            }
+        }
+    }
+}
+
+int launch_gemv(const Gemv& g, hipStream_t st) {
+    SVA_CHECK(g.M >= 1 && g.M <= 4, "gemv: M must be 1..4");
+    SVA_CHECK(g.K % 256 == 0 && g.ldx % 4 == 0, "gemv: K must be a multiple of 256");
+    SVA_CHECK(g.N % 4 == 0, "gemv: N must be a multiple of 4");
+    const int n_units = g.mode == 1 ? g.N / 4 : g.N / 2;
+    dim3 grid((n_units + 3) / 4);
+    const int ki = g.K / 256;
+#define SVA_GV(MR_, KI_) hipLaunchKernelGGL((gemv_kernel<MR_, KI_>), grid, dim3(256), 0, st, g)
+    if (ki == 3) {
+        if (g.M == 1) SVA_GV(1, 3); else if (g.M == 2) SVA_GV(2, 3); else SVA_GV(4, 3);
+    } else if (ki == 9) {
+        if (g.M == 1) SVA_GV(1, 9); else if (g.M == 2) SVA_GV(2, 9); else SVA_GV(4, 9);
+    } else {
+        set_error("gemv: unsupported K (768 or 2304)");
+        return -1;
+    }
+#undef SVA_GV
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// A5 sampler for V <= 1024: one token per thread, bitonic sort (descending, ties by index) with the 45 intra-wave
+// compare-exchange stages done by wave shuffles in registers and only the 10 cross-wave stages through LDS, then
+// softmax, inclusive scan, nucleus cut, temperature softmax and the Exp(1) argmax as in sampler_kernel.  Fused with
+// teacher forcing and the gather of the next fast-AR input embedding.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sampler_small_kernel(const float* __restrict__ logits, int V, int ldl,
+                                                             const float* __restrict__ noise, int ldn,
+                                                             const unsigned long long* __restrict__ seed, const int* __restrict__ frame,
+                                                             int kind, int noise_elem_off, float inv_temp, float top_p,
+                                                             int* __restrict__ tok_raw, int* __restrict__ tok, int tok_stride,
+                                                             const int* __restrict__ forced, int forced_stride,
+                                                             const int* __restrict__ use_forced, const float* __restrict__ emb_table,
+                                                             int D, float* __restrict__ emb_out, int ldo) {
+    __shared__ float xv[1024];
+    __shared__ int xi[1024];
+    __shared__ float fred[16];
+    __shared__ double dred[16];
+    __shared__ int ired[16];
+    __shared__ int chosen;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float v = tid < V ? logits[(long)row * ldl + tid] : -INFINITY;
+    int id = tid;
+    for (int k = 2; k <= 1024; k <<= 1) {
+        const bool desc = (tid & k) == 0;
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            float ov;
+            int oi;
+            if (j >= 64) {
+                __syncthreads();
+                xv[tid] = v; xi[tid] = id;
+                __syncthreads();
+                ov = xv[tid ^ j]; oi = xi[tid ^ j];
+            } else {
+                ov = __shfl_xor(v, j, 64);
+                oi = __shfl_xor(id, j, 64);
+            }
+            const bool lower = (tid & j) == 0;
+            const bool mine_first = (v > ov) || (v == ov && id < oi);       // my element precedes the partner's in descending order
+            const bool keep_first = desc == lower;                          // this position keeps the element that precedes
+            if (mine_first != keep_first) { v = ov; id = oi; }
+        }
+    }
+    // thread t now holds the rank-t element
+    if (tid == 0) fred[0] = v;
+    __syncthreads();
+    const float mx = fred[0];
+    __syncthreads();
+    const float e = tid < V ? expf(v - mx) : 0.f;
+    float s = wave_sum(e);
+    if (lane == 0) fred[wave] = s;
+    __syncthreads();
+    float denom = 0.f;
+    for (int w = 0; w < 16; ++w) denom += fred[w];
+    const double p = (double)(e / denom);
+    double incl = p;                                     // inclusive scan in rank order (double, like torch's CPU cumsum)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) dred[wave] = incl;
+    __syncthreads();
+    double base = 0.0;
+    for (int w = 0; w < wave; ++w) base += dred[w];
+    const float cum = (float)(base + incl);
+    const bool keep = tid < V && (tid == 0 || !(cum > top_p));
+    const float m2 = mx * inv_temp;
+    const float e2 = keep ? expf(v * inv_temp - m2) : 0.f;
+    float s2 = wave_sum(e2);
+    __syncthreads();
+    if (lane == 0) fred[wave] = s2;
+    __syncthreads();
+    float denom2 = 0.f;
+    for (int w = 0; w < 16; ++w) denom2 += fred[w];
+    float best = -1.f;
+    int best_id = 0x7fffffff;
+    if (keep) {
+        const float q = noise ? noise[(long)row * ldn + id] : exp1_noise_dev(seed[row], frame[row], kind, (unsigned)(noise_elem_off + id));
+        best = (e2 / denom2) / q;
+        best_id = id;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi2 = __shfl_xor(best_id, o, 64);
+        if (ob > best || (ob == best && oi2 < best_id)) { best = ob; best_id = oi2; }
+    }
+    __syncthreads();
+    if (lane == 0) { fred[wave] = best; ired[wave] = best_id; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (fred[w] > best || (fred[w] == best && ired[w] < best_id)) { best = fred[w]; best_id = ired[w]; }
+        tok_raw[(long)row * tok_stride] = best_id;
+        int t = best_id;
+        if (forced && *use_forced) t = forced[(long)row * forced_stride];
+        tok[(long)row * tok_stride] = t;
+        chosen = t;
+    }
+    __syncthreads();
+    if (emb_table) {
+        const int t = chosen;
+        for (int c = tid; c < D; c += 1024) emb_out[(long)row * ldo + c] = emb_table[(long)t * D + c];
+    }
+}
+int launch_sampler_small(const float* logits, int rows, int V, int ldl, const float* noise, int ldn,
+                         const unsigned long long* seed, const int* frame, int kind, int noise_elem_off, float temperature,
+                         float top_p, int* tok_raw, int* tok, int tok_stride, const int* forced, int forced_stride,
+                         const int* use_forced, const float* emb_table, int D, float* emb_out, int ldo, hipStream_t st) {
+    SVA_CHECK(V <= 1024, "sampler_small: V <= 1024");
+    const float tclamp = temperature > 1e-5f ? temperature : 1e-5f;
+    hipLaunchKernelGGL(sampler_small_kernel, dim3(rows), dim3(1024), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind, noise_elem_off,
+                       1.0f / tclamp, top_p, tok_raw, tok, tok_stride, forced, forced_stride, use_forced, emb_table, D, emb_out, ldo);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace sva

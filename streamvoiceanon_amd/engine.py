@@ -78,6 +78,8 @@ def load_library():
     lib.sva_get_gemm_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.sva_profile_gemm.argtypes = [vp, i32]
     lib.sva_get_gemm_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    lib.sva_get_gemm_profile_table.argtypes = [vp, vp, C.c_long]
+    lib.sva_get_gemm_profile_table.restype = C.c_long
     lib.sva_bench_gemm.argtypes = [i32] * 9 + [f32p]
     lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
     _lib = lib
@@ -89,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
     "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_encode_window",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_get_tap", "sva_get_timings",
-    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_test_gemm", "sva_bench_gemm",
+    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_bench_gemm",
 ]
 
 
@@ -304,6 +306,11 @@ class Batch:
         t, n = C.c_double(), C.c_long()
         _check(self.lib.sva_get_gemm_profile(self.h, C.byref(t), C.byref(n)), "sva_get_gemm_profile")
         return t.value, n.value
+
+    def gemm_profile_table(self, max_rows=4096):
+        out = np.zeros((max_rows, 6), dtype=np.float64)
+        n = self.lib.sva_get_gemm_profile_table(self.h, _ptr(out), max_rows)
+        return out[:max(n, 0)]
 
     def step_device(self, d_in_ptr, d_out_ptr):
         _check(self.lib.sva_step_device(self.h, C.c_void_p(d_in_ptr), C.c_void_p(d_out_ptr)), "sva_step_device")
