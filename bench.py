@@ -45,7 +45,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24, help="CPU-baseline sample size (chunk-steps)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the captured hipGraph of the steady step (measured slower than eager multi-stream launches on this "
+                         "stack: 5.6 vs 4.8 ms at B=1, the step is GPU-bound, see DESIGN.md)")
+    ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
     return ap.parse_args()
 
 
@@ -107,7 +110,7 @@ def main():
     n = 2048 * c
     W = O.load_synth_weights(0, specs.all_specs())
     eng = E.Engine(W, device=local_rank)
-    batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=not args.no_graph)
+    batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=args.graph)
     # utterances are global ids sharded over ranks (weak scaling: B per rank)
     my_utts = shard_utterances(list(range(world * B)), world)[rank]
     for s, u in enumerate(my_utts):
@@ -197,7 +200,7 @@ def main():
                                f"encode window 128 / vocoder window 64 frames, synthetic 44.1 kHz speech-like audio, "
                                f"synthetic prompt R={args.prompt_frames}, random-init weights of the reference architecture",
                    "streams_per_gpu": B, "chunk_frames": c, "parallelism": f"utterance-parallel x{world}",
-                   "hipgraph": not args.no_graph},
+                   "hipgraph": bool(args.graph)},
         "rtf": round(ms * 1e-3 / (c * FRAME_S), 5), "x_realtime": round(fps * FRAME_S, 2),
         "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm.items()},
         "gathered_utterances": int(gathered.shape[0]) if gathered is not None else B,

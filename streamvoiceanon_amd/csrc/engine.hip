@@ -581,7 +581,10 @@ int enc_frontend_stream(sva_batch* b, const int* step_ptr, int n_chunk, int add)
 
 // pre_module (8-layer causal transformer on T2 tokens, windowed_transformer.py:103-143) + BSQ.  Reads the token
 // features from `xin` without modifying them (the exact-incremental path keeps them as its steady cache).
-int enc_transformer(sva_batch* b, const Act& xin) {
+// need_rows > 0: only the codes of the LAST need_rows tokens are consumed by the caller (streaming keeps codes[-c:],
+// infer_arvc.py:518), so the last layer runs its query / output / FFN rows, the final norm and BSQ for those rows
+// only (its K and V are still computed for every token).  need_rows = 0: all T2 codes (seam API).
+int enc_transformer(sva_batch* b, const Act& xin, int need_rows) {
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
     const int B = b->B, T2 = b->T2, D = c.tr_dim, I = c.tr_inter;
@@ -590,33 +593,39 @@ int enc_transformer(sva_batch* b, const Act& xin) {
     long xr_bs = xin.bstride, xr_off = (long)xin.H * D;
     float* xw = b->tr_x;                     // work copy [B][T2][D]
     const long xw_bs = (long)T2 * D;
-    for (auto& L : e->tr) {
+    const int nl = (int)e->tr.size();
+    for (int li = 0; li < nl; ++li) {
+        TrLayer& L = e->tr[li];
+        const bool tail = need_rows > 0 && li == nl - 1;
+        const int Tr = tail ? need_rows : T2;             // rows of this layer's output that are needed
+        const int r0 = T2 - Tr;
         SVA_TRY(launch_rmsnorm_rows(xr, xr_bs, xr_off, D, B, T2, D, L.attn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
         SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D));
-        SVA_TRY(launch_enc_attention(b->tr_qkv, e->rope_enc, B, T2, c.tr_heads, 64, b->tr_att, st));
+        SVA_TRY(launch_enc_attention(b->tr_qkv, e->rope_enc, B, T2, c.tr_heads, 64, b->tr_att, r0, st));
         ConvGemm po;
         po.gamma = L.ls_attn;
-        po.res = xr; po.r_bstride = xr_bs; po.r_off = xr_off; po.ldr = D;
-        SVA_TRY(gemm_call(b, b->tr_att, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wo, xw, xw_bs, 0, D, po));
+        po.res = xr; po.r_bstride = xr_bs; po.r_off = xr_off + (long)r0 * D; po.ldr = D;
+        SVA_TRY(gemm_call(b, b->tr_att, (long)T2 * D, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.wo, xw, xw_bs, (long)r0 * D, D, po));
         xr = xw; xr_bs = xw_bs; xr_off = 0;
-        SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, 0, D, B, T2, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
+        SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, (long)r0 * D, D, B, Tr, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, (long)r0 * D, D, st));
         ConvGemm pg;
         pg.w13 = 1;
-        SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, 0, I, pg));
+        SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, (long)r0 * I, I, pg));
         ConvGemm pd;
         pd.gamma = L.ls_ffn;
-        pd.res = xw; pd.r_bstride = xw_bs; pd.r_off = 0; pd.ldr = D;
-        SVA_TRY(gemm_call(b, b->tr_g, (long)T2 * I, 0, I, B, T2, 1, 1, 1, I, L.w2, xw, xw_bs, 0, D, pd));
+        pd.res = xw; pd.r_bstride = xw_bs; pd.r_off = (long)r0 * D; pd.ldr = D;
+        SVA_TRY(gemm_call(b, b->tr_g, (long)T2 * I, (long)r0 * I, I, B, Tr, 1, 1, 1, I, L.w2, xw, xw_bs, (long)r0 * D, D, pd));
     }
-    SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, 0, D, B, T2, D, e->tr_norm, 1e-5f, b->tr_z, (long)T2 * D, 0, D, st));
-    SVA_TRY(launch_bsq(b->tr_z, (long)T2 * D, 0, D, B, T2, D, e->bsq_W, e->bsq_b, c.bsq_bits, b->d_codes, b->d_u, st));
+    const int Tr = need_rows > 0 ? need_rows : T2, r0 = T2 - Tr;
+    SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, (long)r0 * D, D, B, Tr, D, e->tr_norm, 1e-5f, b->tr_z, (long)T2 * D, (long)r0 * D, D, st));
+    SVA_TRY(launch_bsq(b->tr_z, (long)T2 * D, (long)r0 * D, D, B, Tr, D, e->bsq_W, e->bsq_b, c.bsq_bits, b->d_codes, b->T2, r0, b->d_u, st));
     return 0;
 }
 
 // full-window formulation (reference: the whole 128-frame window is re-encoded every chunk, infer_arvc.py:505-508)
 int encode(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
     SVA_TRY(enc_frontend_window(b, step_ptr, n_chunk, add, b->T0));
-    return enc_transformer(b, b->d2);
+    return enc_transformer(b, b->d2, 0);
 }
 
 // exact-incremental formulation (SURVEY.md §7 hard part 1): window rows whose causal receptive field still touches
@@ -642,7 +651,7 @@ int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add) 
                              sizeof(float) * (size_t)b->Ht * D, b->B, hipMemcpyDeviceToDevice, st));
     if (par) SVA_TRY(stream_fork(b, b->aux[0], st));                             // join
     (void)c;
-    return enc_transformer(b, b->d2c);
+    return enc_transformer(b, b->d2c, b->p.chunk_frames);
 }
 
 // ---- A: slow / fast transformer passes ------------------------------------------------------------

@@ -28,12 +28,12 @@ int launch_rmsnorm_rows(const float* x, long x_bstride, long x_off, int ldx, int
 
 // causal self-attention of the BSQ pre-transformer: qkv [B, T, 3*D] -> out [B, T, D]; RoPE
 // (adjacent pairs, bf16-rounded table rope[T][hd/2][2]) applied to q and k on load.
-int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out,
+int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out, int row0,
                          hipStream_t st);
 
 // BSQ: u = W z + b (nbits x C), index = sum_d (u_d > 0) << (nbits-1-d); optional L2-normalised u out.
 int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T, int C, const float* W,
-               const float* bias, int nbits, long long* idx_out, float* u_out, hipStream_t st);
+               const float* bias, int nbits, long long* idx_out, int idx_bstride, int idx_off, float* u_out, hipStream_t st);
 
 // ---- dual AR ------------------------------------------------------------------------------
 // RoPE on q,k of qkv rows [M, 3*D] (in place) + KV-cache write at (slot[m], pos[m]).

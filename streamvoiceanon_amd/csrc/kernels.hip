@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
                                                          const float* __restrict__ lb, float eps, float* __restrict__ out,
                                                          long o_bstride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
+    const int row = blockIdx.x * (blockDim.x >> 6) + wave;
     if (row >= rows) return;
     const int b = row / T, t = row - b * T;
     const float* xr = x + (long)b * x_bstride + x_off + (long)t * C;
@@ -155,8 +155,9 @@ int launch_dwconv7_ln(const float* x, long x_bstride, long x_off, int B, int T, 
                       hipStream_t st) {
     SVA_CHECK(C % 64 == 0 && C <= 512, "dwconv7_ln: C must be a multiple of 64, <= 512");
     const int rows = B * T;
-    dim3 grid((rows + 3) / 4);
-#define SVA_DW(N_) hipLaunchKernelGGL((dwconv7_ln_kernel<N_>), grid, dim3(256), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out, o_bstride)
+    const int wpb = rows >= 4096 ? 4 : 1;       // few rows: one wave per workgroup so the rows spread over the CUs
+    dim3 grid((rows + wpb - 1) / wpb);
+#define SVA_DW(N_) hipLaunchKernelGGL((dwconv7_ln_kernel<N_>), grid, dim3(64 * wpb), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out, o_bstride)
     switch (C / 64) {
         case 1: SVA_DW(1); break;
         case 2: SVA_DW(2); break;
@@ -250,7 +251,7 @@ int launch_rmsnorm_rows(const float* x, long x_bstride, long x_off, int ldx, int
 // because window 512 >= T): one workgroup per (head, stream); K (RoPE'd) and V in LDS.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void enc_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ rope,
-                                                            int T, int H, float* __restrict__ out) {
+                                                            int T, int H, float* __restrict__ out, int row0) {
     constexpr int HD = 64, LDK = HD + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                    // [T][65]
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float* __restr
     const float scale = 0.125f;          // 1/sqrt(64)
     // query rows interleaved over (blockIdx.z, wave) so the causal work is balanced; T % (4*gridDim.z) == 0
     // keeps the trip count uniform across the workgroup's waves (barriers inside the loop)
-    for (int r = blockIdx.z * 4 + wave; r < T; r += 4 * gridDim.z) {
+    for (int rb = row0 + blockIdx.z * 4; rb < T; rb += 4 * gridDim.z) {
+        const int r = min(rb + wave, T - 1);          // surplus waves of a short tail recompute the last row (benign)
         if (lane < HD / 2) {
             const float* row = base + (long)r * 3 * D + h * HD;
             const float q0 = row[2 * lane], q1 = row[2 * lane + 1];
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float* __restr
         __syncthreads();
     }
 }
-int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out, hipStream_t st) {
+int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out, int row0, hipStream_t st) {
     SVA_CHECK(hd == 64 && T % 4 == 0, "enc_attention: head_dim must be 64 and T a multiple of 4");
     const size_t smem = ((size_t)T * 65 * 2 + 4 * 64 + 4 * (size_t)T) * sizeof(float);
     SVA_CHECK(smem <= 160 * 1024, "enc_attention: window too long for the LDS-resident kernel");
@@ -317,9 +319,16 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
         SVA_HIP(hipFuncSetAttribute((const void*)enc_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    // rows row0..T-1 are produced; the loop trip count must be uniform over the workgroup's 4 waves (barriers inside),
+    // so a partial row range is walked with one row per workgroup-wave slot (rows >= T fall out of the loop together
+    // only when (T - row0) is a multiple of 4 * qs; otherwise use qs = 1 and pad by predication below)
     int qs = 1;
-    while (qs < 8 && T % (8 * qs) == 0 && (long)H * B * qs < 256) qs *= 2;
-    hipLaunchKernelGGL(enc_attention_kernel, dim3(H, B, qs), dim3(256), smem, st, qkv, rope, T, H, out);
+    if (row0 == 0) {
+        while (qs < 8 && T % (8 * qs) == 0 && (long)H * B * qs < 256) qs *= 2;
+    } else {
+        SVA_CHECK((T - row0) <= 4 || (T - row0) % 4 == 0, "enc_attention: partial row range must be <= 4 rows or a multiple of 4");
+    }
+    hipLaunchKernelGGL(enc_attention_kernel, dim3(H, B, qs), dim3(256), smem, st, qkv, rope, T, H, out, row0);
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -330,7 +339,8 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bsq_kernel(const float* __restrict__ z, long z_bstride, long z_off, int ldz, int T,
                                                   int C, int rows, const float* __restrict__ W, const float* __restrict__ bias,
-                                                  int nbits, long long* __restrict__ idx_out, float* __restrict__ u_out) {
+                                                  int nbits, long long* __restrict__ idx_out, int idx_bstride, int idx_off,
+                                                  float* __restrict__ u_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
@@ -350,17 +360,17 @@ __global__ __launch_bounds__(256) void bsq_kernel(const float* __restrict__ z, l
         const float inv = 1.f / fmaxf(sqrtf(nrm), 1e-12f);      // F.normalize eps
         for (int d = 0; d < nbits; ++d) {
             if (u[d] > 0.f) idx |= 1ll << (nbits - 1 - d);
-            if (u_out) u_out[(long)row * nbits + d] = u[d] * inv;
+            if (u_out) u_out[((long)b * idx_bstride + idx_off + t) * nbits + d] = u[d] * inv;
         }
-        idx_out[row] = idx;
+        idx_out[(long)b * idx_bstride + idx_off + t] = idx;
     }
 }
 int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T, int C, const float* W,
-               const float* bias, int nbits, long long* idx_out, float* u_out, hipStream_t st) {
+               const float* bias, int nbits, long long* idx_out, int idx_bstride, int idx_off, float* u_out, hipStream_t st) {
     SVA_CHECK(nbits <= 16, "bsq: nbits <= 16");
     const int rows = B * T;
     hipLaunchKernelGGL(bsq_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, z, z_bstride, z_off, ldz, T, C, rows, W, bias,
-                       nbits, idx_out, u_out);
+                       nbits, idx_out, idx_bstride, idx_off, u_out);
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -420,27 +430,39 @@ __global__ __launch_bounds__(256) void ar_attention_kernel(const float* __restri
                                                            long slot_stride, int S, float* __restrict__ out) {
     constexpr int HD = 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sc = smem;                 // [S]
-    float* qs = sc + S;               // [64]
-    float* red = qs + HD;             // [8]
-    float* part = red + 8;            // [4][64]
+    float* sc = smem;                 // [S] scores / probabilities
+    float* red = sc + S;              // [8]
+    float* part = red + 8;            // [16][64] partial P.V sums
     const int h = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int D = H * HD;
     const int L = pos[m] + 1;
     const KV* kc = cache + (long)slot[m] * slot_stride + (long)h * S * HD;
     const KV* vc = kc + (long)H * S * HD;
-    if (tid < HD) qs[tid] = qkv[(long)m * 3 * D + h * HD + tid];
-    __syncthreads();
+    // scores: 4 lanes per key row (16 dims each) -> a wave reads 16 consecutive rows = 4 KiB contiguous
+    const int part4 = tid & 3;
+    float q[16];
+    {
+        const float* qr = qkv + (long)m * 3 * D + h * HD + part4 * 16;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) q[d] = qr[d];
+    }
     float mx = -INFINITY;
-    for (int j = tid; j < L; j += 256) {
-        const KV* kr = kc + (long)j * HD;
+    for (int j0 = 0; j0 < L; j0 += 64) {
+        const int j = j0 + (tid >> 2);
         float acc = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < HD; ++d) acc = fmaf(qs[d], from_kv(kr[d]), acc);
+        if (j < L) {
+            const KV* kr = kc + (long)j * HD + part4 * 16;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc = fmaf(q[d], from_kv(kr[d]), acc);
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
         acc *= 0.125f;
-        sc[j] = acc;
-        mx = fmaxf(mx, acc);
+        if (j < L) {
+            if (part4 == 0) sc[j] = acc;
+            mx = fmaxf(mx, acc);
+        }
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
@@ -456,17 +478,31 @@ __global__ __launch_bounds__(256) void ar_attention_kernel(const float* __restri
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     sum = red[4] + red[5] + red[6] + red[7];
-    float acc = 0.f;
-    for (int j = wave; j < L; j += 4) acc = fmaf(sc[j], from_kv(vc[(long)j * HD + lane]), acc);
-    part[wave * HD + lane] = acc;
+    // P.V: thread = (row group jg of 16, float4 column c4 of 16) -> a wave reads 4 consecutive V rows = 1 KiB
+    const int c4 = tid & 15, jg = tid >> 4;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = jg; j < L; j += 16) {
+        const KV* vr = vc + (long)j * HD + c4 * 4;
+        const float pj = sc[j];
+        a4.x = fmaf(pj, from_kv(vr[0]), a4.x);
+        a4.y = fmaf(pj, from_kv(vr[1]), a4.y);
+        a4.z = fmaf(pj, from_kv(vr[2]), a4.z);
+        a4.w = fmaf(pj, from_kv(vr[3]), a4.w);
+    }
+    *reinterpret_cast<float4*>(&part[jg * HD + c4 * 4]) = a4;
     __syncthreads();
-    if (tid < HD) out[(long)m * D + h * HD + tid] = (part[tid] + part[HD + tid] + part[2 * HD + tid] + part[3 * HD + tid]) / sum;
+    if (tid < HD) {
+        float o = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) o += part[g2 * HD + tid];
+        out[(long)m * D + h * HD + tid] = o / sum;
+    }
 }
 template <typename KV>
 int launch_ar_attention(const float* qkv, int M, int H, int hd, const int* slot, const int* pos, const KV* cache,
                         long slot_stride, int S, float* out, hipStream_t st) {
     SVA_CHECK(hd == 64, "ar_attention: head_dim must be 64");
-    const size_t smem = ((size_t)S + 64 + 8 + 256) * sizeof(float);
+    const size_t smem = ((size_t)S + 8 + 16 * 64) * sizeof(float);
     hipLaunchKernelGGL((ar_attention_kernel<KV>), dim3(H, M), dim3(256), smem, st, qkv, H, slot, pos, cache, slot_stride, S, out);
     SVA_HIP(hipGetLastError());
     return 0;
@@ -740,16 +776,16 @@ __global__ __launch_bounds__(256) void shift_history_kernel(const ShiftDesc* __r
     const ShiftDesc d = descs[blockIdx.x];
     float* base = d.ptr + (long)blockIdx.y * d.bstride;
     const long n = (long)d.H * d.C, delta = (long)d.T * d.C;
-    for (long i0 = 0; i0 < n; i0 += 1024) {
-        float v[4];
+    for (long i0 = 0; i0 < n; i0 += 4096) {
+        float v[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 16; ++e) {
             const long i = i0 + threadIdx.x + e * 256;
             v[e] = i < n ? base[i + delta] : 0.f;
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 16; ++e) {
             const long i = i0 + threadIdx.x + e * 256;
             if (i < n) base[i] = v[e];
         }
