@@ -97,9 +97,31 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("SVA_FORCE_DIST") == "1"      # exercise the RCCL code path with a 1-rank group
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL prints banner lines ("Hostname : ...", "Librccl path : ...") on stdout when it initialises; keep stdout
+        # clean for the single JSON line by pointing fd 1 at stderr until the communicator is up
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            t_ = torch.zeros(1, device="cuda")
+            dist.all_reduce(t_)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)      # RCCL's banner sits in the C stdio buffer: flush it to stderr now
+            except Exception:
+                pass
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from oracle import sva_oracle as O            # only to regenerate the synthetic weights + cpu_baseline leg
     from streamvoiceanon_amd import engine as E, specs
@@ -132,24 +154,24 @@ def main():
         run(k); k += 1
     batch.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run(k); k += 1
     batch.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     tm = batch.timings()
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # the trivial gather of per-utterance results (codes of the last step) to rank 0
     codes = batch.tap("audio_codes", (B, 8, c), np.int32)
-    gathered = gather_results(torch.from_numpy(codes).cuda(), world, rank)
+    gathered = gather_results(torch.from_numpy(codes).cuda(), world, rank, force=force_dist)
 
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -186,7 +208,7 @@ def main():
                 "traffic": traffic, "traffic_source": os.path.basename(cands[-1]) if traffic is not None else None, "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
                 "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4)}
     if rank != 0:
-        if world > 1:
+        if world > 1 or force_dist:
             dist.destroy_process_group()
         return
     ms = dt / args.steps * 1e3
@@ -210,7 +232,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, W)
     print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -30,14 +30,14 @@ def shard_utterances(utt_ids: Sequence[int], world: int, lengths: Sequence[int] 
     return out
 
 
-def gather_results(local, world: int, rank: int, dst: int = 0):
+def gather_results(local, world: int, rank: int, dst: int = 0, force: bool = False):
     """Gather equally-shaped per-rank result tensors [n_local, ...] to `dst` -> [world*n_local, ...]
     (None on other ranks).  Direct peer->root sends (dist.gather), not a ring: on MI355X the 7 peers
     arrive on 7 distinct xGMI links of the root."""
     import torch
     import torch.distributed as dist
 
-    if world == 1 or not dist.is_initialized():
+    if (world == 1 and not force) or not dist.is_initialized():
         return local
     bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
     dist.gather(local, bufs, dst=dst)

@@ -280,3 +280,43 @@ def test_inference_wrapper_stream_infer(weights0):
     b.close()
     w.batch.close()
     w.engine.close()
+
+
+def test_incremental_encoder_equals_window_recompute_long_stream(eng, weights0):
+    """Exact-incremental encoder over a stream long enough for the whole 128-frame window to turn over
+    (150 chunks): at every chunk the content code produced by the streaming step must equal the last code of the
+    reference formulation (full-window re-encode, `sva_encode_window`) on the same trailing 128-frame window, and at
+    a few points also the CPU oracle's.  Two streams with different audio in one batch."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    B, n_chunks, W = 2, 150, 128
+    audio = np.stack([synth_utterance(3000 + s, 2048 * n_chunks) for s in range(B)])
+    stream = E.Batch(eng, n_streams=B, skip_semantic=True)
+    for s in range(B):
+        ac, cc, style, timbre = synth_prompt(2000 + s, 107)
+        stream.prefill_prompt(s, cc, ac, style, timbre, noise_seed=3000 + s)
+    stream.begin()
+    full = E.Batch(eng, n_streams=B)
+    window = np.zeros((B, W * 2048), np.float32)
+    mism, checked = 0, 0
+    for i in range(n_chunks):
+        ch = audio[:, i * 2048:(i + 1) * 2048]
+        stream.step(ch)
+        got = stream.tap("content_codes", (B, 1), np.int32)[:, 0]
+        window = np.concatenate([window[:, 2048:], ch], axis=1)
+        if i % 3 == 0 or i >= 125:
+            ref_codes, u = full.encode_window(window, return_u=True)
+            checked += B
+            for s in range(B):
+                if got[s] != ref_codes[s, -1]:
+                    # a flip is only admissible on a frame whose pre-sign margin is inside fp32 noise
+                    assert np.abs(u[s, -1]).min() < 1e-5, (i, s, got[s], ref_codes[s, -1], np.abs(u[s, -1]).min())
+                    mism += 1
+        if i in (60, 149):
+            oc = O.encode_window(torch.from_numpy(window), weights0)[0].numpy()
+            np.testing.assert_array_equal(got, oc[:, -1])
+    stream.close()
+    full.close()
+    assert checked >= 2 * 60 and mism <= 1, (checked, mism)
