@@ -182,7 +182,8 @@ struct sva_batch {
     bool noise_on_device = false;
     // histories (per slot, linear with device counters)
     int hist_cap = 0;
-    int* d_content_hist = nullptr;         // [B][hist_cap]
+    int* d_slot_list = nullptr;            // [B] scratch list of slots for partial delay fills
+    int* d_content_hist = nullptr;         // [B][hist_cap] ring
     int* d_pred_hist = nullptr;            // [B][8][hist_cap]
     int* d_step_content = nullptr;         // [B][chunk] content codes of this step (int32)
     int* d_step_audio = nullptr;           // [B][8][chunk]

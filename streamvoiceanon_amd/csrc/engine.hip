@@ -761,7 +761,7 @@ __global__ void ar_finish_frame_kernel(const int* __restrict__ tok, int ncb, int
     const int f = nframes[b];
     for (int i = 0; i < ncb; ++i) {
         const int t = tok[b * ncb + i];
-        if (f < hist_cap) pred_hist[((long)b * ncb + i) * hist_cap + f] = t;
+        pred_hist[((long)b * ncb + i) * hist_cap + (f & (hist_cap - 1))] = t;     // ring (hist_cap is a power of two)
         step_audio[((long)b * ncb + i) * chunk + ci] = t;
     }
     nframes[b] = f + 1;
@@ -775,7 +775,7 @@ __global__ void append_content_kernel(const long long* __restrict__ codes, int T
     const int n = ncontent[b];
     for (int i = 0; i < chunk; ++i) {
         const int code = (int)codes[(long)b * T2 + T2 - chunk + i];
-        if (n + i < hist_cap) content_hist[(long)b * hist_cap + n + i] = code;
+        content_hist[(long)b * hist_cap + ((n + i) & (hist_cap - 1))] = code;
         step_content[b * chunk + i] = code;
     }
     ncontent[b] = n + chunk;
@@ -827,13 +827,14 @@ __global__ void build_prompt_kernel(const float* __restrict__ spk, int nspk, con
 __global__ void build_delayfill_kernel(const float* __restrict__ content_emb, const int* __restrict__ content_hist, int hist_cap,
                                        const int* __restrict__ ncontent, const float* __restrict__ cached_ref_emb, int max_delay,
                                        const int* __restrict__ last_pos, int d, int D, float* __restrict__ x, int* __restrict__ slot,
-                                       int* __restrict__ pos, float* __restrict__ cached_audio_emb) {
+                                       int* __restrict__ pos, float* __restrict__ cached_audio_emb, const int* __restrict__ slot_list) {
     const int rows = 2 * d - 1;
-    const int b = blockIdx.x / rows, r = blockIdx.x % rows;
+    const int li = blockIdx.x / rows, r = blockIdx.x % rows;
+    const int b = slot_list[li];
     const int i = r >> 1;
-    float* o = x + ((long)b * rows + r) * D;
+    float* o = x + ((long)li * rows + r) * D;
     if ((r & 1) == 0) {
-        const int code = content_hist[(long)b * hist_cap + ncontent[b] - d + i];
+        const int code = content_hist[(long)b * hist_cap + ((ncontent[b] - d + i) & (hist_cap - 1))];
         for (int k = threadIdx.x; k < D; k += blockDim.x) o[k] = content_emb[(long)code * D + k];
     } else {
         for (int k = threadIdx.x; k < D; k += blockDim.x) o[k] = cached_ref_emb[((long)b * max_delay + i) * D + k];
@@ -842,9 +843,13 @@ __global__ void build_delayfill_kernel(const float* __restrict__ content_emb, co
         for (int k = threadIdx.x; k < D; k += blockDim.x)
             cached_audio_emb[(long)b * D + k] = cached_ref_emb[((long)b * max_delay + d - 1) * D + k];
     if (threadIdx.x == 0) {
-        slot[b * rows + r] = b;
-        pos[b * rows + r] = last_pos[b] + 1 + r;
+        slot[li * rows + r] = b;
+        pos[li * rows + r] = last_pos[b] + 1 + r;
     }
+}
+__global__ void add_list_kernel(int* p, const int* list, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[list[i]] += v;
 }
 __global__ void add_vec_kernel(int* p, int n, int v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -953,19 +958,29 @@ int ar_prefill_slot(sva_batch* b, int slot, int R) {
     return 0;
 }
 
-int ar_delay_fill(sva_batch* b) {
+// prefill_src_condition4delay for the given slots (all slots at stream start; the re-prefilled ones later)
+int ar_delay_fill(sva_batch* b, const std::vector<int>& slots) {
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
-    const int B = b->B, D = c.ar_dim, d = b->p.delay, rows = 2 * d - 1;
+    const int n = (int)slots.size(), D = c.ar_dim, d = b->p.delay, rows = 2 * d - 1;
+    if (n == 0) return 0;
     hipStream_t st = b->stream;
-    hipLaunchKernelGGL(build_delayfill_kernel, dim3(B * rows), dim3(256), 0, st, e->content_emb, b->d_content_hist, b->hist_cap,
-                       b->d_ncontent, b->cached_ref_emb, c.max_delay, b->d_last_pos, d, D, b->ax, b->d_slot, b->d_pos, b->cached_audio_emb);
-    SVA_TRY(ar_layers_pass(b, e->ar_layers, B * rows, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
+    SVA_HIP(hipMemcpyAsync(b->d_slot_list, slots.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
+    SVA_HIP(hipStreamSynchronize(st));          // `slots` may be a temporary
+    hipLaunchKernelGGL(build_delayfill_kernel, dim3(n * rows), dim3(256), 0, st, e->content_emb, b->d_content_hist, b->hist_cap,
+                       b->d_ncontent, b->cached_ref_emb, c.max_delay, b->d_last_pos, d, D, b->ax, b->d_slot, b->d_pos, b->cached_audio_emb,
+                       b->d_slot_list);
+    SVA_TRY(ar_layers_pass(b, e->ar_layers, n * rows, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
                            b->kv_slow_slot, c.max_seq_len, b->ax));
-    hipLaunchKernelGGL(add_vec_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_last_pos, B, rows);
-    for (int i = 0; i < B; ++i) b->h_last_pos[i] += rows;
+    hipLaunchKernelGGL(add_list_kernel, dim3((n + 63) / 64), dim3(64), 0, st, b->d_last_pos, b->d_slot_list, n, rows);
+    for (int s_ : slots) b->h_last_pos[s_] += rows;
     SVA_HIP(hipGetLastError());
     return 0;
+}
+int ar_delay_fill(sva_batch* b) {
+    std::vector<int> all(b->B);
+    for (int i = 0; i < b->B; ++i) all[i] = i;
+    return ar_delay_fill(b, all);
 }
 
 // ---- V: streaming vocoder on T new code frames held in d_vcodes [B][8][Tv] -------------------------------
@@ -1211,7 +1226,9 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     SVA_TRY(dev_alloc(A, &b->d_tok_raw, B * ncb));
     SVA_TRY(dev_alloc(A, &b->d_forced, (size_t)B * ncb * chunk));
     SVA_TRY(dev_alloc(A, &b->d_noise, (size_t)B * chunk * (c.ar_vocab + ncb * c.codebook_size)));
-    b->hist_cap = 4096;
+    b->hist_cap = 4096;                      // power of two (ring indexing); >= buffer_frames + delay + chunk
+    SVA_CHECK(p->buffer_frames + p->delay + chunk < b->hist_cap, "buffer_frames too large");
+    SVA_TRY(dev_alloc(A, &b->d_slot_list, B));
     SVA_TRY(dev_alloc(A, &b->d_content_hist, (size_t)B * b->hist_cap));
     SVA_TRY(dev_alloc(A, &b->d_pred_hist, (size_t)B * ncb * b->hist_cap));
     SVA_TRY(dev_alloc(A, &b->d_step_content, (size_t)B * chunk));
@@ -1460,10 +1477,18 @@ int reprefill_slot(sva_batch* b, int slot) {
     SVA_CHECK(na == nc, "re-prefill: content/audio history length mismatch");
     std::vector<int> hc(nc), ha((size_t)ncb * na);
     SVA_HIP(hipStreamSynchronize(b->stream));
-    if (nc) SVA_HIP(hipMemcpy(hc.data(), b->d_content_hist + (long)slot * b->hist_cap + c_lo, sizeof(int) * nc, hipMemcpyDeviceToHost));
-    for (int q = 0; q < ncb; ++q)
-        if (na) SVA_HIP(hipMemcpy(ha.data() + (size_t)q * na, b->d_pred_hist + ((long)slot * ncb + q) * b->hist_cap + (nf - na), sizeof(int) * na,
-                                 hipMemcpyDeviceToHost));
+    {   // the histories are rings of hist_cap entries: fetch the slot's rows and index them on the host (rare path)
+        const int cap = b->hist_cap;
+        std::vector<int> ring(cap);
+        if (nc) {
+            SVA_HIP(hipMemcpy(ring.data(), b->d_content_hist + (long)slot * cap, sizeof(int) * cap, hipMemcpyDeviceToHost));
+            for (int i = 0; i < nc; ++i) hc[i] = ring[(c_lo + i) & (cap - 1)];
+        }
+        for (int q = 0; q < ncb && na; ++q) {
+            SVA_HIP(hipMemcpy(ring.data(), b->d_pred_hist + ((long)slot * ncb + q) * cap, sizeof(int) * cap, hipMemcpyDeviceToHost));
+            for (int i = 0; i < na; ++i) ha[(size_t)q * na + i] = ring[(nf - na + i) & (cap - 1)];
+        }
+    }
     std::vector<int64_t> cc(b->ref_content[slot]);
     for (int i = 0; i < nc; ++i) cc.push_back(hc[i]);
     const int Rn = R + na;
@@ -1536,13 +1561,10 @@ int step_body(sva_batch* b) {
         // re-prefill when current_pos // 2 >= max_seq_frames (:547-564).  Positions are deterministic, so the host
         // mirror decides without a device round trip; doing it after the vocoder instead of before (as the reference
         // does) changes nothing: the vocoder consumes the codes just decoded, the re-prefill only rewrites KV state.
-        bool any = false;
+        std::vector<int> redo;
         for (int i = 0; i < B; ++i)
-            if (b->h_last_pos[i] / 2 >= b->p.max_seq_frames) { SVA_TRY(reprefill_slot(b, i)); any = true; }
-        if (any) {
-            for (int i = 0; i < B; ++i) SVA_CHECK(b->h_last_pos[i] == b->h_last_pos[0], "re-prefill needs equal positions across slots in this round");
-            SVA_TRY(ar_delay_fill(b));
-        }
+            if (b->h_last_pos[i] / 2 >= b->p.max_seq_frames) { SVA_TRY(reprefill_slot(b, i)); redo.push_back(i); }
+        SVA_TRY(ar_delay_fill(b, redo));       // prefill_src_condition4delay(src_content_codes[-d:]) for those slots only
         return 0;
     }
     b->graph_step = false;
@@ -1634,7 +1656,7 @@ __global__ void put_codes_kernel(const long long* __restrict__ src, int n_per, l
     for (int i = 0; i < n_per; ++i) {
         const long long c = src[(long)b * n_per + i];
         codes[(long)b * T2 + T2 - n_per + i] = c;
-        if (n + i < hist_cap) content_hist[(long)b * hist_cap + n + i] = (int)c;
+        content_hist[(long)b * hist_cap + ((n + i) & (hist_cap - 1))] = (int)c;
     }
     ncontent[b] = n + n_per;
 }

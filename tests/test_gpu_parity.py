@@ -320,3 +320,39 @@ def test_incremental_encoder_equals_window_recompute_long_stream(eng, weights0):
     stream.close()
     full.close()
     assert checked >= 2 * 60 and mism <= 1, (checked, mism)
+
+
+def test_reprefill_per_slot_with_unequal_prompts(eng):
+    """Slots with different prompt lengths reach max_seq_frames at different steps: each slot re-prefills on its own
+    (prompt + last buffer frames, then the delay fill for that slot only) and still reproduces its single-stream run."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    n_chunks, lens = 60, (107, 91)
+    prompts = [synth_prompt(2100 + s, lens[s]) for s in range(2)]
+    audio = np.stack([synth_utterance(3100 + s, 2048 * n_chunks) for s in range(2)])
+    kw = dict(max_seq_frames=160, buffer_frames=16)
+
+    def run(slots):
+        b = E.Batch(eng, n_streams=len(slots), **kw)
+        for i, s in enumerate(slots):
+            ac, cc, style, timbre = prompts[s]
+            b.prefill_prompt(i, cc, ac, style, timbre, noise_seed=3100 + s)
+        b.begin()
+        outs, codes, pos = [], [], []
+        for k in range(n_chunks):
+            outs.append(b.step(audio[list(slots), k * 2048:(k + 1) * 2048]))
+            codes.append(b.tap("audio_codes", (len(slots), 8, 1), np.int32))
+            pos.append(b.tap("last_pos", (len(slots),), np.int32).copy())
+        b.close()
+        return np.concatenate(outs, axis=1), np.concatenate(codes, axis=2), np.stack(pos)
+
+    both, codes2, pos2 = run((0, 1))
+    for s in range(2):
+        one, codes1, pos1 = run((s,))
+        np.testing.assert_array_equal(pos2[:, s], pos1[:, 0])
+        np.testing.assert_array_equal(codes2[s], codes1[0])
+        np.testing.assert_array_equal(both[s], one[0])
+    # positions dropped (re-prefill happened) at different steps for the two slots
+    drops = [np.where(np.diff(pos2[:, s]) < 0)[0] for s in range(2)]
+    assert len(drops[0]) > 0 and len(drops[1]) > 0 and drops[0][0] != drops[1][0]
