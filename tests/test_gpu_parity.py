@@ -356,3 +356,43 @@ def test_reprefill_per_slot_with_unequal_prompts(eng):
     # positions dropped (re-prefill happened) at different steps for the two slots
     drops = [np.where(np.diff(pos2[:, s]) < 0)[0] for s in range(2)]
     assert len(drops[0]) > 0 and len(drops[1]) > 0 and drops[0][0] != drops[1][0]
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(delay=3, chunk=2, We=64, R=107, n_chunks=8),          # GUI-style 64-frame window, odd delay, chunk > 1
+    dict(delay=2, chunk=1, We=128, R=300, n_chunks=6),         # prompt longer than max_prompt_frames: quirk (iv), 633-token prefill
+    dict(delay=5, chunk=1, We=128, R=70, n_chunks=9),          # long delay, short prompt (>= 63 frames)
+])
+def test_stream_configs_vs_oracle(eng, weights0, cfg):
+    """Configurations without a reference fixture, checked against the (reference-pinned) CPU oracle: identical content
+    and audio codes under shared noise, PCM within the fp32 tolerance."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    useed, d, c = 4000 + cfg["R"], cfg["delay"], cfg["chunk"]
+    ac, cc, style, timbre = synth_prompt(2200 + cfg["R"], cfg["R"])
+    sess = O.StreamSession(weights0, torch.from_numpy(cc), torch.from_numpy(ac), torch.from_numpy(style), torch.from_numpy(timbre),
+                           noise_fn=lambda f: tuple(torch.from_numpy(a) for a in frame_noise(useed, f)), delay=d,
+                           encode_window_frames=cfg["We"], decode_chunk_frames=c)
+    b = E.Batch(eng, n_streams=1, encode_window_frames=cfg["We"], chunk_frames=c, delay=d)
+    b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=useed)
+    b.begin()
+    n = 2048 * c
+    src = synth_utterance(useed, n * cfg["n_chunks"])
+    frame = 0
+    for i in range(cfg["n_chunks"]):
+        ch = src[i * n:(i + 1) * n]
+        ref = sess.process_one_chunk(torch.from_numpy(ch)[None])[0].numpy()
+        nz = []
+        for k in range(c):
+            ns, nf = frame_noise(useed, frame + k)
+            nz.append(np.concatenate([ns, nf.reshape(-1)]))
+        out = b.step(ch[None], noise=np.stack(nz)[None])
+        np.testing.assert_array_equal(b.tap("content_codes", (1, c), np.int32)[0], sess.src_content_codes[-c:].numpy())
+        if np.abs(ref).max() > 0:
+            np.testing.assert_array_equal(b.tap("audio_codes", (1, 8, c), np.int32)[0], sess.pred_codes[:, -c:].numpy())
+            frame += c
+        assert np.abs(out[0] - ref).max() <= PCM_TOL, i
+    assert int(b.tap("last_pos", (1,), np.int32)[0]) == sess.ar.last_pos
+    b.close()
