@@ -129,6 +129,14 @@ int sva_ar_delay_fill(sva_batch* b, const int64_t* codes);
 int sva_ar_decode_one(sva_batch* b, const int64_t* code, const float* noise, const int32_t* forced, int32_t* codes_out,
                       int32_t* pos_out);
 
+/* Offline conversion, ARVCWrapper.generate (modules/arvc_wrapper.py:82-98 -> DualARWrapper.generate, dual_ar_stream.py:698-762)
+ * on a batch created with n_streams = 1, chunk_frames = 1: one prefill of 33 + 2(R+delay) + 1 tokens, then S-1 decode steps
+ * (the last `delay` frames are driven by the wait4end embeddings).  ref_cc int64[R], ref_ac int32[8][R], src_cc int64[S],
+ * noise float[S][vocab + 8*codebook_size] or NULL (device RNG keyed by noise_seed); codes_out int32[8][S].
+ * Follow with sva_vocode_window(codes, S) for code2wav_fn (evaluations/infer_arvc.py:349-360). */
+int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* ref_ac, int R, const int64_t* src_cc, int S,
+                 const float* style, const float* timbre, uint64_t noise_seed, const float* noise, int32_t* codes_out);
+
 /* taps of the last step: "content_codes" int32[B][chunk], "audio_codes" int32[B][8][chunk] (as int32),
  * "slow_logits" float[B][vocab], "fast_logits" float[B][8][codebook_size], "hidden" float[B][dim],
  * "semantic" int32[B], "last_pos" int32[B], "mel" float[B][T][160] ... ; returns #bytes or <0 */

@@ -43,6 +43,23 @@ class ARVCWrapper:
         self.delay = int(delay)
         print(f"Setting delay to {self.delay} frames")
 
+    # modules/arvc_wrapper.py:82-98 ------------------------------------------------------------------------
+    def generate(self, ref_content_codes, ref_audio_codes, src_content_codes, style_vectors, timbre_latents, noise=None,
+                 **sampling_kwargs):
+        """Offline conversion -> int32 codes [1, 8, S] (the reference returns pred_audio_codes.transpose(0, 1))."""
+        import torch
+
+        kw = dict(self._kw)
+        kw.update({k: sampling_kwargs[k] for k in ("temperature", "top_p") if k in sampling_kwargs})
+        batch = E.Batch(self.engine, n_streams=1, delay=self.delay, **kw)
+        try:
+            codes = batch.generate(_np(ref_content_codes, np.int64), _np(ref_audio_codes, np.int32), _np(src_content_codes, np.int64),
+                                   _np(style_vectors, np.float32), _np(timbre_latents, np.float32).reshape(32, -1),
+                                   noise_seed=self.noise_seed, noise=noise)
+        finally:
+            batch.close()
+        return torch.from_numpy(codes)[None]
+
     # modules/arvc_wrapper.py:100-126 ----------------------------------------------------------------------
     def prefill_prompt(self, ref_content_codes, ref_audio_codes, style_vectors, timbre_latents):
         """ref_content_codes [1, R] int64, ref_audio_codes [1, 8, R] int, style [1, 192], timbre [1, 32, 128]."""

@@ -341,7 +341,16 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
     {
         const int D = c.ar_dim;
         const std::string m = "arvc.decoder.model.";
-        SVA_TRY(P.vec("arvc.embedding.weight", &e->content_emb, (long)c.ar_vocab * D));
+        {   // content embedding followed by the wait4end rows: offline generate() feeds wait4end_j where a content token is due
+            // (dual_ar_stream.py:716), addressed as code = vocab + j
+            const HostTensor* ce = P.find("arvc.embedding.weight");
+            const HostTensor* we = P.find("arvc.decoder.wait4end_embedding.weight");
+            SVA_CHECK(ce && ce->numel() == (long)c.ar_vocab * D, "missing arvc.embedding.weight");
+            std::vector<float> ext((size_t)(c.ar_vocab + c.max_delay) * D, 0.f);
+            memcpy(ext.data(), ce->data.data(), sizeof(float) * (size_t)c.ar_vocab * D);
+            if (we && we->numel() == (long)c.max_delay * D) memcpy(ext.data() + (size_t)c.ar_vocab * D, we->data.data(), sizeof(float) * (size_t)c.max_delay * D);
+            SVA_TRY(upload(e->allocs, &e->content_emb, ext));
+        }
         SVA_TRY(P.vec(m + "codebook_embeddings.weight", &e->codebook_emb, (long)c.codebook_size * c.num_codebooks * D));
         SVA_TRY(P.vec(m + "fast_embeddings.weight", &e->fast_emb, (long)c.codebook_size * D));
         SVA_TRY(P.vec("arvc.decoder.wait4start_embedding.weight", &e->wait4start, (long)c.max_delay * D));
@@ -755,7 +764,7 @@ __global__ void apply_forced_kernel(const int* __restrict__ raw, const int* __re
 __global__ void ar_finish_frame_kernel(const int* __restrict__ tok, int ncb, int* __restrict__ last_pos, int* __restrict__ nframes,
                                        int* __restrict__ pred_hist, int hist_cap, int* __restrict__ step_audio, int chunk, int ci,
                                        const long long* __restrict__ codes, int T2, int code_off, int* __restrict__ content_hist,
-                                       int* __restrict__ ncontent, int B) {
+                                       int* __restrict__ ncontent, int B, int last_pos_inc) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int f = nframes[b];
@@ -765,7 +774,7 @@ __global__ void ar_finish_frame_kernel(const int* __restrict__ tok, int ncb, int
         step_audio[((long)b * ncb + i) * chunk + ci] = t;
     }
     nframes[b] = f + 1;
-    last_pos[b] += 2;
+    last_pos[b] += last_pos_inc;
 }
 
 __global__ void append_content_kernel(const long long* __restrict__ codes, int T2, int chunk, int* __restrict__ content_hist,
@@ -859,18 +868,30 @@ __global__ void add_vec_kernel(int* p, int n, int v) {
 namespace {
 
 // one decoded frame for every stream (decode_one_token_ar, dual_ar_stream.py:1168-1219)
+int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const long long* codes, int codes_ld, int code_off, int last_pos_inc);
+
 int ar_decode_frame(sva_batch* b, int ci) {
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
-    const int B = b->B, D = c.ar_dim, chunk = b->p.chunk_frames, ncb = c.num_codebooks, cbs = c.codebook_size;
+    const int B = b->B, D = c.ar_dim, chunk = b->p.chunk_frames;
     hipStream_t st = b->stream;
     const int code_off = b->T2 - chunk + ci;
     hipLaunchKernelGGL(ar_prepare_step_kernel, dim3(B), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, b->d_codes, b->T2,
                        code_off, b->d_last_pos, D, b->ax, b->d_slot, b->d_pos, b->d_step_content, chunk, ci);
     SVA_TRY(ar_layers_pass(b, e->ar_layers, 2 * B, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
                            b->kv_slow_slot, c.max_seq_len, b->ax));
+    return ar_frame_tail(b, ci, (long)2 * D, (long)D, b->d_codes, b->T2, code_off, 2);
+}
+
+// semantic head + 8-step fast AR + bookkeeping of one frame; the slow hidden state of slot s is row
+// ax[s*hid_stride + hid_off .. +D)  (decode_one_token_ar, dual_ar_stream.py:1181-1219)
+int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const long long* codes, int codes_ld, int code_off, int last_pos_inc) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int B = b->B, D = c.ar_dim, chunk = b->p.chunk_frames, ncb = c.num_codebooks, cbs = c.codebook_size;
+    hipStream_t st = b->stream;
     // hidden = pre-norm state of the content token (forward_generate :340-341); it also seeds the fast AR
-    hipLaunchKernelGGL(copy_rows2_kernel, dim3(B), dim3(256), 0, st, b->ax, (long)2 * D, (long)D, b->hidden, b->xf, D);
+    hipLaunchKernelGGL(copy_rows2_kernel, dim3(B), dim3(256), 0, st, b->ax, hid_stride, hid_off, b->hidden, b->xf, D);
     const int nstride = c.ar_vocab + ncb * cbs;
     const float* noise = b->noise_on_device ? nullptr : b->d_noise + (long)ci * nstride;
     const int ldn = chunk * nstride;
@@ -918,8 +939,8 @@ int ar_decode_frame(sva_batch* b, int ci) {
     // cached_new_audio_emb = embed(codes) (:834); positions advance by 2 (:835-836)
     SVA_TRY(launch_audio_embed(e->codebook_emb, b->d_tok, ncb, 1, B, ncb, cbs, D, b->cached_audio_emb, D, st));
     hipLaunchKernelGGL(ar_finish_frame_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_tok, ncb, b->d_last_pos, b->d_nframes,
-                       b->d_pred_hist, b->hist_cap, b->d_step_audio, chunk, ci, b->d_codes, b->T2, code_off, b->d_content_hist,
-                       b->d_ncontent, B);
+                       b->d_pred_hist, b->hist_cap, b->d_step_audio, chunk, ci, codes, codes_ld, code_off, b->d_content_hist,
+                       b->d_ncontent, B, last_pos_inc);
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -1698,6 +1719,95 @@ extern "C" int sva_ar_decode_one(sva_batch* b, const int64_t* code, const float*
     SVA_HIP(hipMemcpyAsync(codes_out, b->d_step_audio, sizeof(int) * (size_t)B * ncb, hipMemcpyDeviceToHost, st));
     if (pos_out) SVA_HIP(hipMemcpyAsync(pos_out, b->d_last_pos, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, st));
     SVA_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ---- offline ARVCWrapper.generate (modules/arvc_wrapper.py:82-98 + DualARWrapper.generate, dual_ar_stream.py:698-762) ----
+__global__ void put_row_kernel(const float* __restrict__ table, long long code, int D, float* __restrict__ dst) {
+    for (int i = threadIdx.x; i < D; i += blockDim.x) dst[i] = table[code * D + i];
+}
+__global__ void prepare_offline_step_kernel(const float* __restrict__ cached_audio_emb, const float* __restrict__ content_emb,
+                                            const long long* __restrict__ rem, int step, const int* __restrict__ last_pos, int D,
+                                            float* __restrict__ x, int* __restrict__ slot, int* __restrict__ pos) {
+    const long long code = rem[step];
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        x[i] = cached_audio_emb[i];
+        x[D + i] = content_emb[code * D + i];
+    }
+    if (threadIdx.x == 0) { slot[0] = 0; slot[1] = 0; pos[0] = last_pos[0] + 1; pos[1] = last_pos[0] + 2; }
+}
+
+extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* ref_ac, int R, const int64_t* src_cc, int S,
+                            const float* style, const float* timbre, uint64_t noise_seed, const float* noise, int32_t* codes_out) {
+    SVA_CHECK(b && ref_cc && ref_ac && src_cc && style && timbre && codes_out, "sva_generate: null argument");
+    SVA_CHECK(b->B == 1 && b->p.chunk_frames == 1, "sva_generate: the offline path is batch 1 / chunk 1 like the reference");
+    SVA_HIP(hipSetDevice(b->e->device));
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int D = c.ar_dim, d = b->p.delay, ncb = c.num_codebooks, nspk = c.timbre_tokens + 1;
+    hipStream_t st = b->stream;
+    SVA_CHECK(S > d && S <= b->hist_cap, "sva_generate: source length must exceed the delay");
+    const int Rp = R + d, M = nspk + 2 * Rp + 1;
+    SVA_CHECK(M + 2 * (S - 1) <= c.max_seq_len && M <= b->Mmax, "sva_generate: prompt + source exceed the 2048-position KV cache (the reference breaks there too)");
+    SVA_TRY(h2d(b, b->d_style, style, sizeof(float) * c.style_dim));
+    SVA_TRY(h2d(b, b->d_timbre, timbre, sizeof(float) * c.timbre_tokens * c.timbre_dim));
+    unsigned long long sd = noise_seed;
+    SVA_TRY(h2d(b, b->d_seed, &sd, sizeof(sd)));
+    SVA_HIP(hipMemsetAsync(b->d_nframes, 0, sizeof(int), st));
+    b->h_nframes[0] = 0;
+    // prefill_cond = [ref_cond, src_cond[:d]] interleaved with [wait4start[:d], embed(ref_audio)]  (:711-715)
+    std::vector<int64_t> cc(ref_cc, ref_cc + R);
+    for (int i = 0; i < d; ++i) cc.push_back(src_cc[i]);
+    std::vector<int32_t> ac((size_t)ncb * Rp, 0);
+    for (int q = 0; q < ncb; ++q)
+        for (int i = 0; i < R; ++i) ac[(size_t)q * Rp + i] = ref_ac[(size_t)q * R + i];
+    SVA_TRY(stage_prompt(b, cc, ac, Rp));
+    // remaining_cond = [src_cond[d:], wait4end[:d]]  (:716), wait4end_j addressed as vocab + j in the extended table
+    std::vector<int64_t> rem(S);
+    for (int i = 0; i < S; ++i) rem[i] = i < S - d ? src_cc[d + i] : (int64_t)c.ar_vocab + (i - (S - d));
+    long long* d_remq = nullptr;
+    SVA_HIP(hipMalloc((void**)&d_remq, sizeof(long long) * (size_t)S));
+    SVA_HIP(hipMemcpyAsync(d_remq, rem.data(), sizeof(long long) * (size_t)S, hipMemcpyHostToDevice, st));
+    SVA_HIP(hipStreamSynchronize(st));
+    // speaker prefix + prompt rows, then remaining_cond[0] as the last row
+    SVA_TRY(gemm_call(b, b->d_timbre, (long)c.timbre_tokens * c.timbre_dim, 0, c.timbre_dim, 1, c.timbre_tokens, 1, 1, 1, c.timbre_dim, e->context_in,
+                      b->spk, (long)nspk * D, 0, D));
+    SVA_TRY(gemm_call(b, b->d_style, c.style_dim, 0, c.style_dim, 1, 1, 1, 1, 1, c.style_dim, e->style_in, b->spk + (long)c.timbre_tokens * D, D, 0, D));
+    hipLaunchKernelGGL(build_prompt_kernel, dim3(M - 1), dim3(256), 0, st, b->spk, nspk, e->content_emb, e->codebook_emb, e->wait4start,
+                       b->d_prompt_cc, b->d_prompt_ac, b->Pmax, Rp, d, ncb, c.codebook_size, D, b->ax);
+    hipLaunchKernelGGL(put_row_kernel, dim3(1), dim3(256), 0, st, e->content_emb, (long long)rem[0], D, b->ax + (long)(M - 1) * D);
+    std::vector<int> hs(M, 0), hp(M);
+    for (int i = 0; i < M; ++i) hp[i] = i;
+    SVA_HIP(hipMemcpyAsync(b->d_slot, hs.data(), sizeof(int) * M, hipMemcpyHostToDevice, st));
+    SVA_HIP(hipMemcpyAsync(b->d_pos, hp.data(), sizeof(int) * M, hipMemcpyHostToDevice, st));
+    SVA_HIP(hipStreamSynchronize(st));
+    SVA_TRY(ar_layers_pass(b, e->ar_layers, M, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer, b->kv_slow_slot,
+                           c.max_seq_len, b->ax));
+    const int lp = M - 1;
+    SVA_TRY(h2d(b, b->d_last_pos, &lp, sizeof(int)));
+    b->h_last_pos[0] = lp;
+    const int nstride = c.ar_vocab + ncb * c.codebook_size;
+    const int zero = 0;
+    SVA_TRY(h2d(b, b->d_use_forced, &zero, sizeof(int)));
+    b->noise_on_device = (noise == nullptr);
+    for (int i = 0; i < S; ++i) {
+        if (noise) SVA_TRY(h2d(b, b->d_noise, noise + (size_t)i * nstride, sizeof(float) * nstride));
+        if (i == 0) {
+            SVA_TRY(ar_frame_tail(b, 0, 0, (long)(M - 1) * D, d_remq, S, 0, 0));
+        } else {
+            hipLaunchKernelGGL(prepare_offline_step_kernel, dim3(1), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, d_remq, i, b->d_last_pos, D,
+                               b->ax, b->d_slot, b->d_pos);
+            SVA_TRY(ar_layers_pass(b, e->ar_layers, 2, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer, b->kv_slow_slot,
+                                   c.max_seq_len, b->ax));
+            SVA_TRY(ar_frame_tail(b, 0, (long)2 * D, (long)D, d_remq, S, i, 2));
+            b->h_last_pos[0] += 2;
+        }
+        b->h_nframes[0] += 1;
+    }
+    SVA_HIP(hipStreamSynchronize(st));
+    for (int q = 0; q < ncb; ++q)
+        SVA_HIP(hipMemcpy(codes_out + (size_t)q * S, b->d_pred_hist + (size_t)q * b->hist_cap, sizeof(int) * (size_t)S, hipMemcpyDeviceToHost));
+    (void)hipFree(d_remq);
     return 0;
 }
 

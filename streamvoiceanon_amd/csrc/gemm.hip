@@ -10,6 +10,7 @@
 // next tile's global loads are issued before the current tile's MFMAs and written to the other
 // LDS buffer after them (one barrier per K tile).
 #include "sva_common.h"
+#include <stdlib.h>
 
 namespace sva {
 
@@ -380,6 +381,10 @@ static int dispatch_skinny(const ConvGemm& g, hipStream_t st) {
     int kw = 4;
     while (kw < 16 && blocks(mt) * kw < 1024 && nk / (2 * kw) >= 2) kw *= 2;
     if (mt >= 2 && kw == 16) kw = 8;              // register budget of 1024-thread workgroups
+    static const char* env_mt = getenv("SVA_SKINNY_MT");
+    static const char* env_kw = getenv("SVA_SKINNY_KW");
+    if (env_mt) mt = atoi(env_mt) < mt_total ? atoi(env_mt) : (mt_total < 4 ? mt_total : 4);
+    if (env_kw) { kw = atoi(env_kw); if (mt >= 2 && kw == 16) kw = 8; }
     switch (mt) {
         case 1:
             if (kw == 16) return launch_skinny<1, NT, 16, 4>(g, st);

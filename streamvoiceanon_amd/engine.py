@@ -72,6 +72,7 @@ def load_library():
     lib.sva_vocode_reset.argtypes = [vp]
     lib.sva_ar_delay_fill.argtypes = [vp, vp]
     lib.sva_ar_decode_one.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.sva_generate.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, C.c_uint64, vp, vp]
     lib.sva_get_tap.argtypes = [vp, C.c_char_p, vp, C.c_long]
     lib.sva_get_tap.restype = C.c_long
     lib.sva_get_timings.argtypes = [vp, f32p]
@@ -90,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "sva_last_error", "sva_config_default", "sva_stream_params_default", "sva_engine_create",
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
     "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_encode_window",
-    "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_get_tap", "sva_get_timings",
+    "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
     "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_bench_gemm",
 ]
 
@@ -282,6 +283,19 @@ class Batch:
         pos = np.empty((self.B,), dtype=np.int32)
         _check(self.lib.sva_ar_decode_one(self.h, _ptr(c), _ptr(nz), _ptr(fc), _ptr(out), _ptr(pos)), "sva_ar_decode_one")
         return out, pos
+
+    def generate(self, ref_content_codes, ref_audio_codes, src_content_codes, style, timbre, noise_seed=0, noise=None):
+        """offline ARVCWrapper.generate -> codes int32 [8, S]"""
+        cc = np.ascontiguousarray(ref_content_codes, dtype=np.int64).reshape(-1)
+        ac = np.ascontiguousarray(ref_audio_codes, dtype=np.int32).reshape(8, -1)
+        src = np.ascontiguousarray(src_content_codes, dtype=np.int64).reshape(-1)
+        st = np.ascontiguousarray(style, dtype=np.float32).reshape(-1)
+        tm = np.ascontiguousarray(timbre, dtype=np.float32)
+        nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float32).reshape(src.shape[0], self.noise_stride)
+        out = np.empty((8, src.shape[0]), dtype=np.int32)
+        _check(self.lib.sva_generate(self.h, _ptr(cc), _ptr(ac), cc.shape[0], _ptr(src), src.shape[0], _ptr(st), _ptr(tm), int(noise_seed),
+                                     _ptr(nz), _ptr(out)), "sva_generate")
+        return out
 
     def vocode_reset(self):
         _check(self.lib.sva_vocode_reset(self.h), "sva_vocode_reset")

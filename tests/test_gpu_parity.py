@@ -396,3 +396,27 @@ def test_stream_configs_vs_oracle(eng, weights0, cfg):
         assert np.abs(out[0] - ref).max() <= PCM_TOL, i
     assert int(b.tap("last_pos", (1,), np.int32)[0]) == sess.ar.last_pos
     b.close()
+
+
+def test_offline_generate_vs_reference_golden(eng, weights0):
+    """Offline path: ARVCWrapper.generate + code2wav on the fixture captured from the reference's
+    own generate(): identical codes under the shared noise (incl. the wait4end-driven last `delay` frames), PCM within tol."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.arvc_wrapper import ARVCWrapper
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt
+
+    g = load_golden("offline_s0")
+    useed = int(g["audio_seed"])
+    ac, cc, style, timbre = synth_prompt(int(g["prompt_seed"]), int(g["prompt_frames"]))
+    S = g["src_codes"].shape[0]
+    noise = np.stack([np.concatenate([frame_noise(useed, s)[0], frame_noise(useed, s)[1].reshape(-1)]) for s in range(S)])
+    m = ARVCWrapper(eng, delay=int(g["delay"]))
+    codes = m.generate(torch.from_numpy(cc)[None], torch.from_numpy(ac)[None], torch.from_numpy(g["src_codes"])[None],
+                       torch.from_numpy(style)[None], torch.from_numpy(timbre)[None], noise=noise)
+    assert codes.shape == (1, 8, S) and codes.dtype == torch.int32
+    np.testing.assert_array_equal(codes.numpy(), g["codes"])
+    b = E.Batch(eng, n_streams=1, voc_max_frames=S)
+    pcm = b.vocode_window(codes.numpy())
+    np.testing.assert_allclose(pcm[0, -2048:], g["pcm_last"], atol=PCM_TOL)
+    assert abs(float(pcm.astype(np.float64).sum()) - float(g["pcm_sum"])) < 5e-2
+    b.close()
