@@ -96,6 +96,47 @@ class InferenceWrapper:
         self.batch.prefill_prompt(0, cc.reshape(-1), ac.reshape(8, -1), st.reshape(-1), tm.reshape(32, -1), noise_seed=self._noise_seed)
         self.batch.begin()
 
+    # ---- offline -----------------------------------------------------------------------------------------
+    def encode_content(self, wav):
+        """speech_tokenizer.encode on a whole utterance (:334-339) -> int64 codes [S], S = len // 2048.  The utterance is
+        right-padded with zeros to a multiple of 4 frames (causal encoder: earlier codes are unaffected); limited to 256
+        frames by the LDS-resident encoder attention (longer inputs are row N3 follow-up work)."""
+        wav = np.asarray(wav, dtype=np.float32).reshape(-1)
+        S = wav.shape[0] // self.SAMPLES_PER_FRAME
+        Wp = ((S + 3) // 4) * 4
+        if Wp > 256:
+            raise NotImplementedError("offline encode of more than 256 frames (11.9 s) needs the tiled attention kernel (N3 follow-up)")
+        buf = np.zeros(Wp * self.SAMPLES_PER_FRAME, np.float32)
+        buf[:S * self.SAMPLES_PER_FRAME] = wav[:S * self.SAMPLES_PER_FRAME]
+        b = E.Batch(self.engine, n_streams=1, encode_window_frames=Wp)
+        try:
+            codes = b.encode_window(buf[None])[0, :S]
+        finally:
+            b.close()
+        return codes
+
+    def infer(self, src, ref_path=None, out_dir=None, output_path=None, delay=None, ref_crop_lengths=None, alpha=1.0,
+              spk_emb_collate_type="concat_mel", save_result=False, prompt=None, noise_seed=0, **sampling_kwargs):
+        """:261-380 offline conversion: encode the source, ARVCWrapper.generate, code2wav.  `src` is a 44.1 kHz mono float
+        array and the prompt is given as codes/embeddings (file I/O, resampling and the wav -> prompt encoders are rows
+        N1/N2).  Returns the converted waveform as a numpy array like the reference."""
+        if prompt is None:
+            prompt = self.calculate_prompt(ref_path, alpha=alpha, spk_emb_collate_type=spk_emb_collate_type)
+        ref_audio_codes, ref_content_codes, style_vectors, timbre_latents = [
+            np.asarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x) for x in prompt[:4]]
+        src_codes = self.encode_content(src)
+        S = src_codes.shape[0]
+        d = 2 if delay is None else int(delay)
+        kw = {k: sampling_kwargs[k] for k in ("temperature", "top_p") if k in sampling_kwargs}
+        b = E.Batch(self.engine, n_streams=1, delay=d, voc_max_frames=S, **kw)
+        try:
+            codes = b.generate(ref_content_codes.reshape(-1), ref_audio_codes.reshape(8, -1), src_codes, style_vectors.reshape(-1),
+                               timbre_latents.reshape(32, -1), noise_seed=noise_seed)
+            wav = b.vocode_window(codes[None])[0]
+        finally:
+            b.close()
+        return wav
+
     # ---- per chunk ---------------------------------------------------------------------------------------
     def process_one_chunk(self, src_wav_chunk, pitch_shift=0.0):
         """src_wav_chunk [1, 2048*c] (torch or numpy) -> same type/shape (:492-596): zeros for the first `delay` chunks."""

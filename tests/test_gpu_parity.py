@@ -420,3 +420,27 @@ def test_offline_generate_vs_reference_golden(eng, weights0):
     np.testing.assert_allclose(pcm[0, -2048:], g["pcm_last"], atol=PCM_TOL)
     assert abs(float(pcm.astype(np.float64).sum()) - float(g["pcm_sum"])) < 5e-2
     b.close()
+
+
+def test_inference_wrapper_offline_infer(weights0):
+    """InferenceWrapper.infer mirror (offline): encode whole utterance -> generate -> code2wav, against the CPU oracle
+    (codes identical with the device RNG seeded like the oracle's noise, PCM within tol)."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    useed, S = 5000, 14
+    ac, cc, style, timbre = synth_prompt(2300, 60)
+    src = synth_utterance(useed, 2048 * S + 700)               # ragged tail: the reference floors to whole frames
+    w = InferenceWrapper(weights=weights0)
+    wav = w.infer(src, prompt=(ac, cc, style, timbre), delay=2, noise_seed=useed)
+    assert wav.shape == (2048 * S,)
+    src_t = torch.from_numpy(src[:2048 * S])[None]
+    src_codes = O.encode_window(src_t, weights0)[0, 0]
+    np.testing.assert_array_equal(w.encode_content(src), src_codes.numpy())
+    ar = O.DualAR(weights0)
+    codes = ar.generate(torch.from_numpy(cc), torch.from_numpy(ac), src_codes, torch.from_numpy(style), torch.from_numpy(timbre), 2,
+                        noise_fn=lambda s_: tuple(torch.from_numpy(a) for a in frame_noise(useed, s_)))
+    ref = O.vocode_window(codes.long(), weights0)[0, 0].numpy()
+    assert np.abs(wav - ref).max() <= PCM_TOL
+    w.engine.close()
