@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24, help="CPU-baseline sample size (chunk-steps)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the informational 64-stream run that accompanies the B=1 headline")
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured hipGraph of the steady step (measured slower than eager multi-stream launches on this "
                          "stack: 5.6 vs 4.8 ms at B=1, the step is GPU-bound, see DESIGN.md)")
@@ -132,81 +133,87 @@ def main():
     n = 2048 * c
     W = O.load_synth_weights(0, specs.all_specs())
     eng = E.Engine(W, device=local_rank)
-    batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=args.graph)
-    # utterances are global ids sharded over ranks (weak scaling: B per rank)
-    my_utts = shard_utterances(list(range(world * B)), world)[rank]
-    for s, u in enumerate(my_utts):
-        ac, cc, style, timbre = synth_prompt(2000 + u, args.prompt_frames)
-        batch.prefill_prompt(s, cc, ac, style, timbre, noise_seed=1000 + u)
-    batch.begin()
-    n_delay = (2 + c - 1) // c              # chunks that only fill the delay (return zeros)
-    total_chunks = n_delay + args.warmup + args.steps + 2
-    audio = np.stack([synth_utterance(1000 + u, n * total_chunks) for u in my_utts])     # [B, n*total]
-    d_audio = torch.from_numpy(audio).cuda().reshape(B, total_chunks, n).transpose(0, 1).contiguous()   # [chunks, B, n]
-    d_out = torch.empty(B, n, device="cuda")
-    torch.cuda.synchronize()
 
-    def run(i):
-        batch.step_device(d_audio[i].data_ptr(), d_out.data_ptr())
+    def run_workload(B, steps, warmup, want_roofline):
+        """B streams per rank; returns (seconds for `steps` steps [max over ranks], stage timings, gathered count, roofline)"""
+        batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=args.graph)
+        # utterances are global ids sharded over ranks (weak scaling: B per rank)
+        my_utts = shard_utterances(list(range(world * B)), world)[rank]
+        for s_, u in enumerate(my_utts):
+            ac, cc, style, timbre = synth_prompt(2000 + u, args.prompt_frames)
+            batch.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=1000 + u)
+        batch.begin()
+        n_delay = (2 + c - 1) // c              # chunks that only fill the delay (return zeros)
+        total_chunks = n_delay + warmup + steps + 2
+        audio = np.stack([synth_utterance(1000 + u, n * total_chunks) for u in my_utts])     # [B, n*total]
+        d_audio = torch.from_numpy(audio).cuda().reshape(B, total_chunks, n).transpose(0, 1).contiguous()   # [chunks, B, n]
+        d_out = torch.empty(B, n, device="cuda")
+        torch.cuda.synchronize()
 
-    k = 0
-    for _ in range(n_delay + args.warmup):
-        run(k); k += 1
-    batch.sync()
-    torch.cuda.synchronize()
-    if world > 1 or force_dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run(k); k += 1
-    batch.sync()
-    torch.cuda.synchronize()
-    if world > 1 or force_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    tm = batch.timings()
-    if world > 1 or force_dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    # the trivial gather of per-utterance results (codes of the last step) to rank 0
-    codes = batch.tap("audio_codes", (B, 8, c), np.int32)
-    gathered = gather_results(torch.from_numpy(codes).cuda(), world, rank, force=force_dist)
+        def run(i):
+            batch.step_device(d_audio[i].data_ptr(), d_out.data_ptr())
 
-    roof = None
-    if rank == 0 and not args.no_roofline:
-        # dominant kernel = conv_gemm_kernel (f32 MFMA): algorithmic FLOPs of all its launches in one step /
-        # their summed duration, measured with hipEvents on the engine stream (2 profiled steps)
-        batch.profile_gemm(True)
-        run(k); k += 1
+        k = 0
+        for _ in range(n_delay + warmup):
+            run(k); k += 1
         batch.sync()
-        flops, launches = batch.gemm_stats()
-        tot_ms, nl = batch.gemm_profile()
-        if os.environ.get("SVA_GEMM_TABLE"):
-            tab = batch.gemm_profile_table()
-            agg = {}
-            for M_, N_, K_, taps_, mode_, us in tab:
-                key = (int(M_), int(N_), int(K_), int(taps_), int(mode_))
-                a = agg.setdefault(key, [0, 0.0])
-                a[0] += 1; a[1] += us
-            with open(os.environ["SVA_GEMM_TABLE"], "w") as f:
-                f.write("M,N,K,taps,mode,calls,total_us,avg_us,TFLOPs\n")
-                for key, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                    fl = 2.0 * key[0] * key[1] * key[2] * cnt
-                    f.write(",".join(map(str, key)) + f",{cnt},{us:.1f},{us / cnt:.2f},{fl / us / 1e6:.2f}\n")
-        batch.profile_gemm(False)
-        ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        # HBM bytes per conv-GEMM launch from the committed PMC passes of the same command (tools/pmc.sh ->
-        # profiles/rNN_pmc_b<B>.json; rocprofv3 cannot run inside bench.py): reads per the guide's gfx950 correction
-        import glob
-        traffic = None
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_b{B}.json")))
-        if cands and c == 1:
-            traffic = round(json.load(open(cands[-1]))["hbm_bytes_per_launch"], 1)
-        roof = {"bound": "mfma", "kernel": "conv_gemm_kernel (v_mfma_f32_16x16x4_f32)", "achieved": round(ach, 3),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
-                "traffic": traffic, "traffic_source": os.path.basename(cands[-1]) if traffic is not None else None, "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
-                "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4)}
+        torch.cuda.synchronize()
+        if world > 1 or force_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run(k); k += 1
+        batch.sync()
+        torch.cuda.synchronize()
+        if world > 1 or force_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        tm = batch.timings()
+        if world > 1 or force_dist:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        # the trivial gather of per-utterance results (codes of the last step) to rank 0
+        codes = batch.tap("audio_codes", (B, 8, c), np.int32)
+        gathered = gather_results(torch.from_numpy(codes).cuda(), world, rank, force=force_dist)
+        roof = None
+        if rank == 0 and want_roofline:
+            # dominant kernel = conv_gemm_kernel (f32 MFMA): algorithmic FLOPs of all its launches in one step /
+            # their summed duration, measured with hipEvents on the engine stream (single-stream profiled step)
+            batch.profile_gemm(True)
+            run(k); k += 1
+            batch.sync()
+            flops, launches = batch.gemm_stats()
+            tot_ms, nl = batch.gemm_profile()
+            if os.environ.get("SVA_GEMM_TABLE"):
+                tab = batch.gemm_profile_table()
+                agg = {}
+                for M_, N_, K_, taps_, mode_, us in tab:
+                    key = (int(M_), int(N_), int(K_), int(taps_), int(mode_))
+                    a_ = agg.setdefault(key, [0, 0.0])
+                    a_[0] += 1; a_[1] += us
+                with open(os.environ["SVA_GEMM_TABLE"] + (f".b{B}" if B != args.streams else ""), "w") as f:
+                    f.write("M,N,K,taps,mode,calls,total_us,avg_us,TFLOPs\n")
+                    for key, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                        fl = 2.0 * key[0] * key[1] * key[2] * cnt
+                        f.write(",".join(map(str, key)) + f",{cnt},{us:.1f},{us / cnt:.2f},{fl / us / 1e6:.2f}\n")
+            batch.profile_gemm(False)
+            ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+            # HBM bytes per conv-GEMM launch from the committed PMC passes of the same command (tools/pmc.sh ->
+            # profiles/rNN_pmc_b<B>.json; rocprofv3 cannot run inside bench.py): reads per the guide's gfx950 correction
+            import glob
+            traffic, cands = None, sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_b{B}.json")))
+            if cands and c == 1:
+                traffic = round(json.load(open(cands[-1]))["hbm_bytes_per_launch"], 1)
+            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32)", "achieved": round(ach, 3),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
+                    "traffic": traffic, "traffic_source": os.path.basename(cands[-1]) if traffic is not None else None,
+                    "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
+                    "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4)}
+        batch.close()
+        return dt, tm, (int(gathered.shape[0]) if gathered is not None else B), roof
+
+    dt, tm, n_gathered, roof = run_workload(B, args.steps, args.warmup, not args.no_roofline)
     if rank != 0:
         if world > 1 or force_dist:
             dist.destroy_process_group()
@@ -225,10 +232,19 @@ def main():
                    "hipgraph": bool(args.graph)},
         "rtf": round(ms * 1e-3 / (c * FRAME_S), 5), "x_realtime": round(fps * FRAME_S, 2),
         "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm.items()},
-        "gathered_utterances": int(gathered.shape[0]) if gathered is not None else B,
+        "gathered_utterances": n_gathered,
     }
     if roof:
         out["roofline"] = roof
+    if world == 1 and B == 1 and not args.no_batched:
+        # BASELINE.json configs[2] next to the headline single-stream workload: 64 concurrent streams on the same GPU
+        # (the "frames/sec aggregate" half of the metric); informational, `value` above stays the configs[1] number
+        dt2, tm2, _, roof2 = run_workload(64, 10, 3, not args.no_roofline)
+        ms2 = dt2 / 10 * 1e3
+        out["batched_64_streams"] = {"workload": "BASELINE.json configs[2]: 64 concurrent streams, chunk=1, 1 GPU", "ms_per_step": round(ms2, 4),
+                                     "value": round(64 * c * 10 / dt2, 3), "unit": "frames/s", "rtf": round(ms2 * 1e-3 / (c * FRAME_S), 5),
+                                     "x_realtime": round(64 * c * 10 / dt2 * FRAME_S, 2),
+                                     "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm2.items()}, "roofline": roof2}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, W)
     print(json.dumps(out))
