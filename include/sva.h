@@ -114,6 +114,11 @@ int sva_sync(sva_batch* b);
 /* speech_tokenizer.encode (firefly_encoder.py:553-566) on full windows: audio host float[B][W*2048]
  * -> codes int64[B][W] (+ optional L2-normalised pre-sign u float[B][W][13]) */
 int sva_encode_window(sva_batch* b, const float* audio, int64_t* codes_out, float* u_out);
+/* wav2target_fn (infer_arvc.py:168-171) -> FireflyArchitecture.encode (modules/vqgan/modules/firefly.py:560-574) of the
+ * PROMPT on full windows: audio host float[B][W*2048] -> acoustic codes int32[B][8][W] (the ref_audio_codes operand of
+ * sva_prefill_prompt).  Needs the optional voc.backbone.* / voc.quantizer.downsample.* / ...residual_fsq...project_in
+ * tensors; fails with an error if the engine was finalized without them. */
+int sva_firefly_encode(sva_batch* b, const float* audio, int32_t* codes_out);
 /* code2wav_fn (infer_arvc.py:173-176) with the reference's window semantics (zero history):
  * codes host int32[B][8][T] -> pcm float[B][2048*T];  T <= voc_max_frames */
 int sva_vocode_window(sva_batch* b, const int32_t* codes, int T, float* pcm_out);

@@ -452,6 +452,49 @@ def fsq_decode(codes: torch.Tensor, W: dict) -> torch.Tensor:
     return torch.cat(outs, dim=-1).transpose(1, 2)
 
 
+def fsq_encode(z: torch.Tensor, W: dict, return_margin: bool = False):
+    """DownsampleFiniteScalarQuantize.encode after the downsampler, modules/vqgan/modules/fsq.py:108-109 ->
+    GroupedResidualFSQ with one quantizer per group (vector_quantize_pytorch==1.14.24, twin vendored at
+    modules/bicodec_speaker_encoder/fsq/residual_fsq.py:156-260 and finite_scalar_quantization.py:127-154):
+    per group g: x = project_in_g(z[..., 64g:64g+64]); bounded = tanh(x + shift) * half_l - offset with
+    half_l = (L-1)*(1+1e-3)/2, offset = 0.5 for even L, shift = atanh(offset / half_l); digit = round(bounded) + L//2;
+    index = sum digit_d * [1, 8, 40, 200].  z [B, 512, T] -> int32 [B, 8, T] (+ distance of `bounded` to the nearest
+    rounding boundary, for tolerance-aware tests)."""
+    levels = torch.tensor(FSQ_LEVELS, dtype=torch.int32)
+    basis = torch.cumprod(torch.tensor((1,) + FSQ_LEVELS[:-1]), 0).to(torch.int32)
+    half_l = (levels - 1) * (1 + 1e-3) / 2
+    offset = torch.where(levels % 2 == 0, 0.5, 0.0)
+    shift = (offset / half_l).atanh()
+    half_w = levels // 2
+    zt = z.transpose(1, 2)
+    G = len([k for k in W if k.startswith("voc.quantizer.residual_fsq.rvqs.") and k.endswith("project_in.weight")])
+    gd = zt.shape[-1] // G
+    idx, margin = [], []
+    for g in range(G):
+        x = F.linear(zt[..., g * gd:(g + 1) * gd], W[f"voc.quantizer.residual_fsq.rvqs.{g}.project_in.weight"],
+                     W[f"voc.quantizer.residual_fsq.rvqs.{g}.project_in.bias"])
+        bd = (x + shift).tanh() * half_l - offset
+        q = bd.round()
+        idx.append(((q + half_w) * basis).sum(-1).to(torch.int32))
+        margin.append((0.5 - (bd - q).abs()).amin(-1))
+    idx = torch.stack(idx, 1)
+    return (idx, torch.stack(margin, 1)) if return_margin else idx
+
+
+def firefly_encode(audio: torch.Tensor, W: dict, return_margin: bool = False):
+    """wav2target_fn (evaluations/infer_arvc.py:168-171) -> FireflyArchitecture.encode, modules/vqgan/modules/firefly.py:560-574,
+    for full-length inputs (all-ones masks): log-mel -> voc.backbone -> quantizer.downsample (fsq.py:46-59,107) -> FSQ
+    indices.  audio [B, N] -> int32 [B, 8, N // 2048]."""
+    mel = log_mel(audio)
+    feat = convnext_encoder(mel, W, "voc.backbone.")
+    z = feat
+    for i in range(2):
+        p = f"voc.quantizer.downsample.{i}."
+        z = causal_conv1d(z, W[p + "0.conv.weight"], W[p + "0.conv.bias"], stride=2)
+        z = convnext_block(z, W, p + "1.")
+    return fsq_encode(z, W, return_margin)
+
+
 def fsq_upsample(z: torch.Tensor, W: dict) -> torch.Tensor:
     """`self.upsample` of DownsampleFiniteScalarQuantize, fsq.py:61-74,115: two x
     (ConvTranspose k=s=2 + ConvNeXtBlock); built in reversed(enumerate) order so

@@ -67,6 +67,21 @@ struct EncStream {
     int n_shift = 0;
 };
 
+// ConvNeXtEncoder (firefly.py:443-520) + the quantizer's 2x (conv k2 s2 + ConvNeXtBlock) downsampler: the tokenizer
+// front-end and the vocoder's own encoder (firefly.encode, firefly.py:560-574) share this shape
+struct EncFront {
+    Lin stem;                              // conv k7 160 -> 128
+    float *stem_lnw = nullptr, *stem_lnb = nullptr;
+    std::vector<std::vector<CNX>> stages;
+    float* trans_lnw[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* trans_lnb[4] = {nullptr, nullptr, nullptr, nullptr};
+    Lin trans[4];
+    float *final_lnw = nullptr, *final_lnb = nullptr;
+    Lin ds_conv[2];
+    CNX ds_cnx[2];
+    bool loaded = false;
+};
+
 struct ResConv {
     Lin c1, c2;
     int k = 0, dil = 1;
@@ -85,15 +100,7 @@ struct sva_engine {
     sva::Lin mel_fb;                       // [160][1088]  (K padded 1025 -> 1088)
     float2* twiddle = nullptr;             // [1024]
     float* hann = nullptr;                 // [2048]
-    sva::Lin stem;                         // conv k7 160 -> 128
-    float *stem_lnw = nullptr, *stem_lnb = nullptr;
-    std::vector<std::vector<sva::CNX>> stages;
-    float* trans_lnw[4] = {nullptr, nullptr, nullptr, nullptr};
-    float* trans_lnb[4] = {nullptr, nullptr, nullptr, nullptr};
-    sva::Lin trans[4];
-    float *final_lnw = nullptr, *final_lnb = nullptr;
-    sva::Lin ds_conv[2];
-    sva::CNX ds_cnx[2];
+    sva::EncFront tokf;                    // tok.backbone + tok.quantizer.downsample
     std::vector<sva::TrLayer> tr;
     float* tr_norm = nullptr;
     float* rope_enc = nullptr;             // [2048][32][2]
@@ -108,6 +115,8 @@ struct sva_engine {
 
     // ---- vocoder ----
     float *fsq_W = nullptr, *fsq_b = nullptr;   // [8][64][4], [8][64]
+    sva::EncFront vocf;                    // voc.backbone + voc.quantizer.downsample (prompt path, optional)
+    float *fsq_in_W = nullptr, *fsq_in_b = nullptr;   // [8][4][64], [8][4]   residual_fsq.rvqs.g.project_in
     sva::Lin up_conv[2];
     sva::CNX up_cnx[2];
     sva::Lin conv_pre;
@@ -158,6 +167,7 @@ struct sva_batch {
     int Ht = 40;                           // head tokens recomputed every chunk (receptive field 38.25 tokens)
     bool enc_incremental = true;
     long long* d_codes = nullptr;          // [B][T2]
+    int* d_fsq_codes = nullptr;            // [B][8][T2] firefly.encode output
     float* d_u = nullptr;                  // [B][T2][13]
 
     // ---- AR workspace ----

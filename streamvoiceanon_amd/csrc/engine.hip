@@ -280,6 +280,35 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
     SVA_HIP(hipSetDevice(e->device));
     const sva_config& c = e->cfg;
     Packer P{e, ""};
+    // ConvNeXt encoder + 2x (conv k2 s2 + ConvNeXt): shared shape of the tokenizer front-end and of the vocoder's
+    // own encoder (firefly.encode of the prompt)
+    auto load_front = [&](EncFront& F, const std::string& bb, const std::string& qd) -> int {
+        SVA_TRY(P.conv(bb + "downsample_layers.0.0.conv", F.stem, c.enc_dims[0], c.n_mels, 7));
+        SVA_TRY(P.vec(bb + "downsample_layers.0.1.weight", &F.stem_lnw, c.enc_dims[0]));
+        SVA_TRY(P.vec(bb + "downsample_layers.0.1.bias", &F.stem_lnb, c.enc_dims[0]));
+        F.stages.resize(4);
+        for (int i = 0; i < 4; ++i) {
+            if (i > 0) {
+                const std::string d = bb + "downsample_layers." + std::to_string(i) + ".";
+                SVA_TRY(P.vec(d + "0.weight", &F.trans_lnw[i], c.enc_dims[i - 1]));
+                SVA_TRY(P.vec(d + "0.bias", &F.trans_lnb[i], c.enc_dims[i - 1]));
+                SVA_TRY(P.conv(d + "1", F.trans[i], c.enc_dims[i], c.enc_dims[i - 1], 1));
+            }
+            F.stages[i].resize(c.enc_depths[i]);
+            for (int j = 0; j < c.enc_depths[i]; ++j)
+                SVA_TRY(P.cnx(bb + "stages." + std::to_string(i) + "." + std::to_string(j) + ".", F.stages[i][j], c.enc_dims[i]));
+        }
+        SVA_TRY(P.vec(bb + "norm.weight", &F.final_lnw, c.enc_dims[3]));
+        SVA_TRY(P.vec(bb + "norm.bias", &F.final_lnb, c.enc_dims[3]));
+        const int D = c.tr_dim;
+        for (int i = 0; i < 2; ++i) {
+            const std::string d = qd + std::to_string(i) + ".";
+            SVA_TRY(P.conv(d + "0.conv", F.ds_conv[i], D, D, 2));
+            SVA_TRY(P.cnx(d + "1.", F.ds_cnx[i], D));
+        }
+        F.loaded = true;
+        return 0;
+    };
     // ---- encoder ----
     {
         // mel filterbank [1025][160] -> W [160][1088] (K padded with zeros)
@@ -305,30 +334,8 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
         float* twp;
         SVA_TRY(upload(e->allocs, &twp, tw));
         e->twiddle = (float2*)twp;
-        const std::string bb = "tok.backbone.";
-        SVA_TRY(P.conv(bb + "downsample_layers.0.0.conv", e->stem, c.enc_dims[0], c.n_mels, 7));
-        SVA_TRY(P.vec(bb + "downsample_layers.0.1.weight", &e->stem_lnw, c.enc_dims[0]));
-        SVA_TRY(P.vec(bb + "downsample_layers.0.1.bias", &e->stem_lnb, c.enc_dims[0]));
-        e->stages.resize(4);
-        for (int i = 0; i < 4; ++i) {
-            if (i > 0) {
-                const std::string d = bb + "downsample_layers." + std::to_string(i) + ".";
-                SVA_TRY(P.vec(d + "0.weight", &e->trans_lnw[i], c.enc_dims[i - 1]));
-                SVA_TRY(P.vec(d + "0.bias", &e->trans_lnb[i], c.enc_dims[i - 1]));
-                SVA_TRY(P.conv(d + "1", e->trans[i], c.enc_dims[i], c.enc_dims[i - 1], 1));
-            }
-            e->stages[i].resize(c.enc_depths[i]);
-            for (int j = 0; j < c.enc_depths[i]; ++j)
-                SVA_TRY(P.cnx(bb + "stages." + std::to_string(i) + "." + std::to_string(j) + ".", e->stages[i][j], c.enc_dims[i]));
-        }
-        SVA_TRY(P.vec(bb + "norm.weight", &e->final_lnw, c.enc_dims[3]));
-        SVA_TRY(P.vec(bb + "norm.bias", &e->final_lnb, c.enc_dims[3]));
+        SVA_TRY(load_front(e->tokf, "tok.backbone.", "tok.quantizer.downsample."));
         const int D = c.tr_dim;
-        for (int i = 0; i < 2; ++i) {
-            const std::string d = "tok.quantizer.downsample." + std::to_string(i) + ".";
-            SVA_TRY(P.conv(d + "0.conv", e->ds_conv[i], D, D, 2));
-            SVA_TRY(P.cnx(d + "1.", e->ds_cnx[i], D));
-        }
         e->tr.resize(c.tr_layers);
         for (int l = 0; l < c.tr_layers; ++l)
             SVA_TRY(P.llama("tok.quantizer.pre_module.layers." + std::to_string(l) + ".", e->tr[l], D, c.tr_inter, true));
@@ -382,6 +389,21 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
         }
         SVA_TRY(upload(e->allocs, &e->fsq_W, fw));
         SVA_TRY(upload(e->allocs, &e->fsq_b, fb));
+        // prompt path (firefly.encode): optional -- a streaming-only deployment does not ship these tensors
+        if (P.find("voc.backbone.downsample_layers.0.0.conv.weight")) {
+            SVA_TRY(load_front(e->vocf, "voc.backbone.", "voc.quantizer.downsample."));
+            std::vector<float> iw((size_t)G * 4 * gd), ib((size_t)G * 4);
+            for (int g = 0; g < G; ++g) {
+                const std::string p = "voc.quantizer.residual_fsq.rvqs." + std::to_string(g) + ".project_in";
+                const HostTensor* w = P.find(p + ".weight");
+                const HostTensor* b = P.find(p + ".bias");
+                SVA_CHECK(w && b && w->numel() == (long)gd * 4 && b->numel() == 4, ("missing " + p).c_str());
+                memcpy(&iw[(size_t)g * gd * 4], w->data.data(), sizeof(float) * gd * 4);
+                memcpy(&ib[(size_t)g * 4], b->data.data(), sizeof(float) * 4);
+            }
+            SVA_TRY(upload(e->allocs, &e->fsq_in_W, iw));
+            SVA_TRY(upload(e->allocs, &e->fsq_in_b, ib));
+        }
         for (int i = 0; i < 2; ++i) {
             const std::string u = "voc.quantizer.upsample." + std::to_string(i) + ".";
             SVA_TRY(P.conv_t(u + "0.conv", e->up_conv[i], V, V, 2, 2));
@@ -497,8 +519,9 @@ int cnx_block(sva_batch* b, const CNX& c, Act& x, int T, float* h1, float* h2, A
 // Conv front-end (mel -> stem -> 18 ConvNeXt -> 2x (conv k2 s2 + ConvNeXt)) on the FIRST `Tm` mel frames of the
 // current window, zero left padding exactly as the reference's window pass (causal net: row j depends on rows <= j).
 // Tm = T0: the full-window formulation; Tm = head rows: the head pass of the exact-incremental formulation.
-int enc_frontend_window(sva_batch* b, const int* step_ptr, int n_chunk, int add, int Tm) {
+int enc_frontend_window(sva_batch* b, const int* step_ptr, int n_chunk, int add, int Tm, const EncFront* front = nullptr) {
     sva_engine* e = b->e;
+    const EncFront& F = front ? *front : e->tokf;
     const sva_config& c = e->cfg;
     const int B = b->B, T0 = b->T0;
     hipStream_t st = b->stream;
@@ -510,34 +533,34 @@ int enc_frontend_window(sva_batch* b, const int* step_ptr, int n_chunk, int add,
                           (long)b->mel.H * c.n_mels, c.n_mels, p));
     }
     // stem: causal conv k7 + LayerNorm(channels)  (firefly.py:458-468)
-    SVA_TRY(gemm_call(b, b->mel.p, b->mel.bstride, 0, c.n_mels, B, Tm, 1, 1, 7, c.n_mels, e->stem, b->h1, (long)Tm * c.enc_dims[0], 0,
+    SVA_TRY(gemm_call(b, b->mel.p, b->mel.bstride, 0, c.n_mels, B, Tm, 1, 1, 7, c.n_mels, F.stem, b->h1, (long)Tm * c.enc_dims[0], 0,
                       c.enc_dims[0]));
-    SVA_TRY(launch_layernorm_rows(b->h1, (long)Tm * c.enc_dims[0], 0, c.enc_dims[0], B, Tm, c.enc_dims[0], e->stem_lnw, e->stem_lnb,
+    SVA_TRY(launch_layernorm_rows(b->h1, (long)Tm * c.enc_dims[0], 0, c.enc_dims[0], B, Tm, c.enc_dims[0], F.stem_lnw, F.stem_lnb,
                                   1e-6f, b->xs[0].p, b->xs[0].bstride, (long)b->xs[0].H * c.enc_dims[0], c.enc_dims[0], st));
     for (int i = 0; i < 4; ++i) {
         const int C = c.enc_dims[i];
         if (i > 0) {   // LayerNorm(channels) + Conv1d k1  (firefly.py:471-476)
             const int Cp = c.enc_dims[i - 1];
-            SVA_TRY(launch_layernorm_rows(b->xs[i - 1].p, b->xs[i - 1].bstride, (long)b->xs[i - 1].H * Cp, Cp, B, Tm, Cp, e->trans_lnw[i],
-                                          e->trans_lnb[i], 1e-6f, b->h1, (long)Tm * Cp, 0, Cp, st));
-            SVA_TRY(gemm_call(b, b->h1, (long)Tm * Cp, 0, Cp, B, Tm, 1, 1, 1, Cp, e->trans[i], b->xs[i].p, b->xs[i].bstride,
+            SVA_TRY(launch_layernorm_rows(b->xs[i - 1].p, b->xs[i - 1].bstride, (long)b->xs[i - 1].H * Cp, Cp, B, Tm, Cp, F.trans_lnw[i],
+                                          F.trans_lnb[i], 1e-6f, b->h1, (long)Tm * Cp, 0, Cp, st));
+            SVA_TRY(gemm_call(b, b->h1, (long)Tm * Cp, 0, Cp, B, Tm, 1, 1, 1, Cp, F.trans[i], b->xs[i].p, b->xs[i].bstride,
                               (long)b->xs[i].H * C, C));
         }
-        for (auto& blk : e->stages[i]) SVA_TRY(cnx_block(b, blk, b->xs[i], Tm, b->h1, b->h2));
+        for (auto& blk : F.stages[i]) SVA_TRY(cnx_block(b, blk, b->xs[i], Tm, b->h1, b->h2));
     }
     const int D = c.tr_dim;
-    SVA_TRY(launch_layernorm_rows(b->xs[3].p, b->xs[3].bstride, (long)b->xs[3].H * D, D, B, Tm, D, e->final_lnw, e->final_lnb, 1e-6f,
+    SVA_TRY(launch_layernorm_rows(b->xs[3].p, b->xs[3].bstride, (long)b->xs[3].H * D, D, B, Tm, D, F.final_lnw, F.final_lnb, 1e-6f,
                                   b->feat.p, b->feat.bstride, 0, D, st));
     // BSQ downsample x2: conv k2 s2 + ConvNeXtBlock  (bsq_no_upsample.py:48-61)
-    SVA_TRY(conv_act(b, b->feat, Tm / 2, 2, 1, 2, e->ds_conv[0], b->d1));
-    SVA_TRY(cnx_block(b, e->ds_cnx[0], b->d1, Tm / 2, b->h1, b->h2));
+    SVA_TRY(conv_act(b, b->feat, Tm / 2, 2, 1, 2, F.ds_conv[0], b->d1));
+    SVA_TRY(cnx_block(b, F.ds_cnx[0], b->d1, Tm / 2, b->h1, b->h2));
     {
         Act in = b->d1;      // read the new rows (no left padding needed: padL = 0)
         in.p = b->d1.p + (long)b->d1.H * D;
         in.H = 0;
-        SVA_TRY(conv_act(b, in, Tm / 4, 2, 1, 2, e->ds_conv[1], b->d2));
+        SVA_TRY(conv_act(b, in, Tm / 4, 2, 1, 2, F.ds_conv[1], b->d2));
     }
-    SVA_TRY(cnx_block(b, e->ds_cnx[1], b->d2, Tm / 4, b->h1, b->h2));
+    SVA_TRY(cnx_block(b, F.ds_cnx[1], b->d2, Tm / 4, b->h1, b->h2));
     return 0;
 }
 
@@ -546,6 +569,7 @@ int enc_frontend_window(sva_batch* b, const int* step_ptr, int n_chunk, int add,
 // blocks are therefore out-of-place).  The resulting c token rows land in d2c[T2-c, T2).
 int enc_frontend_stream(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
     sva_engine* e = b->e;
+    const EncFront& F = e->tokf;
     const sva_config& c = e->cfg;
     const int B = b->B, nm = 4 * b->p.chunk_frames;
     hipStream_t st = b->stream;
@@ -557,33 +581,33 @@ int enc_frontend_stream(sva_batch* b, const int* step_ptr, int n_chunk, int add)
         SVA_TRY(gemm_call(b, S.mag, (long)nm * 1088, 0, 1088, B, nm, 1, 1, 1, 1088, e->mel_fb, S.mel.p, S.mel.bstride, (long)S.mel.H * c.n_mels,
                           c.n_mels, p));
     }
-    SVA_TRY(conv_act(b, S.mel, nm, 1, 1, 7, e->stem, S.tmp0));
-    SVA_TRY(launch_layernorm_rows(S.tmp0.p, S.tmp0.bstride, 0, c.enc_dims[0], B, nm, c.enc_dims[0], e->stem_lnw, e->stem_lnb, 1e-6f,
+    SVA_TRY(conv_act(b, S.mel, nm, 1, 1, 7, F.stem, S.tmp0));
+    SVA_TRY(launch_layernorm_rows(S.tmp0.p, S.tmp0.bstride, 0, c.enc_dims[0], B, nm, c.enc_dims[0], F.stem_lnw, F.stem_lnb, 1e-6f,
                                   S.x[0][0].p, S.x[0][0].bstride, (long)S.x[0][0].H * c.enc_dims[0], c.enc_dims[0], st));
     for (int i = 0; i < 4; ++i) {
         const int C = c.enc_dims[i];
-        const int nb = (int)e->stages[i].size();
+        const int nb = (int)F.stages[i].size();
         for (int j = 0; j < nb; ++j) {
             Act& out = j + 1 < nb ? S.x[i][j + 1] : S.xout[i];
-            SVA_TRY(cnx_block_t(b, e->stages[i][j], S.x[i][j], nm, S.h1, (long)nm * C, S.h2, (long)nm * 4 * C, &out));
+            SVA_TRY(cnx_block_t(b, F.stages[i][j], S.x[i][j], nm, S.h1, (long)nm * C, S.h2, (long)nm * 4 * C, &out));
         }
         if (i < 3) {
             const int Cn = c.enc_dims[i + 1];
-            SVA_TRY(launch_layernorm_rows(S.xout[i].p, S.xout[i].bstride, 0, C, B, nm, C, e->trans_lnw[i + 1], e->trans_lnb[i + 1], 1e-6f,
+            SVA_TRY(launch_layernorm_rows(S.xout[i].p, S.xout[i].bstride, 0, C, B, nm, C, F.trans_lnw[i + 1], F.trans_lnb[i + 1], 1e-6f,
                                           S.h1, (long)nm * C, 0, C, st));
-            SVA_TRY(gemm_call(b, S.h1, (long)nm * C, 0, C, B, nm, 1, 1, 1, C, e->trans[i + 1], S.x[i + 1][0].p, S.x[i + 1][0].bstride,
+            SVA_TRY(gemm_call(b, S.h1, (long)nm * C, 0, C, B, nm, 1, 1, 1, C, F.trans[i + 1], S.x[i + 1][0].p, S.x[i + 1][0].bstride,
                               (long)S.x[i + 1][0].H * Cn, Cn));
         }
     }
     const int D = c.tr_dim;
-    SVA_TRY(launch_layernorm_rows(S.xout[3].p, S.xout[3].bstride, 0, D, B, nm, D, e->final_lnw, e->final_lnb, 1e-6f, S.feat.p, S.feat.bstride, 0, D, st));
-    SVA_TRY(conv_act(b, S.feat, nm / 2, 2, 1, 2, e->ds_conv[0], S.d1));
-    SVA_TRY(cnx_block_t(b, e->ds_cnx[0], S.d1, nm / 2, S.h1, (long)(nm / 2) * D, S.h2, (long)(nm / 2) * 4 * D, &S.d1o));
-    SVA_TRY(conv_act(b, S.d1o, nm / 4, 2, 1, 2, e->ds_conv[1], S.d2));
+    SVA_TRY(launch_layernorm_rows(S.xout[3].p, S.xout[3].bstride, 0, D, B, nm, D, F.final_lnw, F.final_lnb, 1e-6f, S.feat.p, S.feat.bstride, 0, D, st));
+    SVA_TRY(conv_act(b, S.feat, nm / 2, 2, 1, 2, F.ds_conv[0], S.d1));
+    SVA_TRY(cnx_block_t(b, F.ds_cnx[0], S.d1, nm / 2, S.h1, (long)(nm / 2) * D, S.h2, (long)(nm / 2) * 4 * D, &S.d1o));
+    SVA_TRY(conv_act(b, S.d1o, nm / 4, 2, 1, 2, F.ds_conv[1], S.d2));
     Act tail = b->d2c;                       // rows [T2 - c, T2) of the steady token cache
     tail.p = b->d2c.p + (long)(b->T2 - nm / 4) * D;
     tail.H = 0;
-    SVA_TRY(cnx_block_t(b, e->ds_cnx[1], S.d2, nm / 4, S.h1, (long)(nm / 4) * D, S.h2, (long)(nm / 4) * 4 * D, &tail));
+    SVA_TRY(cnx_block_t(b, F.ds_cnx[1], S.d2, nm / 4, S.h1, (long)(nm / 4) * D, S.h2, (long)(nm / 4) * 4 * D, &tail));
     SVA_TRY(launch_shift_history(S.d_shift, S.n_shift, B, st));
     return 0;
 }
@@ -1202,6 +1226,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
         SVA_HIP(hipMemcpy(b->d_shift_d2c, &dc, sizeof(ShiftDesc), hipMemcpyHostToDevice));
     }
     SVA_TRY(dev_alloc(A, &b->d_codes, (size_t)B * T2));
+    SVA_TRY(dev_alloc(A, &b->d_fsq_codes, (size_t)B * c.num_codebooks * T2));
     SVA_TRY(dev_alloc(A, &b->d_u, (size_t)B * T2 * c.bsq_bits));
     // AR
     const int D = c.ar_dim, S = c.max_seq_len, H = c.ar_heads, ncb = c.num_codebooks;
@@ -1822,6 +1847,31 @@ extern "C" int sva_encode_window(sva_batch* b, const float* audio, int64_t* code
     SVA_HIP(hipEventRecord(b->ev[1], st));
     SVA_HIP(hipMemcpyAsync(codes_out, b->d_codes, sizeof(int64_t) * (size_t)b->B * b->T2, hipMemcpyDeviceToHost, st));
     if (u_out) SVA_HIP(hipMemcpyAsync(u_out, b->d_u, sizeof(float) * (size_t)b->B * b->T2 * b->e->cfg.bsq_bits, hipMemcpyDeviceToHost, st));
+    SVA_HIP(hipStreamSynchronize(st));
+    float t;
+    if (hipEventElapsedTime(&t, b->ev[0], b->ev[1]) == hipSuccess) b->last_ms[0] = t;
+    return 0;
+}
+
+// wav2target_fn (evaluations/infer_arvc.py:168-171) -> FireflyArchitecture.encode (firefly.py:560-574) on full windows:
+// log-mel -> voc.backbone -> quantizer.downsample -> grouped FSQ indices.  Same front-end kernels as the content encoder
+// with the vocoder's weight set; the window buffers are shared, so this does not interleave with a running stream.
+extern "C" int sva_firefly_encode(sva_batch* b, const float* audio, int32_t* codes_out) {
+    SVA_CHECK(b && audio && codes_out, "null argument");
+    sva_engine* e = b->e;
+    SVA_CHECK(e->vocf.loaded, "firefly.encode weights (voc.backbone.*, voc.quantizer.downsample.*, ...project_in) were not loaded");
+    SVA_HIP(hipSetDevice(e->device));
+    hipStream_t st = b->stream;
+    const sva_config& c = e->cfg;
+    SVA_HIP(hipMemcpyAsync(b->ring, audio, sizeof(float) * (size_t)b->B * b->N, hipMemcpyHostToDevice, st));
+    b->gemm_flops = 0; b->gemm_launches = 0;
+    SVA_HIP(hipEventRecord(b->ev[0], st));
+    SVA_TRY(enc_frontend_window(b, nullptr, 0, 0, b->T0, &e->vocf));
+    SVA_TRY(launch_fsq_encode(b->d2.p, b->d2.bstride, (long)b->d2.H * c.voc_dim, c.voc_dim, b->B, b->T2, c.num_codebooks,
+                              c.voc_dim / c.num_codebooks, e->fsq_in_W, e->fsq_in_b, b->d_fsq_codes, (long)c.num_codebooks * b->T2,
+                              b->T2, st));
+    SVA_HIP(hipEventRecord(b->ev[1], st));
+    SVA_HIP(hipMemcpyAsync(codes_out, b->d_fsq_codes, sizeof(int32_t) * (size_t)b->B * c.num_codebooks * b->T2, hipMemcpyDeviceToHost, st));
     SVA_HIP(hipStreamSynchronize(st));
     float t;
     if (hipEventElapsedTime(&t, b->ev[0], b->ev[1]) == hipSuccess) b->last_ms[0] = t;

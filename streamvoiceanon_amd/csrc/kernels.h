@@ -66,6 +66,10 @@ int launch_audio_embed(const float* table, const int* codes, int code_stride, in
 int launch_fsq_decode(const int* codes, long c_bstride, long c_gstride, int B, int T, int G, int gdim,
                       const float* Wout /*[G][gdim][4]*/, const float* bout /*[G][gdim]*/, float* out,
                       long o_bstride, long o_off, int ldo, hipStream_t st);
+// latent -> FSQ index (firefly.encode): x (b, t, g*gdim + j) at x[b*x_bstride + x_off + t*ldx + ...] -> codes (b, g, t)
+int launch_fsq_encode(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int G, int gdim,
+                      const float* Win /*[G][4][gdim]*/, const float* bin /*[G][4]*/, int* codes, long c_bstride,
+                      long c_gstride, hipStream_t st);
 // conv_post (C -> 1, k taps) on silu(x) + tanh: x (b, r, c) at x[b*x_bstride + x_off + r*C + c]; row t reads t..t+k-1
 int launch_conv_post_tanh(const float* x, long x_bstride, long x_off, int B, int T, int C, int k,
                           const float* w /*[k][C]*/, const float* bias, float* pcm, long p_bstride, long p_off,

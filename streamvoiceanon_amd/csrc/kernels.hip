@@ -704,6 +704,57 @@ int launch_audio_embed(const float* table, const int* codes, int code_stride, in
 }
 
 // ------------------------------------------------------------------------------------------
+// FSQ quantize of firefly.encode (modules/vqgan/modules/fsq.py:106-110 -> GroupedResidualFSQ, one quantizer per
+// group; arithmetic twin at modules/bicodec_speaker_encoder/fsq/finite_scalar_quantization.py:127-154):
+// z_g = project_in_g(x[g*64:(g+1)*64]); bounded = tanh(z + shift) * half_l - offset; digit = round(bounded) + L//2;
+// index = sum digit_d * [1, 8, 40, 200].  One wave per (b, t, g), lane = channel of the group.
+// ------------------------------------------------------------------------------------------
+struct FsqConst { float half_l[4], offset[4], shift[4]; };
+__global__ void fsq_encode_kernel(const float* __restrict__ x, long x_bstride, long x_off, int ldx, int T, int G, int gdim,
+                                  const float* __restrict__ Win, const float* __restrict__ bin, FsqConst K,
+                                  int* __restrict__ codes, long c_bstride, long c_gstride) {
+    const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63;
+    const int g = blockIdx.z * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const float* row = x + (long)b * x_bstride + x_off + (long)t * ldx + g * gdim;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = lane; j < gdim; j += 64) {
+        const float v = row[j];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[d] = fmaf(v, Win[((long)g * 4 + d) * gdim + j], acc[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[d] += __shfl_xor(acc[d], o, 64);
+    if (lane == 0) {
+        const int halfw[4] = {4, 2, 2, 2}, basis[4] = {1, 8, 40, 200};
+        int idx = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float z = acc[d] + bin[g * 4 + d];
+            const float bd = tanhf(z + K.shift[d]) * K.half_l[d] - K.offset[d];
+            idx += ((int)rintf(bd) + halfw[d]) * basis[d];      // torch.round = half to even
+        }
+        codes[(long)b * c_bstride + (long)g * c_gstride + t] = idx;
+    }
+}
+int launch_fsq_encode(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int G, int gdim, const float* Win,
+                      const float* bin, int* codes, long c_bstride, long c_gstride, hipStream_t st) {
+    FsqConst K;
+    const int levels[4] = {8, 5, 5, 5};
+    for (int d = 0; d < 4; ++d) {     // FSQ.bound, eps = 1e-3, evaluated in fp32 like the reference's buffers
+        K.half_l[d] = (float)(levels[d] - 1) * (float)(1.0 + 1e-3) / 2.f;
+        K.offset[d] = levels[d] % 2 == 0 ? 0.5f : 0.f;
+        K.shift[d] = atanhf(K.offset[d] / K.half_l[d]);
+    }
+    hipLaunchKernelGGL(fsq_encode_kernel, dim3(T, B, (G + 3) / 4), dim3(256), 0, st, x, x_bstride, x_off, ldx, T, G, gdim, Win,
+                       bin, K, codes, c_bstride, c_gstride);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // V1 FSQ decode (modules/vqgan/modules/fsq.py:112-114; arithmetic of vector_quantize_pytorch
 // 1.14.24, twin at modules/bicodec_speaker_encoder/fsq/finite_scalar_quantization.py:143-162):
 // digits = (idx // [1,8,40,200]) % [8,5,5,5]; code = (digit - half) / half, half = [4,2,2,2];

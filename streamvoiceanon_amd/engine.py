@@ -72,6 +72,7 @@ def load_library():
     lib.sva_vocode_reset.argtypes = [vp]
     lib.sva_ar_delay_fill.argtypes = [vp, vp]
     lib.sva_ar_decode_one.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.sva_firefly_encode.argtypes = [vp, vp, vp]
     lib.sva_generate.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, C.c_uint64, vp, vp]
     lib.sva_get_tap.argtypes = [vp, C.c_char_p, vp, C.c_long]
     lib.sva_get_tap.restype = C.c_long
@@ -90,7 +91,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "sva_last_error", "sva_config_default", "sva_stream_params_default", "sva_engine_create",
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
-    "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_encode_window",
+    "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_encode_window", "sva_firefly_encode",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
     "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_bench_gemm",
 ]
@@ -256,6 +257,15 @@ class Batch:
         u = np.empty((self.B, W, self.engine.cfg.bsq_bits), dtype=np.float32) if return_u else None
         _check(self.lib.sva_encode_window(self.h, _ptr(a), _ptr(codes), _ptr(u)), "sva_encode_window")
         return (codes, u) if return_u else codes
+
+    def firefly_encode(self, audio):
+        """wav2target_fn (evaluations/infer_arvc.py:168-171): audio [B, W*2048] -> acoustic codes int32 [B, 8, W]."""
+        a = np.ascontiguousarray(audio, dtype=np.float32).reshape(self.B, -1)
+        W = self.p.encode_window_frames
+        assert a.shape[1] == W * 2048
+        codes = np.empty((self.B, 8, W), dtype=np.int32)
+        _check(self.lib.sva_firefly_encode(self.h, _ptr(a), _ptr(codes)), "sva_firefly_encode")
+        return codes
 
     def vocode_window(self, codes):
         c = np.ascontiguousarray(codes, dtype=np.int32).reshape(self.B, 8, -1)

@@ -54,11 +54,46 @@ class InferenceWrapper:
         return {k: v for k, v in out.items() if hasattr(v, "dtype") and v.dtype.is_floating_point}
 
     # ---- prompt ------------------------------------------------------------------------------------------
-    def calculate_prompt(self, ref_wav_tensors, alpha=1.0, spk_emb_collate_type="concat_mel"):
-        raise NotImplementedError(
-            "wav -> prompt (CAM++ style vector, SparkTTS timbre latents, firefly.encode audio codes) is row N1 of "
-            "SURVEY.md §8f and not built yet; pass prompt=(ref_audio_codes, ref_content_codes, style_vectors, timbre_latents) "
-            "to prefill_prompt instead")
+    def wav2target_fn(self, waves):
+        """:168-171 firefly.encode of a whole prompt -> acoustic codes int32 [1, 8, R], R = len // 2048 (right-padded with
+        zeros to a multiple of 4 frames for the stride-4 front-end; causal, so the first R columns are unaffected)."""
+        wav = np.asarray(waves.detach().cpu().numpy() if hasattr(waves, "detach") else waves, dtype=np.float32).reshape(-1)
+        R = wav.shape[0] // self.SAMPLES_PER_FRAME
+        Wp = ((R + 3) // 4) * 4
+        buf = np.zeros(Wp * self.SAMPLES_PER_FRAME, np.float32)
+        buf[:R * self.SAMPLES_PER_FRAME] = wav[:R * self.SAMPLES_PER_FRAME]
+        b = E.Batch(self.engine, n_streams=1, encode_window_frames=Wp)
+        try:
+            return b.firefly_encode(buf[None])[:, :, :R]
+        finally:
+            b.close()
+
+    def calculate_prompt(self, ref_wav_tensors, alpha=1.0, spk_emb_collate_type="concat_mel", style_vectors=None,
+                         timbre_latents=None):
+        """:382-441.  The two code streams of the prompt (firefly.encode audio codes, speech-tokenizer content codes) are
+        computed on the device.  The CAM++ style vector and the SparkTTS timbre latents (N1 iii/iv, not built) come from
+        `self.style_encoder(wav)` / `self.timbre_encoder(wav)` callables if the caller installed them, or from the
+        `style_vectors` / `timbre_latents` arguments; alpha noise mixing (:426-427) is applied to them here."""
+        import torch
+
+        ref_list = ref_wav_tensors if isinstance(ref_wav_tensors, (list, tuple)) else [ref_wav_tensors]
+        ref = np.concatenate([np.asarray(r.detach().cpu().numpy() if hasattr(r, "detach") else r, dtype=np.float32).reshape(-1)
+                              for r in ref_list])            # :411 / :415 torch.cat(ref_wav_list, dim=-1)
+        if style_vectors is None:
+            if getattr(self, "style_encoder", None) is None:
+                raise NotImplementedError("CAM++ style encoder (SURVEY.md §8f N1 iii) is not built: pass style_vectors= or set "
+                                          "InferenceWrapper.style_encoder to a callable wav -> [1, 192]")
+            style_vectors = self.style_encoder(ref)
+        if timbre_latents is None:
+            if getattr(self, "timbre_encoder", None) is None:
+                raise NotImplementedError("SparkTTS timbre encoder (SURVEY.md §8f N1 iv) is not built: pass timbre_latents= or set "
+                                          "InferenceWrapper.timbre_encoder to a callable wav -> [1, 32, 128]")
+            timbre_latents = self.timbre_encoder(ref)
+        style_vectors = self.apply_noise_mixing(torch.as_tensor(np.asarray(style_vectors), dtype=torch.float32), alpha)
+        timbre_latents = self.apply_noise_mixing(torch.as_tensor(np.asarray(timbre_latents), dtype=torch.float32), alpha)
+        ref_audio_codes = self.wav2target_fn(ref)                       # :431-434
+        ref_content_codes = self.encode_content(ref)                    # :436-439
+        return ref_audio_codes, ref_content_codes, style_vectors, timbre_latents, ref
 
     def apply_noise_mixing(self, tensor, alpha, gauss=None):
         """:228-232 -- alpha*x + (1-alpha)*(randn*std + mean), global mean / unbiased std."""

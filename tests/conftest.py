@@ -22,7 +22,7 @@ def weights0():
     from streamvoiceanon_amd import specs
 
     torch.set_grad_enabled(False)
-    return O.load_synth_weights(0, specs.all_specs())
+    return O.load_synth_weights(0, specs.all_specs(prompt_path=True))
 
 
 @pytest.fixture(scope="session")

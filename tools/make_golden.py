@@ -226,6 +226,20 @@ def offline_fixture(w, feed, wseed, useed, pseed, src_frames=12, prompt_frames=4
     print("offline fixture", codes.shape)
 
 
+def prompt_fixture(w, wseed, useed, frames=48):
+    """calculate_prompt (evaluations/infer_arvc.py:382-441) with the CAM++ / SparkTTS encoders stubbed by the harness:
+    pins firefly.encode (wav2target_fn, :168-171) and speech_tokenizer.encode of the PROMPT."""
+    wav = torch.from_numpy(synth_utterance(useed, frames * 2048))[None]
+    ac, cc, style, timbre, _ = w.calculate_prompt(wav, alpha=1.0)
+    voc = w.firefly
+    z = voc.quantizer.downsample(voc.backbone(voc.spec_transform(wav)))
+    z_idx = (np.arange(64) * 2039) % z.numel()
+    np.savez_compressed(os.path.join(OUT, f"prompt_s{wseed}.npz"), weight_seed=wseed, audio_seed=useed, n_samples=frames * 2048,
+                        ref_audio_codes=ac[0].numpy().astype(np.int32), ref_content_codes=cc.reshape(-1).numpy(),
+                        z_idx=z_idx, z_val=z.flatten()[z_idx].numpy(), z_last=z[0, :, -1].numpy())
+    print("prompt fixture", tuple(ac.shape), tuple(cc.shape), "distinct audio codes", len(set(ac.flatten().tolist())))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rh.install_stubs()
@@ -236,8 +250,13 @@ def main():
     fb = rh.melscale_fbanks(1025, 0.0, 22050.0, 160, 44100, norm="slaney", mel_scale="slaney")
     np.savez_compressed(os.path.join(OUT, "melfb.npz"), col_sum=fb.sum(0).numpy(), row_sum=fb.sum(1).numpy(),
                         peak=fb.max(0).values.numpy(), argpeak=fb.argmax(0).numpy())
+    only = sys.argv[1] if len(sys.argv) > 1 else None     # e.g. `make_golden.py prompt` adds one fixture without rewriting the rest
     for wseed in (0, 1):
         w = rh.build_wrapper(seed=wseed)
+        if only == "prompt":
+            if wseed == 0:
+                prompt_fixture(w, 0, useed=1004)
+            continue
         print("spec table entries checked:", check_specs(w))
         encoder_fixture(w, wseed, 1000 + wseed)
         if wseed == 0:
@@ -248,6 +267,7 @@ def main():
             stream_fixture(w, feed, "stream_chunk4", 0, useed=1002, pseed=2002, n_chunks=6, chunk=4,
                            full_pcm_frames=(-1,))
             offline_fixture(w, feed, 0, useed=1003, pseed=2003)
+            prompt_fixture(w, 0, useed=1004)
 
 
 if __name__ == "__main__":
