@@ -144,7 +144,8 @@ def main():
             batch.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=1000 + u)
         batch.begin()
         n_delay = (2 + c - 1) // c              # chunks that only fill the delay (return zeros)
-        total_chunks = n_delay + warmup + steps + 2
+        n_lat = 40                              # synchronous per-chunk latency sample after the timed region
+        total_chunks = n_delay + warmup + steps + n_lat + 2
         audio = np.stack([synth_utterance(1000 + u, n * total_chunks) for u in my_utts])     # [B, n*total]
         d_audio = torch.from_numpy(audio).cuda().reshape(B, total_chunks, n).transpose(0, 1).contiguous()   # [chunks, B, n]
         d_out = torch.empty(B, n, device="cuda")
@@ -163,12 +164,24 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             run(k); k += 1
+        t_enq = time.perf_counter() - t0        # host time to enqueue the K steps (the launches are asynchronous)
         batch.sync()
         torch.cuda.synchronize()
         if world > 1 or force_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
         tm = batch.timings()
+        # per-chunk latency as a live caller sees it (enqueue + execute + sync per chunk; outside the timed region)
+        lat = []
+        for _ in range(n_lat):
+            t1 = time.perf_counter()
+            run(k); k += 1
+            batch.sync()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat.sort()
+        extra = {"host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 4),
+                 "sync_latency_ms": {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[min(len(lat) - 1, int(0.99 * len(lat)))], 4),
+                                     "n": n_lat}}
         if world > 1 or force_dist:
             t = torch.tensor([dt], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,9 +224,9 @@ def main():
                     "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
                     "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4)}
         batch.close()
-        return dt, tm, (int(gathered.shape[0]) if gathered is not None else B), roof
+        return dt, tm, (int(gathered.shape[0]) if gathered is not None else B), roof, extra
 
-    dt, tm, n_gathered, roof = run_workload(B, args.steps, args.warmup, not args.no_roofline)
+    dt, tm, n_gathered, roof, extra = run_workload(B, args.steps, args.warmup, not args.no_roofline)
     if rank != 0:
         if world > 1 or force_dist:
             dist.destroy_process_group()
@@ -234,17 +247,18 @@ def main():
         "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm.items()},
         "gathered_utterances": n_gathered,
     }
+    out.update(extra)
     if roof:
         out["roofline"] = roof
     if world == 1 and B == 1 and not args.no_batched:
         # BASELINE.json configs[2] next to the headline single-stream workload: 64 concurrent streams on the same GPU
         # (the "frames/sec aggregate" half of the metric); informational, `value` above stays the configs[1] number
-        dt2, tm2, _, roof2 = run_workload(64, 10, 3, not args.no_roofline)
+        dt2, tm2, _, roof2, extra2 = run_workload(64, 10, 3, not args.no_roofline)
         ms2 = dt2 / 10 * 1e3
         out["batched_64_streams"] = {"workload": "BASELINE.json configs[2]: 64 concurrent streams, chunk=1, 1 GPU", "ms_per_step": round(ms2, 4),
                                      "value": round(64 * c * 10 / dt2, 3), "unit": "frames/s", "rtf": round(ms2 * 1e-3 / (c * FRAME_S), 5),
                                      "x_realtime": round(64 * c * 10 / dt2 * FRAME_S, 2),
-                                     "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm2.items()}, "roofline": roof2}
+                                     "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm2.items()}, "roofline": roof2, **extra2}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, W)
     print(json.dumps(out))

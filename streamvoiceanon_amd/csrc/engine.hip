@@ -25,21 +25,32 @@ void set_error(const std::string& msg) { g_err = msg; }
     } while (0)
 
 template <typename T>
-static int dev_alloc(std::vector<void*>& pool, T** out, size_t n, bool zero = true) {
-    void* p = nullptr;
+static int dev_alloc(DevPool& pool, T** out, size_t n, bool zero = true) {
     if (n == 0) n = 1;
-    SVA_HIP(hipMalloc(&p, n * sizeof(T)));
+    const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    if (bytes > pool.left) {
+        static const char* env = getenv("SVA_ARENA_MB");       // 0: one hipMalloc per tensor (A/B switch)
+        const size_t want = env ? (size_t)atol(env) << 20 : pool.chunk_bytes;
+        const size_t sz = bytes > want ? bytes : want;
+        void* c = nullptr;
+        SVA_HIP(hipMalloc(&c, sz));
+        pool.chunks.push_back(c);
+        pool.cur = (char*)c;
+        pool.left = sz;
+    }
+    void* p = pool.cur;
+    pool.cur += bytes;
+    pool.left -= bytes;
     if (zero) SVA_HIP(hipMemset(p, 0, n * sizeof(T)));
-    pool.push_back(p);
     *out = (T*)p;
     return 0;
 }
-static int upload(std::vector<void*>& pool, float** out, const std::vector<float>& v) {
+static int upload(DevPool& pool, float** out, const std::vector<float>& v) {
     SVA_TRY(dev_alloc(pool, out, v.size(), false));
     SVA_HIP(hipMemcpy(*out, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
-static int alloc_act(std::vector<void*>& pool, Act& a, int B, int H, long Tmax, int C) {
+static int alloc_act(DevPool& pool, Act& a, int B, int H, long Tmax, int C) {
     a.H = H;
     a.C = C;
     a.rows = H + Tmax;
@@ -109,7 +120,7 @@ extern "C" int sva_engine_load_weight(sva_engine* e, const char* name, int ndim,
 extern "C" void sva_engine_destroy(sva_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
-    for (void* p : e->allocs) hipFree(p);
+    for (void* p : e->allocs.chunks) hipFree(p);
     delete e;
 }
 
@@ -650,8 +661,10 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows) {
         SVA_TRY(gemm_call(b, b->tr_g, (long)T2 * I, (long)r0 * I, I, B, Tr, 1, 1, 1, I, L.w2, xw, xw_bs, (long)r0 * D, D, pd));
     }
     const int Tr = need_rows > 0 ? need_rows : T2, r0 = T2 - Tr;
-    SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, (long)r0 * D, D, B, Tr, D, e->tr_norm, 1e-5f, b->tr_z, (long)T2 * D, (long)r0 * D, D, st));
-    SVA_TRY(launch_bsq(b->tr_z, (long)T2 * D, (long)r0 * D, D, B, Tr, D, e->bsq_W, e->bsq_b, c.bsq_bits, b->d_codes, b->T2, r0, b->d_u, st));
+    // final RMSNorm fused into the BSQ projection (normalised rows still land in tr_z for the "z" tap)
+    SVA_CHECK(xw_bs == (long)T2 * D, "enc_transformer: work copy layout");
+    SVA_TRY(launch_bsq(xw, xw_bs, (long)r0 * D, D, B, Tr, D, e->tr_norm, 1e-5f, b->tr_z, e->bsq_W, e->bsq_b, c.bsq_bits, b->d_codes, b->T2, r0,
+                       b->d_u, st));
     return 0;
 }
 
@@ -1337,7 +1350,7 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     hipSetDevice(b->e->device);
     hipStreamSynchronize(b->stream);
     if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
-    for (void* p : b->allocs) hipFree(p);
+    for (void* p : b->allocs.chunks) hipFree(p);
     if (b->hp_in) hipHostFree(b->hp_in);
     if (b->hp_out) hipHostFree(b->hp_out);
     if (b->ev_ok)

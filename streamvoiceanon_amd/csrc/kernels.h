@@ -32,8 +32,9 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
                          hipStream_t st);
 
 // BSQ: u = W z + b (nbits x C), index = sum_d (u_d > 0) << (nbits-1-d); optional L2-normalised u out.
-int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T, int C, const float* W,
-               const float* bias, int nbits, long long* idx_out, int idx_bstride, int idx_off, float* u_out, hipStream_t st);
+int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T, int C, const float* norm_w /*fused RMSNorm or null*/,
+               float eps, float* zn_out /*normalised rows, same layout as z, or null*/, const float* W, const float* bias, int nbits,
+               long long* idx_out, int idx_bstride, int idx_off, float* u_out, hipStream_t st);
 
 // ---- dual AR ------------------------------------------------------------------------------
 // RoPE on q,k of qkv rows [M, 3*D] (in place) + KV-cache write at (slot[m], pos[m]).

@@ -113,7 +113,9 @@ int launch_stft_mag_ring(const float* ring, const int* step, int n_chunk, int ad
 // ConvNeXtBlock prologue: depthwise causal k=7 conv + LayerNorm(eps 1e-6, biased variance)
 // (modules/vqgan/modules/firefly.py:421-427, 92-103, 361-365).  One wave per output row.
 // ------------------------------------------------------------------------------------------
-template <int NPL>
+// NV = float4 groups per lane (C = 256 * NV; C < 256: the upper lanes idle).  All 14 * NV loads of a lane are independent
+// 16-byte loads, so one round trip to L2 covers the row.
+template <int NV>
 __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, long x_bstride, long x_off, int T,
                                                          int C, int rows, const float* __restrict__ wT,
                                                          const float* __restrict__ bias, const float* __restrict__ lw,
@@ -124,51 +126,67 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     if (row >= rows) return;
     const int b = row / T, t = row - b * T;
     const float* xr = x + (long)b * x_bstride + x_off + (long)t * C;
-    float v[NPL];
+    float4 xv[NV][7], wv[NV][7], v[NV];
+    bool on[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        on[i] = c < C;
+        const int cc = on[i] ? c : 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            xv[i][j] = *reinterpret_cast<const float4*>(xr + (long)j * C + cc);
+            wv[i][j] = *reinterpret_cast<const float4*>(wT + j * C + cc);
+        }
+        v[i] = *reinterpret_cast<const float4*>(bias + cc);
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int c = lane + 64 * i;
-        float acc = bias[c];
+    for (int i = 0; i < NV; ++i) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j) acc = fmaf(wT[j * C + c], xr[(long)j * C + c], acc);
-        v[i] = acc;
-        s += acc;
+        for (int j = 0; j < 7; ++j) {       // same tap order as the scalar formulation: acc = fma(w_j, x_j, acc), j ascending
+            v[i].x = fmaf(wv[i][j].x, xv[i][j].x, v[i].x);
+            v[i].y = fmaf(wv[i][j].y, xv[i][j].y, v[i].y);
+            v[i].z = fmaf(wv[i][j].z, xv[i][j].z, v[i].z);
+            v[i].w = fmaf(wv[i][j].w, xv[i][j].w, v[i].w);
+        }
+        if (on[i]) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const float d = v[i] - mean;
-        q = fmaf(d, d, q);
+    for (int i = 0; i < NV; ++i) {
+        if (!on[i]) continue;
+        const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
     const float inv = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
     float* o = out + (long)b * o_bstride + (long)t * C;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int c = lane + 64 * i;
-        o[c] = (v[i] - mean) * inv * lw[c] + lb[c];
+    for (int i = 0; i < NV; ++i) {
+        if (!on[i]) continue;
+        const int c = 4 * (lane + 64 * i);
+        const float4 g = *reinterpret_cast<const float4*>(lw + c), h = *reinterpret_cast<const float4*>(lb + c);
+        float4 r;
+        r.x = (v[i].x - mean) * inv * g.x + h.x;
+        r.y = (v[i].y - mean) * inv * g.y + h.y;
+        r.z = (v[i].z - mean) * inv * g.z + h.z;
+        r.w = (v[i].w - mean) * inv * g.w + h.w;
+        *reinterpret_cast<float4*>(o + c) = r;
     }
 }
 int launch_dwconv7_ln(const float* x, long x_bstride, long x_off, int B, int T, int C, const float* wT,
                       const float* bias, const float* ln_w, const float* ln_b, float eps, float* out, long o_bstride,
                       hipStream_t st) {
-    SVA_CHECK(C % 64 == 0 && C <= 512, "dwconv7_ln: C must be a multiple of 64, <= 512");
+    SVA_CHECK(C % 4 == 0 && C <= 512 && x_bstride % 4 == 0 && x_off % 4 == 0 && o_bstride % 4 == 0,
+              "dwconv7_ln: C must be a multiple of 4, <= 512, float4-aligned rows");
     const int rows = B * T;
     const int wpb = rows >= 4096 ? 4 : 1;       // few rows: one wave per workgroup so the rows spread over the CUs
     dim3 grid((rows + wpb - 1) / wpb);
-#define SVA_DW(N_) hipLaunchKernelGGL((dwconv7_ln_kernel<N_>), grid, dim3(64 * wpb), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out, o_bstride)
-    switch (C / 64) {
-        case 1: SVA_DW(1); break;
-        case 2: SVA_DW(2); break;
-        case 3: SVA_DW(3); break;
-        case 4: SVA_DW(4); break;
-        case 5: SVA_DW(5); break;
-        case 6: SVA_DW(6); break;
-        case 7: SVA_DW(7); break;
-        default: SVA_DW(8); break;
-    }
-#undef SVA_DW
+    if (C <= 256)
+        hipLaunchKernelGGL((dwconv7_ln_kernel<1>), grid, dim3(64 * wpb), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out, o_bstride);
+    else
+        hipLaunchKernelGGL((dwconv7_ln_kernel<2>), grid, dim3(64 * wpb), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out, o_bstride);
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -337,40 +355,75 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
 // E8 BSQ (modules/vqgan/modules/bsq.py:330-369): Linear C->nbits (+bias), L2-normalise,
 // bit_d = u_d > 0, index = sum bit_d << (nbits-1-d) (MSB first, mask buffer :230).
 // ------------------------------------------------------------------------------------------
+// The quantizer's final RMSNorm (pre_module.norm, windowed_transformer.py:248-259) is applied here on the fly
+// (norm_w != null): v_c = x_c * rsqrt(mean(x^2) + eps) * w_c, optionally stored to zn_out.
+// One wave per row; the row lives in registers (C <= 512) and the nbits dot products are independent.
 __global__ __launch_bounds__(256) void bsq_kernel(const float* __restrict__ z, long z_bstride, long z_off, int ldz, int T,
-                                                  int C, int rows, const float* __restrict__ W, const float* __restrict__ bias,
-                                                  int nbits, long long* __restrict__ idx_out, int idx_bstride, int idx_off,
-                                                  float* __restrict__ u_out) {
+                                                  int C, int rows, const float* __restrict__ norm_w, float eps,
+                                                  float* __restrict__ zn_out, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, int nbits, long long* __restrict__ idx_out,
+                                                  int idx_bstride, int idx_off, float* __restrict__ u_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const int b = row / T, t = row - b * T;
     const float* zr = z + (long)b * z_bstride + z_off + (long)t * ldz;
+    float v[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < C ? zr[c] : 0.f;
+        ss = fmaf(v[i], v[i], ss);
+    }
+    if (norm_w) {
+        const float inv = 1.f / sqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                v[i] = v[i] * inv * norm_w[c];
+                if (zn_out) zn_out[(long)b * z_bstride + z_off + (long)t * ldz + c] = v[i];
+            }
+        }
+    }
     float u[16];
-    float nrm = 0.f;
-    for (int d = 0; d < nbits; ++d) {
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        const int dd = d < nbits ? d : nbits - 1;        // no branch around the loads
         float acc = 0.f;
-        for (int c = lane; c < C; c += 64) acc = fmaf(W[d * C + c], zr[c], acc);
-        acc = wave_sum(acc) + bias[d];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            acc = fmaf(W[dd * C + (c < C ? c : 0)], v[i], acc);
+        }
         u[d] = acc;
-        nrm = fmaf(acc, acc, nrm);
+    }
+    float nrm = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        u[d] = wave_sum(u[d]) + bias[d < nbits ? d : nbits - 1];
+        if (d < nbits) nrm = fmaf(u[d], u[d], nrm);
     }
     if (lane == 0) {
         long long idx = 0;
         const float inv = 1.f / fmaxf(sqrtf(nrm), 1e-12f);      // F.normalize eps
-        for (int d = 0; d < nbits; ++d) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            if (d >= nbits) continue;
             if (u[d] > 0.f) idx |= 1ll << (nbits - 1 - d);
             if (u_out) u_out[((long)b * idx_bstride + idx_off + t) * nbits + d] = u[d] * inv;
         }
         idx_out[(long)b * idx_bstride + idx_off + t] = idx;
     }
 }
-int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T, int C, const float* W,
-               const float* bias, int nbits, long long* idx_out, int idx_bstride, int idx_off, float* u_out, hipStream_t st) {
-    SVA_CHECK(nbits <= 16, "bsq: nbits <= 16");
+int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T, int C, const float* norm_w, float eps,
+               float* zn_out, const float* W, const float* bias, int nbits, long long* idx_out, int idx_bstride, int idx_off,
+               float* u_out, hipStream_t st) {
+    SVA_CHECK(nbits <= 16 && C <= 512, "bsq: nbits <= 16, C <= 512");
     const int rows = B * T;
-    hipLaunchKernelGGL(bsq_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, z, z_bstride, z_off, ldz, T, C, rows, W, bias,
-                       nbits, idx_out, idx_bstride, idx_off, u_out);
+    hipLaunchKernelGGL(bsq_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, z, z_bstride, z_off, ldz, T, C, rows, norm_w, eps, zn_out,
+                       W, bias, nbits, idx_out, idx_bstride, idx_off, u_out);
     SVA_HIP(hipGetLastError());
     return 0;
 }
