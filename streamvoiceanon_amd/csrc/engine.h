@@ -183,6 +183,7 @@ struct sva_batch {
     // ---- AR workspace ----
     int Mmax = 0;
     float *ax = nullptr, *ahn = nullptr, *aqkv = nullptr, *aatt = nullptr, *ag = nullptr;
+    float* aatt_part = nullptr;            // [4][H][8][68] split-key attention partials of the fused decode path
     float *xf = nullptr;                   // [B][dim] fast-AR residual stream
     float *slow_logits = nullptr, *fast_logits = nullptr, *hidden = nullptr;
     int *d_slot = nullptr, *d_pos = nullptr;          // [Mmax]

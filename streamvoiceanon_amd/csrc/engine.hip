@@ -643,18 +643,30 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows) {
         const bool tail = need_rows > 0 && li == nl - 1;
         const int Tr = tail ? need_rows : T2;             // rows of this layer's output that are needed
         const int r0 = T2 - Tr;
-        SVA_TRY(launch_rmsnorm_rows(xr, xr_bs, xr_off, D, B, T2, D, L.attn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
-        SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D));
+        // RMSNorm folded into the projection when the small-M kernel runs it (few streams); a separate pass otherwise
+        if (conv_gemm_can_fuse_rms(B * T2, 3 * D)) {
+            ConvGemm pn;
+            pn.rms_w = L.attn_norm; pn.rms_eps = 1e-5f;
+            SVA_TRY(gemm_call(b, xr, xr_bs, xr_off, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D, pn));
+        } else {
+            SVA_TRY(launch_rmsnorm_rows(xr, xr_bs, xr_off, D, B, T2, D, L.attn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
+            SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D));
+        }
         SVA_TRY(launch_enc_attention(b->tr_qkv, e->rope_enc, B, T2, c.tr_heads, 64, b->tr_att, r0, st));
         ConvGemm po;
         po.gamma = L.ls_attn;
         po.res = xr; po.r_bstride = xr_bs; po.r_off = xr_off + (long)r0 * D; po.ldr = D;
         SVA_TRY(gemm_call(b, b->tr_att, (long)T2 * D, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.wo, xw, xw_bs, (long)r0 * D, D, po));
         xr = xw; xr_bs = xw_bs; xr_off = 0;
-        SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, (long)r0 * D, D, B, Tr, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, (long)r0 * D, D, st));
         ConvGemm pg;
         pg.w13 = 1;
-        SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, (long)r0 * I, I, pg));
+        if (conv_gemm_can_fuse_rms(B * Tr, 2 * I)) {
+            pg.rms_w = L.ffn_norm; pg.rms_eps = 1e-5f;
+            SVA_TRY(gemm_call(b, xw, xw_bs, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, (long)r0 * I, I, pg));
+        } else {
+            SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, (long)r0 * D, D, B, Tr, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, (long)r0 * D, D, st));
+            SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, (long)r0 * I, I, pg));
+        }
         ConvGemm pd;
         pd.gamma = L.ls_ffn;
         pd.res = xw; pd.r_bstride = xw_bs; pd.r_off = (long)r0 * D; pd.ldr = D;
@@ -718,9 +730,16 @@ int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int*
             q.Y = b->aqkv; q.ldy = 3 * D; q.mode = 2; q.slot = d_slot; q.pos = d_pos; q.rope = rope; q.kv = cache;
             q.kv_slot_stride = kv_slot; q.S = S; q.H = H;
             SVA_TRY(launch_gemv(q, st));
-            SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
             Gemv o;
-            o.X = b->aatt; o.ldx = D; o.M = M; o.W = L.wo.W; o.N = D; o.K = D; o.res = x; o.ldr = D; o.Y = x; o.ldy = D;
+            o.M = M; o.W = L.wo.W; o.N = D; o.K = D; o.res = x; o.ldr = D; o.Y = x; o.ldy = D;
+            if (S <= 8 && M <= 2) {        // fast AR: attention over <= 8 codebook positions recomputed inside the wo GEMV
+                o.X = b->aqkv; o.ldx = 3 * D; o.mode = 3; o.slot = d_slot; o.pos = d_pos; o.kv = cache; o.kv_slot_stride = kv_slot;
+                o.S = S; o.H = H;
+            } else {                       // slow AR: split-key attention (12 heads x M rows alone leave the chip idle), merged by the wo GEMV
+                const int splits = 8;
+                SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, nullptr, st, b->aatt_part, splits));
+                o.X = b->aatt_part; o.ldx = 0; o.mode = 4; o.S = splits; o.H = H;
+            }
             SVA_TRY(launch_gemv(o, st));
             Gemv u;
             u.X = x; u.ldx = D; u.M = M; u.W = L.w13.W; u.N = 2 * I; u.K = D; u.norm_w = L.ffn_norm; u.eps = 1e-5f;
@@ -1238,6 +1257,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
         SVA_TRY(dev_alloc(A, &b->d_shift_d2c, 1));
         SVA_HIP(hipMemcpy(b->d_shift_d2c, &dc, sizeof(ShiftDesc), hipMemcpyHostToDevice));
     }
+    SVA_TRY(dev_alloc(A, &b->aatt_part, (size_t)4 * c.ar_heads * 8 * 68));
     SVA_TRY(dev_alloc(A, &b->d_codes, (size_t)B * T2));
     SVA_TRY(dev_alloc(A, &b->d_fsq_codes, (size_t)B * c.num_codebooks * T2));
     SVA_TRY(dev_alloc(A, &b->d_u, (size_t)B * T2 * c.bsq_bits));

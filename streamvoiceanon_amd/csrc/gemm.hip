@@ -213,9 +213,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
 // Operand mapping: lane l supplies, for MFMA step j of a block, W[n0 + (l&15)][k0 + 4*(l>>4) + j] and
 // A[m0 + (l&15)][k0 + 4*(l>>4) + j] -- a permutation of k inside the block, identical on both operands.
 // ------------------------------------------------------------------------------------------
-template <int MT, int NT, int KW, int D, bool SILU>
+// AOP: what happens to A on load -- 0 nothing, 1 SiLU (HiFiGAN), 2 RMSNorm of the row (weight folded into the operand,
+// row statistics accumulated on the fly and applied to the accumulators in the epilogue).
+template <int MT, int NT, int KW, int D, int AOP>
 __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) {
-    extern __shared__ __attribute__((aligned(16))) float red[];      // [KW][MT*NT][64][4]
+    constexpr bool SILU = AOP == 1, RMS = AOP == 2;
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [KW][MT*NT][64][4] (+ [KW][MT][16] row sums of squares)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * (16 * NT);
     const int m_base = blockIdx.y * (16 * MT);
@@ -247,8 +250,11 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) 
     // hipcc drain vmcnt(0) at the join): out-of-range blocks re-load the wave's last valid block and are masked.
     const int my_n = nk > wave ? (nk - wave + KW - 1) / KW : 0;          // K blocks owned by this wave
     const int last_kb = my_n > 0 ? wave + (my_n - 1) * KW : 0;
-    float4 wv[D][NT], av[D][MT];
-    auto issue = [&](float4 (&w)[NT], float4 (&a)[MT], int kb) {
+    float4 wv[D][NT], av[D][MT], nv[D];
+    float ssq[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ssq[i] = 0.f;
+    auto issue = [&](float4 (&w)[NT], float4 (&a)[MT], float4& nw, int kb) {
         kb = kb < nk ? kb : last_kb;
         const int tap = kb / kc_tiles;
         const int kc = (kb - tap * kc_tiles) * 16;
@@ -258,9 +264,10 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) 
         for (int j = 0; j < NT; ++j) w[j] = *reinterpret_cast<const float4*>(wp[j] + woff);
 #pragma unroll
         for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(ap[i] + aoff);
+        if (RMS) nw = *reinterpret_cast<const float4*>(g.rms_w + kc + 4 * fg);
     };
 #pragma unroll
-    for (int d = 0; d < D; ++d) issue(wv[d], av[d], wave + d * KW);
+    for (int d = 0; d < D; ++d) issue(wv[d], av[d], nv[d], wave + d * KW);
     for (int it = 0; it < my_n; it += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -274,8 +281,12 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) 
                 a[i] = av[d][i];
                 if (SILU) { a[i].x = silu_f(a[i].x); a[i].y = silu_f(a[i].y); a[i].z = silu_f(a[i].z); a[i].w = silu_f(a[i].w); }
                 a[i].x *= keep; a[i].y *= keep; a[i].z *= keep; a[i].w *= keep;
+                if (RMS) {
+                    ssq[i] += (a[i].x * a[i].x + a[i].y * a[i].y) + (a[i].z * a[i].z + a[i].w * a[i].w);
+                    a[i].x *= nv[d].x; a[i].y *= nv[d].y; a[i].z *= nv[d].z; a[i].w *= nv[d].w;
+                }
             }
-            issue(wv[d], av[d], kb + D * KW);
+            issue(wv[d], av[d], nv[d], kb + D * KW);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -300,6 +311,16 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) 
 #pragma unroll
         for (int j = 0; j < NT; ++j)
             *reinterpret_cast<f32x4*>(&red[((wave * (MT * NT) + i * NT + j) * 64 + lane) * 4]) = acc[i][j];
+    float* redss = red + KW * MT * NT * 256;                          // [KW][MT][16]
+    if (RMS) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float v = ssq[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (fg == 0) redss[(wave * MT + i) * 16 + fr] = v;
+        }
+    }
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
@@ -311,6 +332,18 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) 
             acc[i][j] = s;
         }
     const int col = lane & 15, rq = (lane >> 4) * 4;
+    if (RMS) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float tot = 0.f;
+                for (int w = 0; w < KW; ++w) tot += redss[(w * MT + i) * 16 + rq + r];
+                const float inv = 1.f / sqrtf(tot / (float)Kt + g.rms_eps);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j][r] *= inv;
+            }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -345,26 +378,23 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) 
     }
 }
 
+template <int MT, int NT, int KW, int D, int AOP>
+static int launch_skinny_op(const ConvGemm& g, hipStream_t st) {
+    const size_t smem = ((size_t)KW * MT * NT * 256 + (AOP == 2 ? KW * MT * 16 : 0)) * sizeof(float);
+    dim3 grid((g.N + 16 * NT - 1) / (16 * NT), (g.M + 16 * MT - 1) / (16 * MT));
+    static bool attr = false;
+    if (!attr && smem > 48 * 1024) {
+        SVA_HIP(hipFuncSetAttribute((const void*)skinny_gemm_kernel<MT, NT, KW, D, AOP>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((skinny_gemm_kernel<MT, NT, KW, D, AOP>), grid, dim3(64 * KW), smem, st, g);
+    return 0;
+}
 template <int MT, int NT, int KW, int D>
 static int launch_skinny(const ConvGemm& g, hipStream_t st) {
-    const size_t smem = (size_t)KW * MT * NT * 256 * sizeof(float);
-    dim3 grid((g.N + 16 * NT - 1) / (16 * NT), (g.M + 16 * MT - 1) / (16 * MT));
-    if (g.a_silu) {
-        static bool attr_a = false;
-        if (!attr_a && smem > 48 * 1024) {
-            SVA_HIP(hipFuncSetAttribute((const void*)skinny_gemm_kernel<MT, NT, KW, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_a = true;
-        }
-        hipLaunchKernelGGL((skinny_gemm_kernel<MT, NT, KW, D, true>), grid, dim3(64 * KW), smem, st, g);
-    } else {
-        static bool attr_b = false;
-        if (!attr_b && smem > 48 * 1024) {
-            SVA_HIP(hipFuncSetAttribute((const void*)skinny_gemm_kernel<MT, NT, KW, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_b = true;
-        }
-        hipLaunchKernelGGL((skinny_gemm_kernel<MT, NT, KW, D, false>), grid, dim3(64 * KW), smem, st, g);
-    }
-    return 0;
+    if (g.rms_w) return launch_skinny_op<MT, NT, KW, D, 2>(g, st);
+    if (g.a_silu) return launch_skinny_op<MT, NT, KW, D, 1>(g, st);
+    return launch_skinny_op<MT, NT, KW, D, 0>(g, st);
 }
 
 // Choice of (rows per workgroup = 16*MT, K-split waves KW) for the skinny kernel: enough waves to occupy the 256 CUs
@@ -431,6 +461,7 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
     // under-filled grids (fewer than ~1 tiled workgroup per CU): the barrier-free K-split kernel keeps far more
     // loads in flight per CU than the LDS-staged one and pays for it with extra L2 reads, which are cheap there
     const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+    if (g.rms_w) SVA_CHECK(g.taps == 1 && !g.a_silu && conv_gemm_can_fuse_rms(g.M, g.N), "conv_gemm: fused RMSNorm needs taps == 1 on the small-M path");
     if (g.M <= 64 || (tiles64 < 256 && g.N >= 64) || !c_vec) {      // (the tiled epilogue needs 16-byte aligned C rows)
         // two 16-column tiles per wave halve the A re-reads; worth it once the A panel dominates the L2 traffic
         const bool nt2 = g.w13 || (g.N % 32 == 0 && g.M >= 512 && (long)g.M * g.N >= 256L * 1024);
@@ -452,6 +483,11 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
     }
     SVA_HIP(hipGetLastError());
     return 0;
+}
+
+bool conv_gemm_can_fuse_rms(int M, int N) {
+    const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+    return M <= 64 || (tiles64 < 256 && N >= 64);
 }
 
 }  // namespace sva

@@ -45,7 +45,9 @@ int launch_rope_kvwrite(float* qkv, int M, int H, int hd, const int* slot, const
 // attention of M query rows against their slot's cache, keys 0..pos[m] inclusive.
 template <typename KV>
 int launch_ar_attention(const float* qkv, int M, int H, int hd, const int* slot, const int* pos, const KV* cache,
-                        long slot_stride, int S, float* out, hipStream_t st);
+                        long slot_stride, int S, float* out, hipStream_t st, float* partial = nullptr, int splits = 1);
+// partial != null: split-key decode -- `splits` workgroups per (head, row) write unnormalised partials
+// partial[((m*H + h)*splits + s)*68 + {0..63: P.V, 64: max score, 65: exp-sum}] that gemv mode 4 merges
 
 // nucleus + temperature + Exp(1)-argmax sampler (modules/dual_ar_stream.py:1092-1132), one
 // workgroup per row.  noise: [rows, ldn] or nullptr -> on-device counter RNG keyed by
@@ -100,7 +102,9 @@ struct Gemv {
     const float* bias = nullptr;
     const float* res = nullptr; int ldr = 0;
     float* Y = nullptr; int ldy = 0;
-    int mode = 0;                                         // 0 plain, 1 SwiGLU (w13 interleave), 2 q/k RoPE + KV write
+    int mode = 0;                                         // 0 plain, 1 SwiGLU (w13 interleave), 2 q/k RoPE + KV write,
+                                                          // 3 X = decode attention of the qkv rows over <= 8 cached keys (fast AR)
+                                                          // 4 X = merge of split-key attention partials, S = #splits (slow AR)
     const int* slot = nullptr; const int* pos = nullptr; const float* rope = nullptr;
     float* kv = nullptr; long kv_slot_stride = 0; int S = 0, H = 0;
 };

@@ -480,7 +480,11 @@ template int launch_rope_kvwrite<__half>(float*, int, int, int, const int*, cons
 template <typename KV>
 __global__ __launch_bounds__(256) void ar_attention_kernel(const float* __restrict__ qkv, int H, const int* __restrict__ slot,
                                                            const int* __restrict__ pos, const KV* __restrict__ cache,
-                                                           long slot_stride, int S, float* __restrict__ out) {
+                                                           long slot_stride, int S, float* __restrict__ out,
+                                                           float* __restrict__ partial) {
+    // gridDim.z > 1 (split-key decode, `partial` != null): workgroup z covers keys [z*cl, (z+1)*cl) and writes the
+    // UNnormalised P.V, its score maximum and its exp-sum to partial[((m*H + h)*gridDim.z + z)*68 + {0..63, 64, 65}];
+    // the consumer (gemv mode 4) merges the splits.
     constexpr int HD = 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sc = smem;                 // [S] scores / probabilities
@@ -489,9 +493,16 @@ __global__ __launch_bounds__(256) void ar_attention_kernel(const float* __restri
     const int h = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int D = H * HD;
-    const int L = pos[m] + 1;
+    int L = pos[m] + 1;
     const KV* kc = cache + (long)slot[m] * slot_stride + (long)h * S * HD;
     const KV* vc = kc + (long)H * S * HD;
+    if (partial) {
+        const int cl = (((L + (int)gridDim.z - 1) / (int)gridDim.z) + 15) & ~15;
+        const int j_lo = min((int)blockIdx.z * cl, L);
+        L = min(L - j_lo, cl);                  // keys of this split, re-based to 0
+        kc += (long)j_lo * HD;
+        vc += (long)j_lo * HD;
+    }
     // scores: 4 lanes per key row (16 dims each) -> a wave reads 16 consecutive rows = 4 KiB contiguous
     const int part4 = tid & 3;
     float q[16];
@@ -548,20 +559,27 @@ __global__ __launch_bounds__(256) void ar_attention_kernel(const float* __restri
         float o = 0.f;
 #pragma unroll
         for (int g2 = 0; g2 < 16; ++g2) o += part[g2 * HD + tid];
-        out[(long)m * D + h * HD + tid] = o / sum;
+        if (partial) {
+            float* pw = partial + (((long)m * H + h) * gridDim.z + blockIdx.z) * 68;
+            pw[tid] = o;
+            if (tid == 0) { pw[64] = mx; pw[65] = sum; }
+        } else {
+            out[(long)m * D + h * HD + tid] = o / sum;
+        }
     }
 }
 template <typename KV>
 int launch_ar_attention(const float* qkv, int M, int H, int hd, const int* slot, const int* pos, const KV* cache,
-                        long slot_stride, int S, float* out, hipStream_t st) {
+                        long slot_stride, int S, float* out, hipStream_t st, float* partial, int splits) {
     SVA_CHECK(hd == 64, "ar_attention: head_dim must be 64");
     const size_t smem = ((size_t)S + 8 + 16 * 64) * sizeof(float);
-    hipLaunchKernelGGL((ar_attention_kernel<KV>), dim3(H, M), dim3(256), smem, st, qkv, H, slot, pos, cache, slot_stride, S, out);
+    hipLaunchKernelGGL((ar_attention_kernel<KV>), dim3(H, M, partial ? splits : 1), dim3(256), smem, st, qkv, H, slot, pos, cache, slot_stride,
+                       S, out, partial);
     SVA_HIP(hipGetLastError());
     return 0;
 }
-template int launch_ar_attention<float>(const float*, int, int, int, const int*, const int*, const float*, long, int, float*, hipStream_t);
-template int launch_ar_attention<__half>(const float*, int, int, int, const int*, const int*, const __half*, long, int, float*, hipStream_t);
+template int launch_ar_attention<float>(const float*, int, int, int, const int*, const int*, const float*, long, int, float*, hipStream_t, float*, int);
+template int launch_ar_attention<__half>(const float*, int, int, int, const int*, const int*, const __half*, long, int, float*, hipStream_t, float*, int);
 
 // ------------------------------------------------------------------------------------------
 // A5 sampler (modules/dual_ar_stream.py:1092-1132, defaults T = 0.7, top_p = 0.7, no repetition
@@ -913,7 +931,10 @@ int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStrea
 // statistics cost one extra FMA per element), SwiGLU on the interleaved w1|w3 weight, and for the QKV projection
 // the adjacent-pair RoPE plus the KV-cache write (modules/dual_ar_stream.py:985-990, 967-976, 1004-1016, 141-150).
 // ------------------------------------------------------------------------------------------
-template <int MR, int KI>
+// ATT (mode 3, fast-AR wo projection): the input row is not loaded but computed -- the decode attention of query row m
+// over its <= 8 cached keys (codebook positions), recomputed by every wave (16 lanes per head cooperate on a score),
+// which removes the separate attention launch from the 8 x 4 fast-layer chain.
+template <int MR, int KI, int ATT>
 __global__ __launch_bounds__(256) void gemv_kernel(const Gemv g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int unit = blockIdx.x * 4 + wave;                 // pair index
@@ -944,6 +965,80 @@ __global__ __launch_bounds__(256) void gemv_kernel(const Gemv g) {
         }
     float4 x[MR][KI];
     float ss[MR];
+    if constexpr (ATT == 2) {
+        // mode 4 (slow-AR wo projection): merge the split-key attention partials of row m (ar_attention_kernel, gridDim.z = S
+        // splits): out = sum_s exp(mx_s - mx) o_s / sum_s exp(mx_s - mx) l_s
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int mm = m < g.M ? m : 0;
+            ss[m] = 0.f;
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                const int q4 = lane + 64 * i, h = q4 >> 4, d0 = (q4 & 15) * 4;
+                const float* pw = g.X + ((long)mm * g.H + h) * g.S * 68;
+                float4 o[8];
+                float mxs[8], ls[8], mx = -INFINITY;
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) {
+                    const int s2 = sp < g.S ? sp : g.S - 1;
+                    o[sp] = *reinterpret_cast<const float4*>(pw + s2 * 68 + d0);
+                    mxs[sp] = pw[s2 * 68 + 64];
+                    ls[sp] = sp < g.S ? pw[s2 * 68 + 65] : 0.f;
+                    if (ls[sp] > 0.f) mx = fmaxf(mx, mxs[sp]);
+                }
+                float den = 0.f;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) {
+                    const float wgt = ls[sp] > 0.f ? expf(mxs[sp] - mx) : 0.f;
+                    den = fmaf(wgt, ls[sp], den);
+                    a.x = fmaf(wgt, o[sp].x, a.x); a.y = fmaf(wgt, o[sp].y, a.y); a.z = fmaf(wgt, o[sp].z, a.z); a.w = fmaf(wgt, o[sp].w, a.w);
+                }
+                const float inv = 1.f / den;
+                x[m][i] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+            }
+        }
+    } else if constexpr (ATT == 1) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int mm = m < g.M ? m : 0;
+            const int L = g.pos[mm] + 1;                              // keys 0..pos (Attention.forward mask, dual_ar_stream.py:333)
+            const float* kv_m = g.kv + (long)g.slot[mm] * g.kv_slot_stride;
+            ss[m] = 0.f;
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                const int q4 = lane + 64 * i, h = q4 >> 4, d0 = (q4 & 15) * 4;
+                const float4 qv = *reinterpret_cast<const float4*>(g.X + (long)mm * g.ldx + h * 64 + d0);
+                const float* kc = kv_m + (long)h * g.S * 64 + d0;
+                const float* vc = kc + (long)g.H * g.S * 64;
+                float4 kk[8], vv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int jj = j < L ? j : L - 1;
+                    kk[j] = *reinterpret_cast<const float4*>(kc + jj * 64);
+                    vv[j] = *reinterpret_cast<const float4*>(vc + jj * 64);
+                }
+                float sc[8], mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float a = qv.x * kk[j].x + qv.y * kk[j].y + qv.z * kk[j].z + qv.w * kk[j].w;
+                    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64);
+                    sc[j] = j < L ? a * 0.125f : -INFINITY;
+                    mx = fmaxf(mx, sc[j]);
+                }
+                float sum = 0.f;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float e = j < L ? expf(sc[j] - mx) : 0.f;
+                    sum += e;
+                    o.x = fmaf(e, vv[j].x, o.x); o.y = fmaf(e, vv[j].y, o.y); o.z = fmaf(e, vv[j].z, o.z); o.w = fmaf(e, vv[j].w, o.w);
+                }
+                const float inv = 1.f / sum;
+                x[m][i] = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+            }
+        }
+    } else {
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         const float4* xr = reinterpret_cast<const float4*>(g.X + (long)(m < g.M ? m : 0) * g.ldx);
@@ -958,6 +1053,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const Gemv g) {
             }
             x[m][i] = v;
         }
+    }
     }
     float acc[MR][4];
 #pragma unroll
@@ -1037,7 +1133,22 @@ int launch_gemv(const Gemv& g, hipStream_t st) {
     const int n_units = g.mode == 1 ? g.N / 4 : g.N / 2;
     dim3 grid((n_units + 3) / 4);
     const int ki = g.K / 256;
-#define SVA_GV(MR_, KI_) hipLaunchKernelGGL((gemv_kernel<MR_, KI_>), grid, dim3(256), 0, st, g)
+    if (g.mode == 3) {
+        SVA_CHECK(ki == 3 && g.H * 64 == g.K && g.S <= 8 && g.M <= 2 && !g.norm_w, "gemv: fused attention needs K = H*64 = 768, S <= 8, M <= 2");
+        if (g.M == 1) hipLaunchKernelGGL((gemv_kernel<1, 3, 1>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemv_kernel<2, 3, 1>), grid, dim3(256), 0, st, g);
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
+    if (g.mode == 4) {        // X = split-key attention partials [M][H][S = splits][68]
+        SVA_CHECK(ki == 3 && g.H * 64 == g.K && g.S >= 1 && g.S <= 8 && !g.norm_w, "gemv: partial merge needs K = H*64 = 768, <= 8 splits");
+        if (g.M == 1) hipLaunchKernelGGL((gemv_kernel<1, 3, 2>), grid, dim3(256), 0, st, g);
+        else if (g.M == 2) hipLaunchKernelGGL((gemv_kernel<2, 3, 2>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemv_kernel<4, 3, 2>), grid, dim3(256), 0, st, g);
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
+#define SVA_GV(MR_, KI_) hipLaunchKernelGGL((gemv_kernel<MR_, KI_, 0>), grid, dim3(256), 0, st, g)
     if (ki == 3) {
         if (g.M == 1) SVA_GV(1, 3); else if (g.M == 2) SVA_GV(2, 3); else SVA_GV(4, 3);
     } else if (ki == 9) {

@@ -63,8 +63,12 @@ struct ConvGemm {
     int accumulate = 0;         // C += value   (ParallelBlock mean of three ResBlock branches)
     int a_silu = 0;             // apply SiLU to A on load (HiFiGAN: silu precedes every conv)
     int w13 = 0;                // SwiGLU: W rows interleave w1/w3 in groups of 16; C[., n/2] = silu(a)*b
+    const float* rms_w = nullptr;   // [Cin] fused RMSNorm of the A rows (taps == 1): A' = A * rms_w * rsqrt(mean(A^2) + rms_eps);
+    float rms_eps = 1e-5f;          //       only on the small-M path -- ask conv_gemm_can_fuse_rms() first
 };
 
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
+// true when launch_conv_gemm would route this (M, N) problem to the K-split small-M kernel, which can normalise its A rows
+bool conv_gemm_can_fuse_rms(int M, int N);
 
 }  // namespace sva
