@@ -735,6 +735,9 @@ int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int*
             if (S <= 8 && M <= 2) {        // fast AR: attention over <= 8 codebook positions recomputed inside the wo GEMV
                 o.X = b->aqkv; o.ldx = 3 * D; o.mode = 3; o.slot = d_slot; o.pos = d_pos; o.kv = cache; o.kv_slot_stride = kv_slot;
                 o.S = S; o.H = H;
+            } else if (M > 2) {
+                SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
+                o.X = b->aatt; o.ldx = D;
             } else {                       // slow AR: split-key attention (12 heads x M rows alone leave the chip idle), merged by the wo GEMV
                 const int splits = 8;
                 SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, nullptr, st, b->aatt_part, splits));

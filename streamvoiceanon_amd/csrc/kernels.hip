@@ -718,6 +718,168 @@ __global__ __launch_bounds__(1024) void sampler_kernel(const float* __restrict__
         tok_out[(long)row * tok_stride] = best_id;
     }
 }
+// Register-resident variant for P = 1024 * PER entries (the 8192-way semantic head): thread t owns PER consecutive
+// positions, so of the log2(P)(log2(P)+1)/2 compare-exchange stages only those with partner distance >= 64 * PER go
+// through LDS (10 of 91 for P = 8192); distances < PER stay inside a thread, the rest are wave shuffles.  Same order
+// (descending, ties by smaller id), cumulative sum, cut and argmax rules as sampler_kernel.
+template <int PER>
+__global__ __launch_bounds__(1024) void sampler_reg_kernel(const float* __restrict__ logits, int V, int ldl,
+                                                           const float* __restrict__ noise, int ldn,
+                                                           const unsigned long long* __restrict__ seed, const int* __restrict__ frame,
+                                                           int kind, int noise_elem_off, float inv_temp, float top_p,
+                                                           int* __restrict__ tok_out, int tok_stride) {
+    constexpr int P = 1024 * PER;
+    __shared__ float xv[P];
+    __shared__ unsigned short xi[P];
+    __shared__ double dred[16];
+    __shared__ float fred[16];
+    __shared__ int ired[16];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lg = logits + (long)row * ldl;
+    float v[PER];
+    int id[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        const int e = tid * PER + r;
+        v[r] = e < V ? lg[e] : -INFINITY;
+        id[r] = e;
+    }
+    // my element precedes the other in descending order?
+    auto first = [](float a, int ia, float b, int ib) { return (a > b) || (a == b && ia < ib); };
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64 * PER) {                                   // partner in another wave
+                const int pt = tid ^ (j / PER);
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < PER; ++r) { xv[r * 1024 + tid] = v[r]; xi[r * 1024 + tid] = (unsigned short)id[r]; }
+                __syncthreads();
+                const bool lower = (tid & (j / PER)) == 0;
+                const bool desc = ((tid * PER) & k) == 0;
+#pragma unroll
+                for (int r = 0; r < PER; ++r) {
+                    const float ov = xv[r * 1024 + pt];
+                    const int oi = xi[r * 1024 + pt];
+                    if (first(v[r], id[r], ov, oi) != (desc == lower)) { v[r] = ov; id[r] = oi; }
+                }
+            } else if (j >= PER) {                                 // partner lane in this wave
+                const int dl = j / PER;
+                const bool lower = (lane & dl) == 0;
+                const bool desc = ((tid * PER) & k) == 0;
+#pragma unroll
+                for (int r = 0; r < PER; ++r) {
+                    const float ov = __shfl_xor(v[r], dl, 64);
+                    const int oi = __shfl_xor(id[r], dl, 64);
+                    if (first(v[r], id[r], ov, oi) != (desc == lower)) { v[r] = ov; id[r] = oi; }
+                }
+            } else {                                               // partner inside the thread: static register indices
+#pragma unroll
+                for (int jj = PER / 2; jj > 0; jj >>= 1) {
+                    if (jj != j) continue;
+#pragma unroll
+                    for (int r = 0; r < PER; ++r) {
+                        if (r & jj) continue;
+                        const int l = r | jj;
+                        const bool desc = (((tid * PER) + r) & k) == 0;
+                        const bool a_first = first(v[r], id[r], v[l], id[l]);
+                        if (desc ? !a_first : a_first) {
+                            const float tv = v[r]; v[r] = v[l]; v[l] = tv;
+                            const int ti = id[r]; id[r] = id[l]; id[l] = ti;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // thread t holds ranks t*PER .. t*PER+PER-1
+    __syncthreads();
+    if (tid == 0) fred[0] = v[0];
+    __syncthreads();
+    const float mx = fred[0];
+    __syncthreads();
+    float ev[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        ev[r] = (tid * PER + r) < V ? expf(v[r] - mx) : 0.f;
+        s += ev[r];
+    }
+    s = wave_sum(s);
+    if (lane == 0) fred[wave] = s;
+    __syncthreads();
+    float denom = 0.f;
+    for (int w = 0; w < 16; ++w) denom += fred[w];
+    __syncthreads();
+    double local = 0.0;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) local += (double)(ev[r] / denom);
+    double incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) dred[wave] = incl;
+    __syncthreads();
+    double run = incl - local;
+    for (int w = 0; w < wave; ++w) run += dred[w];
+    int first_rm = P;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        const int i = tid * PER + r;
+        if (i < V) {
+            run += (double)(ev[r] / denom);
+            if (i >= 1 && (float)run > top_p && i < first_rm) first_rm = i;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first_rm = min(first_rm, __shfl_xor(first_rm, o, 64));
+    if (lane == 0) ired[wave] = first_rm;
+    __syncthreads();
+    int ncut = P;
+    for (int w = 0; w < 16; ++w) ncut = min(ncut, ired[w]);
+    if (ncut > V) ncut = V;
+    __syncthreads();
+    const float m2 = mx * inv_temp;
+    float e2[PER];
+    float s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        e2[r] = (tid * PER + r) < ncut ? expf(v[r] * inv_temp - m2) : 0.f;
+        s2 += e2[r];
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) fred[wave] = s2;
+    __syncthreads();
+    float denom2 = 0.f;
+    for (int w = 0; w < 16; ++w) denom2 += fred[w];
+    __syncthreads();
+    float best = -1.f;
+    int best_id = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        if ((tid * PER + r) >= ncut) continue;
+        const float pr = e2[r] / denom2;
+        const float q = noise ? noise[(long)row * ldn + id[r]]
+                              : exp1_noise_dev(seed[row], frame[row], kind, (unsigned)(noise_elem_off + id[r]));
+        const float rr = pr / q;
+        if (rr > best || (rr == best && id[r] < best_id)) { best = rr; best_id = id[r]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_id, o, 64);
+        if (ob > best || (ob == best && oi < best_id)) { best = ob; best_id = oi; }
+    }
+    if (lane == 0) { fred[wave] = best; ired[wave] = best_id; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (fred[w] > best || (fred[w] == best && ired[w] < best_id)) { best = fred[w]; best_id = ired[w]; }
+        tok_out[(long)row * tok_stride] = best_id;
+    }
+}
+
 int launch_sampler(const float* logits, int rows, int V, int ldl, const float* noise, int ldn,
                    const unsigned long long* seed, const int* frame, int kind, int noise_elem_off, float temperature,
                    float top_p, int* tok_out, int tok_stride, hipStream_t st) {
@@ -731,6 +893,13 @@ int launch_sampler(const float* logits, int rows, int V, int ldl, const float* n
         attr_set = true;
     }
     const float tclamp = temperature > 1e-5f ? temperature : 1e-5f;
+    static const bool legacy = getenv("SVA_SAMPLER_LDS") != nullptr;       // A/B switch: the all-LDS bitonic sort
+    if (P == 8192 && !legacy) {
+        hipLaunchKernelGGL((sampler_reg_kernel<8>), dim3(rows), dim3(1024), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
+                           noise_elem_off, 1.0f / tclamp, top_p, tok_out, tok_stride);
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(sampler_kernel, dim3(rows), dim3(1024), smem, st, logits, V, ldl, P, noise, ldn, seed, frame, kind,
                        noise_elem_off, 1.0f / tclamp, top_p, tok_out, tok_stride);
     SVA_HIP(hipGetLastError());
@@ -976,12 +1145,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const Gemv g) {
             for (int i = 0; i < KI; ++i) {
                 const int q4 = lane + 64 * i, h = q4 >> 4, d0 = (q4 & 15) * 4;
                 const float* pw = g.X + ((long)mm * g.H + h) * g.S * 68;
-                float4 o[8];
                 float mxs[8], ls[8], mx = -INFINITY;
 #pragma unroll
                 for (int sp = 0; sp < 8; ++sp) {
                     const int s2 = sp < g.S ? sp : g.S - 1;
-                    o[sp] = *reinterpret_cast<const float4*>(pw + s2 * 68 + d0);
                     mxs[sp] = pw[s2 * 68 + 64];
                     ls[sp] = sp < g.S ? pw[s2 * 68 + 65] : 0.f;
                     if (ls[sp] > 0.f) mx = fmaxf(mx, mxs[sp]);
@@ -990,9 +1157,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const Gemv g) {
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int sp = 0; sp < 8; ++sp) {
+                    const int s2 = sp < g.S ? sp : g.S - 1;
+                    const float4 o = *reinterpret_cast<const float4*>(pw + s2 * 68 + d0);
                     const float wgt = ls[sp] > 0.f ? expf(mxs[sp] - mx) : 0.f;
                     den = fmaf(wgt, ls[sp], den);
-                    a.x = fmaf(wgt, o[sp].x, a.x); a.y = fmaf(wgt, o[sp].y, a.y); a.z = fmaf(wgt, o[sp].z, a.z); a.w = fmaf(wgt, o[sp].w, a.w);
+                    a.x = fmaf(wgt, o.x, a.x); a.y = fmaf(wgt, o.y, a.y); a.z = fmaf(wgt, o.z, a.z); a.w = fmaf(wgt, o.w, a.w);
                 }
                 const float inv = 1.f / den;
                 x[m][i] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
@@ -1141,10 +1310,9 @@ int launch_gemv(const Gemv& g, hipStream_t st) {
         return 0;
     }
     if (g.mode == 4) {        // X = split-key attention partials [M][H][S = splits][68]
-        SVA_CHECK(ki == 3 && g.H * 64 == g.K && g.S >= 1 && g.S <= 8 && !g.norm_w, "gemv: partial merge needs K = H*64 = 768, <= 8 splits");
+        SVA_CHECK(ki == 3 && g.H * 64 == g.K && g.S >= 1 && g.S <= 8 && g.M <= 2 && !g.norm_w, "gemv: partial merge needs K = H*64 = 768, <= 8 splits, M <= 2");
         if (g.M == 1) hipLaunchKernelGGL((gemv_kernel<1, 3, 2>), grid, dim3(256), 0, st, g);
-        else if (g.M == 2) hipLaunchKernelGGL((gemv_kernel<2, 3, 2>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((gemv_kernel<4, 3, 2>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemv_kernel<2, 3, 2>), grid, dim3(256), 0, st, g);
         SVA_HIP(hipGetLastError());
         return 0;
     }

@@ -534,3 +534,30 @@ def test_calculate_prompt_mirror_feeds_stream(weights0):
         b2.firefly_encode(np.zeros((1, 4 * 2048), np.float32))
     b2.close()
     e2.close()
+
+
+def test_semantic_sampler_vs_oracle(eng, weights0):
+    """The 8192-way slow-head sample (computed and discarded by every caller, dual_ar_stream.py:833) from the register-resident
+    bitonic sampler equals the oracle's nucleus sampler on the engine's own slow logits under shared Exp(1) noise."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    ac, cc, style, timbre = synth_prompt(2500, 24)
+    b = E.Batch(eng, n_streams=1)
+    b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=77)
+    b.begin()
+    src = synth_utterance(7300, 2048 * 8)
+    checked = 0
+    for i in range(8):
+        slow, fast = frame_noise(7300, max(i - 2, 0))
+        nz = np.concatenate([slow, fast.reshape(-1)])[None, None]
+        b.step(src[None, i * 2048:(i + 1) * 2048], noise=nz)
+        if i >= 2:
+            lg = torch.from_numpy(b.tap("slow_logits", (1, 8192), np.float32)[0])
+            want = O.sample_token(lg, torch.from_numpy(slow))
+            got = int(b.tap("semantic", (1,), np.int32)[0])
+            assert got == want, (i, got, want)
+            checked += 1
+    assert checked == 6
+    b.close()
