@@ -9,15 +9,33 @@ namespace sva {
 // ------------------------------------------------------------------------------------------
 // wave / block reductions
 // ------------------------------------------------------------------------------------------
+// DPP reductions (no LDS round trips as with __shfl_xor = ds_bpermute): xor-1 / xor-2 inside quads, half-row and row
+// mirrors give every lane its 16-lane row total; row_bcast15 / row_bcast31 chain the four rows into lane 63, which is
+// broadcast through an SGPR.  All lanes return the same value.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);            // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);           // row_half_mirror
+    v += dpp_mov<0x140>(v);           // row_mirror
+    v += dpp_mov<0x142, 0xa>(v);      // row_bcast15 -> rows 1, 3
+    v += dpp_mov<0x143, 0xc>(v);      // row_bcast31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    // bound_ctrl supplies 0 to lanes without a source: harmless for a sum, wrong for a max of negatives -> merge explicitly
+    const float r15 = dpp_mov<0x142, 0xa>(v);
+    v = ((threadIdx.x & 63) >= 16 && (((threadIdx.x & 63) >> 4) & 1)) ? fmaxf(v, r15) : v;
+    const float r31 = dpp_mov<0x143, 0xc>(v);
+    v = ((threadIdx.x & 63) >= 32) ? fmaxf(v, r31) : v;
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float silu_acc(float x) { return x / (1.f + expf(-x)); }
 
@@ -358,61 +376,53 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
 // The quantizer's final RMSNorm (pre_module.norm, windowed_transformer.py:248-259) is applied here on the fly
 // (norm_w != null): v_c = x_c * rsqrt(mean(x^2) + eps) * w_c, optionally stored to zn_out.
 // One wave per row; the row lives in registers (C <= 512) and the nbits dot products are independent.
+template <int NPL, int NB>
 __global__ __launch_bounds__(256) void bsq_kernel(const float* __restrict__ z, long z_bstride, long z_off, int ldz, int T,
-                                                  int C, int rows, const float* __restrict__ norm_w, float eps,
+                                                  int rows, const float* __restrict__ norm_w, float eps,
                                                   float* __restrict__ zn_out, const float* __restrict__ W,
-                                                  const float* __restrict__ bias, int nbits, long long* __restrict__ idx_out,
+                                                  const float* __restrict__ bias, long long* __restrict__ idx_out,
                                                   int idx_bstride, int idx_off, float* __restrict__ u_out) {
+    constexpr int C = 64 * NPL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const int b = row / T, t = row - b * T;
     const float* zr = z + (long)b * z_bstride + z_off + (long)t * ldz;
-    float v[8];
-    float ss = 0.f;
+    float v[NPL], w[NB][NPL];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = c < C ? zr[c] : 0.f;
-        ss = fmaf(v[i], v[i], ss);
-    }
+    for (int i = 0; i < NPL; ++i) v[i] = zr[lane + 64 * i];
+#pragma unroll
+    for (int d = 0; d < NB; ++d)
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) w[d][i] = W[d * C + lane + 64 * i];        // all loads in flight before the first use
     if (norm_w) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) ss = fmaf(v[i], v[i], ss);
         const float inv = 1.f / sqrtf(wave_sum(ss) / (float)C + eps);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = lane + 64 * i;
-            if (c < C) {
-                v[i] = v[i] * inv * norm_w[c];
-                if (zn_out) zn_out[(long)b * z_bstride + z_off + (long)t * ldz + c] = v[i];
-            }
+        for (int i = 0; i < NPL; ++i) v[i] = v[i] * inv * norm_w[lane + 64 * i];
+        if (zn_out) {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) zn_out[(long)b * z_bstride + z_off + (long)t * ldz + lane + 64 * i] = v[i];
         }
     }
-    float u[16];
+    float u[NB], nrm = 0.f;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) {
-        const int dd = d < nbits ? d : nbits - 1;        // no branch around the loads
+    for (int d = 0; d < NB; ++d) {
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = lane + 64 * i;
-            acc = fmaf(W[dd * C + (c < C ? c : 0)], v[i], acc);
-        }
-        u[d] = acc;
-    }
-    float nrm = 0.f;
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-        u[d] = wave_sum(u[d]) + bias[d < nbits ? d : nbits - 1];
-        if (d < nbits) nrm = fmaf(u[d], u[d], nrm);
+        for (int i = 0; i < NPL; ++i) acc = fmaf(w[d][i], v[i], acc);
+        u[d] = wave_sum(acc) + bias[d];
+        nrm = fmaf(u[d], u[d], nrm);
     }
     if (lane == 0) {
         long long idx = 0;
         const float inv = 1.f / fmaxf(sqrtf(nrm), 1e-12f);      // F.normalize eps
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            if (d >= nbits) continue;
-            if (u[d] > 0.f) idx |= 1ll << (nbits - 1 - d);
-            if (u_out) u_out[((long)b * idx_bstride + idx_off + t) * nbits + d] = u[d] * inv;
+        for (int d = 0; d < NB; ++d) {
+            if (u[d] > 0.f) idx |= 1ll << (NB - 1 - d);
+            if (u_out) u_out[((long)b * idx_bstride + idx_off + t) * NB + d] = u[d] * inv;
         }
         idx_out[(long)b * idx_bstride + idx_off + t] = idx;
     }
@@ -420,10 +430,10 @@ __global__ __launch_bounds__(256) void bsq_kernel(const float* __restrict__ z, l
 int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T, int C, const float* norm_w, float eps,
                float* zn_out, const float* W, const float* bias, int nbits, long long* idx_out, int idx_bstride, int idx_off,
                float* u_out, hipStream_t st) {
-    SVA_CHECK(nbits <= 16 && C <= 512, "bsq: nbits <= 16, C <= 512");
+    SVA_CHECK(nbits == 13 && C == 512, "bsq: built for the reference's 13 bits on 512 channels");
     const int rows = B * T;
-    hipLaunchKernelGGL(bsq_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, z, z_bstride, z_off, ldz, T, C, rows, norm_w, eps, zn_out,
-                       W, bias, nbits, idx_out, idx_bstride, idx_off, u_out);
+    hipLaunchKernelGGL((bsq_kernel<8, 13>), dim3((rows + 3) / 4), dim3(256), 0, st, z, z_bstride, z_off, ldz, T, rows, norm_w, eps, zn_out,
+                       W, bias, idx_out, idx_bstride, idx_off, u_out);
     SVA_HIP(hipGetLastError());
     return 0;
 }
