@@ -10,6 +10,9 @@
 // next tile's global loads are issued before the current tile's MFMAs and written to the other
 // LDS buffer after them (one barrier per K tile).
 #include "sva_common.h"
+#include <mutex>
+#include <unordered_map>
+#include <utility>
 #include <stdlib.h>
 
 namespace sva {
@@ -322,48 +325,47 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) 
         }
     }
     __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
+    // tail: the MT row tiles are spread over the waves (each sums the KW partials of its tiles straight from LDS and runs
+    // the epilogue for them) instead of leaving all of it to wave 0
+    const int col = lane & 15, rq = (lane >> 4) * 4;
+    for (int i = wave; i < MT; i += KW) {
+        f32x4 t[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            f32x4 s = acc[i][j];
-            for (int w = 1; w < KW; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * (MT * NT) + i * NT + j) * 64 + lane) * 4]);
-            acc[i][j] = s;
-        }
-    const int col = lane & 15, rq = (lane >> 4) * 4;
-    if (RMS) {
+            f32x4 s = *reinterpret_cast<const f32x4*>(&red[((i * NT + j) * 64 + lane) * 4]);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int w = 1; w < KW; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * (MT * NT) + i * NT + j) * 64 + lane) * 4]);
+            t[j] = s;
+        }
+        if (RMS) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float tot = 0.f;
+#pragma unroll
                 for (int w = 0; w < KW; ++w) tot += redss[(w * MT + i) * 16 + rq + r];
                 const float inv = 1.f / sqrtf(tot / (float)Kt + g.rms_eps);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j][r] *= inv;
+                for (int j = 0; j < NT; ++j) t[j][r] *= inv;
             }
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m_base + i * 16 + rq + r;
             if (m >= g.M) continue;
-            const int b = m / g.T, t = m - b * g.T;
-            float* crow = g.C + (long)b * g.c_bstride + g.c_off + (long)t * g.ldc;
-            const float* rrow = g.res ? g.res + (long)b * g.r_bstride + g.r_off + (long)t * g.ldr : nullptr;
+            const int b = m / g.T, tt = m - b * g.T;
+            float* crow = g.C + (long)b * g.c_bstride + g.c_off + (long)tt * g.ldc;
+            const float* rrow = g.res ? g.res + (long)b * g.r_bstride + g.r_off + (long)tt * g.ldr : nullptr;
             if (g.w13) {
                 if constexpr (NT == 2) {
                     const int n = n0 + col;
-                    if (n < g.N) crow[(n0 >> 1) + col] = silu_f(acc[i][0][r]) * acc[i][1][r];
+                    if (n < g.N) crow[(n0 >> 1) + col] = silu_f(t[0][r]) * t[1][r];
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int n = n0 + j * 16 + col;
                     if (n >= g.N) continue;
-                    float v = acc[i][j][r];
+                    float v = t[j][r];
                     if (g.bias) v += g.bias[n];
                     if (g.act == ACT_GELU) v = gelu_erf(v);
                     else if (g.act == ACT_LOGCLAMP) v = __logf(fmaxf(v, 1e-5f));
@@ -397,24 +399,8 @@ static int launch_skinny(const ConvGemm& g, hipStream_t st) {
     return launch_skinny_op<MT, NT, KW, D, 0>(g, st);
 }
 
-// Choice of (rows per workgroup = 16*MT, K-split waves KW) for the skinny kernel: enough waves to occupy the 256 CUs
-// (>= ~1024 when the problem allows), K slices of at least 2 blocks per wave.
 template <int NT>
-static int dispatch_skinny(const ConvGemm& g, hipStream_t st) {
-    const int mt_total = (g.M + 15) / 16;
-    const long nk = (long)g.taps * g.Cin / 16;
-    const long cols = (g.N + 16 * NT - 1) / (16 * NT);
-    int mt = mt_total < 4 ? mt_total : 4;
-    if (mt == 3 && mt_total == 3) mt = 3;
-    auto blocks = [&](int m) { return cols * ((mt_total + m - 1) / m); };
-    while (mt > 1 && blocks(mt) * 4 < 512) mt = mt > 2 ? 2 : 1;
-    int kw = 4;
-    while (kw < 16 && blocks(mt) * kw < 1024 && nk / (2 * kw) >= 2) kw *= 2;
-    if (mt >= 2 && kw == 16) kw = 8;              // register budget of 1024-thread workgroups
-    static const char* env_mt = getenv("SVA_SKINNY_MT");
-    static const char* env_kw = getenv("SVA_SKINNY_KW");
-    if (env_mt) mt = atoi(env_mt) < mt_total ? atoi(env_mt) : (mt_total < 4 ? mt_total : 4);
-    if (env_kw) { kw = atoi(env_kw); if (mt >= 2 && kw == 16) kw = 8; }
+static int launch_cfg(const ConvGemm& g, hipStream_t st, int mt, int kw) {
     switch (mt) {
         case 1:
             if (kw == 16) return launch_skinny<1, NT, 16, 4>(g, st);
@@ -430,6 +416,87 @@ static int dispatch_skinny(const ConvGemm& g, hipStream_t st) {
             if (kw == 8) return launch_skinny<4, NT, 8, 3>(g, st);
             return launch_skinny<4, NT, 4, 4>(g, st);
     }
+}
+static std::mutex g_tune_mu;
+static std::unordered_map<unsigned long long, std::pair<int, int>> g_tune;
+static float* g_tune_c = nullptr;
+static size_t g_tune_elems = 0;
+
+// Choice of (rows per workgroup = 16*MT, K-split waves KW) for the skinny kernel: enough waves to occupy the 256 CUs
+// (>= ~1024 when the problem allows), K slices of at least 2 blocks per wave.
+template <int NT>
+static int dispatch_skinny(const ConvGemm& g, hipStream_t st) {
+    const int mt_total = (g.M + 15) / 16;
+    const long nk = (long)g.taps * g.Cin / 16;
+    const long cols = (g.N + 16 * NT - 1) / (16 * NT);
+    int mt = mt_total < 4 ? mt_total : 4;
+    auto blocks = [&](int m) { return cols * ((mt_total + m - 1) / m); };
+    // Every row tile of a column block re-reads that block's weights.  Weight-heavy problems (AR layers at M = 64..128:
+    // the panel comes from HBM) keep the tallest workgroup; light ones (encoder at M = 128..160: the panel sits in L2)
+    // trade re-reads for >= ~1.5 workgroups per CU.  Tuned with tools/gemm_sweep4.py.
+    const bool heavy = (long)g.N * g.taps * g.Cin * 4 > (8L << 20);
+    if (heavy) { while (mt > 1 && blocks(mt) * 4 < 512) mt = mt > 2 ? 2 : 1; }
+    else       { while (mt > 1 && blocks(mt) < 384) mt = mt > 2 ? 2 : 1; }
+    int kw = 4;
+    while (kw < 8 && blocks(mt) * kw < 2048 && nk / (2 * kw) >= 2) kw *= 2;
+    if (kw == 8 && blocks(mt) * 8 < 512 && nk / 32 >= 2 && mt == 1) kw = 16;     // a handful of column blocks: split K deeper
+    static const char* env_mt = getenv("SVA_SKINNY_MT");
+    static const char* env_kw = getenv("SVA_SKINNY_KW");
+    if (env_mt) mt = atoi(env_mt) < mt_total ? atoi(env_mt) : (mt_total < 4 ? mt_total : 4);
+    if (env_kw) { kw = atoi(env_kw); if (mt >= 2 && kw == 16) kw = 8; }
+    static const bool tune = !(env_mt || env_kw) && !(getenv("SVA_AUTOTUNE") && atoi(getenv("SVA_AUTOTUNE")) == 0);
+    if (tune) {
+        // Shape-keyed autotune: the first eager launch of a shape times the (rows per workgroup, K split) candidates on
+        // the real operands with the output redirected to scratch, and keeps a candidate only if it beats the
+        // heuristic by > 7 %.  Launches inside a stream capture (and shapes first seen there) use the heuristic.
+        const unsigned long long key = ((unsigned long long)g.M << 44) ^ ((unsigned long long)g.N << 26) ^ ((unsigned long long)(g.taps * g.Cin) << 6) ^
+                                       ((unsigned long long)g.taps << 2) ^ (unsigned long long)(NT - 1) ^ ((unsigned long long)(g.a_silu | (g.rms_w ? 2 : 0)) << 60);
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune.find(key);
+        if (it != g_tune.end()) { mt = it->second.first; kw = it->second.second; }
+        else {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+                const int ldc = g.w13 ? g.N / 2 : g.N;
+                const size_t need = (size_t)g.M * ldc;
+                if (need > g_tune_elems) {
+                    if (g_tune_c) (void)hipFree(g_tune_c);
+                    SVA_HIP(hipMalloc((void**)&g_tune_c, need * sizeof(float)));
+                    g_tune_elems = need;
+                }
+                ConvGemm t = g;
+                t.C = g_tune_c; t.c_bstride = (long)g.T * ldc; t.c_off = 0; t.ldc = ldc;
+                hipEvent_t e0, e1;
+                SVA_HIP(hipEventCreate(&e0)); SVA_HIP(hipEventCreate(&e1));
+                auto time_cfg = [&](int m_, int k_, float* ms) -> int {
+                    SVA_TRY_RC((launch_cfg<NT>(t, st, m_, k_)));
+                    SVA_HIP(hipEventRecord(e0, st));
+                    for (int r = 0; r < 6; ++r) SVA_TRY_RC((launch_cfg<NT>(t, st, m_, k_)));
+                    SVA_HIP(hipEventRecord(e1, st));
+                    SVA_HIP(hipEventSynchronize(e1));
+                    SVA_HIP(hipEventElapsedTime(ms, e0, e1));
+                    return 0;
+                };
+                float base = 0.f, best = 0.f;
+                SVA_TRY_RC(time_cfg(mt, kw, &base));
+                best = base * 0.93f;
+                int bm = mt, bk = kw;
+                const int mts[3] = {1, 2, 4}, kws[3] = {4, 8, 16};
+                for (int a = 0; a < 3; ++a)
+                    for (int c2 = 0; c2 < 3; ++c2) {
+                        const int m_ = mts[a], k_ = kws[c2];
+                        if (m_ > mt_total || (m_ >= 2 && k_ == 16) || nk / k_ < 1 || (m_ == mt && k_ == kw)) continue;
+                        float ms = 0.f;
+                        SVA_TRY_RC(time_cfg(m_, k_, &ms));
+                        if (ms < best) { best = ms; bm = m_; bk = k_; }
+                    }
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+                mt = bm; kw = bk;
+                g_tune[key] = {mt, kw};
+            }
+        }
+    }
+    return launch_cfg<NT>(g, st, mt, kw);
 }
 
 template <int BM, int BN, int WM, int WN, int BK>

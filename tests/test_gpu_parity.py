@@ -352,7 +352,9 @@ def test_reprefill_per_slot_with_unequal_prompts(eng):
         one, codes1, pos1 = run((s,))
         np.testing.assert_array_equal(pos2[:, s], pos1[:, 0])
         np.testing.assert_array_equal(codes2[s], codes1[0])
-        np.testing.assert_array_equal(both[s], one[0])
+        # codes and positions are identical; PCM only to fp32 summation order (the GEMM dispatch is tuned per problem size, so a
+        # 2-stream batch and a 1-stream batch may split K differently)
+        np.testing.assert_allclose(both[s], one[0], rtol=0, atol=PCM_TOL)
     # positions dropped (re-prefill happened) at different steps for the two slots
     drops = [np.where(np.diff(pos2[:, s]) < 0)[0] for s in range(2)]
     assert len(drops[0]) > 0 and len(drops[1]) > 0 and drops[0][0] != drops[1][0]
