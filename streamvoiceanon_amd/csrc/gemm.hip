@@ -13,6 +13,7 @@
 #include <mutex>
 #include <unordered_map>
 #include <utility>
+#include <vector>
 #include <stdlib.h>
 
 namespace sva {
@@ -417,15 +418,8 @@ static int launch_cfg(const ConvGemm& g, hipStream_t st, int mt, int kw) {
             return launch_skinny<4, NT, 4, 4>(g, st);
     }
 }
-static std::mutex g_tune_mu;
-static std::unordered_map<unsigned long long, std::pair<int, int>> g_tune;
-static float* g_tune_c = nullptr;
-static size_t g_tune_elems = 0;
-
-// Choice of (rows per workgroup = 16*MT, K-split waves KW) for the skinny kernel: enough waves to occupy the 256 CUs
-// (>= ~1024 when the problem allows), K slices of at least 2 blocks per wave.
-template <int NT>
-static int dispatch_skinny(const ConvGemm& g, hipStream_t st) {
+// Heuristic choice of (rows per workgroup = 16*MT, K-split waves KW) for the small-M kernel.
+static void skinny_heuristic(const ConvGemm& g, int NT, int* mt_out, int* kw_out) {
     const int mt_total = (g.M + 15) / 16;
     const long nk = (long)g.taps * g.Cin / 16;
     const long cols = (g.N + 16 * NT - 1) / (16 * NT);
@@ -444,59 +438,7 @@ static int dispatch_skinny(const ConvGemm& g, hipStream_t st) {
     static const char* env_kw = getenv("SVA_SKINNY_KW");
     if (env_mt) mt = atoi(env_mt) < mt_total ? atoi(env_mt) : (mt_total < 4 ? mt_total : 4);
     if (env_kw) { kw = atoi(env_kw); if (mt >= 2 && kw == 16) kw = 8; }
-    static const bool tune = !(env_mt || env_kw) && !(getenv("SVA_AUTOTUNE") && atoi(getenv("SVA_AUTOTUNE")) == 0);
-    if (tune) {
-        // Shape-keyed autotune: the first eager launch of a shape times the (rows per workgroup, K split) candidates on
-        // the real operands with the output redirected to scratch, and keeps a candidate only if it beats the
-        // heuristic by > 7 %.  Launches inside a stream capture (and shapes first seen there) use the heuristic.
-        const unsigned long long key = ((unsigned long long)g.M << 44) ^ ((unsigned long long)g.N << 26) ^ ((unsigned long long)(g.taps * g.Cin) << 6) ^
-                                       ((unsigned long long)g.taps << 2) ^ (unsigned long long)(NT - 1) ^ ((unsigned long long)(g.a_silu | (g.rms_w ? 2 : 0)) << 60);
-        std::lock_guard<std::mutex> lk(g_tune_mu);
-        auto it = g_tune.find(key);
-        if (it != g_tune.end()) { mt = it->second.first; kw = it->second.second; }
-        else {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
-                const int ldc = g.w13 ? g.N / 2 : g.N;
-                const size_t need = (size_t)g.M * ldc;
-                if (need > g_tune_elems) {
-                    if (g_tune_c) (void)hipFree(g_tune_c);
-                    SVA_HIP(hipMalloc((void**)&g_tune_c, need * sizeof(float)));
-                    g_tune_elems = need;
-                }
-                ConvGemm t = g;
-                t.C = g_tune_c; t.c_bstride = (long)g.T * ldc; t.c_off = 0; t.ldc = ldc;
-                hipEvent_t e0, e1;
-                SVA_HIP(hipEventCreate(&e0)); SVA_HIP(hipEventCreate(&e1));
-                auto time_cfg = [&](int m_, int k_, float* ms) -> int {
-                    SVA_TRY_RC((launch_cfg<NT>(t, st, m_, k_)));
-                    SVA_HIP(hipEventRecord(e0, st));
-                    for (int r = 0; r < 6; ++r) SVA_TRY_RC((launch_cfg<NT>(t, st, m_, k_)));
-                    SVA_HIP(hipEventRecord(e1, st));
-                    SVA_HIP(hipEventSynchronize(e1));
-                    SVA_HIP(hipEventElapsedTime(ms, e0, e1));
-                    return 0;
-                };
-                float base = 0.f, best = 0.f;
-                SVA_TRY_RC(time_cfg(mt, kw, &base));
-                best = base * 0.93f;
-                int bm = mt, bk = kw;
-                const int mts[3] = {1, 2, 4}, kws[3] = {4, 8, 16};
-                for (int a = 0; a < 3; ++a)
-                    for (int c2 = 0; c2 < 3; ++c2) {
-                        const int m_ = mts[a], k_ = kws[c2];
-                        if (m_ > mt_total || (m_ >= 2 && k_ == 16) || nk / k_ < 1 || (m_ == mt && k_ == kw)) continue;
-                        float ms = 0.f;
-                        SVA_TRY_RC(time_cfg(m_, k_, &ms));
-                        if (ms < best) { best = ms; bm = m_; bk = k_; }
-                    }
-                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-                mt = bm; kw = bk;
-                g_tune[key] = {mt, kw};
-            }
-        }
-    }
-    return launch_cfg<NT>(g, st, mt, kw);
+    *mt_out = mt; *kw_out = kw;
 }
 
 template <int BM, int BN, int WM, int WN, int BK>
@@ -514,6 +456,51 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
     return 0;
 }
 
+// One dispatch decision: kind 0 = small-M K-split kernel (a = rows/16 per workgroup, b = K-split waves, c = 16-column
+// tiles per wave); kind 1 = LDS-tiled kernel (a: 0 = 64x64, 1 = 128x128, 2 = 128x32, 3 = 256x16).
+struct Choice { int kind, a, b, c; };
+
+static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
+    if (ch.kind == 0) return ch.c == 2 ? launch_cfg<2>(g, st, ch.a, ch.b) : launch_cfg<1>(g, st, ch.a, ch.b);
+    const int bk = g.Cin % 64 == 0 ? 64 : (g.Cin % 32 == 0 ? 32 : 16);
+    switch (ch.a) {
+        case 3: return launch_t<256, 16, 4, 1, 16>(g, st);
+        case 2: return bk >= 32 ? launch_t<128, 32, 4, 1, 32>(g, st) : launch_t<128, 32, 4, 1, 16>(g, st);
+        case 1: return bk >= 32 ? launch_t<128, 128, 2, 2, 32>(g, st) : launch_t<128, 128, 2, 2, 16>(g, st);
+        default:
+            if (bk == 64) return launch_t<64, 64, 2, 2, 64>(g, st);
+            if (bk == 32) return launch_t<64, 64, 2, 2, 32>(g, st);
+            return launch_t<64, 64, 2, 2, 16>(g, st);
+    }
+}
+
+static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
+    // the K tile is as deep as Cin allows (bytes in flight per workgroup hide the L2/HBM latency of the register-staged
+    // pipeline); 128x128 tiles only when they still fill the 256 CUs
+    const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    // under-filled grids (fewer than ~1 tiled workgroup per CU): the barrier-free K-split kernel keeps far more
+    // loads in flight per CU than the LDS-staged one and pays for it with extra L2 reads, which are cheap there
+    const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+    if (g.M <= 64 || (tiles64 < 256 && g.N >= 64) || !c_vec) {      // (the tiled epilogue needs 16-byte aligned C rows)
+        // two 16-column tiles per wave halve the A re-reads; worth it once the A panel dominates the L2 traffic
+        const bool nt2 = g.w13 || (g.N % 32 == 0 && g.M >= 512 && (long)g.M * g.N >= 256L * 1024);
+        Choice ch{0, 1, 4, nt2 ? 2 : 1};
+        skinny_heuristic(g, ch.c, &ch.a, &ch.b);
+        return ch;
+    }
+    if (g.N <= 16 && !g.w13) return Choice{1, 3, 0, 0};
+    if (g.N <= 32) return Choice{1, 2, 0, 0};
+    // 128x128 tiles only when their last (partial) round over the 256 CUs does not cost more than the lower operand
+    // reuse of 64x64 tiles (e.g. 320 big tiles = 2 rounds for 1.25 rounds of work)
+    if (big >= 256 && ((big + 255) / 256) * 4.0 <= ((tiles64 + 255) / 256) * 1.25) return Choice{1, 1, 0, 0};
+    return Choice{1, 0, 0, 0};
+}
+
+static std::mutex g_tune_mu;
+static std::unordered_map<unsigned long long, Choice> g_tune;
+static float* g_tune_c = nullptr;
+static size_t g_tune_elems = 0;
+
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
     SVA_CHECK(g.Cin % 16 == 0 && g.Cin > 0, "conv_gemm: Cin must be a multiple of 16");
     SVA_CHECK(g.lda % 4 == 0 && (g.a_off % 4) == 0 && (g.a_bstride % 4) == 0, "conv_gemm: A must be float4-aligned");
@@ -521,33 +508,80 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
                        (!g.res || (g.ldr % 4 == 0 && g.r_off % 4 == 0 && g.r_bstride % 4 == 0));
     SVA_CHECK(g.M > 0 && g.N > 0 && g.T > 0, "conv_gemm: empty problem");
     if (g.w13) SVA_CHECK(g.N % 32 == 0, "conv_gemm: w13 needs N % 32 == 0");
-    // tile selection: the K tile is as deep as Cin allows (bytes in flight per workgroup hide the L2/HBM
-    // latency of the register-staged pipeline); 128x128 tiles only when they still fill the 256 CUs
-    const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    const int bk = g.Cin % 64 == 0 ? 64 : (g.Cin % 32 == 0 ? 32 : 16);
-    // under-filled grids (fewer than ~1 tiled workgroup per CU): the barrier-free K-split kernel keeps far more
-    // loads in flight per CU than the LDS-staged one and pays for it with extra L2 reads, which are cheap there
-    const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
     if (g.rms_w) SVA_CHECK(g.taps == 1 && !g.a_silu && conv_gemm_can_fuse_rms(g.M, g.N), "conv_gemm: fused RMSNorm needs taps == 1 on the small-M path");
-    if (g.M <= 64 || (tiles64 < 256 && g.N >= 64) || !c_vec) {      // (the tiled epilogue needs 16-byte aligned C rows)
-        // two 16-column tiles per wave halve the A re-reads; worth it once the A panel dominates the L2 traffic
-        const bool nt2 = g.w13 || (g.N % 32 == 0 && g.M >= 512 && (long)g.M * g.N >= 256L * 1024);
-        SVA_TRY_RC(nt2 ? dispatch_skinny<2>(g, st) : dispatch_skinny<1>(g, st));
-    } else if (g.N <= 16 && !g.w13) {
-        SVA_TRY_RC((launch_t<256, 16, 4, 1, 16>(g, st)));
-    } else if (g.N <= 32) {
-        if (bk >= 32) SVA_TRY_RC((launch_t<128, 32, 4, 1, 32>(g, st)));
-        else SVA_TRY_RC((launch_t<128, 32, 4, 1, 16>(g, st)));
-    } else if (big >= 256 && ((big + 255) / 256) * 4.0 <= ((tiles64 + 255) / 256) * 1.25) {
-        // 128x128 tiles only when their last (partial) round over the 256 CUs does not cost more than the lower
-        // operand reuse of 64x64 tiles (e.g. 320 big tiles = 2 rounds for 1.25 rounds of work)
-        if (bk >= 32) SVA_TRY_RC((launch_t<128, 128, 2, 2, 32>(g, st)));
-        else SVA_TRY_RC((launch_t<128, 128, 2, 2, 16>(g, st)));
-    } else {
-        if (bk == 64) SVA_TRY_RC((launch_t<64, 64, 2, 2, 64>(g, st)));
-        else if (bk == 32) SVA_TRY_RC((launch_t<64, 64, 2, 2, 32>(g, st)));
-        else SVA_TRY_RC((launch_t<64, 64, 2, 2, 16>(g, st)));
+    Choice ch = heuristic_choice(g, c_vec);
+    static const bool tune = !(getenv("SVA_SKINNY_MT") || getenv("SVA_SKINNY_KW")) && !(getenv("SVA_AUTOTUNE") && atoi(getenv("SVA_AUTOTUNE")) == 0);
+    if (tune) {
+        // Shape-keyed autotune: the first eager launch of a problem shape times the candidate kernels / configurations on
+        // the real operands with the output redirected to scratch, and keeps a candidate only if it beats the heuristic
+        // by > 7 %.  Launches inside a stream capture (and shapes first seen there) use the heuristic.
+        const unsigned long long flags = (unsigned long long)(g.a_silu ? 1 : 0) | (g.rms_w ? 2 : 0) | (g.w13 ? 4 : 0) | (c_vec ? 8 : 0) | (g.accumulate ? 16 : 0);
+        const unsigned long long key = ((unsigned long long)g.M << 40) ^ ((unsigned long long)g.N << 24) ^ ((unsigned long long)(g.taps * g.Cin) << 8) ^
+                                       ((unsigned long long)g.taps << 4) ^ (flags << 58) ^ (unsigned long long)(g.stride & 15);
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune.find(key);
+        if (it != g_tune.end()) ch = it->second;
+        else {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+                const int ldc = g.w13 ? g.N / 2 : g.N;
+                const size_t need = (size_t)g.M * ldc;
+                if (need > g_tune_elems) {
+                    if (g_tune_c) (void)hipFree(g_tune_c);
+                    SVA_HIP(hipMalloc((void**)&g_tune_c, need * sizeof(float)));
+                    g_tune_elems = need;
+                }
+                ConvGemm t = g;
+                t.C = g_tune_c; t.c_bstride = (long)g.T * ldc; t.c_off = 0; t.ldc = ldc;
+                hipEvent_t e0, e1;
+                SVA_HIP(hipEventCreate(&e0)); SVA_HIP(hipEventCreate(&e1));
+                auto time_choice = [&](const Choice& c, float* ms) -> int {
+                    SVA_TRY_RC(launch_choice(t, st, c));
+                    SVA_HIP(hipEventRecord(e0, st));
+                    for (int r = 0; r < 5; ++r) SVA_TRY_RC(launch_choice(t, st, c));
+                    SVA_HIP(hipEventRecord(e1, st));
+                    SVA_HIP(hipEventSynchronize(e1));
+                    SVA_HIP(hipEventElapsedTime(ms, e0, e1));
+                    return 0;
+                };
+                std::vector<Choice> cand;
+                const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+                const bool must_skinny = g.rms_w || !c_vec;
+                if (must_skinny || tiles64 < 1024) {
+                    const int mt_total = (g.M + 15) / 16;
+                    const long nk = (long)g.taps * g.Cin / 16;
+                    for (int nt = 1; nt <= 2; ++nt) {
+                        if (g.w13 && nt == 1) continue;
+                        if (nt == 2 && g.N % 32 != 0) continue;
+                        const int mts[3] = {1, 2, 4}, kws[3] = {4, 8, 16};
+                        for (int a = 0; a < 3; ++a)
+                            for (int b2 = 0; b2 < 3; ++b2) {
+                                if (mts[a] > mt_total || (mts[a] >= 2 && kws[b2] == 16) || nk / kws[b2] < 1) continue;
+                                cand.push_back(Choice{0, mts[a], kws[b2], nt});
+                            }
+                    }
+                }
+                if (!must_skinny) {
+                    if (g.N > 32) cand.push_back(Choice{1, 0, 0, 0});
+                    if (g.M >= 128 && g.N >= 128) cand.push_back(Choice{1, 1, 0, 0});
+                    if (g.N <= 64) cand.push_back(Choice{1, 2, 0, 0});
+                    if (g.N <= 16 && !g.w13) cand.push_back(Choice{1, 3, 0, 0});
+                }
+                float base = 0.f;
+                SVA_TRY_RC(time_choice(ch, &base));
+                float best = base * 0.93f;
+                for (const Choice& c : cand) {
+                    if (c.kind == ch.kind && c.a == ch.a && c.b == ch.b && c.c == ch.c) continue;
+                    float ms = 0.f;
+                    SVA_TRY_RC(time_choice(c, &ms));
+                    if (ms < best) { best = ms; ch = c; }
+                }
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+                g_tune[key] = ch;
+            }
+        }
     }
+    SVA_TRY_RC(launch_choice(g, st, ch));
     SVA_HIP(hipGetLastError());
     return 0;
 }
