@@ -37,6 +37,21 @@ __device__ __forceinline__ float wave_max(float v) {
     v = ((threadIdx.x & 63) >= 32) ? fmaxf(v, r31) : v;
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// value of lane (l ^ DL): DPP for the distances a row (16 lanes) can serve, ds_bpermute beyond
+template <int DL>
+__device__ __forceinline__ int lane_xor_i(int v) {
+    if constexpr (DL == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
+    else if constexpr (DL == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    else if constexpr (DL == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);    // row_ror:8
+    else if constexpr (DL == 4) {
+        const int up = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0xf, true);                    // row_shl:4  (from lane + 4)
+        const int dn = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);                    // row_shr:4  (from lane - 4)
+        return (threadIdx.x & 4) ? dn : up;
+    } else return __shfl_xor(v, DL, 64);
+}
+template <int DL>
+__device__ __forceinline__ float lane_xor_f(float v) { return __builtin_bit_cast(float, lane_xor_i<DL>(__builtin_bit_cast(int, v))); }
+
 __device__ __forceinline__ float silu_acc(float x) { return x / (1.f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------
@@ -732,13 +747,17 @@ __global__ __launch_bounds__(1024) void sampler_kernel(const float* __restrict__
 // positions, so of the log2(P)(log2(P)+1)/2 compare-exchange stages only those with partner distance >= 64 * PER go
 // through LDS (10 of 91 for P = 8192); distances < PER stay inside a thread, the rest are wave shuffles.  Same order
 // (descending, ties by smaller id), cumulative sum, cut and argmax rules as sampler_kernel.
-template <int PER>
-__global__ __launch_bounds__(1024) void sampler_reg_kernel(const float* __restrict__ logits, int V, int ldl,
+template <int THREADS, int PER>
+__global__ __launch_bounds__(THREADS) void sampler_reg_kernel(const float* __restrict__ logits, int V, int ldl,
                                                            const float* __restrict__ noise, int ldn,
                                                            const unsigned long long* __restrict__ seed, const int* __restrict__ frame,
                                                            int kind, int noise_elem_off, float inv_temp, float top_p,
-                                                           int* __restrict__ tok_out, int tok_stride) {
-    constexpr int P = 1024 * PER;
+                                                           int* __restrict__ tok_out, int tok_stride,
+                                                           // optional fusion (fast-AR heads): teacher forcing + gather of the next input embedding
+                                                           int* __restrict__ tok, const int* __restrict__ forced, int forced_stride,
+                                                           const int* __restrict__ use_forced, const float* __restrict__ emb_table, int D,
+                                                           float* __restrict__ emb_out, int ldo) {
+    constexpr int P = THREADS * PER, NW = THREADS / 64;
     __shared__ float xv[P];
     __shared__ unsigned short xi[P];
     __shared__ double dred[16];
@@ -762,26 +781,35 @@ __global__ __launch_bounds__(1024) void sampler_reg_kernel(const float* __restri
                 const int pt = tid ^ (j / PER);
                 __syncthreads();
 #pragma unroll
-                for (int r = 0; r < PER; ++r) { xv[r * 1024 + tid] = v[r]; xi[r * 1024 + tid] = (unsigned short)id[r]; }
+                for (int r = 0; r < PER; ++r) { xv[r * THREADS + tid] = v[r]; xi[r * THREADS + tid] = (unsigned short)id[r]; }
                 __syncthreads();
                 const bool lower = (tid & (j / PER)) == 0;
                 const bool desc = ((tid * PER) & k) == 0;
 #pragma unroll
                 for (int r = 0; r < PER; ++r) {
-                    const float ov = xv[r * 1024 + pt];
-                    const int oi = xi[r * 1024 + pt];
+                    const float ov = xv[r * THREADS + pt];
+                    const int oi = xi[r * THREADS + pt];
                     if (first(v[r], id[r], ov, oi) != (desc == lower)) { v[r] = ov; id[r] = oi; }
                 }
             } else if (j >= PER) {                                 // partner lane in this wave
                 const int dl = j / PER;
                 const bool lower = (lane & dl) == 0;
                 const bool desc = ((tid * PER) & k) == 0;
-#pragma unroll
-                for (int r = 0; r < PER; ++r) {
-                    const float ov = __shfl_xor(v[r], dl, 64);
-                    const int oi = __shfl_xor(id[r], dl, 64);
-                    if (first(v[r], id[r], ov, oi) != (desc == lower)) { v[r] = ov; id[r] = oi; }
+#define SVA_XSTAGE(DL_)                                                                              \
+    _Pragma("unroll") for (int r = 0; r < PER; ++r) {                                                \
+        const float ov = lane_xor_f<DL_>(v[r]);                                                      \
+        const int oi = lane_xor_i<DL_>(id[r]);                                                       \
+        if (first(v[r], id[r], ov, oi) != (desc == lower)) { v[r] = ov; id[r] = oi; }                \
+    }
+                switch (dl) {
+                    case 1: SVA_XSTAGE(1) break;
+                    case 2: SVA_XSTAGE(2) break;
+                    case 4: SVA_XSTAGE(4) break;
+                    case 8: SVA_XSTAGE(8) break;
+                    case 16: SVA_XSTAGE(16) break;
+                    default: SVA_XSTAGE(32) break;
                 }
+#undef SVA_XSTAGE
             } else {                                               // partner inside the thread: static register indices
 #pragma unroll
                 for (int jj = PER / 2; jj > 0; jj >>= 1) {
@@ -818,7 +846,7 @@ __global__ __launch_bounds__(1024) void sampler_reg_kernel(const float* __restri
     if (lane == 0) fred[wave] = s;
     __syncthreads();
     float denom = 0.f;
-    for (int w = 0; w < 16; ++w) denom += fred[w];
+    for (int w = 0; w < NW; ++w) denom += fred[w];
     __syncthreads();
     double local = 0.0;
 #pragma unroll
@@ -847,7 +875,7 @@ __global__ __launch_bounds__(1024) void sampler_reg_kernel(const float* __restri
     if (lane == 0) ired[wave] = first_rm;
     __syncthreads();
     int ncut = P;
-    for (int w = 0; w < 16; ++w) ncut = min(ncut, ired[w]);
+    for (int w = 0; w < NW; ++w) ncut = min(ncut, ired[w]);
     if (ncut > V) ncut = V;
     __syncthreads();
     const float m2 = mx * inv_temp;
@@ -862,7 +890,7 @@ __global__ __launch_bounds__(1024) void sampler_reg_kernel(const float* __restri
     if (lane == 0) fred[wave] = s2;
     __syncthreads();
     float denom2 = 0.f;
-    for (int w = 0; w < 16; ++w) denom2 += fred[w];
+    for (int w = 0; w < NW; ++w) denom2 += fred[w];
     __syncthreads();
     float best = -1.f;
     int best_id = 0x7fffffff;
@@ -884,9 +912,20 @@ __global__ __launch_bounds__(1024) void sampler_reg_kernel(const float* __restri
     if (lane == 0) { fred[wave] = best; ired[wave] = best_id; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 16; ++w)
+        for (int w = 1; w < NW; ++w)
             if (fred[w] > best || (fred[w] == best && ired[w] < best_id)) { best = fred[w]; best_id = ired[w]; }
         tok_out[(long)row * tok_stride] = best_id;
+        if (tok) {
+            int t = best_id;
+            if (forced && *use_forced) t = forced[(long)row * forced_stride];
+            tok[(long)row * tok_stride] = t;
+            ired[0] = t;
+        }
+    }
+    if (emb_table) {
+        __syncthreads();
+        const int t = ired[0];
+        for (int c = tid; c < D; c += THREADS) emb_out[(long)row * ldo + c] = emb_table[(long)t * D + c];
     }
 }
 
@@ -905,8 +944,9 @@ int launch_sampler(const float* logits, int rows, int V, int ldl, const float* n
     const float tclamp = temperature > 1e-5f ? temperature : 1e-5f;
     static const bool legacy = getenv("SVA_SAMPLER_LDS") != nullptr;       // A/B switch: the all-LDS bitonic sort
     if (P == 8192 && !legacy) {
-        hipLaunchKernelGGL((sampler_reg_kernel<8>), dim3(rows), dim3(1024), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
-                           noise_elem_off, 1.0f / tclamp, top_p, tok_out, tok_stride);
+        hipLaunchKernelGGL((sampler_reg_kernel<1024, 8>), dim3(rows), dim3(1024), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
+                           noise_elem_off, 1.0f / tclamp, top_p, tok_out, tok_stride, (int*)nullptr, (const int*)nullptr, 0,
+                           (const int*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0);
         SVA_HIP(hipGetLastError());
         return 0;
     }
@@ -1452,6 +1492,28 @@ int launch_sampler_small(const float* logits, int rows, int V, int ldl, const fl
                          const int* use_forced, const float* emb_table, int D, float* emb_out, int ldo, hipStream_t st) {
     SVA_CHECK(V <= 1024, "sampler_small: V <= 1024");
     const float tclamp = temperature > 1e-5f ? temperature : 1e-5f;
+    static const int variant = getenv("SVA_SAMPLER_SMALL") ? atoi(getenv("SVA_SAMPLER_SMALL")) : 0;     // A/B switch
+    if (variant == 2) {
+        hipLaunchKernelGGL((sampler_reg_kernel<512, 2>), dim3(rows), dim3(512), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
+                           noise_elem_off, 1.0f / tclamp, top_p, tok_raw, tok_stride, tok, forced, forced_stride, use_forced, emb_table, D,
+                           emb_out, ldo);
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
+    if (variant == 3) {
+        hipLaunchKernelGGL((sampler_reg_kernel<1024, 1>), dim3(rows), dim3(1024), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
+                           noise_elem_off, 1.0f / tclamp, top_p, tok_raw, tok_stride, tok, forced, forced_stride, use_forced, emb_table, D,
+                           emb_out, ldo);
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
+    if (variant == 1) {     // 256 threads x 4 entries: 3 LDS exchange stages instead of 10, 4 waves at the barriers instead of 16
+        hipLaunchKernelGGL((sampler_reg_kernel<256, 4>), dim3(rows), dim3(256), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
+                           noise_elem_off, 1.0f / tclamp, top_p, tok_raw, tok_stride, tok, forced, forced_stride, use_forced, emb_table, D,
+                           emb_out, ldo);
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(sampler_small_kernel, dim3(rows), dim3(1024), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind, noise_elem_off,
                        1.0f / tclamp, top_p, tok_raw, tok, tok_stride, forced, forced_stride, use_forced, emb_table, D, emb_out, ldo);
     SVA_HIP(hipGetLastError());
