@@ -162,6 +162,11 @@ long sva_get_gemm_profile_table(sva_batch* b, double* out, long max_rows);
 /* kernel unit-test hook: C = A[M,K] * W[N,K]^T (+bias) through the conv-GEMM kernel (host arrays) */
 int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C);
 
+/* same through one specific dispatch choice of the autotuned GEMM (kind 0: small-M K-split kernel, a = 16-row tiles per
+ * workgroup, b = K-split waves, c = 16-column tiles per wave; kind 1: LDS-tiled kernel, a = tile variant 0..6) */
+int sva_test_gemm_choice(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int kind,
+                         int a, int b, int c);
+
 /* microbenchmark of the conv-GEMM dispatcher: conv over [B][(taps-1)*dil + T][Cin] -> [B][T][N]; mode bits:
  * 1 GELU, 2 gamma+residual, 4 SiLU-on-load, 8 SwiGLU (w13); returns avg microseconds per launch in out_us[0] */
 int sva_bench_gemm(int device, int B, int T, int N, int Cin, int taps, int dil, int mode, int iters, float* out_us);

@@ -15,6 +15,7 @@
 #include <utility>
 #include <vector>
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace sva {
 
@@ -33,7 +34,8 @@ template <int BM, int BN, int WM, int WN, int BK>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
     constexpr int TM = BM / WM, TN = BN / WN;     // wave tile
     constexpr int MI = TM / 16, NI = TN / 16;
-    constexpr int LS = BK + 2;                    // LDS row stride: (2*row + k) % 32 is conflict-free for ds_read_b32
+    constexpr int LS = BK + 4;                    // LDS row stride: 16-byte aligned rows; row*LS mod 64 banks is a permutation of
+                                                  // the multiples of 4 over 16 rows, so the ds_read_b128 fragments are conflict-free
     constexpr int F4R = BK / 4;                   // float4 per tile row
     constexpr int RPP = 256 / F4R;                // rows covered per pass of the 256 threads
     constexpr int A_LD = (BM + RPP - 1) / RPP;
@@ -101,17 +103,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
             if (a_on[i]) {
                 float4 v = ra[i];
                 if (g.a_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                float* d = As + ((buf * BM + lrow + i * RPP) * LS + kq * 4);     // 8-byte aligned (LS even)
-                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
-                *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+                *reinterpret_cast<float4*>(As + ((buf * BM + lrow + i * RPP) * LS + kq * 4)) = v;
             }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i)
             if (b_on[i]) {
                 float4 v = rb[i];
-                float* d = Bs + ((buf * BN + lrow + i * RPP) * LS + kq * 4);
-                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
-                *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+                *reinterpret_cast<float4*>(Bs + ((buf * BN + lrow + i * RPP) * LS + kq * 4)) = v;
             }
     };
 
@@ -122,20 +120,33 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
-        const float* Ab = As + (buf * BM + wm * TM + fr) * LS + fk;
-        const float* Bb = Bs + (buf * BN + wn * TN + fr) * LS + fk;
+        // One ds_read_b128 per fragment and 16 k: lane (fr, fk) supplies k = 16*blk + 4*fk + j to MFMA step j of the block --
+        // a permutation of k inside the block, identical on both operands (same trick as the small-M kernel).
+        const float* Ab = As + (buf * BM + wm * TM + fr) * LS + fk * 4;
+        const float* Bb = Bs + (buf * BN + wn * TN + fr) * LS + fk * 4;
 #pragma unroll
-        for (int ks = 0; ks < BK; ks += 4) {
-            float af[MI], bf[NI];
+        for (int ks = 0; ks < BK; ks += 16) {
+            float4 af[MI], bf[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = Ab[i * 16 * LS + ks];
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 16 * LS + ks);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = Bb[j * 16 * LS + ks];
+            for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 16 * LS + ks);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
@@ -443,7 +454,7 @@ static void skinny_heuristic(const ConvGemm& g, int NT, int* mt_out, int* kw_out
 
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_t(const ConvGemm& g, hipStream_t st) {
-    constexpr size_t smem_ab = (size_t)2 * (BM + BN) * (BK + 2) * sizeof(float);
+    constexpr size_t smem_ab = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     constexpr size_t smem_c = (size_t)BM * (BN + 4) * sizeof(float);          // epilogue staging tile reuses the buffers
     constexpr size_t smem = smem_ab > smem_c ? smem_ab : smem_c;
     static bool attr_set = false;
@@ -457,7 +468,8 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
 }
 
 // One dispatch decision: kind 0 = small-M K-split kernel (a = rows/16 per workgroup, b = K-split waves, c = 16-column
-// tiles per wave); kind 1 = LDS-tiled kernel (a: 0 = 64x64, 1 = 128x128, 2 = 128x32, 3 = 256x16).
+// tiles per wave); kind 1 = LDS-tiled kernel (a: 0 = 64x64, 1 = 128x128, 2 = 128x32, 3 = 256x16, 4 = 128x64, 5 = 64x128,
+// 6 = 256x64; 4..6 are reached through the autotuner only).
 struct Choice { int kind, a, b, c; };
 
 static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
@@ -467,6 +479,9 @@ static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
         case 3: return launch_t<256, 16, 4, 1, 16>(g, st);
         case 2: return bk >= 32 ? launch_t<128, 32, 4, 1, 32>(g, st) : launch_t<128, 32, 4, 1, 16>(g, st);
         case 1: return bk >= 32 ? launch_t<128, 128, 2, 2, 32>(g, st) : launch_t<128, 128, 2, 2, 16>(g, st);
+        case 4: return bk >= 32 ? launch_t<128, 64, 2, 2, 32>(g, st) : launch_t<128, 64, 2, 2, 16>(g, st);
+        case 5: return bk >= 32 ? launch_t<64, 128, 2, 2, 32>(g, st) : launch_t<64, 128, 2, 2, 16>(g, st);
+        case 6: return bk >= 32 ? launch_t<256, 64, 4, 1, 32>(g, st) : launch_t<256, 64, 4, 1, 16>(g, st);
         default:
             if (bk == 64) return launch_t<64, 64, 2, 2, 64>(g, st);
             if (bk == 32) return launch_t<64, 64, 2, 2, 32>(g, st);
@@ -564,6 +579,9 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
                 if (!must_skinny) {
                     if (g.N > 32) cand.push_back(Choice{1, 0, 0, 0});
                     if (g.M >= 128 && g.N >= 128) cand.push_back(Choice{1, 1, 0, 0});
+                    if (g.M >= 128 && g.N >= 64) cand.push_back(Choice{1, 4, 0, 0});
+                    if (g.M >= 64 && g.N >= 128) cand.push_back(Choice{1, 5, 0, 0});
+                    if (g.M >= 256 && g.N >= 64) cand.push_back(Choice{1, 6, 0, 0});
                     if (g.N <= 64) cand.push_back(Choice{1, 2, 0, 0});
                     if (g.N <= 16 && !g.w13) cand.push_back(Choice{1, 3, 0, 0});
                 }
@@ -577,11 +595,27 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
                     if (ms < best) { best = ms; ch = c; }
                 }
                 (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+                static const bool tlog = getenv("SVA_TUNE_LOG") != nullptr;
+                if (tlog)
+                    fprintf(stderr, "[sva tune] M=%d N=%d K=%d taps=%d flags=%llu: heuristic %.1f us -> kind %d (%d,%d,%d) %.1f us\n", g.M, g.N,
+                            g.taps * g.Cin, g.taps, flags, base * 200.f, ch.kind, ch.a, ch.b, ch.c, (best < base * 0.93f ? best : base) * 200.f);
                 g_tune[key] = ch;
             }
         }
     }
     SVA_TRY_RC(launch_choice(g, st, ch));
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// test hook: run one specific dispatch choice (kind 0: a = rows/16, b = K split, c = column tiles; kind 1: a = tile variant)
+int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, int b, int c) {
+    SVA_CHECK(g.Cin % 16 == 0 && g.lda % 4 == 0, "conv_gemm_choice: alignment");
+    SVA_CHECK(kind == 0 || kind == 1, "conv_gemm_choice: kind");
+    if (kind == 0) SVA_CHECK((a == 1 || a == 2 || a == 3 || a == 4) && (b == 4 || b == 8 || (b == 16 && a == 1)) && (c == 1 || (c == 2 && g.N % 32 == 0)),
+                             "conv_gemm_choice: bad small-M configuration");
+    else SVA_CHECK(a >= 0 && a <= 6 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: bad tile variant");
+    SVA_TRY_RC(launch_choice(g, st, Choice{kind, a, b, c}));
     SVA_HIP(hipGetLastError());
     return 0;
 }

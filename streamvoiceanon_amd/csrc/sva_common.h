@@ -70,5 +70,6 @@ struct ConvGemm {
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
 // true when launch_conv_gemm would route this (M, N) problem to the K-split small-M kernel, which can normalise its A rows
 bool conv_gemm_can_fuse_rms(int M, int N);
+int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, int b, int c);   // unit-test hook
 
 }  // namespace sva

@@ -6,7 +6,16 @@
 
 using namespace sva;
 
+static int test_gemm_impl(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, const int* choice);
 extern "C" int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C) {
+    return test_gemm_impl(device, M, N, K, A, W, bias, C, nullptr);
+}
+extern "C" int sva_test_gemm_choice(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int kind,
+                                    int a, int b, int c) {
+    const int ch[4] = {kind, a, b, c};
+    return test_gemm_impl(device, M, N, K, A, W, bias, C, ch);
+}
+static int test_gemm_impl(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, const int* choice) {
     SVA_HIP(hipSetDevice(device));
     float *dA, *dW, *dB = nullptr, *dC;
     SVA_HIP(hipMalloc(&dA, sizeof(float) * (size_t)M * K));
@@ -21,7 +30,7 @@ extern "C" int sva_test_gemm(int device, int M, int N, int K, const float* A, co
     ConvGemm g;
     g.A = dA; g.a_bstride = (long)M * K; g.lda = K; g.T = M; g.M = M; g.Cin = K; g.taps = 1;
     g.W = dW; g.N = N; g.bias = dB; g.C = dC; g.c_bstride = (long)M * N; g.ldc = N;
-    int rc = launch_conv_gemm(g, 0);
+    int rc = choice ? launch_conv_gemm_choice(g, 0, choice[0], choice[1], choice[2], choice[3]) : launch_conv_gemm(g, 0);
     if (rc) return rc;
     SVA_HIP(hipDeviceSynchronize());
     SVA_HIP(hipMemcpy(C, dC, sizeof(float) * (size_t)M * N, hipMemcpyDeviceToHost));

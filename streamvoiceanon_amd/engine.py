@@ -84,6 +84,7 @@ def load_library():
     lib.sva_get_gemm_profile_table.restype = C.c_long
     lib.sva_bench_gemm.argtypes = [i32] * 9 + [f32p]
     lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.sva_test_gemm_choice.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32]
     _lib = lib
     return lib
 
@@ -93,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
     "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_encode_window", "sva_firefly_encode",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
-    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_bench_gemm",
+    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm",
 ]
 
 
@@ -357,6 +358,19 @@ def test_gemm(A, W, bias=None, device=0):
     out = np.empty((M, N), dtype=np.float32)
     b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
     _check(lib.sva_test_gemm(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out)), "sva_test_gemm")
+    return out
+
+
+def test_gemm_choice(A, W, choice, bias=None, device=0):
+    """C = A @ W.T (+bias) through ONE dispatch choice (kind, a, b, c) of the autotuned GEMM (see include/sva.h)."""
+    lib = load_library()
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    M, K = A.shape
+    N = W.shape[0]
+    out = np.empty((M, N), dtype=np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    _check(lib.sva_test_gemm_choice(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out), *[int(x) for x in choice]), "sva_test_gemm_choice")
     return out
 
 

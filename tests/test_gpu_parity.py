@@ -563,3 +563,27 @@ def test_semantic_sampler_vs_oracle(eng, weights0):
             checked += 1
     assert checked == 6
     b.close()
+
+
+def test_every_gemm_dispatch_choice_vs_fp64():
+    """The GEMM dispatcher autotunes between kernels and configurations at run time, so EVERY choice it can make is
+    checked against an fp64 product on ragged shapes (M not a multiple of any tile, N a multiple of 4 / 32 only)."""
+    from streamvoiceanon_amd import engine as E
+
+    rng = np.random.default_rng(5)
+    skinny = [(0, mt, kw, nt) for nt in (1, 2) for mt in (1, 2, 4) for kw in (4, 8, 16) if not (mt >= 2 and kw == 16)]
+    tiled = [(1, v, 0, 0) for v in range(7)]
+    for (M, N, K) in ((200, 192, 256), (77, 96, 1024), (515, 288, 128)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = rng.standard_normal((N, K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
+        tol = 2e-6 * np.sqrt(K) * 4 + 1e-5
+        for ch in skinny + tiled:
+            if ch[0] == 0 and ch[3] == 2 and N % 32:
+                continue
+            if ch[0] == 1 and ((ch[1] in (1, 4, 6) and M < 128) or (ch[1] in (1, 5) and N < 128)):
+                continue        # the tuner never offers tiles larger than the problem
+            out = E.test_gemm_choice(A, W, ch, bias=bias)
+            err = np.abs(out - ref).max()
+            assert err <= tol * np.abs(ref).max(), (M, N, K, ch, err)
