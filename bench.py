@@ -215,12 +215,15 @@ def main():
             # HBM bytes per conv-GEMM launch from the committed PMC passes of the same command (tools/pmc.sh ->
             # profiles/rNN_pmc_b<B>.json; rocprofv3 cannot run inside bench.py): reads per the guide's gfx950 correction
             import glob
-            traffic, cands = None, sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_b{B}.json")))
+            traffic, mfma_util, cands = None, None, sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_b{B}.json")))
             if cands and c == 1:
-                traffic = round(json.load(open(cands[-1]))["hbm_bytes_per_launch"], 1)
+                pj = json.load(open(cands[-1]))
+                traffic = round(pj["hbm_bytes_per_launch"], 1)
+                mfma_util = round(pj["gemm_mfma_util"], 4) if pj.get("gemm_mfma_util") is not None else None
             roof = {"bound": "mfma", "kernel": "conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32)", "achieved": round(ach, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
                     "traffic": traffic, "traffic_source": os.path.basename(cands[-1]) if traffic is not None else None,
+                    "mfma_util_pmc": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024) over the same kernels (tools/pmc.sh)
                     "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
                     "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4)}
         batch.close()

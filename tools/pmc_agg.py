@@ -7,7 +7,7 @@ import sys
 
 tag = sys.argv[1]
 per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
-for name in ("RD", "WR"):
+for name in ("RD", "WR", "MFMA", "MOPS"):
     for f in glob.glob(f"gpurun_out/pmc_{tag}_{name}/*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
             a = per[row["Kernel_Name"]][row["Counter_Name"]]
@@ -25,18 +25,31 @@ for k, cs in per.items():
     # FETCH_SIZE definition (64 B / request, 32 B for _32B) with the gfx950 x2 on the wide part
     d["read_bytes_avg"] = rdreq32 * 32 + (rdreq - rdreq32) * 64 * 2
     d["write_bytes_avg"] = wr[1] / max(wr[0], 1) * 1024
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs and cs["GRBM_GUI_ACTIVE"][1] > 0:
+        # matrix-pipe occupancy: busy cycles summed over the 1024 SIMDs / (GPU-active cycles x 1024); rocprofv3 reports
+        # GRBM_GUI_ACTIVE summed over the 8 XCDs (a 15 us dispatch shows ~8 x 36 k cycles), hence x 1024 / 8 = x 128
+        d["mfma_busy_cycles_avg"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"][1] / max(cs["SQ_VALU_MFMA_BUSY_CYCLES"][0], 1)
+        d["gui_active_cycles_avg"] = cs["GRBM_GUI_ACTIVE"][1] / max(cs["GRBM_GUI_ACTIVE"][0], 1)
+        d["mfma_util"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (cs["GRBM_GUI_ACTIVE"][1] * 128.0)
+    if "SQ_INSTS_VALU_MFMA_MOPS_F32" in cs:
+        d["mfma_mops_f32_avg"] = cs["SQ_INSTS_VALU_MFMA_MOPS_F32"][1] / max(cs["SQ_INSTS_VALU_MFMA_MOPS_F32"][0], 1)
     out[k] = d
 gemm = {k: v for k, v in out.items() if "gemm_kernel" in k}
 n = sum(v["calls"] for v in gemm.values()) or 1
 rd = sum(v["read_bytes_avg"] * v["calls"] for v in gemm.values()) / n
 wr = sum(v["write_bytes_avg"] * v["calls"] for v in gemm.values()) / n
+busy = sum(per[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1] for k in gemm if "SQ_VALU_MFMA_BUSY_CYCLES" in per[k])
+act = sum(per[k]["GRBM_GUI_ACTIVE"][1] for k in gemm if "GRBM_GUI_ACTIVE" in per[k])
 summary = {
     "tag": tag,
     "note": "per-launch averages over every conv-GEMM dispatch (tiled + skinny kernels) of the profiled bench run incl. prompt prefill; "
             "reads = 32 B x RDREQ_32B + 2 x 64 B x (RDREQ - RDREQ_32B) (FETCH_SIZE definition + gfx950 x2 correction of "
             "MI355X_MICROARCH.md); writes = WRITE_SIZE KiB x 1024 (uncalibrated)",
+    "gemm_mfma_util": (busy / (act * 128.0)) if act > 0 else None,
+    "gemm_mfma_util_note": "sum SQ_VALU_MFMA_BUSY_CYCLES (all 1024 SIMDs) / (sum GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 x 1024) over the conv-GEMM dispatches (gfx94x-style MfmaUtil; "
+                           "rocprofv3 ships no gfx950 derived-metric section)",
     "gemm_launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
     "kernels": dict(sorted(out.items(), key=lambda kv: -(kv[1]["read_bytes_avg"] + kv[1]["write_bytes_avg"]) * kv[1]["calls"])[:20]),
 }
 json.dump(summary, open(f"gpurun_out/pmc_{tag}.json", "w"), indent=1)
-print(json.dumps({k: summary[k] for k in ("gemm_launches", "read_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch")}))
+print(json.dumps({k: summary[k] for k in ("gemm_mfma_util", "gemm_launches", "read_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch")}))
