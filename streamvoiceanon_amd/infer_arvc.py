@@ -11,6 +11,8 @@ with raw reference audio raises NotImplementedError naming the missing rows.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import engine as E
@@ -131,6 +133,49 @@ class InferenceWrapper:
         self.batch.prefill_prompt(0, cc.reshape(-1), ac.reshape(8, -1), st.reshape(-1), tm.reshape(32, -1), noise_seed=self._noise_seed)
         self.batch.begin()
 
+    # ---- files ---------------------------------------------------------------------------
+    def _load_src(self, src):
+        """librosa.load(src_path, sr=self.sr) (:274, 615) when given a path; arrays pass through."""
+        if isinstance(src, (str, os.PathLike)):
+            from . import audio_io
+
+            return audio_io.load(os.fspath(src), self.sr)[0], os.fspath(src)
+        return np.asarray(src, dtype=np.float32).reshape(-1), None
+
+    def load_and_crop_references(self, ref_paths, crop_lengths):
+        """:250-260 -- paths are loaded at self.sr and cropped to crop_len seconds; arrays pass through the same crop."""
+        from . import audio_io
+
+        out = []
+        for ref_p, crop_len in zip(ref_paths, crop_lengths):
+            w = audio_io.load(os.fspath(ref_p), self.sr)[0] if isinstance(ref_p, (str, os.PathLike)) else np.asarray(ref_p, np.float32).reshape(-1)
+            if crop_len is not None:
+                w = w[:int(crop_len * self.sr)]
+            out.append(w)
+        return out
+
+    def process_ref_paths(self, ref_path, ref_crop_lengths=None):
+        """:234-248 -- one reference or a list; one crop length for all or one per reference."""
+        ref_paths = list(ref_path) if isinstance(ref_path, (list, tuple)) else [ref_path]
+        if ref_crop_lengths is None or not isinstance(ref_crop_lengths, (list, tuple)):
+            crop = [ref_crop_lengths] * len(ref_paths)
+        else:
+            assert len(ref_crop_lengths) == len(ref_paths)
+            crop = list(ref_crop_lengths)
+        return ref_paths, crop
+
+    def _save(self, pred_wave, src_path, ref_path, out_dir, output_path=None):
+        """:363-379 / :676-688 output naming + torchaudio.save (32-bit float WAVE)."""
+        from . import audio_io
+
+        src_name = os.path.splitext(os.path.basename(src_path))[0] if src_path else "src"
+        refs = ref_path if isinstance(ref_path, (list, tuple)) else [ref_path]
+        ref_name = "_".join(os.path.splitext(os.path.basename(os.fspath(r)))[0] if isinstance(r, (str, os.PathLike)) else "ref" for r in refs)
+        out_path = output_path or os.path.join(out_dir or (os.path.dirname(src_path) if src_path else "."), f"{src_name}_{ref_name}.wav")
+        audio_io.write_wav(out_path, pred_wave, self.sr)
+        print(f"Output saved to {out_path}")
+        return out_path
+
     # ---- offline -----------------------------------------------------------------------------------------
     def encode_content(self, wav):
         """speech_tokenizer.encode on a whole utterance (:334-339) -> int64 codes [S], S = len // 2048.  The utterance is
@@ -155,8 +200,12 @@ class InferenceWrapper:
         """:261-380 offline conversion: encode the source, ARVCWrapper.generate, code2wav.  `src` is a 44.1 kHz mono float
         array and the prompt is given as codes/embeddings (file I/O, resampling and the wav -> prompt encoders are rows
         N1/N2).  Returns the converted waveform as a numpy array like the reference."""
+        src, src_path = self._load_src(src)
         if prompt is None:
-            prompt = self.calculate_prompt(ref_path, alpha=alpha, spk_emb_collate_type=spk_emb_collate_type)
+            refs = self.load_and_crop_references(*self.process_ref_paths(ref_path, ref_crop_lengths))
+            prompt = self.calculate_prompt(refs, alpha=alpha, spk_emb_collate_type=spk_emb_collate_type,
+                                           style_vectors=sampling_kwargs.pop("style_vectors", None),
+                                           timbre_latents=sampling_kwargs.pop("timbre_latents", None))
         ref_audio_codes, ref_content_codes, style_vectors, timbre_latents = [
             np.asarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x) for x in prompt[:4]]
         src_codes = self.encode_content(src)
@@ -170,6 +219,8 @@ class InferenceWrapper:
             wav = b.vocode_window(codes[None])[0]
         finally:
             b.close()
+        if save_result:
+            self._save(wav, src_path, ref_path, out_dir, output_path)
         return wav
 
     # ---- per chunk ---------------------------------------------------------------------------------------
@@ -186,10 +237,17 @@ class InferenceWrapper:
 
     def stream_infer(self, src, ref_path=None, out_dir=None, encode_window_frames=128, decode_window_frames=64, max_prompt_frames=256,
                      max_seq_frames=768, buffer_frames=32, decode_chunk_frames=1, delay=None, ref_crop_lengths=None, alpha=1.0,
-                     spk_emb_collate_type="concat_mel", save_result=False, prompt=None, noise_seed=0):
-        """:598-689.  `src` is a 44.1 kHz mono float array (file I/O + resampling are row N2)."""
-        src = np.asarray(src, dtype=np.float32).reshape(-1)
-        self.prefill_prompt(None if prompt is not None else ref_path, max_prompt_frames=max_prompt_frames,
+                     spk_emb_collate_type="concat_mel", save_result=False, prompt=None, noise_seed=0, style_vectors=None,
+                     timbre_latents=None):
+        """:598-689.  `src` / `ref_path`: wav paths (loaded and resampled to 44.1 kHz, audio_io.py) or float arrays already at
+        44.1 kHz; `style_vectors` / `timbre_latents` stand in for the CAM++ / SparkTTS encoders (N1 iii/iv) unless the
+        prompt is given whole."""
+        src, src_path = self._load_src(src)
+        if prompt is None:
+            refs = self.load_and_crop_references(*self.process_ref_paths(ref_path, ref_crop_lengths))
+            prompt = self.calculate_prompt(refs, alpha=alpha, spk_emb_collate_type=spk_emb_collate_type, style_vectors=style_vectors,
+                                           timbre_latents=timbre_latents)
+        self.prefill_prompt(None, max_prompt_frames=max_prompt_frames,
                             delay=2 if delay is None else delay, alpha=alpha, spk_emb_collate_type=spk_emb_collate_type,
                             prompt=prompt, noise_seed=noise_seed)
         self.setup_stream_caches(encode_window_frames, decode_window_frames, max_seq_frames, buffer_frames, decode_chunk_frames)
@@ -197,4 +255,7 @@ class InferenceWrapper:
         pad = n - (src.shape[0] % n)              # :648-649 pads a FULL extra chunk when already aligned
         src = np.concatenate([np.zeros(pad, np.float32), src])
         outs = [self.process_one_chunk(src[i:i + n][None]) for i in range(0, src.shape[0], n)]
-        return np.concatenate(outs, axis=1).reshape(-1)
+        pred = np.concatenate(outs, axis=1).reshape(-1)
+        if save_result:
+            self._save(pred, src_path, ref_path, out_dir)
+        return pred

@@ -587,3 +587,71 @@ def test_every_gemm_dispatch_choice_vs_fp64():
             out = E.test_gemm_choice(A, W, ch, bias=bias)
             err = np.abs(out - ref).max()
             assert err <= tol * np.abs(ref).max(), (M, N, K, ch, err)
+
+
+def test_config5_anonymisation_prompt_and_chunk4(weights0):
+    """BASELINE.json configs[4] on one GPU: three reference wavs concatenated (`concat_mel`, infer_arvc.py:413-424), alpha = 0.7
+    noise mixing of the style / timbre embeddings (:228-232, same Gaussian draws on both sides), prompt codes computed on the
+    device, then chunk = 4 streaming; compared with the oracle fed the oracle's own prompt."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    refs = [synth_utterance(7400 + i, 2048 * 22 + 100 * i) for i in range(3)]      # R = 66 >= the 64-frame vocoder window fill
+    _, _, style, timbre = synth_prompt(2600, 8)
+    alpha, useed, c, n_chunks = 0.7, 7410, 4, 4
+    w = InferenceWrapper(weights=weights0)
+    torch.manual_seed(99)
+    ac, cc, st, tm, ref_cat = w.calculate_prompt([torch.from_numpy(r)[None] for r in refs], alpha=alpha, style_vectors=style,
+                                                 timbre_latents=timbre)
+    cat = np.concatenate(refs)
+    R = cat.shape[0] // 2048
+    assert ac.shape == (1, 8, R) and np.array_equal(np.asarray(ref_cat).reshape(-1), cat)
+    torch.manual_seed(99)
+    st_o = O.apply_noise_mixing(torch.from_numpy(style), alpha, torch.randn(style.shape))
+    tm_o = O.apply_noise_mixing(torch.from_numpy(timbre), alpha, torch.randn(timbre.shape))
+    np.testing.assert_allclose(np.asarray(st).reshape(-1), st_o.numpy().reshape(-1), atol=1e-6)
+    np.testing.assert_allclose(np.asarray(tm).reshape(-1), tm_o.numpy().reshape(-1), atol=1e-6)
+    xt = torch.from_numpy(cat[:R * 2048])[None]
+    ac_o, margin = O.firefly_encode(xt, weights0, return_margin=True)
+    cc_o = O.encode_window(xt, weights0)[0, 0]
+    np.testing.assert_array_equal(cc, cc_o.numpy())
+    assert (ac[0] != ac_o[0].numpy()).mean() <= 0.02 and np.array_equal(ac[0][margin[0].numpy() > 2e-3], ac_o[0].numpy()[margin[0].numpy() > 2e-3])
+    # stream with the ORACLE's prompt on both sides so a legitimate FSQ boundary flip cannot leak into the comparison
+    sess = O.StreamSession(weights0, cc_o, ac_o[0], st_o.reshape(-1), tm_o, delay=2, decode_chunk_frames=c,
+                           noise_fn=lambda f: tuple(torch.from_numpy(a) for a in frame_noise(useed, f)))
+    w.prefill_prompt(prompt=(ac_o.numpy(), cc_o.numpy(), st_o.numpy(), tm_o.numpy()), delay=2, noise_seed=useed)
+    w.setup_stream_caches(encode_window_frames=128, decode_chunk_frames=c, delay=2)
+    src = synth_utterance(useed, 2048 * c * n_chunks)
+    for i in range(n_chunks):
+        ch = src[i * 2048 * c:(i + 1) * 2048 * c]
+        ref = sess.process_one_chunk(torch.from_numpy(ch)[None])[0].numpy()
+        out = np.asarray(w.process_one_chunk(ch[None])).reshape(-1)
+        assert np.abs(out - ref).max() <= PCM_TOL, i
+    w.engine.close()
+
+
+def test_stream_infer_from_wav_files(weights0, tmp_path):
+    """File-level drop-in: 24 kHz source and reference wavs on disk -> load + polyphase resample to 44.1 kHz
+    -> device prompt codes -> streaming conversion -> wav written; equals the array-level path fed the same resampled audio."""
+    from streamvoiceanon_amd import audio_io
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    src24 = synth_utterance(7500, 24000)[:20000]
+    ref24 = synth_utterance(7501, 30000)
+    audio_io.write_wav(str(tmp_path / "src.wav"), src24, 24000)
+    audio_io.write_wav(str(tmp_path / "ref.wav"), ref24, 24000)
+    _, _, style, timbre = synth_prompt(2700, 8)
+    w = InferenceWrapper(weights=weights0)
+    out = w.stream_infer(str(tmp_path / "src.wav"), ref_path=str(tmp_path / "ref.wav"), out_dir=str(tmp_path), delay=2, ref_crop_lengths=1.0,
+                         style_vectors=style, timbre_latents=timbre, save_result=True, noise_seed=11)
+    saved, sr = audio_io.read_wav(str(tmp_path / "src_ref.wav"))
+    assert sr == 44100 and np.array_equal(saved[0], out)
+    src44 = audio_io.resample(src24, 24000, 44100)
+    ref44 = audio_io.resample(ref24, 24000, 44100)[:44100]              # ref_crop_lengths = 1.0 s
+    assert out.shape[0] == (src44.shape[0] // 2048 + 1) * 2048 and np.isfinite(out).all()
+    out2 = w.stream_infer(src44, ref_path=ref44, delay=2, style_vectors=style, timbre_latents=timbre, noise_seed=11)
+    np.testing.assert_array_equal(out, out2)
+    assert np.abs(out[2 * 2048:]).max() > 1e-3
+    w.engine.close()
