@@ -233,6 +233,8 @@ struct sva_batch {
     sva::Act X[5];                         // resblock inputs
     sva::Act tb[5][3][3];                  // c1 outputs
     sva::Act yb[5][3][2];                  // y_{b,1}, y_{b,2}
+    sva::Act y3[5][3];                     // y_{b,3}: branch outputs before the ParallelBlock mean (no history)
+    bool voc_grouped = true;               // the three ResBlock branches of a level share one launch per conv stage
     float* d_pcm = nullptr;                // [B][2048*Tv]
     int* d_vcodes = nullptr;               // [B][8][Tv]
     std::vector<sva::ShiftDesc> shift_host;

@@ -289,6 +289,7 @@ struct Packer {
 extern "C" int sva_engine_finalize(sva_engine* e) {
     SVA_CHECK(e && !e->finalized, "bad engine");
     SVA_HIP(hipSetDevice(e->device));
+    (void)hipGetLastError();       // drop a stale error of an unchecked teardown call (hipFree / hip*Destroy) of an earlier handle
     const sva_config& c = e->cfg;
     Packer P{e, ""};
     // ConvNeXt encoder + 2x (conv k2 s2 + ConvNeXt): shared shape of the tokenizer front-end and of the vocoder's
@@ -502,6 +503,60 @@ int conv_act(sva_batch* b, const Act& in, int T_out, int stride, int dil, int ta
     SVA_CHECK(in.H >= padL, "conv_act: not enough history rows");
     return gemm_call(b, in.p, in.bstride, (long)(in.H - padL) * in.C, in.C, b->B, T_out, stride, dil, taps, in.C, w, out.p,
                      out.bstride, (long)out.H * out.C, out.C, proto);
+}
+
+// descriptor of the same causal conv without launching it (grouped launches)
+int conv_desc(sva_batch* b, const Act& in, int T_out, int dil, int taps, const Lin& w, Act& out, ConvGemm& g) {
+    const int padL = (taps - 1) * dil;
+    SVA_CHECK(in.H >= padL, "conv_desc: not enough history rows");
+    SVA_CHECK(w.K == taps * in.C, "conv_desc: weight K mismatch");
+    g.A = in.p; g.a_bstride = in.bstride; g.a_off = (long)(in.H - padL) * in.C; g.lda = in.C;
+    g.T = T_out; g.M = b->B * T_out; g.stride = 1; g.dil = dil; g.taps = taps; g.Cin = in.C;
+    g.W = w.W; g.N = w.N; g.bias = w.b;
+    g.C = out.p; g.c_bstride = out.bstride; g.c_off = (long)out.H * out.C; g.ldc = out.C;
+    return 0;
+}
+// n <= 3 same-shape problems in one launch (bookkeeping as gemm_call: one "launch", summed FLOPs)
+int gemm_group_call(sva_batch* b, const ConvGemm* gs, int n) {
+    double fl = 0;
+    int kmax = 0, tmax = 0;
+    for (int i = 0; i < n; ++i) {
+        fl += 2.0 * gs[i].M * (double)gs[i].N * gs[i].taps * gs[i].Cin;
+        if (gs[i].taps * gs[i].Cin > kmax) { kmax = gs[i].taps * gs[i].Cin; tmax = gs[i].taps; }
+    }
+    b->gemm_flops += fl;
+    b->gemm_launches += 1;
+    if (b->prof_on) {
+        if (b->prof_n + 2 > (int)b->prof_ev.size()) {
+            const size_t old = b->prof_ev.size();
+            b->prof_ev.resize(old + 512);
+            for (size_t i = old; i < b->prof_ev.size(); ++i) SVA_HIP(hipEventCreate(&b->prof_ev[i]));
+        }
+        // table row: the group as one problem with the summed K (its FLOPs = 2 M N sum K)
+        int ksum = 0;
+        for (int i = 0; i < n; ++i) ksum += gs[i].taps * gs[i].Cin;
+        b->prof_shapes.push_back({gs[0].M, gs[0].N, ksum, tmax, 16 + gs[0].a_silu * 4 + (gs[0].res ? 2 : 0)});
+        SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n], b->stream));
+        int rc = launch_conv_gemm_group(gs, n, b->stream);
+        SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n + 1], b->stream));
+        b->prof_n += 2;
+        return rc;
+    }
+    return launch_conv_gemm_group(gs, n, b->stream);
+}
+
+__global__ void mean3_kernel(const float* __restrict__ y0, const float* __restrict__ y1, const float* __restrict__ y2, long y_bstride,
+                             float* __restrict__ out, long o_bstride, long o_off, long n4) {
+    // ParallelBlock: torch.stack([...]).mean(0) (firefly.py:214-215) of the three branch outputs, float4 lanes
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 a = reinterpret_cast<const float4*>(y0 + (long)b * y_bstride)[i];
+    const float4 c = reinterpret_cast<const float4*>(y1 + (long)b * y_bstride)[i];
+    const float4 d = reinterpret_cast<const float4*>(y2 + (long)b * y_bstride)[i];
+    float4 r;
+    r.x = ((a.x + c.x) + d.x) / 3.0f; r.y = ((a.y + c.y) + d.y) / 3.0f; r.z = ((a.z + c.z) + d.z) / 3.0f; r.w = ((a.w + c.w) + d.w) / 3.0f;
+    reinterpret_cast<float4*>(out + (long)b * o_bstride + o_off)[i] = r;
 }
 
 // ConvNeXtBlock (firefly.py:421-440) on x rows [x.H, x.H+T); result into `out` rows [out.H, out.H+T)
@@ -757,17 +812,29 @@ int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int*
     for (size_t l = 0; l < layers.size(); ++l) {
         TrLayer& L = layers[l];
         float* cache = kv + (long)l * kv_layer;
-        SVA_TRY(launch_rmsnorm_rows(x, (long)M * D, 0, D, 1, M, D, L.attn_norm, 1e-5f, b->ahn, (long)M * D, 0, D, st));
-        SVA_TRY(gemm_call(b, b->ahn, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.wqkv, b->aqkv, (long)M * 3 * D, 0, 3 * D));
+        // RMSNorm folded into the projection whenever the small-M kernel runs it (M up to a few hundred rows)
+        if (conv_gemm_can_fuse_rms(M, 3 * D)) {
+            ConvGemm pn;
+            pn.rms_w = L.attn_norm; pn.rms_eps = 1e-5f;
+            SVA_TRY(gemm_call(b, x, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.wqkv, b->aqkv, (long)M * 3 * D, 0, 3 * D, pn));
+        } else {
+            SVA_TRY(launch_rmsnorm_rows(x, (long)M * D, 0, D, 1, M, D, L.attn_norm, 1e-5f, b->ahn, (long)M * D, 0, D, st));
+            SVA_TRY(gemm_call(b, b->ahn, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.wqkv, b->aqkv, (long)M * 3 * D, 0, 3 * D));
+        }
         SVA_TRY(launch_rope_kvwrite<float>(b->aqkv, M, H, 64, d_slot, d_pos, rope, cache, kv_slot, S, st));
         SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
         ConvGemm po;
         po.res = x; po.r_bstride = (long)M * D; po.r_off = 0; po.ldr = D;
         SVA_TRY(gemm_call(b, b->aatt, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.wo, x, (long)M * D, 0, D, po));
-        SVA_TRY(launch_rmsnorm_rows(x, (long)M * D, 0, D, 1, M, D, L.ffn_norm, 1e-5f, b->ahn, (long)M * D, 0, D, st));
         ConvGemm pg;
         pg.w13 = 1;
-        SVA_TRY(gemm_call(b, b->ahn, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.w13, b->ag, (long)M * I, 0, I, pg));
+        if (conv_gemm_can_fuse_rms(M, 2 * I)) {
+            pg.rms_w = L.ffn_norm; pg.rms_eps = 1e-5f;
+            SVA_TRY(gemm_call(b, x, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.w13, b->ag, (long)M * I, 0, I, pg));
+        } else {
+            SVA_TRY(launch_rmsnorm_rows(x, (long)M * D, 0, D, 1, M, D, L.ffn_norm, 1e-5f, b->ahn, (long)M * D, 0, D, st));
+            SVA_TRY(gemm_call(b, b->ahn, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.w13, b->ag, (long)M * I, 0, I, pg));
+        }
         ConvGemm pd;
         pd.res = x; pd.r_bstride = (long)M * D; pd.r_off = 0; pd.ldr = D;
         SVA_TRY(gemm_call(b, b->ag, (long)M * I, 0, I, 1, M, 1, 1, 1, I, L.w2, x, (long)M * D, 0, D, pd));
@@ -1096,6 +1163,31 @@ int vocode(sva_batch* b, int T, bool shift) {
         // chains of 6 convs: branch 0 stays on the main stream, branches 1/2 run on side streams; the last conv of each
         // branch accumulates (x 1/3) into the level output in the fixed order 0, 1, 2 (event chain => deterministic sum).
         Act& out = b->S[i + 1];
+        if (b->voc_grouped) {
+            // one launch per conv stage for the three branches (same M, N, Cin; k = 3 / 7 / 11 taps): 12 launches + the
+            // mean per level instead of 18 on three streams -- at small B the step is bound by the number of kernels
+            Act* y[3] = {&b->X[i], &b->X[i], &b->X[i]};
+            for (int j = 0; j < 3; ++j) {
+                ConvGemm g1[3], g2[3];
+                for (int br = 0; br < 3; ++br) {
+                    const ResConv& rcv = e->res[i][br][j];
+                    g1[br].a_silu = 1;
+                    SVA_TRY(conv_desc(b, *y[br], (int)Tl, rcv.dil, rcv.k, rcv.c1, b->tb[i][br][j], g1[br]));
+                    Act& dst = j < 2 ? b->yb[i][br][j] : b->y3[i][br];
+                    g2[br].a_silu = 1;
+                    g2[br].res = y[br]->p; g2[br].r_bstride = y[br]->bstride; g2[br].r_off = (long)y[br]->H * Cout; g2[br].ldr = Cout;
+                    SVA_TRY(conv_desc(b, b->tb[i][br][j], (int)Tl, rcv.dil, rcv.k, rcv.c2, dst, g2[br]));
+                }
+                SVA_TRY(gemm_group_call(b, g1, 3));
+                SVA_TRY(gemm_group_call(b, g2, 3));
+                for (int br = 0; br < 3; ++br) y[br] = j < 2 ? &b->yb[i][br][j] : &b->y3[i][br];
+            }
+            const long n4 = Tl * Cout / 4;
+            hipLaunchKernelGGL(mean3_kernel, dim3((unsigned)((n4 + 255) / 256), B), dim3(256), 0, st, b->y3[i][0].p, b->y3[i][1].p, b->y3[i][2].p,
+                               b->y3[i][0].bstride, out.p, out.bstride, (long)out.H * Cout, n4);
+            SVA_HIP(hipGetLastError());
+            continue;
+        }
         const bool par = b->concurrency;
         if (par) {
             SVA_TRY(stream_fork(b, st, b->aux[0]));
@@ -1169,6 +1261,7 @@ int register_shift(sva_batch* b, Act& a, int rows_per_frame) {
 extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_batch** out) {
     SVA_CHECK(e && p && out && e->finalized, "engine not finalized");
     SVA_HIP(hipSetDevice(e->device));
+    (void)hipGetLastError();
     const sva_config& c = e->cfg;
     sva_batch* b = new sva_batch();
     b->e = e;
@@ -1182,7 +1275,8 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     for (int i = 0; i < 2; ++i) SVA_HIP(hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking));
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
     if (const char* ev = getenv("SVA_CONCURRENCY")) b->concurrency = atoi(ev) != 0;
-    if (const char* ev = getenv("SVA_FUSED_DECODE")) b->fused_decode = atoi(ev) != 0;      // 0: single stream (PMC profiling)
+    if (const char* ev = getenv("SVA_FUSED_DECODE")) b->fused_decode = atoi(ev) != 0;
+    if (const char* ev = getenv("SVA_VOC_GROUPED")) b->voc_grouped = atoi(ev) != 0;      // 0: single stream (PMC profiling)
     auto& A = b->allocs;
     const int chunk = p->chunk_frames;
     // control block
@@ -1353,6 +1447,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
                     SVA_TRY(register_shift(b, b->yb[i][br][j], rpf));
                 }
             }
+        for (int br = 0; br < 3; ++br) SVA_TRY(alloc_act(A, b->y3[i][br], B, 0, rows, ch));
         SVA_TRY(alloc_act(A, b->S[i + 1], B, i < 4 ? 1 : e->post_k - 1, rows, ch));
         SVA_TRY(register_shift(b, b->S[i + 1], rpf));
     }
@@ -1414,6 +1509,7 @@ extern "C" int sva_prefill_prompt(sva_batch* b, int slot, const int64_t* ref_con
                                   const float* style, const float* timbre, uint64_t noise_seed) {
     SVA_CHECK(b && slot >= 0 && slot < b->B && ref_content_codes && ref_audio_codes && style && timbre, "bad argument");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     const sva_config& c = b->e->cfg;
     const int ncb = c.num_codebooks;
     std::vector<int64_t> cc(ref_content_codes, ref_content_codes + R);
@@ -1439,6 +1535,7 @@ extern "C" int sva_prefill_prompt(sva_batch* b, int slot, const int64_t* ref_con
 extern "C" int sva_vocode_reset(sva_batch* b) {
     SVA_CHECK(b, "null batch");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     auto zero = [&](Act& a) -> int {
         SVA_HIP(hipMemsetAsync(a.p, 0, sizeof(float) * (size_t)b->B * a.bstride, b->stream));
         return 0;
@@ -1476,6 +1573,7 @@ int download_pcm(sva_batch* b, int T, float* pcm_out) {
 extern "C" int sva_vocode_stream(sva_batch* b, const int32_t* codes, int T, float* pcm_out) {
     SVA_CHECK(b && codes && pcm_out, "null argument");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     SVA_TRY(upload_vcodes(b, codes, T));
     SVA_TRY(vocode(b, T, true));
     return download_pcm(b, T, pcm_out);
@@ -1490,6 +1588,7 @@ extern "C" int sva_vocode_window(sva_batch* b, const int32_t* codes, int T, floa
 extern "C" int sva_streams_begin(sva_batch* b) {
     SVA_CHECK(b, "null batch");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     const int B = b->B, ncb = b->e->cfg.num_codebooks, c = b->p.chunk_frames;
     for (int i = 0; i < B; ++i) SVA_CHECK(b->prefilled[i], "every slot needs sva_prefill_prompt before sva_streams_begin");
     // setup_stream_caches (infer_arvc.py:443-460)
@@ -1675,6 +1774,7 @@ int step_body(sva_batch* b) {
 extern "C" int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const float* noise, const int32_t* forced_codes) {
     SVA_CHECK(b && pcm_in && pcm_out && b->begun, "sva_step: bad argument or sva_streams_begin not called");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     const sva_config& c = b->e->cfg;
     const int B = b->B, chunk = b->p.chunk_frames, n = 2048 * chunk, ncb = c.num_codebooks;
     hipStream_t st = b->stream;
@@ -1705,6 +1805,7 @@ extern "C" int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const
 extern "C" int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm_out) {
     SVA_CHECK(b && d_pcm_in && d_pcm_out && b->begun, "sva_step_device: bad argument");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     const int B = b->B, n = 2048 * b->p.chunk_frames;
     hipStream_t st = b->stream;
     SVA_HIP(hipMemcpyAsync(b->d_chunk, d_pcm_in, sizeof(float) * (size_t)B * n, hipMemcpyDeviceToDevice, st));
@@ -1720,6 +1821,7 @@ extern "C" int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm
 extern "C" int sva_sync(sva_batch* b) {
     SVA_CHECK(b, "null batch");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     SVA_HIP(hipStreamSynchronize(b->stream));
     float t;
     if (!b->graph_step)
@@ -1746,6 +1848,7 @@ __global__ void put_codes_kernel(const long long* __restrict__ src, int n_per, l
 extern "C" int sva_ar_delay_fill(sva_batch* b, const int64_t* codes) {
     SVA_CHECK(b && codes && b->begun, "sva_ar_delay_fill: bad argument");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     const int B = b->B, d = b->p.delay;
     long long* tmp = (long long*)b->d_noise;       // scratch (>= B*d*8 bytes)
     SVA_TRY(h2d(b, tmp, codes, sizeof(int64_t) * (size_t)B * d));
@@ -1762,6 +1865,7 @@ extern "C" int sva_ar_decode_one(sva_batch* b, const int64_t* code, const float*
     SVA_CHECK(b && code && codes_out && b->begun && b->delay_filled, "sva_ar_decode_one: bad argument / delay not filled");
     SVA_CHECK(b->p.chunk_frames == 1, "sva_ar_decode_one needs chunk_frames == 1");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     const sva_config& c = b->e->cfg;
     const int B = b->B, ncb = c.num_codebooks;
     hipStream_t st = b->stream;
@@ -1803,6 +1907,7 @@ extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* 
     SVA_CHECK(b && ref_cc && ref_ac && src_cc && style && timbre && codes_out, "sva_generate: null argument");
     SVA_CHECK(b->B == 1 && b->p.chunk_frames == 1, "sva_generate: the offline path is batch 1 / chunk 1 like the reference");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
     const int D = c.ar_dim, d = b->p.delay, ncb = c.num_codebooks, nspk = c.timbre_tokens + 1;
@@ -1875,6 +1980,7 @@ extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* 
 extern "C" int sva_encode_window(sva_batch* b, const float* audio, int64_t* codes_out, float* u_out) {
     SVA_CHECK(b && audio && codes_out, "null argument");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     hipStream_t st = b->stream;
     SVA_HIP(hipMemcpyAsync(b->ring, audio, sizeof(float) * (size_t)b->B * b->N, hipMemcpyHostToDevice, st));
     b->gemm_flops = 0; b->gemm_launches = 0;
@@ -1897,6 +2003,7 @@ extern "C" int sva_firefly_encode(sva_batch* b, const float* audio, int32_t* cod
     sva_engine* e = b->e;
     SVA_CHECK(e->vocf.loaded, "firefly.encode weights (voc.backbone.*, voc.quantizer.downsample.*, ...project_in) were not loaded");
     SVA_HIP(hipSetDevice(e->device));
+    (void)hipGetLastError();
     hipStream_t st = b->stream;
     const sva_config& c = e->cfg;
     SVA_HIP(hipMemcpyAsync(b->ring, audio, sizeof(float) * (size_t)b->B * b->N, hipMemcpyHostToDevice, st));
@@ -1965,6 +2072,7 @@ extern "C" int sva_profile_gemm(sva_batch* b, int enable) {
 extern "C" int sva_get_gemm_profile(sva_batch* b, double* total_ms, long* launches) {
     SVA_CHECK(b && total_ms && launches, "null argument");
     SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
     SVA_HIP(hipStreamSynchronize(b->stream));
     double tot = 0;
     for (int i = 0; i + 1 < b->prof_n; i += 2) {

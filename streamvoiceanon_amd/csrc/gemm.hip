@@ -31,7 +31,8 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 template <int BM, int BN, int WM, int WN, int BK>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmGroup gg) {
+    const ConvGemm& g = gg.g[blockIdx.z];
     constexpr int TM = BM / WM, TN = BN / WN;     // wave tile
     constexpr int MI = TM / 16, NI = TN / 16;
     constexpr int LS = BK + 4;                    // LDS row stride: 16-byte aligned rows; row*LS mod 64 banks is a permutation of
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemm g) {
 // AOP: what happens to A on load -- 0 nothing, 1 SiLU (HiFiGAN), 2 RMSNorm of the row (weight folded into the operand,
 // row statistics accumulated on the fly and applied to the accumulators in the epilogue).
 template <int MT, int NT, int KW, int D, int AOP>
-__global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) {
+__global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGroup gg) {
+    const ConvGemm& g = gg.g[blockIdx.z];
     constexpr bool SILU = AOP == 1, RMS = AOP == 2;
     extern __shared__ __attribute__((aligned(16))) float red[];      // [KW][MT*NT][64][4] (+ [KW][MT][16] row sums of squares)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -392,16 +394,21 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemm g) 
     }
 }
 
+// set by launch_conv_gemm_group around the dispatch: the launchers then send the whole group (grid.z = members)
+static thread_local const ConvGemmGroup* t_group = nullptr;
+
 template <int MT, int NT, int KW, int D, int AOP>
 static int launch_skinny_op(const ConvGemm& g, hipStream_t st) {
     const size_t smem = ((size_t)KW * MT * NT * 256 + (AOP == 2 ? KW * MT * 16 : 0)) * sizeof(float);
-    dim3 grid((g.N + 16 * NT - 1) / (16 * NT), (g.M + 16 * MT - 1) / (16 * MT));
+    ConvGemmGroup gg;
+    if (t_group) gg = *t_group; else gg.g[0] = g;
+    dim3 grid((g.N + 16 * NT - 1) / (16 * NT), (g.M + 16 * MT - 1) / (16 * MT), gg.n);
     static bool attr = false;
     if (!attr && smem > 48 * 1024) {
         SVA_HIP(hipFuncSetAttribute((const void*)skinny_gemm_kernel<MT, NT, KW, D, AOP>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL((skinny_gemm_kernel<MT, NT, KW, D, AOP>), grid, dim3(64 * KW), smem, st, g);
+    hipLaunchKernelGGL((skinny_gemm_kernel<MT, NT, KW, D, AOP>), grid, dim3(64 * KW), smem, st, gg);
     return 0;
 }
 template <int MT, int NT, int KW, int D>
@@ -462,8 +469,10 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
         SVA_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK>), grid, dim3(256), smem, st, g);
+    ConvGemmGroup gg;
+    if (t_group) gg = *t_group; else gg.g[0] = g;
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, gg.n);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK>), grid, dim3(256), smem, st, gg);
     return 0;
 }
 
@@ -516,7 +525,35 @@ static std::unordered_map<unsigned long long, Choice> g_tune;
 static float* g_tune_c = nullptr;
 static size_t g_tune_elems = 0;
 
-int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
+static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n);
+int launch_conv_gemm(const ConvGemm& g, hipStream_t st) { return launch_conv_gemm_impl(g, st, 1); }
+
+int launch_conv_gemm_group(const ConvGemm* gs, int n, hipStream_t st) {
+    SVA_CHECK(n >= 1 && n <= 3, "conv_gemm_group: 1..3 members");
+    if (n == 1) return launch_conv_gemm_impl(gs[0], st, 1);
+    ConvGemmGroup gg;
+    gg.n = n;
+    int lead = 0;
+    for (int i = 0; i < n; ++i) {
+        const ConvGemm& a = gs[i];
+        const ConvGemm& r = gs[0];
+        SVA_CHECK(a.M == r.M && a.T == r.T && a.N == r.N && a.Cin == r.Cin && a.stride == r.stride && a.a_silu == r.a_silu && a.w13 == r.w13 &&
+                  a.act == r.act && a.accumulate == r.accumulate && !a.rms_w && a.ldc % 4 == r.ldc % 4 && (a.res != nullptr) == (r.res != nullptr) &&
+                  (a.gamma != nullptr) == (r.gamma != nullptr) && (a.bias != nullptr) == (r.bias != nullptr),
+                  "conv_gemm_group: members must share shape and epilogue");
+        SVA_CHECK(a.lda % 4 == 0 && a.a_off % 4 == 0 && a.a_bstride % 4 == 0 && a.c_off % 4 == r.c_off % 4 && a.c_bstride % 4 == r.c_bstride % 4 &&
+                  (!a.res || (a.ldr % 4 == r.ldr % 4 && a.r_off % 4 == r.r_off % 4 && a.r_bstride % 4 == r.r_bstride % 4)),
+                  "conv_gemm_group: alignment classes must match");
+        gg.g[i] = a;
+        if (a.taps > gs[lead].taps) lead = i;
+    }
+    t_group = &gg;                       // the dispatch decision is taken for (and timed on) the member with the longest K
+    const int rc = launch_conv_gemm_impl(gs[lead], st, n);
+    t_group = nullptr;
+    return rc;
+}
+
+static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n) {
     SVA_CHECK(g.Cin % 16 == 0 && g.Cin > 0, "conv_gemm: Cin must be a multiple of 16");
     SVA_CHECK(g.lda % 4 == 0 && (g.a_off % 4) == 0 && (g.a_bstride % 4) == 0, "conv_gemm: A must be float4-aligned");
     const bool c_vec = g.N % 4 == 0 && g.ldc % 4 == 0 && g.c_off % 4 == 0 && g.c_bstride % 4 == 0 &&
@@ -530,7 +567,8 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
         // Shape-keyed autotune: the first eager launch of a problem shape times the candidate kernels / configurations on
         // the real operands with the output redirected to scratch, and keeps a candidate only if it beats the heuristic
         // by > 7 %.  Launches inside a stream capture (and shapes first seen there) use the heuristic.
-        const unsigned long long flags = (unsigned long long)(g.a_silu ? 1 : 0) | (g.rms_w ? 2 : 0) | (g.w13 ? 4 : 0) | (c_vec ? 8 : 0) | (g.accumulate ? 16 : 0);
+        const unsigned long long flags = (unsigned long long)(g.a_silu ? 1 : 0) | (g.rms_w ? 2 : 0) | (g.w13 ? 4 : 0) | (c_vec ? 8 : 0) | (g.accumulate ? 16 : 0) |
+                                         (group_n > 1 ? 32 : 0);
         const unsigned long long key = ((unsigned long long)g.M << 40) ^ ((unsigned long long)g.N << 24) ^ ((unsigned long long)(g.taps * g.Cin) << 8) ^
                                        ((unsigned long long)g.taps << 4) ^ (flags << 58) ^ (unsigned long long)(g.stride & 15);
         std::lock_guard<std::mutex> lk(g_tune_mu);
@@ -540,7 +578,7 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
                 const int ldc = g.w13 ? g.N / 2 : g.N;
-                const size_t need = (size_t)g.M * ldc;
+                const size_t need = (size_t)g.M * ldc * (size_t)group_n;
                 if (need > g_tune_elems) {
                     if (g_tune_c) (void)hipFree(g_tune_c);
                     SVA_HIP(hipMalloc((void**)&g_tune_c, need * sizeof(float)));
@@ -548,6 +586,16 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
                 }
                 ConvGemm t = g;
                 t.C = g_tune_c; t.c_bstride = (long)g.T * ldc; t.c_off = 0; t.ldc = ldc;
+                // a group is timed as a group, every member's output redirected to its own scratch slab
+                const ConvGemmGroup* real_group = t_group;
+                ConvGemmGroup tg;
+                if (real_group) {
+                    tg = *real_group;
+                    for (int i = 0; i < tg.n; ++i) {
+                        tg.g[i].C = g_tune_c + (size_t)i * g.M * ldc; tg.g[i].c_bstride = (long)g.T * ldc; tg.g[i].c_off = 0; tg.g[i].ldc = ldc;
+                    }
+                    t_group = &tg;
+                }
                 hipEvent_t e0, e1;
                 SVA_HIP(hipEventCreate(&e0)); SVA_HIP(hipEventCreate(&e1));
                 auto time_choice = [&](const Choice& c, float* ms) -> int {
@@ -595,6 +643,7 @@ int launch_conv_gemm(const ConvGemm& g, hipStream_t st) {
                     if (ms < best) { best = ms; ch = c; }
                 }
                 (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+                t_group = real_group;
                 static const bool tlog = getenv("SVA_TUNE_LOG") != nullptr;
                 if (tlog)
                     fprintf(stderr, "[sva tune] M=%d N=%d K=%d taps=%d flags=%llu: heuristic %.1f us -> kind %d (%d,%d,%d) %.1f us\n", g.M, g.N,

@@ -67,7 +67,15 @@ struct ConvGemm {
     float rms_eps = 1e-5f;          //       only on the small-M path -- ask conv_gemm_can_fuse_rms() first
 };
 
+// up to three independent problems of identical shape (M, N, Cin, stride, epilogue flags; taps / dilation / pointers may
+// differ) in ONE launch: blockIdx.z picks the member.  The three ResBlock branches (k = 3, 7, 11) of a HiFiGAN level.
+struct ConvGemmGroup {
+    ConvGemm g[3];
+    int n = 1;
+};
+
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
+int launch_conv_gemm_group(const ConvGemm* gs, int n, hipStream_t st);
 // true when launch_conv_gemm would route this (M, N) problem to the K-split small-M kernel, which can normalise its A rows
 bool conv_gemm_can_fuse_rms(int M, int N);
 int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, int b, int c);   // unit-test hook
