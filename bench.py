@@ -172,14 +172,17 @@ def main():
         dt = time.perf_counter() - t0
         tm = batch.timings()
         # per-chunk latency as a live caller sees it (enqueue + execute + sync per chunk; outside the timed region)
-        lat = []
+        lat, enq = [], []
         for _ in range(n_lat):
             t1 = time.perf_counter()
             run(k); k += 1
+            t2 = time.perf_counter()
             batch.sync()
             lat.append((time.perf_counter() - t1) * 1e3)
-        lat.sort()
-        extra = {"host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 4),
+            enq.append((t2 - t1) * 1e3)
+        lat.sort(); enq.sort()
+        extra = {"host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 4),          # back-to-back (includes queue back-pressure)
+                 "host_enqueue_ms_idle_queue": round(enq[len(enq) // 2], 4),          # median with an empty queue: the pure host cost
                  "sync_latency_ms": {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[min(len(lat) - 1, int(0.99 * len(lat)))], 4),
                                      "n": n_lat}}
         if world > 1 or force_dist:

@@ -361,8 +361,157 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float* __restr
         __syncthreads();
     }
 }
+// MFMA formulation for windows of up to 128 tokens (the streaming configurations): S = Q K^T and O = P V run on
+// v_mfma_f32_16x16x4_f32 (fp32 operands: the BSQ bits downstream need fp32).  One workgroup per (head, stream, query
+// split); K (RoPE applied) and V^T of the head live in LDS with 16-byte-aligned, bank-rotating row strides; each wave owns
+// one 16-row query tile at a time: Q fragments come straight from global memory (RoPE in registers), the 16 x T score tile
+// stays in accumulators, softmax statistics are reduced over the 16 lanes of an accumulator row with DPP, P goes through a
+// wave-private LDS slab into the A operand of the second product.  Causal tiles above the diagonal are skipped.
+typedef float attn_f32x4 __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ float row16_xor(float v) {       // value of lane ^ OFF inside a 16-lane row
+    if constexpr (OFF == 1) return dpp_mov<0xB1>(v);
+    else if constexpr (OFF == 2) return dpp_mov<0x4E>(v);
+    else if constexpr (OFF == 8) return dpp_mov<0x128>(v);                    // row_ror:8
+    else {                                                                    // 4: row_shl / row_shr by 4, picked per lane
+        const float up = dpp_mov<0x104>(v), dn = dpp_mov<0x114>(v);
+        return (threadIdx.x & 4) ? dn : up;
+    }
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, row16_xor<1>(v)); v = fmaxf(v, row16_xor<2>(v)); v = fmaxf(v, row16_xor<4>(v)); v = fmaxf(v, row16_xor<8>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += row16_xor<1>(v); v += row16_xor<2>(v); v += row16_xor<4>(v); v += row16_xor<8>(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void enc_attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rope,
+                                                                 int T, int H, float* __restrict__ out, int row0) {
+    constexpr int HD = 64, LK = HD + 4, NTM = 8;          // up to 8 key tiles (T <= 128)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LV = T + 4;
+    float* Ks = smem;                                     // [T][68]    K with RoPE
+    float* Vt = Ks + (long)T * LK;                        // [64][T+4]  V transposed
+    float* Ps = Vt + (long)HD * LV;                       // [4 waves][16][T+4]
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    const int D = H * HD;
+    const float* base = qkv + (long)b * T * 3 * D;
+    for (int idx = tid; idx < T * (HD / 2); idx += 256) {
+        const int t = idx / (HD / 2), p = idx - t * (HD / 2);
+        const float* row = base + (long)t * 3 * D + h * HD + 2 * p;
+        const float2 kk = *reinterpret_cast<const float2*>(row + D);
+        const float2 vv = *reinterpret_cast<const float2*>(row + 2 * D);
+        const float2 cs = *reinterpret_cast<const float2*>(rope + ((long)t * (HD / 2) + p) * 2);
+        *reinterpret_cast<float2*>(Ks + t * LK + 2 * p) = make_float2(kk.x * cs.x - kk.y * cs.y, kk.y * cs.x + kk.x * cs.y);
+        Vt[(2 * p) * LV + t] = vv.x;
+        Vt[(2 * p + 1) * LV + t] = vv.y;
+    }
+    __syncthreads();
+    float* Pw = Ps + (long)wave * 16 * LV;
+    const int n_tiles = T / 16;
+    const int first_tile = row0 / 16;
+    // query tiles first_tile .. n_tiles-1, dealt to (query split, wave) round-robin from the heaviest (last) tile down
+    for (int u = blockIdx.z * 4 + wave; u < n_tiles - first_tile; u += 4 * gridDim.z) {
+        const int rt = n_tiles - 1 - u;
+        const int r0 = rt * 16;
+        // Q fragments with RoPE: lane (fr, fk) holds dims 16*blk + 4*fk .. +3 of row r0 + fr
+        float4 qa[4];
+        {
+            const float* qrow = base + (long)(r0 + fr) * 3 * D + h * HD + 4 * fk;
+            const float* rrow = rope + (long)(r0 + fr) * HD + 4 * fk;        // (cos, sin) pairs: 2 floats per dim pair
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const float4 q = *reinterpret_cast<const float4*>(qrow + 16 * blk);
+                const float4 cs = *reinterpret_cast<const float4*>(rrow + 16 * blk);      // c0 s0 c1 s1 of pairs (4fk+16blk)/2, +1
+                qa[blk] = make_float4(q.x * cs.x - q.y * cs.y, q.y * cs.x + q.x * cs.y, q.z * cs.z - q.w * cs.w, q.w * cs.z + q.z * cs.w);
+            }
+        }
+        attn_f32x4 s[NTM];
+#pragma unroll
+        for (int kt = 0; kt < NTM; ++kt) {
+            s[kt] = (attn_f32x4){0.f, 0.f, 0.f, 0.f};
+            if (kt <= rt) {
+                const float* kp = Ks + (kt * 16 + fr) * LK + 4 * fk;
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    const float4 kb = *reinterpret_cast<const float4*>(kp + 16 * blk);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[blk].x, kb.x, s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[blk].y, kb.y, s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[blk].z, kb.z, s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[blk].w, kb.w, s[kt], 0, 0, 0);
+                }
+            }
+        }
+        // accumulator element r of a lane: row 4*fk + r, key 16*kt + fr.  Scale, causal mask on the diagonal tile, softmax.
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NTM; ++kt)
+            if (kt <= rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[kt][r] * 0.125f;
+                    if (kt == rt && fr > 4 * fk + r) v = -INFINITY;
+                    s[kt][r] = v;
+                    mx[r] = fmaxf(mx[r], v);
+                }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[r] = row16_max(mx[r]);
+#pragma unroll
+        for (int kt = 0; kt < NTM; ++kt)
+            if (kt <= rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = expf(s[kt][r] - mx[r]);
+                    sum[r] += e;
+                    Pw[(4 * fk + r) * LV + kt * 16 + fr] = e;
+                }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = row16_sum(sum[r]);
+        __builtin_amdgcn_wave_barrier();
+        attn_f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (attn_f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt <= rt; ++kt) {
+            const float4 pa = *reinterpret_cast<const float4*>(Pw + fr * LV + kt * 16 + 4 * fk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float4 vb = *reinterpret_cast<const float4*>(Vt + (dt * 16 + fr) * LV + kt * 16 + 4 * fk);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.x, vb.x, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.y, vb.y, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.z, vb.z, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.w, vb.w, o[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = 1.f / sum[r];
+            float* orow = out + ((long)b * T + r0 + 4 * fk + r) * D + h * HD + fr;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) orow[dt * 16] = o[dt][r] * inv;
+        }
+        __builtin_amdgcn_wave_barrier();      // the next tile of this wave overwrites Pw
+    }
+}
+
 int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out, int row0, hipStream_t st) {
     SVA_CHECK(hd == 64 && T % 4 == 0, "enc_attention: head_dim must be 64 and T a multiple of 4");
+    static const bool valu_only = getenv("SVA_ENC_ATTN_VALU") != nullptr;          // A/B switch
+    if (T % 16 == 0 && T <= 128 && !valu_only) {
+        const size_t sm = ((size_t)T * 68 + 64 * (size_t)(T + 4) + 4 * 16 * (size_t)(T + 4)) * sizeof(float);
+        static bool attr_m = false;
+        if (!attr_m) {
+            SVA_HIP(hipFuncSetAttribute((const void*)enc_attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_m = true;
+        }
+        const int tiles = T / 16 - row0 / 16;
+        int qsplit = 1;                                    // more workgroups per (head, stream) while the chip is under-filled
+        while (qsplit * 4 < tiles && (long)H * B * qsplit < 128) qsplit *= 2;
+        hipLaunchKernelGGL(enc_attention_mfma_kernel, dim3(H, B, qsplit), dim3(256), sm, st, qkv, rope, T, H, out, row0);
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
     const size_t smem = ((size_t)T * 65 * 2 + 4 * 64 + 4 * (size_t)T) * sizeof(float);
     SVA_CHECK(smem <= 160 * 1024, "enc_attention: window too long for the LDS-resident kernel");
     static bool attr_set = false;
