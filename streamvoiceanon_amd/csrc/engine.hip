@@ -1572,6 +1572,7 @@ int download_pcm(sva_batch* b, int T, float* pcm_out) {
 
 extern "C" int sva_vocode_stream(sva_batch* b, const int32_t* codes, int T, float* pcm_out) {
     SVA_CHECK(b && codes && pcm_out, "null argument");
+    SVA_CHECK(T >= 1 && T <= b->Tv, "vocode: T out of range (1 .. voc_max_frames)");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
     SVA_TRY(upload_vcodes(b, codes, T));
@@ -1580,6 +1581,8 @@ extern "C" int sva_vocode_stream(sva_batch* b, const int32_t* codes, int T, floa
 }
 
 extern "C" int sva_vocode_window(sva_batch* b, const int32_t* codes, int T, float* pcm_out) {
+    SVA_CHECK(b && codes && pcm_out, "null argument");
+    SVA_CHECK(T >= 1 && T <= b->Tv, "vocode: T out of range (1 .. voc_max_frames)");
     SVA_TRY(sva_vocode_reset(b));
     SVA_TRY(sva_vocode_stream(b, codes, T, pcm_out));
     return sva_vocode_reset(b);

@@ -364,6 +364,7 @@ def test_reprefill_per_slot_with_unequal_prompts(eng):
     dict(delay=3, chunk=2, We=64, R=107, n_chunks=8),          # GUI-style 64-frame window, odd delay, chunk > 1
     dict(delay=2, chunk=1, We=128, R=300, n_chunks=6),         # prompt longer than max_prompt_frames: quirk (iv), 633-token prefill
     dict(delay=5, chunk=1, We=128, R=70, n_chunks=9),          # long delay, short prompt (>= 63 frames)
+    dict(delay=8, chunk=1, We=128, R=80, n_chunks=12),         # max_delay: every wait4start / wait4end row is used
 ])
 def test_stream_configs_vs_oracle(eng, weights0, cfg):
     """Configurations without a reference fixture, checked against the (reference-pinned) CPU oracle: identical content
@@ -655,3 +656,36 @@ def test_stream_infer_from_wav_files(weights0, tmp_path):
     np.testing.assert_array_equal(out, out2)
     assert np.abs(out[2 * 2048:]).max() > 1e-3
     w.engine.close()
+
+
+def test_error_behaviour(eng):
+    """Misuse is refused with a negative return code and a message (raised as RuntimeError by the binding); nothing
+    silently falls back.  Mirrors the reference's failure modes where it has them (delay 0 breaks its re-prefill; a prompt
+    not longer than the delay cannot be laid out, dual_ar_stream.py:698-716)."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt
+
+    with pytest.raises(RuntimeError, match="delay 0"):
+        E.Batch(eng, n_streams=1, delay=0)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        E.Batch(eng, n_streams=1, encode_window_frames=130)
+    b = E.Batch(eng, n_streams=2)
+    ac, cc, style, timbre = synth_prompt(2800, 20)
+    with pytest.raises(RuntimeError, match="sva_streams_begin not called"):
+        b.step(np.zeros((2, 2048), np.float32))
+    b.prefill_prompt(0, cc, ac, style, timbre)
+    with pytest.raises(RuntimeError, match="every slot"):
+        b.begin()                                                    # slot 1 has no prompt
+    with pytest.raises(RuntimeError, match="bad argument"):
+        b.prefill_prompt(2, cc, ac, style, timbre)                   # slot out of range
+    with pytest.raises(RuntimeError, match="longer than the delay"):
+        b.prefill_prompt(1, cc[:2], ac[:, :2], style, timbre)        # R <= delay
+    with pytest.raises(RuntimeError, match="T out of range"):
+        b.vocode_window(np.zeros((2, 8, 4096), np.int32))
+    b.prefill_prompt(1, cc, ac, style, timbre)
+    b.begin()
+    out = b.step(np.zeros((2, 2048), np.float32))                    # silent input is fine: zeros during the delay
+    assert out.shape == (2, 2048) and not out.any()
+    b.close()
+    with pytest.raises(RuntimeError):
+        E.Engine({"tok.nothing": torch.zeros(1)})                    # missing tensors are named, not defaulted
