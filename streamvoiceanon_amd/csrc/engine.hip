@@ -821,8 +821,12 @@ int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int*
             SVA_TRY(launch_rmsnorm_rows(x, (long)M * D, 0, D, 1, M, D, L.attn_norm, 1e-5f, b->ahn, (long)M * D, 0, D, st));
             SVA_TRY(gemm_call(b, b->ahn, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.wqkv, b->aqkv, (long)M * 3 * D, 0, 3 * D));
         }
-        SVA_TRY(launch_rope_kvwrite<float>(b->aqkv, M, H, 64, d_slot, d_pos, rope, cache, kv_slot, S, st));
-        SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
+        if (S <= 8) {
+            SVA_TRY(launch_ar_fast_attention(b->aqkv, M, H, d_slot, d_pos, rope, cache, kv_slot, S, b->aatt, st));
+        } else {
+            SVA_TRY(launch_rope_kvwrite<float>(b->aqkv, M, H, 64, d_slot, d_pos, rope, cache, kv_slot, S, st));
+            SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
+        }
         ConvGemm po;
         po.res = x; po.r_bstride = (long)M * D; po.r_off = 0; po.ldr = D;
         SVA_TRY(gemm_call(b, b->aatt, (long)M * D, 0, D, 1, M, 1, 1, 1, D, L.wo, x, (long)M * D, 0, D, po));

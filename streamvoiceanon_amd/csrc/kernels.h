@@ -42,6 +42,9 @@ int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T
 template <typename KV>
 int launch_rope_kvwrite(float* qkv, int M, int H, int hd, const int* slot, const int* pos, const float* rope,
                         KV* cache, long slot_stride, int S, hipStream_t st);
+// RoPE + KV write + attention over <= 8 cached positions in one launch (fast AR, batched decode; fp32 cache)
+int launch_ar_fast_attention(const float* qkv, int M, int H, const int* slot, const int* pos, const float* rope, float* cache,
+                             long slot_stride, int S, float* out, hipStream_t st);
 // attention of M query rows against their slot's cache, keys 0..pos[m] inclusive.
 template <typename KV>
 int launch_ar_attention(const float* qkv, int M, int H, int hd, const int* slot, const int* pos, const KV* cache,

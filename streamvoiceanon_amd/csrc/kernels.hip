@@ -756,6 +756,62 @@ template int launch_ar_attention<float>(const float*, int, int, int, const int*,
 template int launch_ar_attention<__half>(const float*, int, int, int, const int*, const int*, const __half*, long, int, float*, hipStream_t, float*, int);
 
 // ------------------------------------------------------------------------------------------
+// Fast-AR attention for batched decode (cache of <= 8 codebook positions): RoPE on q / k, the KV-cache write and the
+// attention itself in one launch, one WAVE per (row, head), lane = head dimension.  Replaces rope_kvwrite + ar_attention
+// (two launches of 256-thread workgroups with LDS and barriers for at most 8 keys).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ar_fast_attention_kernel(const float* __restrict__ qkv, int H, int M, const int* __restrict__ slot,
+                                                                const int* __restrict__ pos, const float* __restrict__ rope,
+                                                                float* __restrict__ cache, long slot_stride, int S, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= M * H) return;
+    const int m = unit / H, h = unit - m * H;
+    const int D = H * 64, p = pos[m];
+    const float* row = qkv + (long)m * 3 * D + h * 64;
+    float q = row[lane], k = row[D + lane];
+    const float v = row[2 * D + lane];
+    {   // adjacent-pair rotation (dual_ar_stream.py:1004-1016): even lane holds x0, odd lane x1 of the pair
+        const float c = rope[((long)p * 32 + (lane >> 1)) * 2], sn = rope[((long)p * 32 + (lane >> 1)) * 2 + 1];
+        const float qo = dpp_mov<0xB1>(q), ko = dpp_mov<0xB1>(k);           // partner of the pair (lane ^ 1)
+        q = (lane & 1) ? q * c + qo * sn : q * c - qo * sn;
+        k = (lane & 1) ? k * c + ko * sn : k * c - ko * sn;
+    }
+    float* kc = cache + (long)slot[m] * slot_stride + (long)h * S * 64;
+    float* vc = kc + (long)H * S * 64;
+    kc[(long)p * 64 + lane] = k;
+    vc[(long)p * 64 + lane] = v;
+    float kk[8], vv[8], sc[8], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int jj = j < p ? j : 0;
+        kk[j] = j < p ? kc[jj * 64 + lane] : k;           // j == p: this token (just written); j > p: masked below
+        vv[j] = j < p ? vc[jj * 64 + lane] : v;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float d = wave_sum(q * kk[j]) * 0.125f;
+        sc[j] = j <= p ? d : -INFINITY;
+        mx = fmaxf(mx, sc[j]);
+    }
+    float sum = 0.f, o = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float e = j <= p ? expf(sc[j] - mx) : 0.f;
+        sum += e;
+        o = fmaf(e, vv[j], o);
+    }
+    out[(long)m * D + h * 64 + lane] = o / sum;
+}
+int launch_ar_fast_attention(const float* qkv, int M, int H, const int* slot, const int* pos, const float* rope, float* cache,
+                             long slot_stride, int S, float* out, hipStream_t st) {
+    SVA_CHECK(S <= 8, "ar_fast_attention: cache of at most 8 positions");
+    hipLaunchKernelGGL(ar_fast_attention_kernel, dim3((M * H + 3) / 4), dim3(256), 0, st, qkv, H, M, slot, pos, rope, cache, slot_stride, S, out);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // A5 sampler (modules/dual_ar_stream.py:1092-1132, defaults T = 0.7, top_p = 0.7, no repetition
 // penalty): sort descending, inclusive cumsum of softmax, drop every sorted entry with
 // cum > top_p except rank 0 (no right shift), divide by max(T, 1e-5), softmax, argmax(p / q),
