@@ -265,8 +265,18 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
     const int nk = g.taps * kc_tiles;
     // software pipeline, D K-blocks in flight per wave.  No branch around any load (a conditional load makes
     // hipcc drain vmcnt(0) at the join): out-of-range blocks re-load the wave's last valid block and are masked.
+#ifdef SVA_KPAIR
+    // waves own PAIRS of adjacent 16-wide K blocks, so both 64-byte halves of every 128-byte line of a weight row are
+    // requested by the same wave back to back
+    const int npairs = (nk + 1) / 2;
+    const int my_n = npairs > wave ? 2 * ((npairs - wave + KW - 1) / KW) : 0;
+    const int last_kb = 0;
+    auto kbq = [&](int q) { return ((q >> 1) * KW + wave) * 2 + (q & 1); };
+#else
     const int my_n = nk > wave ? (nk - wave + KW - 1) / KW : 0;          // K blocks owned by this wave
     const int last_kb = my_n > 0 ? wave + (my_n - 1) * KW : 0;
+    auto kbq = [&](int q) { return wave + q * KW; };
+#endif
     float4 wv[D][NT], av[D][MT], nv[D];
     float ssq[MT];
 #pragma unroll
@@ -284,11 +294,11 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
         if (RMS) nw = *reinterpret_cast<const float4*>(g.rms_w + kc + 4 * fg);
     };
 #pragma unroll
-    for (int d = 0; d < D; ++d) issue(wv[d], av[d], nv[d], wave + d * KW);
+    for (int d = 0; d < D; ++d) issue(wv[d], av[d], nv[d], kbq(d));
     for (int it = 0; it < my_n; it += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const int kb = wave + (it + d) * KW;
+            const int kb = kbq(it + d);
             const float keep = kb < nk ? 1.f : 0.f;
             float4 w[NT], a[MT];
 #pragma unroll
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
                     a[i].x *= nv[d].x; a[i].y *= nv[d].y; a[i].z *= nv[d].z; a[i].w *= nv[d].w;
                 }
             }
-            issue(wv[d], av[d], nv[d], kb + D * KW);
+            issue(wv[d], av[d], nv[d], kbq(it + d + D));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -418,22 +428,31 @@ static int launch_skinny(const ConvGemm& g, hipStream_t st) {
     return launch_skinny_op<MT, NT, KW, D, 0>(g, st);
 }
 
+#ifndef SVA_D18
+#define SVA_D116 4
+#define SVA_D18 6
+#define SVA_D14 8
+#define SVA_D28 4
+#define SVA_D24 6
+#define SVA_D48 3
+#define SVA_D44 4
+#endif
 template <int NT>
 static int launch_cfg(const ConvGemm& g, hipStream_t st, int mt, int kw) {
     switch (mt) {
         case 1:
-            if (kw == 16) return launch_skinny<1, NT, 16, 4>(g, st);
-            if (kw == 8) return launch_skinny<1, NT, 8, 6>(g, st);
-            return launch_skinny<1, NT, 4, 8>(g, st);
+            if (kw == 16) return launch_skinny<1, NT, 16, SVA_D116>(g, st);
+            if (kw == 8) return launch_skinny<1, NT, 8, SVA_D18>(g, st);
+            return launch_skinny<1, NT, 4, SVA_D14>(g, st);
         case 2:
-            if (kw == 8) return launch_skinny<2, NT, 8, 4>(g, st);
-            return launch_skinny<2, NT, 4, 6>(g, st);
+            if (kw == 8) return launch_skinny<2, NT, 8, SVA_D28>(g, st);
+            return launch_skinny<2, NT, 4, SVA_D24>(g, st);
         case 3:
-            if (kw == 8) return launch_skinny<3, NT, 8, 4>(g, st);
-            return launch_skinny<3, NT, 4, 4>(g, st);
+            if (kw == 8) return launch_skinny<3, NT, 8, SVA_D28>(g, st);
+            return launch_skinny<3, NT, 4, SVA_D44>(g, st);
         default:
-            if (kw == 8) return launch_skinny<4, NT, 8, 3>(g, st);
-            return launch_skinny<4, NT, 4, 4>(g, st);
+            if (kw == 8) return launch_skinny<4, NT, 8, SVA_D48>(g, st);
+            return launch_skinny<4, NT, 4, SVA_D44>(g, st);
     }
 }
 // Heuristic choice of (rows per workgroup = 16*MT, K-split waves KW) for the small-M kernel.

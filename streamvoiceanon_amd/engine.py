@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsva_hip.so")
+LIB_PATH = os.environ.get("SVA_LIB_PATH") or os.path.join(_HERE, "libsva_hip.so")      # override: A/B builds of the kernels
 
 
 class SvaConfig(C.Structure):
