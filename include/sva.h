@@ -163,7 +163,8 @@ long sva_get_gemm_profile_table(sva_batch* b, double* out, long max_rows);
 int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C);
 
 /* same through one specific dispatch choice of the autotuned GEMM (kind 0: small-M K-split kernel, a = 16-row tiles per
- * workgroup, b = K-split waves, c = 16-column tiles per wave; kind 1: LDS-tiled kernel, a = tile variant 0..6) */
+ * workgroup, b = K-split waves, c = 16-column tiles per wave; kind 1: LDS-tiled kernel, a = tile variant 0..6; kind 2: the
+ * small-M kernel with its K axis also split over c >> 4 workgroups, c & 15 = column tiles; launched twice) */
 int sva_test_gemm_choice(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int kind,
                          int a, int b, int c);
 

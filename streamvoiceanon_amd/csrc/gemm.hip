@@ -233,7 +233,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmGroup gg) 
 // row statistics accumulated on the fly and applied to the accumulators in the epilogue).
 template <int MT, int NT, int KW, int D, int AOP>
 __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGroup gg) {
-    const ConvGemm& g = gg.g[blockIdx.z];
+    // blockIdx.z: member of a group, or (single problem) the K split this workgroup owns
+    const ConvGemm& g = gg.g[gg.n > 1 ? blockIdx.z : 0];
+    const int Z = gg.n > 1 ? 1 : g.ksplit, ks = gg.n > 1 ? 0 : (int)blockIdx.z;
     constexpr bool SILU = AOP == 1, RMS = AOP == 2;
     extern __shared__ __attribute__((aligned(16))) float red[];      // [KW][MT*NT][64][4] (+ [KW][MT][16] row sums of squares)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -265,24 +267,18 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
     const int nk = g.taps * kc_tiles;
     // software pipeline, D K-blocks in flight per wave.  No branch around any load (a conditional load makes
     // hipcc drain vmcnt(0) at the join): out-of-range blocks re-load the wave's last valid block and are masked.
-#ifdef SVA_KPAIR
-    // waves own PAIRS of adjacent 16-wide K blocks, so both 64-byte halves of every 128-byte line of a weight row are
-    // requested by the same wave back to back
-    const int npairs = (nk + 1) / 2;
-    const int my_n = npairs > wave ? 2 * ((npairs - wave + KW - 1) / KW) : 0;
-    const int last_kb = 0;
-    auto kbq = [&](int q) { return ((q >> 1) * KW + wave) * 2 + (q & 1); };
-#else
-    const int my_n = nk > wave ? (nk - wave + KW - 1) / KW : 0;          // K blocks owned by this wave
-    const int last_kb = my_n > 0 ? wave + (my_n - 1) * KW : 0;
-    auto kbq = [&](int q) { return wave + q * KW; };
-#endif
+    // this workgroup's share of the K blocks (grid-level split), interleaved over its waves
+    const int kb_lo = (int)((long)ks * nk / Z), kb_hi = (int)((long)(ks + 1) * nk / Z);
+    const int nk_loc = kb_hi - kb_lo;
+    const int my_n = nk_loc > wave ? (nk_loc - wave + KW - 1) / KW : 0;          // K blocks owned by this wave
+    const int last_kb = my_n > 0 ? kb_lo + wave + (my_n - 1) * KW : kb_lo;
+    auto kbq = [&](int q) { return kb_lo + wave + q * KW; };
     float4 wv[D][NT], av[D][MT], nv[D];
     float ssq[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) ssq[i] = 0.f;
     auto issue = [&](float4 (&w)[NT], float4 (&a)[MT], float4& nw, int kb) {
-        kb = kb < nk ? kb : last_kb;
+        kb = kb < kb_hi ? kb : last_kb;
         const int tap = kb / kc_tiles;
         const int kc = (kb - tap * kc_tiles) * 16;
         const long aoff = (long)tap * g.dil * g.lda + kc;
@@ -299,7 +295,7 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int kb = kbq(it + d);
-            const float keep = kb < nk ? 1.f : 0.f;
+            const float keep = kb < kb_hi ? 1.f : 0.f;
             float4 w[NT], a[MT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) w[j] = wv[d][j];
@@ -352,26 +348,7 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
     // tail: the MT row tiles are spread over the waves (each sums the KW partials of its tiles straight from LDS and runs
     // the epilogue for them) instead of leaving all of it to wave 0
     const int col = lane & 15, rq = (lane >> 4) * 4;
-    for (int i = wave; i < MT; i += KW) {
-        f32x4 t[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            f32x4 s = *reinterpret_cast<const f32x4*>(&red[((i * NT + j) * 64 + lane) * 4]);
-#pragma unroll
-            for (int w = 1; w < KW; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * (MT * NT) + i * NT + j) * 64 + lane) * 4]);
-            t[j] = s;
-        }
-        if (RMS) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float tot = 0.f;
-#pragma unroll
-                for (int w = 0; w < KW; ++w) tot += redss[(w * MT + i) * 16 + rq + r];
-                const float inv = 1.f / sqrtf(tot / (float)Kt + g.rms_eps);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) t[j][r] *= inv;
-            }
-        }
+    auto epilogue = [&](int i, f32x4 (&t)[NT]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m_base + i * 16 + rq + r;
@@ -401,11 +378,91 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
                 }
             }
         }
+    };
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x, n_tiles = gridDim.x * gridDim.y;
+    for (int i = wave; i < MT; i += KW) {
+        f32x4 t[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4 s = *reinterpret_cast<const f32x4*>(&red[((i * NT + j) * 64 + lane) * 4]);
+#pragma unroll
+            for (int w = 1; w < KW; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * (MT * NT) + i * NT + j) * 64 + lane) * 4]);
+            t[j] = s;
+        }
+        if (RMS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < KW; ++w) tot += redss[(w * MT + i) * 16 + rq + r];
+                const float inv = 1.f / sqrtf(tot / (float)Kt + g.rms_eps);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) t[j][r] *= inv;
+            }
+        }
+        if (Z == 1) {
+            epilogue(i, t);
+        } else {          // raw partial tile of this K split, register layout (1 KiB per 16x16 tile, coalesced)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *reinterpret_cast<f32x4*>(g.ks_ws + ((((long)ks * n_tiles + tile) * MT + i) * NT + j) * 256 + lane * 4) = t[j];
+        }
+    }
+    if (Z == 1) return;
+    // The last workgroup to arrive for this output tile sums the Z partials in split order (deterministic) and runs the
+    // epilogue.  ks_ws / ks_cnt are uncached memory: a store is globally visible once it has been acknowledged (vmcnt),
+    // which the workgroup-scope release before the barrier waits for.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = atomicAdd(g.ks_cnt + tile, 1u);
+        if (old == (unsigned)(Z - 1)) g.ks_cnt[tile] = 0;          // re-armed for the next launch on this stream
+        reinterpret_cast<unsigned*>(red)[0] = old;
+    }
+    __syncthreads();
+    if (reinterpret_cast<const unsigned*>(red)[0] != (unsigned)(Z - 1)) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int i = wave; i < MT; i += KW) {
+        f32x4 t[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4 s = *reinterpret_cast<const f32x4*>(g.ks_ws + (((long)tile * MT + i) * NT + j) * 256 + lane * 4);
+            for (int z = 1; z < Z; ++z)
+                s += *reinterpret_cast<const f32x4*>(g.ks_ws + ((((long)z * n_tiles + tile) * MT + i) * NT + j) * 256 + lane * 4);
+            t[j] = s;
+        }
+        epilogue(i, t);
     }
 }
 
 // set by launch_conv_gemm_group around the dispatch: the launchers then send the whole group (grid.z = members)
 static thread_local const ConvGemmGroup* t_group = nullptr;
+// grid-level K split requested by the dispatch choice for the next small-M launch
+static thread_local int t_ksplit = 1;
+// split-K scratch (partial tiles + arrival counters), one per stream: launches on one stream are ordered, so they can
+// share it; concurrent streams must not
+struct KsScratch { float* ws = nullptr; unsigned* cnt = nullptr; };
+static std::mutex g_ks_mu;
+static std::unordered_map<hipStream_t, KsScratch> g_ks;
+constexpr size_t KS_WS_FLOATS = (size_t)8 << 20;      // 32 MiB of partial tiles
+constexpr int KS_CNT = 1 << 16;
+static int ks_scratch(hipStream_t st, KsScratch* out) {
+    std::lock_guard<std::mutex> lk(g_ks_mu);
+    auto it = g_ks.find(st);
+    if (it != g_ks.end()) { *out = it->second; return 0; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { *out = KsScratch(); return 0; }   // no allocation inside a capture
+    KsScratch k;
+    // UNCACHED device memory: partial tiles and counters bypass the (per-XCD, mutually incoherent) L2s, so the hand-off
+    // needs no agent-scope fence -- an agent-scope release / acquire per workgroup writes back / invalidates the whole
+    // L2 and serialises (measured: + 0.37 us per workgroup)
+    SVA_HIP(hipExtMallocWithFlags((void**)&k.ws, KS_WS_FLOATS * sizeof(float), hipDeviceMallocUncached));
+    SVA_HIP(hipExtMallocWithFlags((void**)&k.cnt, KS_CNT * sizeof(unsigned), hipDeviceMallocUncached));
+    SVA_HIP(hipMemset(k.cnt, 0, KS_CNT * sizeof(unsigned)));
+    g_ks[st] = k;
+    *out = k;
+    return 0;
+}
 
 template <int MT, int NT, int KW, int D, int AOP>
 static int launch_skinny_op(const ConvGemm& g, hipStream_t st) {
@@ -413,6 +470,17 @@ static int launch_skinny_op(const ConvGemm& g, hipStream_t st) {
     ConvGemmGroup gg;
     if (t_group) gg = *t_group; else gg.g[0] = g;
     dim3 grid((g.N + 16 * NT - 1) / (16 * NT), (g.M + 16 * MT - 1) / (16 * MT), gg.n);
+    if (gg.n == 1) {
+        int Z = AOP == 2 ? 1 : t_ksplit;                  // (the fused RMSNorm needs the whole row in one workgroup)
+        const long nkb = (long)g.taps * g.Cin / 16;
+        if (Z > nkb) Z = (int)nkb;
+        const size_t tiles = (size_t)grid.x * grid.y;
+        KsScratch k;
+        if (Z > 1 && (tiles > (size_t)KS_CNT || (size_t)Z * tiles * MT * NT * 256 > KS_WS_FLOATS)) Z = 1;
+        if (Z > 1) { SVA_TRY_RC(ks_scratch(st, &k)); if (!k.ws) Z = 1; }
+        gg.g[0].ksplit = Z; gg.g[0].ks_ws = k.ws; gg.g[0].ks_cnt = k.cnt;
+        grid.z = Z;
+    }
     static bool attr = false;
     if (!attr && smem > 48 * 1024) {
         SVA_HIP(hipFuncSetAttribute((const void*)skinny_gemm_kernel<MT, NT, KW, D, AOP>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
@@ -498,10 +566,15 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
 // One dispatch decision: kind 0 = small-M K-split kernel (a = rows/16 per workgroup, b = K-split waves, c = 16-column
 // tiles per wave); kind 1 = LDS-tiled kernel (a: 0 = 64x64, 1 = 128x128, 2 = 128x32, 3 = 256x16, 4 = 128x64, 5 = 64x128,
 // 6 = 256x64; 4..6 are reached through the autotuner only).
-struct Choice { int kind, a, b, c; };
+struct Choice { int kind, a, b, c; int z = 1; };      // z: grid-level K split of the small-M kernel
 
 static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
-    if (ch.kind == 0) return ch.c == 2 ? launch_cfg<2>(g, st, ch.a, ch.b) : launch_cfg<1>(g, st, ch.a, ch.b);
+    if (ch.kind == 0) {
+        t_ksplit = ch.z;
+        const int rc = ch.c == 2 ? launch_cfg<2>(g, st, ch.a, ch.b) : launch_cfg<1>(g, st, ch.a, ch.b);
+        t_ksplit = 1;
+        return rc;
+    }
     const int bk = g.Cin % 64 == 0 ? 64 : (g.Cin % 32 == 0 ? 32 : 16);
     switch (ch.a) {
         case 3: return launch_t<256, 16, 4, 1, 16>(g, st);
@@ -529,6 +602,13 @@ static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
         const bool nt2 = g.w13 || (g.N % 32 == 0 && g.M >= 512 && (long)g.M * g.N >= 256L * 1024);
         Choice ch{0, 1, 4, nt2 ? 2 : 1};
         skinny_heuristic(g, ch.c, &ch.a, &ch.b);
+        // A workgroup ingests 16*(MT + NT) rows of K floats and a CU sustains only ~40 GB/s of loads (tools/gemm_kscale.py:
+        // time grows with K alone), so when the tiles do not cover the 256 CUs the K axis is split over more workgroups
+        const long wgs = (long)((g.N + 16 * ch.c - 1) / (16 * ch.c)) * (((g.M + 15) / 16 + ch.a - 1) / ch.a);
+        const long nkb = (long)g.taps * g.Cin / 16;
+        while (ch.z < 8 && wgs * ch.z * 2 <= 256 && nkb / (2L * ch.z * ch.b) >= 2) ch.z *= 2;
+        static const char* env_z = getenv("SVA_SKINNY_Z");
+        if (env_z) ch.z = atoi(env_z);
         return ch;
     }
     if (g.N <= 16 && !g.w13) return Choice{1, 3, 0, 0};
@@ -640,6 +720,10 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                             for (int b2 = 0; b2 < 3; ++b2) {
                                 if (mts[a] > mt_total || (mts[a] >= 2 && kws[b2] == 16) || nk / kws[b2] < 1) continue;
                                 cand.push_back(Choice{0, mts[a], kws[b2], nt});
+                                if (g.rms_w || group_n > 1) continue;
+                                const long wgs = (long)((g.N + 16 * nt - 1) / (16 * nt)) * ((mt_total + mts[a] - 1) / mts[a]);
+                                for (int z = 2; z <= 8; z *= 2)
+                                    if (wgs * z <= 512 && nk / ((long)z * kws[b2]) >= 1) cand.push_back(Choice{0, mts[a], kws[b2], nt, z});
                             }
                     }
                 }
@@ -656,7 +740,7 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                 SVA_TRY_RC(time_choice(ch, &base));
                 float best = base * 0.93f;
                 for (const Choice& c : cand) {
-                    if (c.kind == ch.kind && c.a == ch.a && c.b == ch.b && c.c == ch.c) continue;
+                    if (c.kind == ch.kind && c.a == ch.a && c.b == ch.b && c.c == ch.c && c.z == ch.z) continue;
                     float ms = 0.f;
                     SVA_TRY_RC(time_choice(c, &ms));
                     if (ms < best) { best = ms; ch = c; }
@@ -665,8 +749,8 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                 t_group = real_group;
                 static const bool tlog = getenv("SVA_TUNE_LOG") != nullptr;
                 if (tlog)
-                    fprintf(stderr, "[sva tune] M=%d N=%d K=%d taps=%d flags=%llu: heuristic %.1f us -> kind %d (%d,%d,%d) %.1f us\n", g.M, g.N,
-                            g.taps * g.Cin, g.taps, flags, base * 200.f, ch.kind, ch.a, ch.b, ch.c, (best < base * 0.93f ? best : base) * 200.f);
+                    fprintf(stderr, "[sva tune] M=%d N=%d K=%d taps=%d flags=%llu: heuristic %.1f us -> kind %d (%d,%d,%d) z%d %.1f us\n", g.M, g.N,
+                            g.taps * g.Cin, g.taps, flags, base * 200.f, ch.kind, ch.a, ch.b, ch.c, ch.z, (best < base * 0.93f ? best : base) * 200.f);
                 g_tune[key] = ch;
             }
         }
@@ -684,6 +768,16 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
                              "conv_gemm_choice: bad small-M configuration");
     else SVA_CHECK(a >= 0 && a <= 6 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: bad tile variant");
     SVA_TRY_RC(launch_choice(g, st, Choice{kind, a, b, c}));
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+int launch_conv_gemm_choice_z(const ConvGemm& g, hipStream_t st, int a, int b, int c, int z) {
+    SVA_CHECK(g.Cin % 16 == 0 && g.lda % 4 == 0, "conv_gemm_choice: alignment");
+    SVA_CHECK((a == 1 || a == 2 || a == 3 || a == 4) && (b == 4 || b == 8 || (b == 16 && a == 1)) && (c == 1 || (c == 2 && g.N % 32 == 0)) && z >= 1 && z <= 8,
+              "conv_gemm_choice: bad small-M configuration");
+    Choice ch{0, a, b, c};
+    ch.z = z;
+    SVA_TRY_RC(launch_choice(g, st, ch));
     SVA_HIP(hipGetLastError());
     return 0;
 }

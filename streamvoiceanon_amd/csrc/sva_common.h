@@ -63,6 +63,9 @@ struct ConvGemm {
     int accumulate = 0;         // C += value   (ParallelBlock mean of three ResBlock branches)
     int a_silu = 0;             // apply SiLU to A on load (HiFiGAN: silu precedes every conv)
     int w13 = 0;                // SwiGLU: W rows interleave w1/w3 in groups of 16; C[., n/2] = silu(a)*b
+    int ksplit = 1;                 // set by the dispatcher: K split over `ksplit` workgroups (blockIdx.z), partial tiles in
+    float* ks_ws = nullptr;         //   ks_ws, arrival counters in ks_cnt; the last workgroup of a tile sums them in
+    unsigned* ks_cnt = nullptr;     //   split order (deterministic) and runs the epilogue
     const float* rms_w = nullptr;   // [Cin] fused RMSNorm of the A rows (taps == 1): A' = A * rms_w * rsqrt(mean(A^2) + rms_eps);
     float rms_eps = 1e-5f;          //       only on the small-M path -- ask conv_gemm_can_fuse_rms() first
 };
@@ -79,5 +82,6 @@ int launch_conv_gemm_group(const ConvGemm* gs, int n, hipStream_t st);
 // true when launch_conv_gemm would route this (M, N) problem to the K-split small-M kernel, which can normalise its A rows
 bool conv_gemm_can_fuse_rms(int M, int N);
 int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, int b, int c);   // unit-test hook
+int launch_conv_gemm_choice_z(const ConvGemm& g, hipStream_t st, int a, int b, int c, int z);        // small-M kernel with a grid-level K split
 
 }  // namespace sva
