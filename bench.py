@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=60, help="CPU-baseline sample size (chunk-steps)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the informational 64-stream run that accompanies the B=1 headline")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="do not overlap encoder / AR / vocoder of consecutive chunk-steps (default: overlapped on three streams "
+                         "when <= 16 streams share the GPU -- same results, it is the throughput of simulated streaming; the "
+                         "latency a caller sees when it synchronises every chunk is reported as sync_latency_ms either way)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured hipGraph of the steady step (measured slower than eager multi-stream launches on this "
                          "stack: 5.6 vs 4.8 ms at B=1, the step is GPU-bound, see DESIGN.md)")
@@ -149,7 +153,8 @@ def main():
 
     def run_workload(B, steps, warmup, want_roofline):
         """B streams per rank; returns (seconds for `steps` steps [max over ranks], stage timings, gathered count, roofline)"""
-        batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=args.graph)
+        pipelined = bool(args.pipeline) and B <= 16 and not args.graph      # 64 streams already fill the chip: no gain there
+        batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=args.graph, pipeline=pipelined)
         # utterances are global ids sharded over ranks (weak scaling: B per rank)
         my_utts = shard_utterances(list(range(world * B)), world)[rank]
         for s_, u in enumerate(my_utts):
@@ -183,7 +188,6 @@ def main():
         if world > 1 or force_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
-        tm = batch.timings()
         # per-chunk latency as a live caller sees it (enqueue + execute + sync per chunk; outside the timed region)
         lat, enq = [], []
         for _ in range(n_lat):
@@ -193,6 +197,7 @@ def main():
             batch.sync()
             lat.append((time.perf_counter() - t1) * 1e3)
             enq.append((t2 - t1) * 1e3)
+        tm = batch.timings()          # of the last, individually synchronised step: its stages ran back to back, not overlapped
         lat.sort(); enq.sort()
         extra = {"host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 4),          # back-to-back (includes queue back-pressure)
                  "host_enqueue_ms_idle_queue": round(enq[len(enq) // 2], 4),          # median with an empty queue: the pure host cost
@@ -261,7 +266,7 @@ def main():
                                f"encode window 128 / vocoder window 64 frames, synthetic 44.1 kHz speech-like audio, "
                                f"synthetic prompt R={args.prompt_frames}, random-init weights of the reference architecture",
                    "streams_per_gpu": B, "chunk_frames": c, "parallelism": f"utterance-parallel x{world}",
-                   "hipgraph": bool(args.graph)},
+                   "hipgraph": bool(args.graph), "stage_pipelining": bool(args.pipeline) and B <= 16 and not args.graph},
         "rtf": round(ms * 1e-3 / (c * FRAME_S), 5), "x_realtime": round(fps * FRAME_S, 2),
         "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm.items()},
         "gathered_utterances": n_gathered,

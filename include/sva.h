@@ -70,6 +70,9 @@ typedef struct sva_stream_params {
     int voc_max_frames;        /* largest T accepted by sva_vocode_window / one streaming call (>= chunk) */
     int use_graph;             /* capture the steady-state step in a hipGraph */
     int skip_semantic;         /* skip the semantic-token head whose sample every caller discards (:833) */
+    int pipeline;              /* sva_step_device only: run encoder / AR / vocoder of consecutive chunk-steps on three streams
+                                * (E(n+1) || A(n) || V(n-1)); same results, higher throughput for simulated streaming; a caller that
+                                * synchronises per chunk sees the unpipelined latency */
 } sva_stream_params;
 
 const char* sva_last_error(void);
@@ -106,7 +109,9 @@ int sva_streams_begin(sva_batch* b);
  *           order (slow head first, then the 8 codebooks), or NULL = on-device counter RNG
  *   forced_codes host int32[B][8][chunk] teacher-forces the AR (parity tests), or NULL */
 int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const float* noise, const int32_t* forced_codes);
-/* same with device pointers (no host copies); asynchronous on the engine stream */
+/* same with device pointers (no host copies); asynchronous: d_pcm_in must stay valid and d_pcm_out must not be read until
+ * sva_sync() (or a later synchronous call on the handle) returns.  With sva_stream_params.pipeline the stages of consecutive
+ * calls overlap on three streams. */
 int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm_out);
 int sva_sync(sva_batch* b);
 

@@ -145,6 +145,13 @@ struct sva_batch {
     hipStream_t stream = nullptr;          // current launch stream (== main except inside a forked branch)
     hipStream_t main_stream = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr};   // side streams for independent sub-chains (fork / join by events)
+    // stage pipelining over consecutive chunk-steps (sva_step_device, p.pipeline): AR and vocoder streams, hand-off events
+    hipStream_t sa = nullptr, sv = nullptr;
+    hipStream_t out_stream = nullptr;      // stream that holds the PCM of the last step
+    bool allow_pipe = false, pipe_dirty = false;
+    hipEvent_t pipe_evVc = nullptr, pipe_evR = nullptr, pipe_evA[2] = {nullptr, nullptr};
+    long long* d_codes_buf[2] = {nullptr, nullptr};
+    int pipe_parity = 0;
     hipEvent_t evpool[64];
     int evi = 0;
     bool concurrency = true;

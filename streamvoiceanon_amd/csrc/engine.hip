@@ -62,6 +62,9 @@ static int alloc_act(DevPool& pool, Act& a, int B, int H, long Tmax, int C) {
 
 using namespace sva;
 
+// joins the AR / vocoder streams of the pipelined mode back into the main stream (no-op when nothing is in flight there)
+namespace { int quiesce(sva_batch* b); }
+
 // ============================================================================================
 // config defaults
 // ============================================================================================
@@ -1276,11 +1279,23 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     if (b->p.voc_max_frames < p->chunk_frames) b->p.voc_max_frames = p->chunk_frames;
     SVA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     b->main_stream = b->stream;
-    for (int i = 0; i < 2; ++i) SVA_HIP(hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking));
+    // The runtime multiplexes streams onto a few hardware queues (4 by default) in creation order, and two streams that
+    // share a hardware queue serialise -- including a stream stuck behind another one's event wait.  So only the streams a
+    // configuration really uses are created: main, the encoder's side stream, then (pipelined mode) AR and vocoder.
+    SVA_HIP(hipStreamCreateWithFlags(&b->aux[0], hipStreamNonBlocking));
+    if (const char* ev = getenv("SVA_VOC_GROUPED")) b->voc_grouped = atoi(ev) != 0;
+    if (b->p.pipeline) {
+        SVA_CHECK(b->voc_grouped, "stage pipelining needs the grouped vocoder launches");
+        SVA_HIP(hipStreamCreateWithFlags(&b->sa, hipStreamNonBlocking));
+        SVA_HIP(hipStreamCreateWithFlags(&b->sv, hipStreamNonBlocking));
+    } else if (!b->voc_grouped) {
+        SVA_HIP(hipStreamCreateWithFlags(&b->aux[1], hipStreamNonBlocking));
+    }
+    b->out_stream = b->stream;
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
     if (const char* ev = getenv("SVA_CONCURRENCY")) b->concurrency = atoi(ev) != 0;
     if (const char* ev = getenv("SVA_FUSED_DECODE")) b->fused_decode = atoi(ev) != 0;
-    if (const char* ev = getenv("SVA_VOC_GROUPED")) b->voc_grouped = atoi(ev) != 0;      // 0: single stream (PMC profiling)
+    // SVA_CONCURRENCY=0: single stream (PMC profiling)
     auto& A = b->allocs;
     const int chunk = p->chunk_frames;
     // control block
@@ -1359,7 +1374,9 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
         SVA_HIP(hipMemcpy(b->d_shift_d2c, &dc, sizeof(ShiftDesc), hipMemcpyHostToDevice));
     }
     SVA_TRY(dev_alloc(A, &b->aatt_part, (size_t)4 * c.ar_heads * 8 * 68));
-    SVA_TRY(dev_alloc(A, &b->d_codes, (size_t)B * T2));
+    SVA_TRY(dev_alloc(A, &b->d_codes_buf[0], (size_t)B * T2));
+    SVA_TRY(dev_alloc(A, &b->d_codes_buf[1], (size_t)B * T2));
+    b->d_codes = b->d_codes_buf[0];
     SVA_TRY(dev_alloc(A, &b->d_fsq_codes, (size_t)B * c.num_codebooks * T2));
     SVA_TRY(dev_alloc(A, &b->d_u, (size_t)B * T2 * c.bsq_bits));
     // AR
@@ -1479,6 +1496,8 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
         for (int i = 0; i < 5; ++i) hipEventDestroy(b->ev[i]);
     for (auto& ev : b->prof_ev) hipEventDestroy(ev);
     for (int i = 0; i < 2; ++i) if (b->aux[i]) { hipStreamSynchronize(b->aux[i]); hipStreamDestroy(b->aux[i]); }
+    if (b->sa) { hipStreamSynchronize(b->sa); hipStreamDestroy(b->sa); }
+    if (b->sv) { hipStreamSynchronize(b->sv); hipStreamDestroy(b->sv); }
     for (int i = 0; i < 64; ++i) hipEventDestroy(b->evpool[i]);
     hipStreamDestroy(b->main_stream);
     delete b;
@@ -1514,6 +1533,7 @@ extern "C" int sva_prefill_prompt(sva_batch* b, int slot, const int64_t* ref_con
     SVA_CHECK(b && slot >= 0 && slot < b->B && ref_content_codes && ref_audio_codes && style && timbre, "bad argument");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     const sva_config& c = b->e->cfg;
     const int ncb = c.num_codebooks;
     std::vector<int64_t> cc(ref_content_codes, ref_content_codes + R);
@@ -1540,6 +1560,7 @@ extern "C" int sva_vocode_reset(sva_batch* b) {
     SVA_CHECK(b, "null batch");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     auto zero = [&](Act& a) -> int {
         SVA_HIP(hipMemsetAsync(a.p, 0, sizeof(float) * (size_t)b->B * a.bstride, b->stream));
         return 0;
@@ -1579,6 +1600,7 @@ extern "C" int sva_vocode_stream(sva_batch* b, const int32_t* codes, int T, floa
     SVA_CHECK(T >= 1 && T <= b->Tv, "vocode: T out of range (1 .. voc_max_frames)");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     SVA_TRY(upload_vcodes(b, codes, T));
     SVA_TRY(vocode(b, T, true));
     return download_pcm(b, T, pcm_out);
@@ -1596,6 +1618,7 @@ extern "C" int sva_streams_begin(sva_batch* b) {
     SVA_CHECK(b, "null batch");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     const int B = b->B, ncb = b->e->cfg.num_codebooks, c = b->p.chunk_frames;
     for (int i = 0; i < B; ++i) SVA_CHECK(b->prefilled[i], "every slot needs sva_prefill_prompt before sva_streams_begin");
     // setup_stream_caches (infer_arvc.py:443-460)
@@ -1712,6 +1735,81 @@ int steady_launches(sva_batch* b, bool timing_events) {
     return 0;
 }
 
+// Pipelined steady step (sva_step_device with p.pipeline): the three stages of chunk-step n go to three streams,
+//   main: E(n)   ->   sa: A(n)   ->   sv: V(n)
+// chained by events, so that E(n+1), A(n) and V(n-1) overlap on the GPU.  Hazards between consecutive steps:
+//   * d_codes (E writes, A reads to the end of its frame): double-buffered, swapped per step;
+//   * d_step_audio (A writes at the end of a frame, V copies it first thing): A(n+1) waits for V(n)'s copy;
+//   * content history (E appends, a re-prefill on sa reads): E(n+1) waits for the re-prefill of step n.
+// Every other buffer is private to its stage.
+int steady_pipelined(sva_batch* b) {
+    const sva_config& c = b->e->cfg;
+    const int B = b->B, chunk = b->p.chunk_frames, n = 2048 * chunk, ncb = c.num_codebooks;
+    hipStream_t se = b->main_stream, sa = b->sa, sv = b->sv;
+    if (!b->pipe_dirty) {            // entering the pipelined regime: the side streams must see all serial work so far
+        hipEvent_t ev = next_event(b);
+        SVA_HIP(hipEventRecord(ev, se));
+        SVA_HIP(hipStreamWaitEvent(sa, ev, 0));
+        SVA_HIP(hipStreamWaitEvent(sv, ev, 0));
+        b->pipe_evVc = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr;
+    }
+    const int par = b->pipe_parity;
+    b->d_codes = b->d_codes_buf[par];
+    b->pipe_parity ^= 1;
+    // back-pressure: this step's encoder overwrites the code buffer that A(n-2) read, so E may lead A by at most two steps
+    if (b->pipe_evA[par]) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evA[par], 0));
+    if (b->pipe_evR) { SVA_HIP(hipStreamWaitEvent(se, b->pipe_evR, 0)); b->pipe_evR = nullptr; }
+    b->stream = se;
+    SVA_HIP(hipEventRecord(b->ev[0], se));
+    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->d_chunk, n, se));
+    SVA_TRY(b->enc_incremental ? encode_incremental(b, b->d_step, n, 1) : encode(b, b->d_step, n, 1));
+    hipLaunchKernelGGL(inc_kernel, dim3(1), dim3(64), 0, se, b->d_step, 1);
+    hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, se, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
+                       b->d_ncontent, b->d_step_content, B);
+    SVA_HIP(hipEventRecord(b->ev[1], se));
+    hipEvent_t evE = next_event(b);
+    SVA_HIP(hipEventRecord(evE, se));
+    // A(n)
+    SVA_HIP(hipStreamWaitEvent(sa, evE, 0));
+    if (b->pipe_evVc) SVA_HIP(hipStreamWaitEvent(sa, b->pipe_evVc, 0));
+    b->stream = sa;
+    int rc = 0;
+    for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
+    if (rc) { b->stream = se; return rc; }
+    SVA_HIP(hipEventRecord(b->ev[2], sa));
+    hipEvent_t evA = next_event(b);
+    SVA_HIP(hipEventRecord(evA, sa));
+    b->pipe_evA[par] = evA;
+    // V(n)
+    SVA_HIP(hipStreamWaitEvent(sv, evA, 0));
+    b->stream = sv;
+    hipError_t he = hipMemcpy2DAsync(b->d_vcodes, sizeof(int) * b->Tv, b->d_step_audio, sizeof(int) * chunk, sizeof(int) * chunk, (size_t)B * ncb,
+                                     hipMemcpyDeviceToDevice, sv);
+    if (he == hipSuccess) { b->pipe_evVc = next_event(b); he = hipEventRecord(b->pipe_evVc, sv); }
+    if (he != hipSuccess) { b->stream = se; SVA_HIP(he); }
+    rc = vocode(b, chunk, true);
+    b->stream = se;
+    if (rc) return rc;
+    SVA_HIP(hipEventRecord(b->ev[3], sv));
+    b->pipe_dirty = true;
+    b->out_stream = sv;
+    return 0;
+}
+
+int quiesce(sva_batch* b) {
+    if (!b || !b->pipe_dirty) return 0;
+    hipStream_t se = b->main_stream;
+    hipEvent_t e1 = next_event(b), e2 = next_event(b);
+    SVA_HIP(hipEventRecord(e1, b->sa));
+    SVA_HIP(hipEventRecord(e2, b->sv));
+    SVA_HIP(hipStreamWaitEvent(se, e1, 0));
+    SVA_HIP(hipStreamWaitEvent(se, e2, 0));
+    b->pipe_dirty = false;
+    b->pipe_evVc = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr;
+    b->out_stream = se;
+    return 0;
+}
+
 int step_body(sva_batch* b) {
     sva_engine* e = b->e;
     (void)e;
@@ -1720,7 +1818,13 @@ int step_body(sva_batch* b) {
     const bool steady = b->delay_filled && (b->h_ncontent + chunk >= d);
     if (steady) {
         const bool graph_ok = b->p.use_graph && b->noise_on_device && !b->forced_now && !b->prof_on;
-        if (graph_ok && b->steady_eager_steps >= 2) {
+        const bool pipe_ok = b->p.pipeline && b->sa && b->allow_pipe && b->noise_on_device && !b->forced_now && !b->prof_on && !b->p.use_graph &&
+                             b->voc_grouped && b->steady_eager_steps >= 2;
+        if (!pipe_ok) SVA_TRY(quiesce(b));
+        if (pipe_ok) {
+            SVA_TRY(steady_pipelined(b));
+            b->graph_step = false;
+        } else if (graph_ok && b->steady_eager_steps >= 2) {
             if (!b->graph_ready) {
                 // capture once: every launch argument is a fixed device pointer or a constant; per-step variation
                 // (ring position, KV positions, frame counters, sampler noise keys) lives in device memory
@@ -1750,12 +1854,22 @@ int step_body(sva_batch* b) {
         // mirror decides without a device round trip; doing it after the vocoder instead of before (as the reference
         // does) changes nothing: the vocoder consumes the codes just decoded, the re-prefill only rewrites KV state.
         std::vector<int> redo;
-        for (int i = 0; i < B; ++i)
-            if (b->h_last_pos[i] / 2 >= b->p.max_seq_frames) { SVA_TRY(reprefill_slot(b, i)); redo.push_back(i); }
-        SVA_TRY(ar_delay_fill(b, redo));       // prefill_src_condition4delay(src_content_codes[-d:]) for those slots only
-        return 0;
+        if (b->pipe_dirty) b->stream = b->sa;  // pipelined: the KV rewrite belongs to the AR stream (it already waited for E of this step)
+        int rrc = 0;
+        for (int i = 0; i < B && !rrc; ++i)
+            if (b->h_last_pos[i] / 2 >= b->p.max_seq_frames) { rrc = reprefill_slot(b, i); redo.push_back(i); }
+        if (!rrc) rrc = ar_delay_fill(b, redo);       // prefill_src_condition4delay(src_content_codes[-d:]) for those slots only
+        if (b->pipe_dirty) {
+            b->stream = b->main_stream;
+            if (!rrc && !redo.empty()) {       // E of the next step must not append to the content history before this has read it
+                b->pipe_evR = next_event(b);
+                SVA_HIP(hipEventRecord(b->pipe_evR, b->sa));
+            }
+        }
+        return rrc;
     }
     b->graph_step = false;
+    SVA_TRY(quiesce(b));
     SVA_HIP(hipEventRecord(b->ev[0], st));
     // E0: shift window / append chunk (:495-496), then E1..E8
     SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->d_chunk, n, st));
@@ -1782,6 +1896,7 @@ extern "C" int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const
     SVA_CHECK(b && pcm_in && pcm_out && b->begun, "sva_step: bad argument or sva_streams_begin not called");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     const sva_config& c = b->e->cfg;
     const int B = b->B, chunk = b->p.chunk_frames, n = 2048 * chunk, ncb = c.num_codebooks;
     hipStream_t st = b->stream;
@@ -1814,14 +1929,20 @@ extern "C" int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
     const int B = b->B, n = 2048 * b->p.chunk_frames;
-    hipStream_t st = b->stream;
+    hipStream_t st = b->main_stream;
+    b->stream = st;
     SVA_HIP(hipMemcpyAsync(b->d_chunk, d_pcm_in, sizeof(float) * (size_t)B * n, hipMemcpyDeviceToDevice, st));
     b->noise_on_device = true;
     b->forced_now = false;
     SVA_HIP(hipMemsetAsync(b->d_use_forced, 0, sizeof(int), st));
     b->gemm_flops = 0; b->gemm_launches = 0;
-    SVA_TRY(step_body(b));
-    SVA_HIP(hipMemcpy2DAsync(d_pcm_out, sizeof(float) * n, b->d_pcm, sizeof(float) * 2048 * b->Tv, sizeof(float) * n, B, hipMemcpyDeviceToDevice, st));
+    b->allow_pipe = true;
+    b->out_stream = st;
+    const int rc = step_body(b);
+    b->allow_pipe = false;
+    if (rc) return rc;
+    SVA_HIP(hipMemcpy2DAsync(d_pcm_out, sizeof(float) * n, b->d_pcm, sizeof(float) * 2048 * b->Tv, sizeof(float) * n, B, hipMemcpyDeviceToDevice,
+                             b->out_stream));
     return 0;
 }
 
@@ -1829,6 +1950,7 @@ extern "C" int sva_sync(sva_batch* b) {
     SVA_CHECK(b, "null batch");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     SVA_HIP(hipStreamSynchronize(b->stream));
     float t;
     if (!b->graph_step)
@@ -1856,6 +1978,7 @@ extern "C" int sva_ar_delay_fill(sva_batch* b, const int64_t* codes) {
     SVA_CHECK(b && codes && b->begun, "sva_ar_delay_fill: bad argument");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     const int B = b->B, d = b->p.delay;
     long long* tmp = (long long*)b->d_noise;       // scratch (>= B*d*8 bytes)
     SVA_TRY(h2d(b, tmp, codes, sizeof(int64_t) * (size_t)B * d));
@@ -1873,6 +1996,7 @@ extern "C" int sva_ar_decode_one(sva_batch* b, const int64_t* code, const float*
     SVA_CHECK(b->p.chunk_frames == 1, "sva_ar_decode_one needs chunk_frames == 1");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     const sva_config& c = b->e->cfg;
     const int B = b->B, ncb = c.num_codebooks;
     hipStream_t st = b->stream;
@@ -1915,6 +2039,7 @@ extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* 
     SVA_CHECK(b->B == 1 && b->p.chunk_frames == 1, "sva_generate: the offline path is batch 1 / chunk 1 like the reference");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
     const int D = c.ar_dim, d = b->p.delay, ncb = c.num_codebooks, nspk = c.timbre_tokens + 1;
@@ -1988,6 +2113,7 @@ extern "C" int sva_encode_window(sva_batch* b, const float* audio, int64_t* code
     SVA_CHECK(b && audio && codes_out, "null argument");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     hipStream_t st = b->stream;
     SVA_HIP(hipMemcpyAsync(b->ring, audio, sizeof(float) * (size_t)b->B * b->N, hipMemcpyHostToDevice, st));
     b->gemm_flops = 0; b->gemm_launches = 0;
@@ -2080,6 +2206,7 @@ extern "C" int sva_get_gemm_profile(sva_batch* b, double* total_ms, long* launch
     SVA_CHECK(b && total_ms && launches, "null argument");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     SVA_HIP(hipStreamSynchronize(b->stream));
     double tot = 0;
     for (int i = 0; i + 1 < b->prof_n; i += 2) {

@@ -32,7 +32,7 @@ class SvaStreamParams(C.Structure):
         ("n_streams", C.c_int), ("encode_window_frames", C.c_int), ("decode_window_frames", C.c_int),
         ("chunk_frames", C.c_int), ("delay", C.c_int), ("max_seq_frames", C.c_int), ("buffer_frames", C.c_int),
         ("max_prompt_frames", C.c_int), ("temperature", C.c_float), ("top_p", C.c_float),
-        ("voc_max_frames", C.c_int), ("use_graph", C.c_int), ("skip_semantic", C.c_int),
+        ("voc_max_frames", C.c_int), ("use_graph", C.c_int), ("skip_semantic", C.c_int), ("pipeline", C.c_int),
     ]
 
 
@@ -202,7 +202,7 @@ class Batch:
 
     def __init__(self, engine: Engine, n_streams=1, encode_window_frames=128, decode_window_frames=64, chunk_frames=1,
                  delay=2, max_seq_frames=768, buffer_frames=32, max_prompt_frames=256, temperature=0.7, top_p=0.7,
-                 voc_max_frames=None, use_graph=False, skip_semantic=False):
+                 voc_max_frames=None, use_graph=False, skip_semantic=False, pipeline=False):
         self.engine = engine
         self.lib = engine.lib
         p = SvaStreamParams()
@@ -212,6 +212,7 @@ class Batch:
         p.max_prompt_frames, p.temperature, p.top_p = max_prompt_frames, temperature, top_p
         p.voc_max_frames = voc_max_frames or chunk_frames
         p.use_graph, p.skip_semantic = int(use_graph), int(skip_semantic)
+        p.pipeline = int(pipeline)
         self.p = p
         self.B, self.chunk = n_streams, chunk_frames
         self.h = C.c_void_p()

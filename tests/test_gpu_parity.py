@@ -691,3 +691,43 @@ def test_error_behaviour(eng):
     b.close()
     with pytest.raises(RuntimeError):
         E.Engine({"tok.nothing": torch.zeros(1)})                    # missing tensors are named, not defaulted
+
+
+def test_stage_pipelining_equals_serial(eng):
+    """sva_step_device with p.pipeline (E(n+1) || A(n) || V(n-1) on three streams) reproduces the serial stepping bit for
+    bit over 70 chunks of two unequal streams, across re-prefills (max_seq_frames = 160) and with a tap + host-buffer step
+    interleaved (which quiesce the pipeline)."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    n_chunks, B = 70, 2
+    audio = torch.from_numpy(np.stack([synth_utterance(7600 + i, 2048 * n_chunks) for i in range(B)])).cuda()
+    chunks = audio.reshape(B, n_chunks, 2048).transpose(0, 1).contiguous()      # persistent: the engine reads its input asynchronously
+    torch.cuda.synchronize()
+
+    def run(pipeline):
+        b = E.Batch(eng, n_streams=B, max_seq_frames=160, buffer_frames=16, pipeline=pipeline)
+        for i in range(B):
+            ac, cc, style, timbre = synth_prompt(2900 + i, 40 + 30 * i)
+            b.prefill_prompt(i, cc, ac, style, timbre, noise_seed=500 + i)
+        b.begin()
+        out = torch.zeros(n_chunks, B, 2048, device="cuda")
+        pos = []
+        for k in range(n_chunks):
+            x = chunks[k]
+            if k == 33:                                                # a synchronous host-buffer step in the middle
+                out[k] = torch.from_numpy(b.step(x.cpu().numpy())).cuda()
+            else:
+                b.step_device(x.data_ptr(), out[k].data_ptr())
+            if k in (20, 50):
+                pos.append(b.tap("last_pos", (B,), np.int32).copy())   # taps drain the pipeline first
+        b.sync()
+        res = out.cpu().numpy()
+        b.close()
+        return res, np.stack(pos)
+
+    serial, pos_s = run(False)
+    piped, pos_p = run(True)
+    np.testing.assert_array_equal(pos_s, pos_p)
+    assert np.abs(serial[3:]).max() > 1e-3
+    np.testing.assert_array_equal(serial, piped)

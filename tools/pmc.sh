@@ -11,7 +11,7 @@ run() {  # name, counters...
   local NAME=$1; shift
   rm -rf gpurun_out/pmc_${TAG}_${NAME}
   SVA_CONCURRENCY=0 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${TAG}_${NAME} -o p -- \
-      python bench.py --no-cpu-baseline --no-roofline --no-graph "${BENCH_ARGS[@]}" > gpurun_out/pmc_${TAG}_${NAME}.log 2>&1
+      python bench.py --no-cpu-baseline --no-roofline --no-pipeline "${BENCH_ARGS[@]}" > gpurun_out/pmc_${TAG}_${NAME}.log 2>&1
   echo "pass ${NAME} rc=$?"
 }
 BENCH_ARGS=("$@")
