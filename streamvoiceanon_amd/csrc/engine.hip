@@ -2157,6 +2157,7 @@ extern "C" int sva_firefly_encode(sva_batch* b, const float* audio, int32_t* cod
 extern "C" long sva_get_tap(sva_batch* b, const char* what, void* out, long out_bytes) {
     if (!b || !what || !out) { set_error("null argument"); return -1; }
     hipSetDevice(b->e->device);
+    if (quiesce(b)) return -2;            // pipelined mode: join the stage streams first
     const sva_config& c = b->e->cfg;
     const std::string w(what);
     const void* src = nullptr;
