@@ -114,6 +114,10 @@ int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const float* noi
  * calls overlap on three streams. */
 int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm_out);
 int sva_sync(sva_batch* b);
+/* stream_infer's chunk loop (evaluations/infer_arvc.py:650-675) in one call: n_chunks consecutive sva_step_device steps over
+ * host arrays pcm_in / pcm_out float[B][n_chunks * 2048 * chunk] (staged through device memory, stages pipelined when
+ * sva_stream_params.pipeline is set), synchronised on return.  Same results as n_chunks calls of sva_step with noise = NULL. */
+int sva_stream_chunks(sva_batch* b, const float* pcm_in, float* pcm_out, int n_chunks);
 
 /* ---- seam-level entry points (parity tests, drop-in for the module calls) ------------------ */
 /* speech_tokenizer.encode (firefly_encoder.py:553-566) on full windows: audio host float[B][W*2048]

@@ -1946,6 +1946,33 @@ extern "C" int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm
     return 0;
 }
 
+extern "C" int sva_stream_chunks(sva_batch* b, const float* pcm_in, float* pcm_out, int n_chunks) {
+    SVA_CHECK(b && pcm_in && pcm_out && b->begun && n_chunks >= 1, "sva_stream_chunks: bad argument");
+    SVA_HIP(hipSetDevice(b->e->device));
+    (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
+    const int B = b->B, n = 2048 * b->p.chunk_frames;
+    const size_t per = (size_t)B * n;
+    float *d_in = nullptr, *d_out = nullptr;
+    SVA_HIP(hipMalloc((void**)&d_in, sizeof(float) * per * n_chunks));
+    SVA_HIP(hipMalloc((void**)&d_out, sizeof(float) * per * n_chunks));
+    hipStream_t st = b->main_stream;
+    // [B][n_chunks*n] on the host <-> [n_chunks][B][n] on the device (one contiguous block per step)
+    int rc = 0;
+    for (int k = 0; k < n_chunks && !rc; ++k)
+        if (hipMemcpy2DAsync(d_in + per * k, sizeof(float) * n, pcm_in + (size_t)k * n, sizeof(float) * n * n_chunks, sizeof(float) * n, B,
+                             hipMemcpyHostToDevice, st) != hipSuccess) { set_error("sva_stream_chunks: upload failed"); rc = -2; }
+    for (int k = 0; k < n_chunks && !rc; ++k) rc = sva_step_device(b, d_in + per * k, d_out + per * k);
+    if (!rc) rc = sva_sync(b);
+    for (int k = 0; k < n_chunks && !rc; ++k)
+        if (hipMemcpy2DAsync(pcm_out + (size_t)k * n, sizeof(float) * n * n_chunks, d_out + per * k, sizeof(float) * n, sizeof(float) * n, B,
+                             hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("sva_stream_chunks: download failed"); rc = -2; }
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) { set_error("sva_stream_chunks: sync failed"); rc = -2; }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
 extern "C" int sva_sync(sva_batch* b) {
     SVA_CHECK(b, "null batch");
     SVA_HIP(hipSetDevice(b->e->device));

@@ -73,6 +73,7 @@ def load_library():
     lib.sva_ar_delay_fill.argtypes = [vp, vp]
     lib.sva_ar_decode_one.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.sva_firefly_encode.argtypes = [vp, vp, vp]
+    lib.sva_stream_chunks.argtypes = [vp, vp, vp, i32]
     lib.sva_generate.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, C.c_uint64, vp, vp]
     lib.sva_get_tap.argtypes = [vp, C.c_char_p, vp, C.c_long]
     lib.sva_get_tap.restype = C.c_long
@@ -92,7 +93,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "sva_last_error", "sva_config_default", "sva_stream_params_default", "sva_engine_create",
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
-    "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_encode_window", "sva_firefly_encode",
+    "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_stream_chunks", "sva_encode_window", "sva_firefly_encode",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
     "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm",
 ]
@@ -340,6 +341,16 @@ class Batch:
 
     def step_device(self, d_in_ptr, d_out_ptr):
         _check(self.lib.sva_step_device(self.h, C.c_void_p(d_in_ptr), C.c_void_p(d_out_ptr)), "sva_step_device")
+
+    def stream_chunks(self, pcm_in):
+        """n consecutive chunk-steps over a host array [B, n_chunks * 2048 * chunk] in one call (device RNG; stages pipelined
+        when the batch was created with pipeline=True) -> converted audio of the same shape."""
+        x = np.ascontiguousarray(pcm_in, dtype=np.float32).reshape(self.B, -1)
+        n = 2048 * self.chunk
+        assert x.shape[1] % n == 0 and x.shape[1] >= n
+        out = np.empty_like(x)
+        _check(self.lib.sva_stream_chunks(self.h, _ptr(x), _ptr(out), x.shape[1] // n), "sva_stream_chunks")
+        return out
 
     def sync(self):
         _check(self.lib.sva_sync(self.h), "sva_sync")

@@ -118,7 +118,7 @@ class InferenceWrapper:
         print(f"Setting delay to {self.delay} frames")
 
     def setup_stream_caches(self, encode_window_frames=96, decode_window_frames=64, max_seq_frames=768, buffer_frames=32,
-                            decode_chunk_frames=1, delay=None):
+                            decode_chunk_frames=1, delay=None, pipeline=False):
         assert self._prompt is not None, "call prefill_prompt first (as stream_infer does, :631-645)"
         if delay is not None:
             self.delay = int(delay)
@@ -128,7 +128,7 @@ class InferenceWrapper:
         self.batch = E.Batch(self.engine, n_streams=1, encode_window_frames=encode_window_frames,
                              decode_window_frames=decode_window_frames, chunk_frames=decode_chunk_frames, delay=self.delay,
                              max_seq_frames=max_seq_frames, buffer_frames=buffer_frames, max_prompt_frames=self.max_prompt_frames,
-                             use_graph=self.use_graph)
+                             use_graph=self.use_graph, pipeline=pipeline and not self.use_graph)
         ac, cc, st, tm = self._prompt
         self.batch.prefill_prompt(0, cc.reshape(-1), ac.reshape(8, -1), st.reshape(-1), tm.reshape(32, -1), noise_seed=self._noise_seed)
         self.batch.begin()
@@ -250,12 +250,14 @@ class InferenceWrapper:
         self.prefill_prompt(None, max_prompt_frames=max_prompt_frames,
                             delay=2 if delay is None else delay, alpha=alpha, spk_emb_collate_type=spk_emb_collate_type,
                             prompt=prompt, noise_seed=noise_seed)
-        self.setup_stream_caches(encode_window_frames, decode_window_frames, max_seq_frames, buffer_frames, decode_chunk_frames)
+        self.setup_stream_caches(encode_window_frames, decode_window_frames, max_seq_frames, buffer_frames, decode_chunk_frames,
+                                 pipeline=True)
         n = self.SAMPLES_PER_FRAME * decode_chunk_frames
         pad = n - (src.shape[0] % n)              # :648-649 pads a FULL extra chunk when already aligned
         src = np.concatenate([np.zeros(pad, np.float32), src])
-        outs = [self.process_one_chunk(src[i:i + n][None]) for i in range(0, src.shape[0], n)]
-        pred = np.concatenate(outs, axis=1).reshape(-1)
+        # the chunk loop (:650-675) in one engine call: the whole file is known, so the stages of consecutive chunks
+        # overlap on the GPU; chunk by chunk through process_one_chunk gives the same samples
+        pred = self.batch.stream_chunks(src[None])[0]
         if save_result:
             self._save(pred, src_path, ref_path, out_dir)
         return pred

@@ -731,3 +731,23 @@ def test_stage_pipelining_equals_serial(eng):
     np.testing.assert_array_equal(pos_s, pos_p)
     assert np.abs(serial[3:]).max() > 1e-3
     np.testing.assert_array_equal(serial, piped)
+
+
+def test_stream_infer_one_call_equals_chunk_by_chunk(weights0):
+    """InferenceWrapper.stream_infer runs its chunk loop as one pipelined engine call (sva_stream_chunks); feeding the same
+    padded source chunk by chunk through process_one_chunk (synchronous host buffers) gives the same samples."""
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    ac, cc, style, timbre = synth_prompt(3000, 50)
+    src = synth_utterance(7700, 2048 * 20 + 500)
+    w = InferenceWrapper(weights=weights0)
+    whole = w.stream_infer(src, prompt=(ac, cc, style, timbre), delay=2, noise_seed=21)
+    w.prefill_prompt(prompt=(ac, cc, style, timbre), delay=2, noise_seed=21)
+    w.setup_stream_caches(encode_window_frames=128, decode_chunk_frames=1)
+    pad = 2048 - src.shape[0] % 2048
+    padded = np.concatenate([np.zeros(pad, np.float32), src])
+    parts = [np.asarray(w.process_one_chunk(padded[i:i + 2048][None])).reshape(-1) for i in range(0, padded.shape[0], 2048)]
+    np.testing.assert_array_equal(whole, np.concatenate(parts))
+    assert whole.shape == padded.shape and np.abs(whole[3 * 2048:]).max() > 1e-3
+    w.engine.close()
