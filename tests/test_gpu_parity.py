@@ -751,3 +751,37 @@ def test_stream_infer_one_call_equals_chunk_by_chunk(weights0):
     np.testing.assert_array_equal(whole, np.concatenate(parts))
     assert whole.shape == padded.shape and np.abs(whole[3 * 2048:]).max() > 1e-3
     w.engine.close()
+
+
+def test_config3_64_streams_10s_properties(eng):
+    """BASELINE.json configs[2] at full size: 64 concurrent 10 s utterances (216 chunks, prompt R = 107) through the pipelined
+    one-call path.  Size-independent properties: slots fed the same utterance / prompt / seed agree bit for bit wherever they
+    sit in the batch; a slot equals its solo run (codes identical, PCM to fp32 summation order); the slow-AR position follows
+    p = 33 + 2R + (2d - 1) + 2n - 1 with no re-prefill; output is finite, bounded and not silent."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    B, n_chunks, R, d = 64, 216, 107, 2
+    utts = [synth_utterance(1000 + u, 2048 * n_chunks) for u in range(32)]
+    prompts = [synth_prompt(2000 + u, R) for u in range(32)]
+    b = E.Batch(eng, n_streams=B, pipeline=True)
+    for s_ in range(B):
+        ac, cc, style, timbre = prompts[s_ % 32]
+        b.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=9000 + s_ % 32)
+    b.begin()
+    x = np.stack([utts[s_ % 32] for s_ in range(B)])
+    out = b.stream_chunks(x)
+    pos = b.tap("last_pos", (B,), np.int32)
+    b.close()
+    assert out.shape == (B, 2048 * n_chunks) and np.isfinite(out).all() and np.abs(out).max() <= 1.0
+    np.testing.assert_array_equal(out[:32], out[32:])                       # position in the batch does not matter
+    n_frames = n_chunks - d
+    assert (pos == 33 + 2 * R + (2 * d - 1) + 2 * n_frames - 1).all()
+    assert not out[:, :d * 2048].any() and np.abs(out[:, d * 2048:]).max() > 0.01
+    solo = E.Batch(eng, n_streams=1, pipeline=True)
+    ac, cc, style, timbre = prompts[5]
+    solo.prefill_prompt(0, cc, ac, style, timbre, noise_seed=9005)
+    solo.begin()
+    one = solo.stream_chunks(utts[5][None])
+    solo.close()
+    assert np.abs(one[0] - out[5]).max() <= PCM_TOL
