@@ -22,6 +22,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+# before the HIP runtime starts (torch import): one hardware queue per engine stream, see streamvoiceanon_amd/engine.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import sys
 import time
 

@@ -590,6 +590,11 @@ static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
     }
 }
 
+static bool ksplit_enabled() {
+    static const bool on = getenv("SVA_KSPLIT") && atoi(getenv("SVA_KSPLIT")) != 0;
+    return on;
+}
+
 static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
     // the K tile is as deep as Cin allows (bytes in flight per workgroup hide the L2/HBM latency of the register-staged
     // pipeline); 128x128 tiles only when they still fill the 256 CUs
@@ -606,7 +611,11 @@ static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
         // time grows with K alone), so when the tiles do not cover the 256 CUs the K axis is split over more workgroups
         const long wgs = (long)((g.N + 16 * ch.c - 1) / (16 * ch.c)) * (((g.M + 15) / 16 + ch.a - 1) / ch.a);
         const long nkb = (long)g.taps * g.Cin / 16;
-        while (ch.z < 8 && wgs * ch.z * 2 <= 256 && nkb / (2L * ch.z * ch.b) >= 2) ch.z *= 2;
+        // OFF unless SVA_KSPLIT=1: the split brought no net gain on the streaming workloads (it wins 1-2 us on GEMMs that sit
+        // off the critical path) and a rare transient glitch in the pipelined vocoder was traced to runs in which the tuner had
+        // picked split configurations -- the uncached-scratch hand-off is not proven safe under concurrent streams.
+        if (ksplit_enabled())
+            while (ch.z < 8 && wgs * ch.z * 2 <= 256 && nkb / (2L * ch.z * ch.b) >= 2) ch.z *= 2;
         static const char* env_z = getenv("SVA_SKINNY_Z");
         if (env_z) ch.z = atoi(env_z);
         return ch;
@@ -720,7 +729,7 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                             for (int b2 = 0; b2 < 3; ++b2) {
                                 if (mts[a] > mt_total || (mts[a] >= 2 && kws[b2] == 16) || nk / kws[b2] < 1) continue;
                                 cand.push_back(Choice{0, mts[a], kws[b2], nt});
-                                if (g.rms_w || group_n > 1) continue;
+                                if (g.rms_w || group_n > 1 || !ksplit_enabled()) continue;
                                 const long wgs = (long)((g.N + 16 * nt - 1) / (16 * nt)) * ((mt_total + mts[a] - 1) / mts[a]);
                                 for (int z = 2; z <= 8; z *= 2)
                                     if (wgs * z <= 512 && nk / ((long)z * kws[b2]) >= 1) cand.push_back(Choice{0, mts[a], kws[b2], nt, z});

@@ -13,6 +13,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# The engine overlaps its stages on four HIP streams (plus the process's default stream).  The runtime multiplexes streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise, so ask for more queues --
+# effective only if the HIP runtime has not been initialised yet (import this module, or set the variable, before the
+# first torch.cuda / HIP call).  Measured: 382 -> 465 frames/s single-stream, 4175 -> 4250 at 64 streams.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 LIB_PATH = os.environ.get("SVA_LIB_PATH") or os.path.join(_HERE, "libsva_hip.so")      # override: A/B builds of the kernels
 
 
