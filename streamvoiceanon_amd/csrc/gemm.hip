@@ -410,9 +410,11 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
     }
     if (Z == 1) return;
     // The last workgroup to arrive for this output tile sums the Z partials in split order (deterministic) and runs the
-    // epilogue.  ks_ws / ks_cnt are uncached memory: a store is globally visible once it has been acknowledged (vmcnt),
-    // which the workgroup-scope release before the barrier waits for.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // epilogue.  ks_ws / ks_cnt are uncached memory, so the reader needs no L2 invalidate; the WRITERS do need an agent-scope
+    // release: with a workgroup-scope one (stores merely acknowledged) another XCD occasionally read a stale partial
+    // (tools/pipe_stress.py with SVA_KSPLIT=1 caught it), and the agent-scope release makes the split slower than not
+    // splitting on every shape measured -- which is why the feature stays off.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) {
         const unsigned old = atomicAdd(g.ks_cnt + tile, 1u);
@@ -611,9 +613,8 @@ static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
         // time grows with K alone), so when the tiles do not cover the 256 CUs the K axis is split over more workgroups
         const long wgs = (long)((g.N + 16 * ch.c - 1) / (16 * ch.c)) * (((g.M + 15) / 16 + ch.a - 1) / ch.a);
         const long nkb = (long)g.taps * g.Cin / 16;
-        // OFF unless SVA_KSPLIT=1: the split brought no net gain on the streaming workloads (it wins 1-2 us on GEMMs that sit
-        // off the critical path) and a rare transient glitch in the pipelined vocoder was traced to runs in which the tuner had
-        // picked split configurations -- the uncached-scratch hand-off is not proven safe under concurrent streams.
+        // OFF unless SVA_KSPLIT=1: with the release the hand-off needs for correctness (see the kernel) a split launch is
+        // slower than an unsplit one on every shape of this model.
         if (ksplit_enabled())
             while (ch.z < 8 && wgs * ch.z * 2 <= 256 && nkb / (2L * ch.z * ch.b) >= 2) ch.z *= 2;
         static const char* env_z = getenv("SVA_SKINNY_Z");
