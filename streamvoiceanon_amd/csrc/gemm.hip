@@ -31,17 +31,18 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 template <int BM, int BN, int WM, int WN, int BK>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmGroup gg) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvGemmGroup gg) {
+    constexpr int NTH = 64 * WM * WN;             // 4 or 8 waves
     const ConvGemm& g = gg.g[blockIdx.z];
     constexpr int TM = BM / WM, TN = BN / WN;     // wave tile
     constexpr int MI = TM / 16, NI = TN / 16;
     constexpr int LS = BK + 4;                    // LDS row stride: 16-byte aligned rows; row*LS mod 64 banks is a permutation of
                                                   // the multiples of 4 over 16 rows, so the ds_read_b128 fragments are conflict-free
     constexpr int F4R = BK / 4;                   // float4 per tile row
-    constexpr int RPP = 256 / F4R;                // rows covered per pass of the 256 threads
+    constexpr int RPP = NTH / F4R;                // rows covered per pass of the workgroup's threads
     constexpr int A_LD = (BM + RPP - 1) / RPP;
     constexpr int B_LD = (BN + RPP - 1) / RPP;
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                             // [2][BM][LS]
     float* Bs = smem + 2 * BM * LS;               // [2][BN][LS]
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmGroup gg) 
     if (g.w13) {
         // SwiGLU: tile columns alternate 16 x w1 | 16 x w3; output column (n0 >> 1) + c
         constexpr int OC4 = BN / 8;                // float4 chunks of output per row
-        for (int idx = tid; idx < BM * OC4; idx += 256) {
+        for (int idx = tid; idx < BM * OC4; idx += NTH) {
             const int row = idx / OC4, q = idx - row * OC4;
             const int m = bm0 + row;
             const int grp = q >> 2, c4 = (q & 3) * 4;       // 16-wide group, offset inside it
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmGroup gg) 
         return;
     }
     constexpr int C4 = BN / 4;
-    for (int idx = tid; idx < BM * C4; idx += 256) {
+    for (int idx = tid; idx < BM * C4; idx += NTH) {
         const int row = idx / C4, c4 = (idx - row * C4) * 4;
         const int m = bm0 + row, n = bn0 + c4;
         if (m >= g.M || n >= g.N) continue;
@@ -561,13 +562,13 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
     ConvGemmGroup gg;
     if (t_group) gg = *t_group; else gg.g[0] = g;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, gg.n);
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK>), grid, dim3(256), smem, st, gg);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK>), grid, dim3(64 * WM * WN), smem, st, gg);
     return 0;
 }
 
 // One dispatch decision: kind 0 = small-M K-split kernel (a = rows/16 per workgroup, b = K-split waves, c = 16-column
 // tiles per wave); kind 1 = LDS-tiled kernel (a: 0 = 64x64, 1 = 128x128, 2 = 128x32, 3 = 256x16, 4 = 128x64, 5 = 64x128,
-// 6 = 256x64; 4..6 are reached through the autotuner only).
+// 6 = 256x64, 7 = 256x128 on 8 waves; 4..7 are reached through the autotuner only).
 struct Choice { int kind, a, b, c; int z = 1; };      // z: grid-level K split of the small-M kernel
 
 static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
@@ -585,6 +586,7 @@ static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
         case 4: return bk >= 32 ? launch_t<128, 64, 2, 2, 32>(g, st) : launch_t<128, 64, 2, 2, 16>(g, st);
         case 5: return bk >= 32 ? launch_t<64, 128, 2, 2, 32>(g, st) : launch_t<64, 128, 2, 2, 16>(g, st);
         case 6: return bk >= 32 ? launch_t<256, 64, 4, 1, 32>(g, st) : launch_t<256, 64, 4, 1, 16>(g, st);
+        case 7: return bk >= 32 ? launch_t<256, 128, 4, 2, 32>(g, st) : launch_t<256, 128, 4, 2, 16>(g, st);       // 8 waves, 64x64 per wave
         default:
             if (bk == 64) return launch_t<64, 64, 2, 2, 64>(g, st);
             if (bk == 32) return launch_t<64, 64, 2, 2, 32>(g, st);
@@ -743,6 +745,7 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                     if (g.M >= 128 && g.N >= 64) cand.push_back(Choice{1, 4, 0, 0});
                     if (g.M >= 64 && g.N >= 128) cand.push_back(Choice{1, 5, 0, 0});
                     if (g.M >= 256 && g.N >= 64) cand.push_back(Choice{1, 6, 0, 0});
+                    if (g.M >= 256 && g.N >= 128) cand.push_back(Choice{1, 7, 0, 0});
                     if (g.N <= 64) cand.push_back(Choice{1, 2, 0, 0});
                     if (g.N <= 16 && !g.w13) cand.push_back(Choice{1, 3, 0, 0});
                 }
@@ -776,7 +779,7 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
     SVA_CHECK(kind == 0 || kind == 1, "conv_gemm_choice: kind");
     if (kind == 0) SVA_CHECK((a == 1 || a == 2 || a == 3 || a == 4) && (b == 4 || b == 8 || (b == 16 && a == 1)) && (c == 1 || (c == 2 && g.N % 32 == 0)),
                              "conv_gemm_choice: bad small-M configuration");
-    else SVA_CHECK(a >= 0 && a <= 6 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: bad tile variant");
+    else SVA_CHECK(a >= 0 && a <= 7 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: bad tile variant");
     SVA_TRY_RC(launch_choice(g, st, Choice{kind, a, b, c}));
     SVA_HIP(hipGetLastError());
     return 0;
