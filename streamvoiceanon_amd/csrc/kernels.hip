@@ -1180,19 +1180,20 @@ int launch_gather_rows(const float* table, const int* idx, int idx_stride, int i
 // codebook_embeddings[code_i + i * codebook_size]
 __global__ void audio_embed_kernel(const float* __restrict__ table, const int* __restrict__ codes, int code_stride,
                                    int cb_stride, int ncb, int codebook_size, int D, float* __restrict__ out, int ldo) {
+    // one output element per thread (grid.y covers D): the ncb gathers of a thread are independent loads
     const int r = blockIdx.x;
-    for (int c = threadIdx.x; c < D; c += blockDim.x) {
-        float acc = 0.f;
-        for (int i = 0; i < ncb; ++i) {
-            const int code = codes[(long)r * code_stride + (long)i * cb_stride];
-            acc += table[((long)code + (long)i * codebook_size) * D + c];
-        }
-        out[(long)r * ldo + c] = acc;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float acc = 0.f;
+    for (int i = 0; i < ncb; ++i) {
+        const int code = codes[(long)r * code_stride + (long)i * cb_stride];
+        acc += table[((long)code + (long)i * codebook_size) * D + c];
     }
+    out[(long)r * ldo + c] = acc;
 }
 int launch_audio_embed(const float* table, const int* codes, int code_stride, int cb_stride, int rows, int ncb,
                        int codebook_size, int D, float* out, int ldo, hipStream_t st) {
-    hipLaunchKernelGGL(audio_embed_kernel, dim3(rows), dim3(256), 0, st, table, codes, code_stride, cb_stride, ncb,
+    hipLaunchKernelGGL(audio_embed_kernel, dim3(rows, (D + 255) / 256), dim3(256), 0, st, table, codes, code_stride, cb_stride, ncb,
                        codebook_size, D, out, ldo);
     SVA_HIP(hipGetLastError());
     return 0;
@@ -1619,8 +1620,14 @@ __global__ __launch_bounds__(1024) void sampler_small_kernel(const float* __rest
                 __syncthreads();
                 ov = xv[tid ^ j]; oi = xi[tid ^ j];
             } else {
-                ov = __shfl_xor(v, j, 64);
-                oi = __shfl_xor(id, j, 64);
+                switch (j) {        // DPP inside a 16-lane row, ds_bpermute beyond
+                    case 1: ov = lane_xor_f<1>(v); oi = lane_xor_i<1>(id); break;
+                    case 2: ov = lane_xor_f<2>(v); oi = lane_xor_i<2>(id); break;
+                    case 4: ov = lane_xor_f<4>(v); oi = lane_xor_i<4>(id); break;
+                    case 8: ov = lane_xor_f<8>(v); oi = lane_xor_i<8>(id); break;
+                    case 16: ov = lane_xor_f<16>(v); oi = lane_xor_i<16>(id); break;
+                    default: ov = lane_xor_f<32>(v); oi = lane_xor_i<32>(id); break;
+                }
             }
             const bool lower = (tid & j) == 0;
             const bool mine_first = (v > ov) || (v == ov && id < oi);       // my element precedes the partner's in descending order
