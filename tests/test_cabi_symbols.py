@@ -47,3 +47,31 @@ def test_no_cpu_fallback_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         E.Engine({})
+
+
+def _struct_fields(name):
+    """(type, field, array length) of a struct in include/sva.h, in declaration order."""
+    src = open(os.path.join(ROOT, "include", "sva.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, flags=re.S).group(1)
+    out = []
+    for ty, field, arr in re.findall(r"\b(int|float)\s+([a-z_0-9]+)(?:\[(\d+)\])?\s*;", body):
+        out.append((ty, field, int(arr) if arr else 0))
+    return out
+
+
+def test_ctypes_structs_mirror_the_header():
+    """The ctypes Structures of the binding have the header's fields, types and order: a mismatch would corrupt memory
+    silently (the library writes sizeof(struct) bytes through the pointer it is given)."""
+    from streamvoiceanon_amd import engine as E
+
+    for cname, py in (("sva_config", E.SvaConfig), ("sva_stream_params", E.SvaStreamParams)):
+        want = _struct_fields(cname)
+        got = []
+        for field, ctype in py._fields_:
+            if hasattr(ctype, "_length_"):
+                got.append(("int" if ctype._type_ is ctypes.c_int else "float", field, ctype._length_))
+            else:
+                got.append(("int" if ctype is ctypes.c_int else "float", field, 0))
+        assert got == want, cname
+        assert ctypes.sizeof(py) == sum(4 * max(n, 1) for _, _, n in want)
