@@ -208,6 +208,7 @@ struct sva_batch {
     int* d_forced = nullptr;               // [B][8][chunk]
     float* d_noise = nullptr;              // [B][chunk][vocab + 8*cb]
     bool noise_on_device = false;
+    int h_use_forced = -1;                 // host mirror of d_use_forced (-1 = unknown): skips the per-step reset launch
     // histories (per slot, linear with device counters)
     int hist_cap = 0;
     int* d_slot_list = nullptr;            // [B] scratch list of slots for partial delay fills
@@ -243,6 +244,14 @@ struct sva_batch {
     sva::Act y3[5][3];                     // y_{b,3}: branch outputs before the ParallelBlock mean (no history)
     bool voc_grouped = true;               // the three ResBlock branches of a level share one launch per conv stage
     float* d_pcm = nullptr;                // [B][2048*Tv]
+    // per-step redirections of the device-buffer step (no staging copies): chunk source, PCM destination, codes source
+    const float* step_src = nullptr;       // ring_write reads the caller's chunk directly
+    float* pcm_dst = nullptr;              // conv_post_tanh writes straight into the caller's buffer ([B][2048*chunk])
+    long pcm_dst_bstride = 0;
+    const int* voc_codes = nullptr;        // FSQ decode reads the step's audio codes in place
+    long voc_codes_bstride = 0, voc_codes_gstride = 0;
+    hipEvent_t voc_codes_event = nullptr;  // recorded right after the FSQ decode has been enqueued (pipelined hand-off)
+    bool pcm_direct_done = false;
     int* d_vcodes = nullptr;               // [B][8][Tv]
     std::vector<sva::ShiftDesc> shift_host;
     sva::ShiftDesc* d_shift = nullptr;

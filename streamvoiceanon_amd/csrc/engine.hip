@@ -590,7 +590,8 @@ int cnx_block(sva_batch* b, const CNX& c, Act& x, int T, float* h1, float* h2, A
 // Conv front-end (mel -> stem -> 18 ConvNeXt -> 2x (conv k2 s2 + ConvNeXt)) on the FIRST `Tm` mel frames of the
 // current window, zero left padding exactly as the reference's window pass (causal net: row j depends on rows <= j).
 // Tm = T0: the full-window formulation; Tm = head rows: the head pass of the exact-incremental formulation.
-int enc_frontend_window(sva_batch* b, const int* step_ptr, int n_chunk, int add, int Tm, const EncFront* front = nullptr) {
+int enc_frontend_window(sva_batch* b, const int* step_ptr, int n_chunk, int add, int Tm, const EncFront* front = nullptr,
+                        Act* tokens_out = nullptr) {
     sva_engine* e = b->e;
     const EncFront& F = front ? *front : e->tokf;
     const sva_config& c = e->cfg;
@@ -631,7 +632,11 @@ int enc_frontend_window(sva_batch* b, const int* step_ptr, int n_chunk, int add,
         in.H = 0;
         SVA_TRY(conv_act(b, in, Tm / 4, 2, 1, 2, F.ds_conv[1], b->d2));
     }
-    SVA_TRY(cnx_block(b, F.ds_cnx[1], b->d2, Tm / 4, b->h1, b->h2));
+    if (tokens_out) {            // last block out of place: its rows land in the caller's token buffer (rows [H, H + Tm/4))
+        SVA_TRY(cnx_block(b, F.ds_cnx[1], b->d2, Tm / 4, b->h1, b->h2, tokens_out));
+    } else {
+        SVA_TRY(cnx_block(b, F.ds_cnx[1], b->d2, Tm / 4, b->h1, b->h2));
+    }
     return 0;
 }
 
@@ -764,9 +769,7 @@ int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add) 
     int rc = enc_frontend_stream(b, step_ptr, n_chunk, add);                     // c newest tokens -> d2c tail
     b->stream = st;
     if (rc) return rc;
-    SVA_TRY(enc_frontend_window(b, step_ptr, n_chunk, add, 4 * b->Ht));            // head pass -> d2 rows [0, Ht)
-    SVA_HIP(hipMemcpy2DAsync(b->d2c.p, sizeof(float) * b->d2c.bstride, b->d2.p + (long)b->d2.H * D, sizeof(float) * b->d2.bstride,
-                             sizeof(float) * (size_t)b->Ht * D, b->B, hipMemcpyDeviceToDevice, st));
+    SVA_TRY(enc_frontend_window(b, step_ptr, n_chunk, add, 4 * b->Ht, nullptr, &b->d2c));   // head pass -> d2c rows [0, Ht) directly
     if (par) SVA_TRY(stream_fork(b, b->aux[0], st));                             // join
     (void)c;
     return enc_transformer(b, b->d2c, b->p.chunk_frames);
@@ -913,8 +916,10 @@ __global__ void ar_finish_frame_kernel(const int* __restrict__ tok, int ncb, int
 }
 
 __global__ void append_content_kernel(const long long* __restrict__ codes, int T2, int chunk, int* __restrict__ content_hist,
-                                      int hist_cap, int* __restrict__ ncontent, int* __restrict__ step_content, int B) {
+                                      int hist_cap, int* __restrict__ ncontent, int* __restrict__ step_content, int B,
+                                      int* __restrict__ step_counter) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && step_counter) *step_counter += 1;          // the chunk counter (ring position) advances with the step
     if (b >= B) return;
     const int n = ncontent[b];
     for (int i = 0; i < chunk; ++i) {
@@ -1146,7 +1151,9 @@ int vocode(sva_batch* b, int T, bool shift) {
     const int B = b->B, V = c.voc_dim, G = c.num_codebooks;
     hipStream_t st = b->stream;
     SVA_CHECK(T >= 1 && T <= b->Tv, "vocode: T out of range");
-    SVA_TRY(launch_fsq_decode(b->d_vcodes, (long)G * b->Tv, b->Tv, B, T, G, V / G, e->fsq_W, e->fsq_b, b->zq.p, b->zq.bstride, 0, V, st));
+    if (b->voc_codes) SVA_TRY(launch_fsq_decode(b->voc_codes, b->voc_codes_bstride, b->voc_codes_gstride, B, T, G, V / G, e->fsq_W, e->fsq_b, b->zq.p, b->zq.bstride, 0, V, st));
+    else SVA_TRY(launch_fsq_decode(b->d_vcodes, (long)G * b->Tv, b->Tv, B, T, G, V / G, e->fsq_W, e->fsq_b, b->zq.p, b->zq.bstride, 0, V, st));
+    if (b->voc_codes_event) SVA_HIP(hipEventRecord(b->voc_codes_event, st));
     // upsample.0/1: ConvTranspose k=s=2 (stateless) + ConvNeXtBlock  (fsq.py:61-74)
     SVA_TRY(gemm_call(b, b->zq.p, b->zq.bstride, 0, V, B, T, 1, 1, 1, V, e->up_conv[0], b->u0.p, b->u0.bstride, (long)b->u0.H * V, 2 * V));
     SVA_TRY(cnx_block(b, e->up_cnx[0], b->u0, 2 * T, b->vh1, b->vh2, &b->v0));
@@ -1240,7 +1247,8 @@ int vocode(sva_batch* b, int T, bool shift) {
         if (par) SVA_TRY(stream_fork(b, b->aux[1], st));      // join: branch 2's last conv is ordered after 0 and 1
     }
     SVA_TRY(launch_conv_post_tanh(b->S[5].p, b->S[5].bstride, (long)(b->S[5].H - (e->post_k - 1)) * b->S[5].C, B, (int)Tl, b->S[5].C, e->post_k,
-                                  e->post_w, e->post_b, b->d_pcm, 2048L * b->Tv, 0, st));
+                                  e->post_w, e->post_b, b->pcm_dst ? b->pcm_dst : b->d_pcm, b->pcm_dst ? b->pcm_dst_bstride : 2048L * b->Tv, 0, st));
+    if (b->pcm_dst) b->pcm_direct_done = true;
     if (shift) {
         // update T in the descriptors if it changed (host table re-uploaded; rare)
         bool dirty = false;
@@ -1744,17 +1752,17 @@ int steady_launches(sva_batch* b, bool timing_events) {
     const int B = b->B, chunk = b->p.chunk_frames, n = 2048 * chunk, ncb = c.num_codebooks;
     hipStream_t st = b->stream;
     if (timing_events) SVA_HIP(hipEventRecord(b->ev[0], st));
-    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->d_chunk, n, st));
+    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, st));
     SVA_TRY(b->enc_incremental ? encode_incremental(b, b->d_step, n, 1) : encode(b, b->d_step, n, 1));
-    hipLaunchKernelGGL(inc_kernel, dim3(1), dim3(64), 0, st, b->d_step, 1);
     hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
-                       b->d_ncontent, b->d_step_content, B);
+                       b->d_ncontent, b->d_step_content, B, b->d_step);
     if (timing_events) SVA_HIP(hipEventRecord(b->ev[1], st));
     for (int ci = 0; ci < chunk; ++ci) SVA_TRY(ar_decode_frame(b, ci));          // :534-538
     if (timing_events) SVA_HIP(hipEventRecord(b->ev[2], st));
-    SVA_HIP(hipMemcpy2DAsync(b->d_vcodes, sizeof(int) * b->Tv, b->d_step_audio, sizeof(int) * chunk, sizeof(int) * chunk, (size_t)B * ncb,
-                             hipMemcpyDeviceToDevice, st));
-    SVA_TRY(vocode(b, chunk, true));
+    b->voc_codes = b->d_step_audio; b->voc_codes_bstride = (long)ncb * chunk; b->voc_codes_gstride = chunk;      // read in place
+    const int vrc = vocode(b, chunk, true);
+    b->voc_codes = nullptr;
+    if (vrc) return vrc;
     if (timing_events) SVA_HIP(hipEventRecord(b->ev[3], st));
     return 0;
 }
@@ -1785,11 +1793,10 @@ int steady_pipelined(sva_batch* b) {
     if (b->pipe_evR) { SVA_HIP(hipStreamWaitEvent(se, b->pipe_evR, 0)); b->pipe_evR = nullptr; }
     b->stream = se;
     SVA_HIP(hipEventRecord(b->ev[0], se));
-    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->d_chunk, n, se));
+    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
     SVA_TRY(b->enc_incremental ? encode_incremental(b, b->d_step, n, 1) : encode(b, b->d_step, n, 1));
-    hipLaunchKernelGGL(inc_kernel, dim3(1), dim3(64), 0, se, b->d_step, 1);
     hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, se, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
-                       b->d_ncontent, b->d_step_content, B);
+                       b->d_ncontent, b->d_step_content, B, b->d_step);
     SVA_HIP(hipEventRecord(b->ev[1], se));
     hipEvent_t evE = next_event(b);
     SVA_HIP(hipEventRecord(evE, se));
@@ -1807,11 +1814,11 @@ int steady_pipelined(sva_batch* b) {
     // V(n)
     SVA_HIP(hipStreamWaitEvent(sv, evA, 0));
     b->stream = sv;
-    hipError_t he = hipMemcpy2DAsync(b->d_vcodes, sizeof(int) * b->Tv, b->d_step_audio, sizeof(int) * chunk, sizeof(int) * chunk, (size_t)B * ncb,
-                                     hipMemcpyDeviceToDevice, sv);
-    if (he == hipSuccess) { b->pipe_evVc = next_event(b); he = hipEventRecord(b->pipe_evVc, sv); }
-    if (he != hipSuccess) { b->stream = se; SVA_HIP(he); }
+    b->voc_codes = b->d_step_audio; b->voc_codes_bstride = (long)ncb * chunk; b->voc_codes_gstride = chunk;      // read in place ...
+    b->pipe_evVc = next_event(b);
+    b->voc_codes_event = b->pipe_evVc;       // ... and A(n+1) may overwrite them once the FSQ decode has run
     rc = vocode(b, chunk, true);
+    b->voc_codes = nullptr; b->voc_codes_event = nullptr;
     b->stream = se;
     if (rc) return rc;
     SVA_HIP(hipEventRecord(b->ev[3], sv));
@@ -1896,11 +1903,10 @@ int step_body(sva_batch* b) {
     SVA_TRY(quiesce(b));
     SVA_HIP(hipEventRecord(b->ev[0], st));
     // E0: shift window / append chunk (:495-496), then E1..E8
-    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->d_chunk, n, st));
+    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, st));
     SVA_TRY(b->enc_incremental ? encode_incremental(b, b->d_step, n, 1) : encode(b, b->d_step, n, 1));
-    hipLaunchKernelGGL(inc_kernel, dim3(1), dim3(64), 0, st, b->d_step, 1);
     hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
-                       b->d_ncontent, b->d_step_content, B);
+                       b->d_ncontent, b->d_step_content, B, b->d_step);
     b->h_step += 1;
     b->h_ncontent += chunk;
     SVA_HIP(hipEventRecord(b->ev[1], st));
@@ -1932,6 +1938,7 @@ extern "C" int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const
     b->forced_now = forced_codes != nullptr;
     const int uf = forced_codes ? 1 : 0;
     SVA_HIP(hipMemcpyAsync(b->d_use_forced, &uf, sizeof(int), hipMemcpyHostToDevice, st));
+    b->h_use_forced = uf;
     if (forced_codes) SVA_HIP(hipMemcpyAsync(b->d_forced, forced_codes, sizeof(int) * (size_t)B * ncb * chunk, hipMemcpyHostToDevice, st));
     SVA_HIP(hipStreamSynchronize(st));
     b->gemm_flops = 0; b->gemm_launches = 0;
@@ -1955,18 +1962,26 @@ extern "C" int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm
     const int B = b->B, n = 2048 * b->p.chunk_frames;
     hipStream_t st = b->main_stream;
     b->stream = st;
-    SVA_HIP(hipMemcpyAsync(b->d_chunk, d_pcm_in, sizeof(float) * (size_t)B * n, hipMemcpyDeviceToDevice, st));
+    // no staging: the ring write reads the caller's chunk, the vocoder's last kernel writes the caller's PCM buffer and
+    // the FSQ decode reads the step's codes in place (each staging copy was a kernel of its own in a chain whose length is
+    // what bounds the step)
+    const bool direct = !b->p.use_graph;       // a captured graph bakes its pointers: it keeps the fixed staging buffers
+    if (direct) b->step_src = d_pcm_in;
+    else SVA_HIP(hipMemcpyAsync(b->d_chunk, d_pcm_in, sizeof(float) * (size_t)B * n, hipMemcpyDeviceToDevice, st));
     b->noise_on_device = true;
     b->forced_now = false;
-    SVA_HIP(hipMemsetAsync(b->d_use_forced, 0, sizeof(int), st));
+    if (b->h_use_forced != 0) { SVA_HIP(hipMemsetAsync(b->d_use_forced, 0, sizeof(int), st)); b->h_use_forced = 0; }
     b->gemm_flops = 0; b->gemm_launches = 0;
     b->allow_pipe = true;
     b->out_stream = st;
+    b->pcm_dst = direct ? d_pcm_out : nullptr; b->pcm_dst_bstride = n; b->pcm_direct_done = false;
     const int rc = step_body(b);
     b->allow_pipe = false;
+    b->step_src = nullptr; b->pcm_dst = nullptr;
     if (rc) return rc;
-    SVA_HIP(hipMemcpy2DAsync(d_pcm_out, sizeof(float) * n, b->d_pcm, sizeof(float) * 2048 * b->Tv, sizeof(float) * n, B, hipMemcpyDeviceToDevice,
-                             b->out_stream));
+    if (!b->pcm_direct_done)     // delay warm-up steps run no vocoder: their zeros come from d_pcm
+        SVA_HIP(hipMemcpy2DAsync(d_pcm_out, sizeof(float) * n, b->d_pcm, sizeof(float) * 2048 * b->Tv, sizeof(float) * n, B, hipMemcpyDeviceToDevice,
+                                 b->out_stream));
     return 0;
 }
 
@@ -2060,6 +2075,7 @@ extern "C" int sva_ar_decode_one(sva_batch* b, const int64_t* code, const float*
     if (noise) SVA_TRY(h2d(b, b->d_noise, noise, sizeof(float) * (size_t)B * (c.ar_vocab + ncb * c.codebook_size)));
     const int uf = forced ? 1 : 0;
     SVA_TRY(h2d(b, b->d_use_forced, &uf, sizeof(int)));
+    b->h_use_forced = uf;
     if (forced) SVA_TRY(h2d(b, b->d_forced, forced, sizeof(int) * (size_t)B * ncb));
     SVA_TRY(ar_decode_frame(b, 0));
     for (int i = 0; i < B; ++i) { b->h_last_pos[i] += 2; b->h_nframes[i] += 1; }
@@ -2138,6 +2154,7 @@ extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* 
     const int nstride = c.ar_vocab + ncb * c.codebook_size;
     const int zero = 0;
     SVA_TRY(h2d(b, b->d_use_forced, &zero, sizeof(int)));
+    b->h_use_forced = 0;
     b->noise_on_device = (noise == nullptr);
     for (int i = 0; i < S; ++i) {
         if (noise) SVA_TRY(h2d(b, b->d_noise, noise + (size_t)i * nstride, sizeof(float) * nstride));
