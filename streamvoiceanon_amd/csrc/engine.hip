@@ -572,10 +572,18 @@ int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs
     SVA_CHECK(x.H >= 6 && x.C == C, "cnx_block: bad activation");
     Act& o = out ? *out : x;
     SVA_CHECK(o.C == C, "cnx_block: bad output activation");
-    SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, h1_bs, b->stream));
     ConvGemm p1;
     p1.act = ACT_GELU;
-    SVA_TRY(gemm_call(b, h1, h1_bs, 0, C, b->B, T, 1, 1, 1, C, c.pw1, h2, h2_bs, 0, 4 * C, p1));
+    static const bool fuse_off = getenv("SVA_CNX_FUSE") && atoi(getenv("SVA_CNX_FUSE")) == 0;          // A/B switch
+    if (b->B * T <= 16 && C <= 512 && !fuse_off) {
+        // a handful of rows (streaming pass, upsampler at small B): depthwise conv + LayerNorm happen in the prologue of the
+        // pointwise GEMM (every column block recomputes them -- a few thousand FMAs -- instead of a launch of their own)
+        p1.dw_wT = c.dwT; p1.dw_b = c.dwb; p1.ln_w = c.lnw; p1.ln_b = c.lnb; p1.ln_eps = 1e-6f;
+        SVA_TRY(gemm_call(b, x.p, x.bstride, (long)(x.H - 6) * C, C, b->B, T, 1, 1, 1, C, c.pw1, h2, h2_bs, 0, 4 * C, p1));
+    } else {
+        SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, h1_bs, b->stream));
+        SVA_TRY(gemm_call(b, h1, h1_bs, 0, C, b->B, T, 1, 1, 1, C, c.pw1, h2, h2_bs, 0, 4 * C, p1));
+    }
     ConvGemm p2;
     p2.gamma = c.gamma;
     p2.res = x.p; p2.r_bstride = x.bstride; p2.r_off = (long)x.H * C; p2.ldr = C;

@@ -10,6 +10,8 @@
 // next tile's global loads are issued before the current tile's MFMAs and written to the other
 // LDS buffer after them (one barrier per K tile).
 #include "sva_common.h"
+#include <array>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 #include <utility>
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
     // blockIdx.z: member of a group, or (single problem) the K split this workgroup owns
     const ConvGemm& g = gg.g[gg.n > 1 ? blockIdx.z : 0];
     const int Z = gg.n > 1 ? 1 : g.ksplit, ks = gg.n > 1 ? 0 : (int)blockIdx.z;
-    constexpr bool SILU = AOP == 1, RMS = AOP == 2;
+    constexpr bool SILU = AOP == 1, RMS = AOP == 2, DWLN = AOP == 3;
     extern __shared__ __attribute__((aligned(16))) float red[];      // [KW][MT*NT][64][4] (+ [KW][MT][16] row sums of squares)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * (16 * NT);
@@ -264,6 +266,52 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // AOP 3: ConvNeXt prologue -- rows of this tile = LayerNorm(depthwise k7 conv) of x, one wave per row, kept in LDS with a
+    // padded row stride (the K loop then reads its A fragments from there instead of from global memory)
+    const int a_ld = g.Cin + 4;
+    float* a_s = red + KW * MT * NT * 256;                 // [16*MT][Cin + 4]
+    if constexpr (DWLN) {
+        const int C = g.Cin;
+        for (int r = wave; r < 16 * MT; r += KW) {
+            const int m = m_base + r;
+            float* dst = a_s + r * a_ld;
+            if (m >= g.M) {
+                for (int c = lane; c < C; c += 64) dst[c] = 0.f;
+                continue;
+            }
+            const int b = m / g.T, t = m - b * g.T;
+            const float* xr = g.A + (long)b * g.a_bstride + g.a_off + (long)t * g.lda;      // tap 0 row
+            float v[8], sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = lane + 64 * i;
+                float acc = 0.f;
+                if (c < C) {
+                    acc = g.dw_b[c];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc = fmaf(g.dw_wT[j * C + c], xr[(long)j * g.lda + c], acc);
+                    sum += acc;
+                }
+                v[i] = acc;
+            }
+            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (lane + 64 * i < C) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+            q += __shfl_xor(q, 8, 64); q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            const float inv = 1.f / sqrtf(q / (float)C + g.ln_eps);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = lane + 64 * i;
+                if (c < C) dst[c] = (v[i] - mean) * inv * g.ln_w[c] + g.ln_b[c];
+            }
+        }
+        __syncthreads();
+    }
     const int kc_tiles = g.Cin / 16;
     const int nk = g.taps * kc_tiles;
     // software pipeline, D K-blocks in flight per wave.  No branch around any load (a conditional load makes
@@ -286,8 +334,13 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
         const long woff = (long)tap * g.Cin + kc;
 #pragma unroll
         for (int j = 0; j < NT; ++j) w[j] = *reinterpret_cast<const float4*>(wp[j] + woff);
+        if constexpr (DWLN) {            // A fragments come from the LDS tile written by the prologue (no latency to hide)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(ap[i] + aoff);
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(a_s + (i * 16 + fr) * a_ld + kc + 4 * fg);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(ap[i] + aoff);
+        }
         if (RMS) nw = *reinterpret_cast<const float4*>(g.rms_w + kc + 4 * fg);
     };
 #pragma unroll
@@ -469,7 +522,7 @@ static int ks_scratch(hipStream_t st, KsScratch* out) {
 
 template <int MT, int NT, int KW, int D, int AOP>
 static int launch_skinny_op(const ConvGemm& g, hipStream_t st) {
-    const size_t smem = ((size_t)KW * MT * NT * 256 + (AOP == 2 ? KW * MT * 16 : 0)) * sizeof(float);
+    const size_t smem = ((size_t)KW * MT * NT * 256 + (AOP == 2 ? KW * MT * 16 : 0) + (AOP == 3 ? (size_t)16 * MT * (g.Cin + 4) : 0)) * sizeof(float);
     ConvGemmGroup gg;
     if (t_group) gg = *t_group; else gg.g[0] = g;
     dim3 grid((g.N + 16 * NT - 1) / (16 * NT), (g.M + 16 * MT - 1) / (16 * MT), gg.n);
@@ -494,6 +547,10 @@ static int launch_skinny_op(const ConvGemm& g, hipStream_t st) {
 }
 template <int MT, int NT, int KW, int D>
 static int launch_skinny(const ConvGemm& g, hipStream_t st) {
+    if (g.dw_wT) {
+        if constexpr (MT == 1 && NT == 1) return launch_skinny_op<MT, NT, KW, D, 3>(g, st);
+        else { set_error("conv_gemm: the fused ConvNeXt prologue runs on one 16-row tile"); return -1; }
+    }
     if (g.rms_w) return launch_skinny_op<MT, NT, KW, D, 2>(g, st);
     if (g.a_silu) return launch_skinny_op<MT, NT, KW, D, 1>(g, st);
     return launch_skinny_op<MT, NT, KW, D, 0>(g, st);
@@ -632,7 +689,7 @@ static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
 }
 
 static std::mutex g_tune_mu;
-static std::unordered_map<unsigned long long, Choice> g_tune;
+static std::map<std::array<int, 6>, Choice> g_tune;      // (M, N, K, taps, epilogue / prologue flags, stride)
 static float* g_tune_c = nullptr;
 static size_t g_tune_elems = 0;
 
@@ -672,6 +729,8 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
     SVA_CHECK(g.M > 0 && g.N > 0 && g.T > 0, "conv_gemm: empty problem");
     if (g.w13) SVA_CHECK(g.N % 32 == 0, "conv_gemm: w13 needs N % 32 == 0");
     if (g.rms_w) SVA_CHECK(g.taps == 1 && !g.a_silu && conv_gemm_can_fuse_rms(g.M, g.N), "conv_gemm: fused RMSNorm needs taps == 1 on the small-M path");
+    if (g.dw_wT) SVA_CHECK(g.taps == 1 && g.M <= 16 && g.Cin <= 512 && !g.a_silu && !g.rms_w && !g.w13 && group_n == 1 && g.dw_b && g.ln_w && g.ln_b,
+                           "conv_gemm: the fused ConvNeXt prologue needs taps == 1, M <= 16, Cin <= 512");
     Choice ch = heuristic_choice(g, c_vec);
     static const bool tune = !(getenv("SVA_SKINNY_MT") || getenv("SVA_SKINNY_KW")) && !(getenv("SVA_AUTOTUNE") && atoi(getenv("SVA_AUTOTUNE")) == 0);
     if (tune) {
@@ -679,9 +738,8 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
         // the real operands with the output redirected to scratch, and keeps a candidate only if it beats the heuristic
         // by > 7 %.  Launches inside a stream capture (and shapes first seen there) use the heuristic.
         const unsigned long long flags = (unsigned long long)(g.a_silu ? 1 : 0) | (g.rms_w ? 2 : 0) | (g.w13 ? 4 : 0) | (c_vec ? 8 : 0) | (g.accumulate ? 16 : 0) |
-                                         (group_n > 1 ? 32 : 0);
-        const unsigned long long key = ((unsigned long long)g.M << 40) ^ ((unsigned long long)g.N << 24) ^ ((unsigned long long)(g.taps * g.Cin) << 8) ^
-                                       ((unsigned long long)g.taps << 4) ^ (flags << 58) ^ (unsigned long long)(g.stride & 15);
+                                         (group_n > 1 ? 32 : 0) | (g.dw_wT ? 64 : 0);
+        const std::array<int, 6> key = {g.M, g.N, g.taps * g.Cin, g.taps, (int)flags, g.stride};
         std::lock_guard<std::mutex> lk(g_tune_mu);
         auto it = g_tune.find(key);
         if (it != g_tune.end()) ch = it->second;
@@ -729,13 +787,13 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                 };
                 std::vector<Choice> cand;
                 const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-                const bool must_skinny = g.rms_w || !c_vec;
+                const bool must_skinny = g.rms_w || g.dw_wT || !c_vec;
                 if (must_skinny || tiles64 < 1024) {
                     const int mt_total = (g.M + 15) / 16;
                     const long nk = (long)g.taps * g.Cin / 16;
                     for (int nt = 1; nt <= 2; ++nt) {
                         if (g.w13 && nt == 1) continue;
-                        if (nt == 2 && g.N % 32 != 0) continue;
+                        if (nt == 2 && (g.N % 32 != 0 || g.dw_wT)) continue;
                         const int mts[3] = {1, 2, 4}, kws[3] = {4, 8, 16};
                         for (int a = 0; a < 3; ++a)
                             for (int b2 = 0; b2 < 3; ++b2) {

@@ -66,6 +66,13 @@ struct ConvGemm {
     int ksplit = 1;                 // set by the dispatcher: K split over `ksplit` workgroups (blockIdx.z), partial tiles in
     float* ks_ws = nullptr;         //   ks_ws, arrival counters in ks_cnt; the last workgroup of a tile sums them in
     unsigned* ks_cnt = nullptr;     //   split order (deterministic) and runs the epilogue
+    // fused ConvNeXt prologue (small-M kernel, M <= 16, taps == 1): the A rows are LayerNorm(dwconv7(x)) computed on the fly;
+    // A then addresses the FIRST tap row (t - 6) of x, dw_wT is [7][Cin] tap-major, ln_* the LayerNorm affine
+    const float* dw_wT = nullptr;
+    const float* dw_b = nullptr;
+    const float* ln_w = nullptr;
+    const float* ln_b = nullptr;
+    float ln_eps = 1e-6f;
     const float* rms_w = nullptr;   // [Cin] fused RMSNorm of the A rows (taps == 1): A' = A * rms_w * rsqrt(mean(A^2) + rms_eps);
     float rms_eps = 1e-5f;          //       only on the small-M path -- ask conv_gemm_can_fuse_rms() first
 };
