@@ -177,6 +177,12 @@ int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* 
 int sva_test_gemm_choice(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int kind,
                          int a, int b, int c);
 
+/* kernel unit-test hook: the nucleus sampler of decode_one (modules/dual_ar_stream.py:1092-1132) over logits[rows][V] with
+ * explicit Exp(1) draws noise[rows][V], through one implementation: 1 LDS bitonic sort, 2 register sort, 3/4/5 threshold
+ * bisection (workgroup shapes).  us_out (may be NULL) = average microseconds per launch over `iters` launches */
+int sva_test_sampler(int device, int variant, int rows, int V, const float* logits, const float* noise, float temperature,
+                     float top_p, int* tok_out, int iters, float* us_out);
+
 /* microbenchmark of the conv-GEMM dispatcher: conv over [B][(taps-1)*dil + T][Cin] -> [B][T][N]; mode bits:
  * 1 GELU, 2 gamma+residual, 4 SiLU-on-load, 8 SwiGLU (w13); returns avg microseconds per launch in out_us[0] */
 int sva_bench_gemm(int device, int B, int T, int N, int Cin, int taps, int dil, int mode, int iters, float* out_us);

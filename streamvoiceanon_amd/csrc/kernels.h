@@ -116,6 +116,8 @@ int launch_gemv(const Gemv& g, hipStream_t st);
 // sampler for vocabularies <= 1024 without a sort (rank by counting), fused with teacher forcing and the embedding
 // gather of the sampled token:  tok_raw[row*tok_stride] = sample;  tok[...] = forced ? forced : sample;
 // emb_out[row, :] = emb_table[tok, :]  (emb_table may be null)
+int launch_sampler_variant(int variant, const float* logits, int rows, int V, int ldl, const float* noise, int ldn,
+                           const unsigned long long* seed, const int* frame, float temperature, float top_p, int* tok_out, hipStream_t st);
 int launch_sampler_small(const float* logits, int rows, int V, int ldl, const float* noise, int ldn,
                          const unsigned long long* seed, const int* frame, int kind, int noise_elem_off, float temperature,
                          float top_p, int* tok_raw, int* tok, int tok_stride, const int* forced, int forced_stride,

@@ -1134,6 +1134,201 @@ __global__ __launch_bounds__(THREADS) void sampler_reg_kernel(const float* __res
     }
 }
 
+// Sort-free variant.  The nucleus rule only needs to know, for each entry, whether the probability mass of the entries
+// that precede it in descending order (itself included) exceeds top_p; without ties that mass is F(p_i) = sum of all
+// p_j >= p_i, a non-increasing step function of the threshold.  So instead of sorting, bisect the threshold over the
+// float bit pattern of p (monotone for p >= 0): kb = the largest key whose F (double accumulator, compared after the
+// cast to float like the sorted scan) exceeds top_p.  Entries with key > kb are kept, entries below are cut, the
+// entries AT kb are resolved in id order (the sort's tie rule) from F(kb + 1) by repeated addition, and the top entry
+// is always kept.  ~30 block reductions of one double instead of 91 compare-exchange stages.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_mov_d(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_mov_d<0xB1>(v);
+    v += dpp_mov_d<0x4E>(v);
+    v += dpp_mov_d<0x141>(v);
+    v += dpp_mov_d<0x140>(v);
+    v += dpp_mov_d<0x142, 0xa>(v);
+    v += dpp_mov_d<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+template <int THREADS, int PER>
+__global__ __launch_bounds__(THREADS) void sampler_bisect_kernel(const float* __restrict__ logits, int V, int ldl,
+                                                              const float* __restrict__ noise, int ldn,
+                                                              const unsigned long long* __restrict__ seed, const int* __restrict__ frame,
+                                                              int kind, int noise_elem_off, float inv_temp, float top_p,
+                                                              int* __restrict__ tok_out, int tok_stride,
+                                                              int* __restrict__ tok, const int* __restrict__ forced, int forced_stride,
+                                                              const int* __restrict__ use_forced, const float* __restrict__ emb_table, int D,
+                                                              float* __restrict__ emb_out, int ldo) {
+    constexpr int NW = THREADS / 64;
+    __shared__ double dred[2][NW];
+    __shared__ float fred[2][NW];
+    __shared__ int ired[NW + 1];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lg = logits + (long)row * ldl;
+    int slot = 0;
+    auto block_sum_d = [&](double x) {
+        x = wave_sum_d(x);
+        if (lane == 0) dred[slot][wave] = x;
+        __syncthreads();
+        // second level: lane i takes the partial of wave i % NW, the first log2(NW) DPP steps sum each aligned group of NW lanes
+        double t = dred[slot][lane & (NW - 1)];
+        if constexpr (NW >= 2) t += dpp_mov_d<0xB1>(t);
+        if constexpr (NW >= 4) t += dpp_mov_d<0x4E>(t);
+        if constexpr (NW >= 8) t += dpp_mov_d<0x141>(t);
+        if constexpr (NW >= 16) t += dpp_mov_d<0x140>(t);
+        slot ^= 1;
+        return t;
+    };
+    auto block_sum_f = [&](float x) {
+        x = wave_sum(x);
+        if (lane == 0) fred[slot][wave] = x;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += fred[slot][w];
+        slot ^= 1;
+        return t;
+    };
+    float l[PER];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        const int e = tid + r * THREADS;
+        l[r] = e < V ? lg[e] : -INFINITY;
+        m = fmaxf(m, l[r]);
+    }
+    m = wave_max(m);
+    if (lane == 0) fred[slot][wave] = m;
+    __syncthreads();
+    float mx = fred[slot][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, fred[slot][w]);
+    slot ^= 1;
+    float p[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        p[r] = (tid + r * THREADS) < V ? expf(l[r] - mx) : 0.f;
+        s += p[r];
+    }
+    const float denom = block_sum_f(s);
+    unsigned key[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        p[r] = p[r] / denom;
+        key[r] = __builtin_bit_cast(unsigned, p[r]);
+    }
+    auto mass_from = [&](unsigned k) {          // F(k) = sum of p with key >= k
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) t += key[r] >= k ? (double)p[r] : 0.0;
+        return block_sum_d(t);
+    };
+    bool keep[PER];
+    if (!((float)mass_from(0u) > top_p)) {      // nothing exceeds top_p: the whole distribution is kept
+#pragma unroll
+        for (int r = 0; r < PER; ++r) keep[r] = (tid + r * THREADS) < V;
+    } else {
+        unsigned lo = 0u, hi = __builtin_bit_cast(unsigned, 1.0f / denom) + 2u;      // every key < hi (p <= 1 / denom up to rounding)
+        if (hi > 0x3F800001u) hi = 0x3F800001u;
+        while (hi - lo > 1u) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            if ((float)mass_from(mid) > top_p) lo = mid; else hi = mid;
+        }
+        const unsigned kb = lo;
+        const float pb = __builtin_bit_cast(float, kb);
+        double above = 0.0;
+        float ties = 0.f;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            above += key[r] > kb ? (double)p[r] : 0.0;
+            ties += (key[r] == kb && (tid + r * THREADS) < V) ? 1.f : 0.f;
+        }
+        const double base = block_sum_d(above);
+        const int cnt = (int)block_sum_f(ties);
+        int nk = 0;                                       // ties kept, in id order: cumulative mass by repeated addition like the scan
+        double run = base;
+        for (int j = 0; j < cnt; ++j) {
+            run += (double)pb;
+            if ((float)run > top_p) break;
+            ++nk;
+        }
+        if (base == 0.0 && nk == 0) nk = 1;              // the top entry is never cut
+        int id_cut = -1;
+        if (nk >= cnt) id_cut = 0x7fffffff;
+        else if (nk > 0) {                                // the nk-th smallest id among the ties
+            int ilo = -1, ihi = V - 1;
+            while (ihi - ilo > 1) {
+                const int mid = ilo + ((ihi - ilo) >> 1);
+                float c = 0.f;
+#pragma unroll
+                for (int r = 0; r < PER; ++r) c += (key[r] == kb && (tid + r * THREADS) <= mid) ? 1.f : 0.f;
+                if ((int)block_sum_f(c) >= nk) ihi = mid; else ilo = mid;
+            }
+            id_cut = ihi;
+        }
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int e = tid + r * THREADS;
+            keep[r] = e < V && (key[r] > kb || (key[r] == kb && e <= id_cut));
+        }
+    }
+    const float m2 = mx * inv_temp;
+    float e2[PER];
+    float s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        e2[r] = keep[r] ? expf(l[r] * inv_temp - m2) : 0.f;
+        s2 += e2[r];
+    }
+    const float denom2 = block_sum_f(s2);
+    float best = -1.f;
+    int best_id = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        if (!keep[r]) continue;
+        const int e = tid + r * THREADS;
+        const float pr = e2[r] / denom2;
+        const float q = noise ? noise[(long)row * ldn + e] : exp1_noise_dev(seed[row], frame[row], kind, (unsigned)(noise_elem_off + e));
+        const float rr = pr / q;
+        if (rr > best || (rr == best && e < best_id)) { best = rr; best_id = e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_id, o, 64);
+        if (ob > best || (ob == best && oi < best_id)) { best = ob; best_id = oi; }
+    }
+    if (lane == 0) { fred[slot][wave] = best; ired[wave] = best_id; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w)
+            if (fred[slot][w] > best || (fred[slot][w] == best && ired[w] < best_id)) { best = fred[slot][w]; best_id = ired[w]; }
+        tok_out[(long)row * tok_stride] = best_id;
+        int t = best_id;
+        if (tok) {
+            if (forced && *use_forced) t = forced[(long)row * forced_stride];
+            tok[(long)row * tok_stride] = t;
+        }
+        ired[NW] = t;
+    }
+    if (emb_table) {
+        __syncthreads();
+        const int t = ired[NW];
+        for (int c = tid; c < D; c += THREADS) emb_out[(long)row * ldo + c] = emb_table[(long)t * D + c];
+    }
+}
+static int sampler_mode() {      // A/B switch: SVA_SAMPLER_SORT=1 restores the sorting kernels
+    static const int m = getenv("SVA_SAMPLER_SORT") ? atoi(getenv("SVA_SAMPLER_SORT")) : 0;
+    return m;
+}
+
 int launch_sampler(const float* logits, int rows, int V, int ldl, const float* noise, int ldn,
                    const unsigned long long* seed, const int* frame, int kind, int noise_elem_off, float temperature,
                    float top_p, int* tok_out, int tok_stride, hipStream_t st) {
@@ -1148,6 +1343,19 @@ int launch_sampler(const float* logits, int rows, int V, int ldl, const float* n
     }
     const float tclamp = temperature > 1e-5f ? temperature : 1e-5f;
     static const bool legacy = getenv("SVA_SAMPLER_LDS") != nullptr;       // A/B switch: the all-LDS bitonic sort
+    if (P == 8192 && !legacy && !sampler_mode()) {
+        static const int bv = getenv("SVA_SAMPLER_BISECT") ? atoi(getenv("SVA_SAMPLER_BISECT")) : 0;
+        if (bv == 1)
+            hipLaunchKernelGGL((sampler_bisect_kernel<512, 16>), dim3(rows), dim3(512), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
+                               noise_elem_off, 1.0f / tclamp, top_p, tok_out, tok_stride, (int*)nullptr, (const int*)nullptr, 0,
+                               (const int*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0);
+        else
+            hipLaunchKernelGGL((sampler_bisect_kernel<1024, 8>), dim3(rows), dim3(1024), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
+                               noise_elem_off, 1.0f / tclamp, top_p, tok_out, tok_stride, (int*)nullptr, (const int*)nullptr, 0,
+                               (const int*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0);
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
     if (P == 8192 && !legacy) {
         hipLaunchKernelGGL((sampler_reg_kernel<1024, 8>), dim3(rows), dim3(1024), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
                            noise_elem_off, 1.0f / tclamp, top_p, tok_out, tok_stride, (int*)nullptr, (const int*)nullptr, 0,
@@ -1705,6 +1913,20 @@ int launch_sampler_small(const float* logits, int rows, int V, int ldl, const fl
     SVA_CHECK(V <= 1024, "sampler_small: V <= 1024");
     const float tclamp = temperature > 1e-5f ? temperature : 1e-5f;
     static const int variant = getenv("SVA_SAMPLER_SMALL") ? atoi(getenv("SVA_SAMPLER_SMALL")) : 0;     // A/B switch
+    static const int sbv = getenv("SVA_SAMPLER_SMALL_BISECT") ? atoi(getenv("SVA_SAMPLER_SMALL_BISECT")) : 1;
+    if (variant == 0 && !sampler_mode() && sbv) {
+#define SVA_BIS(T_, P_)                                                                                                          \
+    hipLaunchKernelGGL((sampler_bisect_kernel<T_, P_>), dim3(rows), dim3(T_), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind, \
+                       noise_elem_off, 1.0f / tclamp, top_p, tok_raw, tok_stride, tok, forced, forced_stride, use_forced, emb_table, D, \
+                       emb_out, ldo)
+        if (sbv == 2) SVA_BIS(128, 8);
+        else if (sbv == 3) SVA_BIS(64, 16);
+        else if (sbv == 4) SVA_BIS(512, 2);
+        else SVA_BIS(256, 4);
+#undef SVA_BIS
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
     if (variant == 2) {
         hipLaunchKernelGGL((sampler_reg_kernel<512, 2>), dim3(rows), dim3(512), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
                            noise_elem_off, 1.0f / tclamp, top_p, tok_raw, tok_stride, tok, forced, forced_stride, use_forced, emb_table, D,
@@ -1728,6 +1950,44 @@ int launch_sampler_small(const float* logits, int rows, int V, int ldl, const fl
     }
     hipLaunchKernelGGL(sampler_small_kernel, dim3(rows), dim3(1024), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind, noise_elem_off,
                        1.0f / tclamp, top_p, tok_raw, tok, tok_stride, forced, forced_stride, use_forced, emb_table, D, emb_out, ldo);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// unit-test / microbenchmark entry: one explicit implementation of the A5 sampler.
+//   1 LDS bitonic sort, 2 register sort, 3 / 4 / 5 threshold bisection (1024x8 | 256x4, 512x16 | 128x8, 64x16 for V <= 1024)
+int launch_sampler_variant(int variant, const float* logits, int rows, int V, int ldl, const float* noise, int ldn,
+                           const unsigned long long* seed, const int* frame, float temperature, float top_p, int* tok_out, hipStream_t st) {
+    const float it = 1.0f / (temperature > 1e-5f ? temperature : 1e-5f);
+    int P = 1024;
+    while (P < V) P <<= 1;
+    SVA_CHECK(P <= 16384, "sampler: vocabulary too large");
+#define SVA_ARGS logits, V, ldl, noise, ldn, seed, frame, 0, 0, it, top_p, tok_out, 1
+#define SVA_NOFUSE (int*)nullptr, (const int*)nullptr, 0, (const int*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0
+    if (variant == 1) {
+        SVA_HIP(hipFuncSetAttribute((const void*)sampler_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        hipLaunchKernelGGL(sampler_kernel, dim3(rows), dim3(1024), (size_t)P * 6 + 16 * 8 + 16 * 4 + 16 * 4, st, logits, V, ldl, P, noise, ldn,
+                           seed, frame, 0, 0, it, top_p, tok_out, 1);
+    } else if (variant == 2) {
+        SVA_CHECK(P == 8192 || P == 1024, "sampler variant 2: V <= 1024 or 4096 < V <= 8192");
+        if (P == 8192) hipLaunchKernelGGL((sampler_reg_kernel<1024, 8>), dim3(rows), dim3(1024), 0, st, SVA_ARGS, SVA_NOFUSE);
+        else hipLaunchKernelGGL(sampler_small_kernel, dim3(rows), dim3(1024), 0, st, logits, V, ldl, noise, ldn, seed, frame, 0, 0, it, top_p,
+                                tok_out, tok_out, 1, (const int*)nullptr, 0, (const int*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0);
+    } else if (variant >= 3 && variant <= 5) {
+        SVA_CHECK(P == 8192 || P == 1024, "sampler variant 3-5: V <= 1024 or 4096 < V <= 8192");
+        if (P == 8192) {
+            if (variant == 3) hipLaunchKernelGGL((sampler_bisect_kernel<1024, 8>), dim3(rows), dim3(1024), 0, st, SVA_ARGS, SVA_NOFUSE);
+            else hipLaunchKernelGGL((sampler_bisect_kernel<512, 16>), dim3(rows), dim3(512), 0, st, SVA_ARGS, SVA_NOFUSE);
+        } else {
+            if (variant == 3) hipLaunchKernelGGL((sampler_bisect_kernel<256, 4>), dim3(rows), dim3(256), 0, st, SVA_ARGS, SVA_NOFUSE);
+            else if (variant == 4) hipLaunchKernelGGL((sampler_bisect_kernel<128, 8>), dim3(rows), dim3(128), 0, st, SVA_ARGS, SVA_NOFUSE);
+            else hipLaunchKernelGGL((sampler_bisect_kernel<64, 16>), dim3(rows), dim3(64), 0, st, SVA_ARGS, SVA_NOFUSE);
+        }
+    } else {
+        SVA_CHECK(false, "sampler variant: 1..5");
+    }
+#undef SVA_ARGS
+#undef SVA_NOFUSE
     SVA_HIP(hipGetLastError());
     return 0;
 }

@@ -89,3 +89,38 @@ extern "C" int sva_bench_gemm(int device, int B, int T, int N, int Cin, int taps
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
     return 0;
 }
+
+// A5 sampler through one explicit implementation (see launch_sampler_variant); noise = the Exp(1) draws [rows, V].
+// us_out (optional) = average microseconds per launch over `iters` back-to-back launches.
+extern "C" int sva_test_sampler(int device, int variant, int rows, int V, const float* logits, const float* noise, float temperature,
+                                float top_p, int* tok_out, int iters, float* us_out) {
+    SVA_HIP(hipSetDevice(device));
+    float *dL, *dN;
+    int* dT;
+    const size_t n = (size_t)rows * V;
+    SVA_HIP(hipMalloc(&dL, sizeof(float) * n));
+    SVA_HIP(hipMalloc(&dN, sizeof(float) * n));
+    SVA_HIP(hipMalloc(&dT, sizeof(int) * rows));
+    SVA_HIP(hipMemcpy(dL, logits, sizeof(float) * n, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(dN, noise, sizeof(float) * n, hipMemcpyHostToDevice));
+    int rc = launch_sampler_variant(variant, dL, rows, V, V, dN, V, nullptr, nullptr, temperature, top_p, dT, 0);
+    if (!rc) {
+        SVA_HIP(hipDeviceSynchronize());
+        SVA_HIP(hipMemcpy(tok_out, dT, sizeof(int) * rows, hipMemcpyDeviceToHost));
+        if (us_out && iters > 0) {
+            hipEvent_t e0, e1;
+            SVA_HIP(hipEventCreate(&e0));
+            SVA_HIP(hipEventCreate(&e1));
+            SVA_HIP(hipEventRecord(e0, 0));
+            for (int i = 0; i < iters && !rc; ++i) rc = launch_sampler_variant(variant, dL, rows, V, V, dN, V, nullptr, nullptr, temperature, top_p, dT, 0);
+            SVA_HIP(hipEventRecord(e1, 0));
+            SVA_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            SVA_HIP(hipEventElapsedTime(&ms, e0, e1));
+            us_out[0] = ms * 1000.f / iters;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+    }
+    (void)hipFree(dL); (void)hipFree(dN); (void)hipFree(dT);
+    return rc;
+}

@@ -92,6 +92,7 @@ def load_library():
     lib.sva_bench_gemm.argtypes = [i32] * 9 + [f32p]
     lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
     lib.sva_test_gemm_choice.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32]
+    lib.sva_test_sampler.argtypes = [i32, i32, i32, i32, vp, vp, C.c_float, C.c_float, vp, i32, f32p]
     _lib = lib
     return lib
 
@@ -101,7 +102,7 @@ EXPORTED_SYMBOLS = [
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
     "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_stream_chunks", "sva_encode_window", "sva_firefly_encode",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
-    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm",
+    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm", "sva_test_sampler",
 ]
 
 
@@ -390,6 +391,21 @@ def test_gemm_choice(A, W, choice, bias=None, device=0):
     b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
     _check(lib.sva_test_gemm_choice(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out), *[int(x) for x in choice]), "sva_test_gemm_choice")
     return out
+
+
+def test_sampler(logits, noise, variant, temperature=0.7, top_p=0.7, iters=0, device=0):
+    """tokens [rows] of the nucleus sampler through ONE implementation (see include/sva.h); with iters > 0 also the average
+    microseconds per launch -> (tokens, us)."""
+    lib = load_library()
+    L = np.ascontiguousarray(logits, dtype=np.float32)
+    Q = np.ascontiguousarray(noise, dtype=np.float32)
+    rows, V = L.shape
+    assert Q.shape == L.shape
+    out = np.empty(rows, dtype=np.int32)
+    us = (C.c_float * 1)()
+    _check(lib.sva_test_sampler(device, int(variant), rows, V, _ptr(L), _ptr(Q), float(temperature), float(top_p), _ptr(out), int(iters),
+                                us if iters > 0 else None), "sva_test_sampler")
+    return (out, float(us[0])) if iters > 0 else out
 
 
 def bench_gemm(B, T, N, Cin, taps=1, dil=1, mode=0, iters=50, device=0):

@@ -785,3 +785,36 @@ def test_config3_64_streams_10s_properties(eng):
     one = solo.stream_chunks(utts[5][None])
     solo.close()
     assert np.abs(one[0] - out[5]).max() <= PCM_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V", [1000, 8192])
+def test_sampler_implementations_vs_oracle_and_each_other(V):
+    """dual_ar_stream.py:1092-1132 -- every implementation of the nucleus sampler (LDS sort, register sort, the sort-free
+    threshold bisection in its workgroup shapes) returns the oracle's token on random rows, and the same token as the sorting
+    kernel (ties broken by the smaller id) on rows built from ties, uniform logits, underflowing tails and extreme top_p."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+    rng = np.random.default_rng(V)
+    rows = 48
+    L = (rng.standard_normal((rows, V)) * rng.uniform(0.5, 8.0, (rows, 1))).astype(np.float32)
+    Q = (rng.exponential(1.0, (rows, V)) + 1e-9).astype(np.float32)
+    variants = (1, 2, 3, 4) if V > 1024 else (1, 2, 3, 4, 5)
+    for tp, temp in ((0.7, 0.7), (0.9, 1.0), (0.05, 0.7), (1.0, 0.7)):
+        want = np.array([O.sample_token(torch.from_numpy(L[r]), torch.from_numpy(Q[r]), temp, tp) for r in range(rows)])
+        for var in variants:
+            got = E.test_sampler(L, Q, var, temperature=temp, top_p=tp)
+            assert (got == want).all(), (V, tp, temp, var, np.nonzero(got != want)[0][:8])
+    # rows where the descending order has ties: the kernels' rule (smaller id first) is the contract, checked across implementations
+    T = L.copy()
+    T[0, :] = 0.25                                     # uniform: top_p keeps the first ceil-ish(top_p * V) ids
+    T[1, :] = np.round(T[1, :])                        # heavy ties everywhere
+    T[2, 17] = T[2, 911] = T[2, 5] = T[2].max() + 3.0  # tie at the top
+    T[3, :] = -200.0; T[3, 40:44] = 0.0                # everything else underflows to p = 0
+    T[4, :] = np.floor(T[4, :] * 2) / 2
+    T[5, :] = 1e4 * np.sign(T[5, :])                   # two huge tie classes
+    for tp, temp in ((0.7, 0.7), (0.3, 1.3), (1.0, 0.7), (0.999, 0.5)):
+        base = E.test_sampler(T, Q, 1, temperature=temp, top_p=tp)
+        for var in variants[1:]:
+            got = E.test_sampler(T, Q, var, temperature=temp, top_p=tp)
+            assert (got == base).all(), (V, tp, temp, var, np.nonzero(got != base)[0][:8])
