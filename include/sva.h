@@ -177,6 +177,11 @@ int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* 
 int sva_test_gemm_choice(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int kind,
                          int a, int b, int c);
 
+/* host cost (microseconds) of enqueueing one kernel from the calling thread, measured over `iters` launches of a one-element
+ * kernel into an idle stream.  A single-stream step is ~430 launches, so the enqueueing thread's launch rate bounds the step
+ * rate; on a multi-socket host it depends on the core the thread runs on -- see engine.py pin_enqueue_thread() */
+int sva_host_launch_cost(int device, int iters, float* us_per_launch);
+
 /* kernel unit-test hook: the nucleus sampler of decode_one (modules/dual_ar_stream.py:1092-1132) over logits[rows][V] with
  * explicit Exp(1) draws noise[rows][V], through one implementation: 1 LDS bitonic sort, 2 register sort, 3/4/5 threshold
  * bisection (workgroup shapes).  us_out (may be NULL) = average microseconds per launch over `iters` launches */

@@ -1287,14 +1287,37 @@ namespace {
 struct StreamSet { hipStream_t main = nullptr, aux0 = nullptr, sa = nullptr, sv = nullptr, aux1 = nullptr; };
 std::mutex g_streams_mu;
 std::map<int, StreamSet> g_streams;          // per device, process lifetime
-int get_streams(int device, bool need_aux1, StreamSet* out) {
+// `partitioned`: the AR stream and the encoder / vocoder streams get disjoint compute-unit masks (hipExtStreamCreateWithCUMask;
+// mask bit i -> XCD i % 8, so every range is spread over all XCDs).  With few streams the three stage chains are strings of
+// short dependent kernels that each leave most of the chip idle, yet when they share CUs the AR chain's kernels queue behind
+// the encoder's and vocoder's workgroups: measured at 1 stream 2.11 -> 1.80 ms per step with AR on 96 CUs and E/V on the
+// other 160; the gain shrinks with the batch (+20 % at 2-4 streams, +9 % at 8) and turns into a loss from 16 streams on,
+// where the GEMMs want the whole chip.  SVA_CU_PART="alo,an,elo,en,vlo,vn" overrides the ranges, SVA_CU_PART=off disables.
+int get_streams(int device, bool need_aux1, bool partitioned, StreamSet* out) {
     std::lock_guard<std::mutex> lk(g_streams_mu);
-    StreamSet& s = g_streams[device];
+    int part[6] = {0, 96, 96, 160, 96, 160};
+    if (const char* e = getenv("SVA_CU_PART")) {
+        if (!strcmp(e, "off")) partitioned = false;
+        else sscanf(e, "%d,%d,%d,%d,%d,%d", part, part + 1, part + 2, part + 3, part + 4, part + 5);
+    }
+    if (partitioned) {
+        hipDeviceProp_t prop;
+        SVA_HIP(hipGetDeviceProperties(&prop, device));
+        if (prop.multiProcessorCount != 256) partitioned = false;         // the ranges are sized for the 256 CUs of an MI355X
+    }
+    StreamSet& s = g_streams[device * 2 + (partitioned ? 1 : 0)];
     if (!s.main) {
-        SVA_HIP(hipStreamCreateWithFlags(&s.main, hipStreamNonBlocking));
-        SVA_HIP(hipStreamCreateWithFlags(&s.aux0, hipStreamNonBlocking));
-        SVA_HIP(hipStreamCreateWithFlags(&s.sa, hipStreamNonBlocking));
-        SVA_HIP(hipStreamCreateWithFlags(&s.sv, hipStreamNonBlocking));
+        auto make = [&](hipStream_t* st, int lo, int n) -> int {
+            if (!partitioned || n <= 0 || n >= 256) { SVA_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking)); return 0; }
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = lo; i < lo + n && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+            SVA_HIP(hipExtStreamCreateWithCUMask(st, 8, mask));
+            return 0;
+        };
+        SVA_TRY(make(&s.main, part[2], part[3]));
+        SVA_TRY(make(&s.aux0, part[2], part[3]));
+        SVA_TRY(make(&s.sa, part[0], part[1]));
+        SVA_TRY(make(&s.sv, part[4], part[5]));
     }
     if (need_aux1 && !s.aux1) SVA_HIP(hipStreamCreateWithFlags(&s.aux1, hipStreamNonBlocking));     // legacy three-stream vocoder only
     *out = s;
@@ -1324,7 +1347,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     if (b->p.pipeline) SVA_CHECK(b->voc_grouped, "stage pipelining needs the grouped vocoder launches");
     {
         StreamSet ss;
-        SVA_TRY(get_streams(e->device, !b->voc_grouped, &ss));
+        SVA_TRY(get_streams(e->device, !b->voc_grouped, b->p.pipeline && B <= 8, &ss));
         b->stream = b->main_stream = ss.main;
         b->aux[0] = ss.aux0;
         b->aux[1] = b->voc_grouped ? nullptr : ss.aux1;

@@ -2,6 +2,9 @@
 #include "../../include/sva.h"
 #include "kernels.h"
 #include <algorithm>
+#include <chrono>
+#include <map>
+#include <mutex>
 #include <vector>
 
 using namespace sva;
@@ -123,4 +126,29 @@ extern "C" int sva_test_sampler(int device, int variant, int rows, int V, const 
     }
     (void)hipFree(dL); (void)hipFree(dN); (void)hipFree(dT);
     return rc;
+}
+
+// Host cost of enqueueing one kernel from the calling thread (microseconds), measured with `iters` launches of a one-element
+// kernel into an otherwise idle stream.  A single-stream step is ~430 launches, so the launch rate of the enqueueing thread
+// bounds the step rate, and on a two-socket host it depends on which core the thread runs on (measured 3.7 vs 4.8 us);
+// engine.py pin_enqueue_thread() uses this to place the thread.
+extern "C" int sva_host_launch_cost(int device, int iters, float* us_per_launch) {
+    SVA_CHECK(iters > 0 && us_per_launch, "host_launch_cost: iters > 0 and an output pointer");
+    SVA_HIP(hipSetDevice(device));
+    static std::mutex mu;
+    static std::map<int, std::pair<hipStream_t, int*>> res;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& r = res[device];
+    if (!r.first) {
+        SVA_HIP(hipStreamCreateWithFlags(&r.first, hipStreamNonBlocking));
+        SVA_HIP(hipMalloc((void**)&r.second, 64 * sizeof(int)));
+    }
+    for (int i = 0; i < 32; ++i) if (int rc = launch_fill_i32(r.second, 1, i, r.first)) return rc;
+    SVA_HIP(hipStreamSynchronize(r.first));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) if (int rc = launch_fill_i32(r.second, 1, i, r.first)) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
+    SVA_HIP(hipStreamSynchronize(r.first));
+    *us_per_launch = (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
+    return 0;
 }

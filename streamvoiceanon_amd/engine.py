@@ -92,6 +92,7 @@ def load_library():
     lib.sva_bench_gemm.argtypes = [i32] * 9 + [f32p]
     lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
     lib.sva_test_gemm_choice.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32]
+    lib.sva_host_launch_cost.argtypes = [i32, i32, f32p]
     lib.sva_test_sampler.argtypes = [i32, i32, i32, i32, vp, vp, C.c_float, C.c_float, vp, i32, f32p]
     _lib = lib
     return lib
@@ -102,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
     "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_stream_chunks", "sva_encode_window", "sva_firefly_encode",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
-    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm", "sva_test_sampler",
+    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
 ]
 
 
@@ -391,6 +392,42 @@ def test_gemm_choice(A, W, choice, bias=None, device=0):
     b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
     _check(lib.sva_test_gemm_choice(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out), *[int(x) for x in choice]), "sva_test_gemm_choice")
     return out
+
+
+def host_launch_cost(device=0, iters=300):
+    """microseconds the calling thread spends enqueueing one kernel (idle stream)"""
+    us = (C.c_float * 1)()
+    _check(load_library().sva_host_launch_cost(device, int(iters), us), "sva_host_launch_cost")
+    return float(us[0])
+
+
+def pin_enqueue_thread(device=0, group=8, iters=300):
+    """Place the calling (enqueueing) thread on the group of `group` consecutive CPUs from which kernel launches to `device`
+    are cheapest, among the CPUs the thread may run on now.  One streaming step is ~430 kernel launches; at 1-8 streams the
+    enqueue rate of this thread is as tight a bound as the GPU's dependent-kernel chains, and it varies by ~30 % between
+    core groups of a two-socket host (distance to the GPU's PCIe root).  Only the calling thread moves (sched_setaffinity on
+    its tid); runtime helper threads that already exist keep their placement, so call this after the first batch has run.
+    Returns (chosen cpu list, {first cpu of group: us per launch})."""
+    import os
+    allowed = sorted(os.sched_getaffinity(0))
+    groups = {}
+    for c in allowed:
+        groups.setdefault(c // group, []).append(c)
+    if len(groups) <= 1:
+        return allowed, {}
+    table = {}
+    try:
+        for g, cpus in sorted(groups.items()):
+            os.sched_setaffinity(0, {cpus[0]})
+            host_launch_cost(device, 64)                       # settle on the core
+            table[cpus[0]] = min(host_launch_cost(device, iters), host_launch_cost(device, iters))
+        best = min(table, key=table.get)
+        chosen = groups[best // group]
+    except Exception:
+        os.sched_setaffinity(0, set(allowed))
+        raise
+    os.sched_setaffinity(0, set(chosen))
+    return chosen, table
 
 
 def test_sampler(logits, noise, variant, temperature=0.7, top_p=0.7, iters=0, device=0):
