@@ -1290,22 +1290,28 @@ std::map<int, StreamSet> g_streams;          // per device, process lifetime
 // `partitioned`: the AR stream and the encoder / vocoder streams get disjoint compute-unit masks (hipExtStreamCreateWithCUMask;
 // mask bit i -> XCD i % 8, so every range is spread over all XCDs).  With few streams the three stage chains are strings of
 // short dependent kernels that each leave most of the chip idle, yet when they share CUs the AR chain's kernels queue behind
-// the encoder's and vocoder's workgroups: measured at 1 stream 2.11 -> 1.80 ms per step with AR on 96 CUs and E/V on the
-// other 160; the gain shrinks with the batch (+20 % at 2-4 streams, +9 % at 8) and turns into a loss from 16 streams on,
-// where the GEMMs want the whole chip.  SVA_CU_PART="alo,an,elo,en,vlo,vn" overrides the ranges, SVA_CU_PART=off disables.
-int get_streams(int device, bool need_aux1, bool partitioned, StreamSet* out) {
+// the encoder's and vocoder's workgroups.  The gain shrinks with the batch and turns into a loss from 16 streams on, where
+// the GEMMs want the whole chip.  SVA_CU_PART="alo,an,elo,en,vlo,vn" overrides the ranges, SVA_CU_PART=off disables.
+int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSet* out) {
     std::lock_guard<std::mutex> lk(g_streams_mu);
+    // variant 1 (one stream): AR 96 CUs | encoder 136 | vocoder 24 -- 2.11 -> 1.75 ms per step; the vocoder needs >= 24 CUs and
+    // the landscape is not smooth (96/138/22 and 92/140/24 lose everything again).  variant 2 (2..8 streams): AR 96 | encoder
+    // and vocoder share the other 160 (+23 % at 2 and 4 streams, +11 % at 8; the three-way split is worse there).
+    bool partitioned = n_streams_if_pipelined >= 1 && n_streams_if_pipelined <= 8;
+    int variant = !partitioned ? 0 : n_streams_if_pipelined == 1 ? 1 : 2;
     int part[6] = {0, 96, 96, 160, 96, 160};
+    if (variant == 1) { part[3] = 136; part[4] = 232; part[5] = 24; }
     if (const char* e = getenv("SVA_CU_PART")) {
         if (!strcmp(e, "off")) partitioned = false;
-        else sscanf(e, "%d,%d,%d,%d,%d,%d", part, part + 1, part + 2, part + 3, part + 4, part + 5);
+        else if (partitioned) { sscanf(e, "%d,%d,%d,%d,%d,%d", part, part + 1, part + 2, part + 3, part + 4, part + 5); variant = 3; }
     }
     if (partitioned) {
         hipDeviceProp_t prop;
         SVA_HIP(hipGetDeviceProperties(&prop, device));
         if (prop.multiProcessorCount != 256) partitioned = false;         // the ranges are sized for the 256 CUs of an MI355X
     }
-    StreamSet& s = g_streams[device * 2 + (partitioned ? 1 : 0)];
+    if (!partitioned) variant = 0;
+    StreamSet& s = g_streams[device * 4 + variant];
     if (!s.main) {
         auto make = [&](hipStream_t* st, int lo, int n) -> int {
             if (!partitioned || n <= 0 || n >= 256) { SVA_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking)); return 0; }
@@ -1347,7 +1353,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     if (b->p.pipeline) SVA_CHECK(b->voc_grouped, "stage pipelining needs the grouped vocoder launches");
     {
         StreamSet ss;
-        SVA_TRY(get_streams(e->device, !b->voc_grouped, b->p.pipeline && B <= 8, &ss));
+        SVA_TRY(get_streams(e->device, !b->voc_grouped, b->p.pipeline ? B : 0, &ss));
         b->stream = b->main_stream = ss.main;
         b->aux[0] = ss.aux0;
         b->aux[1] = b->voc_grouped ? nullptr : ss.aux1;
