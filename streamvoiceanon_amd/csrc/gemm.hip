@@ -411,9 +411,12 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
             float* crow = g.C + (long)b * g.c_bstride + g.c_off + (long)tt * g.ldc;
             const float* rrow = g.res ? g.res + (long)b * g.r_bstride + g.r_off + (long)tt * g.ldr : nullptr;
             if (g.w13) {
-                if constexpr (NT == 2) {
-                    const int n = n0 + col;
-                    if (n < g.N) crow[(n0 >> 1) + col] = silu_f(t[0][r]) * t[1][r];
+                if constexpr (NT % 2 == 0) {          // column tiles come in (gate, up) pairs
+#pragma unroll
+                    for (int jp = 0; jp < NT / 2; ++jp) {
+                        const int n = n0 + jp * 32 + col;
+                        if (n < g.N) crow[(n0 >> 1) + jp * 16 + col] = silu_f(t[2 * jp][r]) * t[2 * jp + 1][r];
+                    }
                 }
             } else {
 #pragma unroll
@@ -567,6 +570,13 @@ static int launch_skinny(const ConvGemm& g, hipStream_t st) {
 #endif
 template <int NT>
 static int launch_cfg(const ConvGemm& g, hipStream_t st, int mt, int kw) {
+    if constexpr (NT == 4) {      // 64-column workgroups: rows x K-split waves in {16, 32, 64} x {4, 8}
+        switch (mt) {
+            case 1: return kw == 8 ? launch_skinny<1, 4, 8, 4>(g, st) : launch_skinny<1, 4, 4, 4>(g, st);
+            case 2: return kw == 8 ? launch_skinny<2, 4, 8, 3>(g, st) : launch_skinny<2, 4, 4, 3>(g, st);
+            default: return kw == 8 ? launch_skinny<4, 4, 8, 2>(g, st) : launch_skinny<4, 4, 4, 2>(g, st);
+        }
+    }
     switch (mt) {
         case 1:
             if (kw == 16) return launch_skinny<1, NT, 16, SVA_D116>(g, st);
@@ -631,7 +641,7 @@ struct Choice { int kind, a, b, c; int z = 1; };      // z: grid-level K split o
 static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
     if (ch.kind == 0) {
         t_ksplit = ch.z;
-        const int rc = ch.c == 2 ? launch_cfg<2>(g, st, ch.a, ch.b) : launch_cfg<1>(g, st, ch.a, ch.b);
+        const int rc = ch.c == 4 ? launch_cfg<4>(g, st, ch.a, ch.b) : ch.c == 2 ? launch_cfg<2>(g, st, ch.a, ch.b) : launch_cfg<1>(g, st, ch.a, ch.b);
         t_ksplit = 1;
         return rc;
     }
@@ -791,13 +801,15 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                 if (must_skinny || tiles64 < 1024) {
                     const int mt_total = (g.M + 15) / 16;
                     const long nk = (long)g.taps * g.Cin / 16;
-                    for (int nt = 1; nt <= 2; ++nt) {
+                    for (int nt = 1; nt <= 4; nt *= 2) {
                         if (g.w13 && nt == 1) continue;
                         if (nt == 2 && (g.N % 32 != 0 || g.dw_wT)) continue;
+                        if (nt == 4 && (g.N % 64 != 0 || g.dw_wT || g.M < 32)) continue;       // 64-column workgroups: a third of the operand reads per output
                         const int mts[3] = {1, 2, 4}, kws[3] = {4, 8, 16};
                         for (int a = 0; a < 3; ++a)
                             for (int b2 = 0; b2 < 3; ++b2) {
                                 if (mts[a] > mt_total || (mts[a] >= 2 && kws[b2] == 16) || nk / kws[b2] < 1) continue;
+                                if (nt == 4 && kws[b2] == 16) continue;
                                 cand.push_back(Choice{0, mts[a], kws[b2], nt});
                                 if (g.rms_w || group_n > 1 || !ksplit_enabled()) continue;
                                 const long wgs = (long)((g.N + 16 * nt - 1) / (16 * nt)) * ((mt_total + mts[a] - 1) / mts[a]);
@@ -844,7 +856,8 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
 int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, int b, int c) {
     SVA_CHECK(g.Cin % 16 == 0 && g.lda % 4 == 0, "conv_gemm_choice: alignment");
     SVA_CHECK(kind == 0 || kind == 1, "conv_gemm_choice: kind");
-    if (kind == 0) SVA_CHECK((a == 1 || a == 2 || a == 3 || a == 4) && (b == 4 || b == 8 || (b == 16 && a == 1)) && (c == 1 || (c == 2 && g.N % 32 == 0)),
+    if (kind == 0) SVA_CHECK((a == 1 || a == 2 || a == 3 || a == 4) && (b == 4 || b == 8 || (b == 16 && a == 1)) &&
+                                 (c == 1 || (c == 2 && g.N % 32 == 0) || (c == 4 && g.N % 64 == 0 && a != 3 && b != 16)),
                              "conv_gemm_choice: bad small-M configuration");
     else SVA_CHECK(a >= 0 && a <= 7 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: bad tile variant");
     SVA_TRY_RC(launch_choice(g, st, Choice{kind, a, b, c}));
@@ -853,7 +866,8 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
 }
 int launch_conv_gemm_choice_z(const ConvGemm& g, hipStream_t st, int a, int b, int c, int z) {
     SVA_CHECK(g.Cin % 16 == 0 && g.lda % 4 == 0, "conv_gemm_choice: alignment");
-    SVA_CHECK((a == 1 || a == 2 || a == 3 || a == 4) && (b == 4 || b == 8 || (b == 16 && a == 1)) && (c == 1 || (c == 2 && g.N % 32 == 0)) && z >= 1 && z <= 8,
+    SVA_CHECK((a == 1 || a == 2 || a == 3 || a == 4) && (b == 4 || b == 8 || (b == 16 && a == 1)) &&
+                  (c == 1 || (c == 2 && g.N % 32 == 0) || (c == 4 && g.N % 64 == 0 && a != 3 && b != 16)) && z >= 1 && z <= 8,
               "conv_gemm_choice: bad small-M configuration");
     Choice ch{0, a, b, c};
     ch.z = z;

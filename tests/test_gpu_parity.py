@@ -572,18 +572,18 @@ def test_every_gemm_dispatch_choice_vs_fp64():
     from streamvoiceanon_amd import engine as E
 
     rng = np.random.default_rng(5)
-    skinny = [(0, mt, kw, nt) for nt in (1, 2) for mt in (1, 2, 4) for kw in (4, 8, 16) if not (mt >= 2 and kw == 16)]
+    skinny = [(0, mt, kw, nt) for nt in (1, 2, 4) for mt in (1, 2, 4) for kw in (4, 8, 16) if not ((mt >= 2 or nt == 4) and kw == 16)]
     tiled = [(1, v, 0, 0) for v in range(8)]
     # kind 2: the small-M kernel with the K axis also split over z workgroups (last arriver reduces); c = nt + 16 * z
     skinny += [(2, mt, kw, nt + 16 * z) for (_, mt, kw, nt) in list(skinny) for z in (2, 4, 8)]
-    for (M, N, K) in ((200, 192, 256), (77, 96, 1024), (515, 288, 128)):
+    for (M, N, K) in ((200, 192, 256), (77, 96, 1024), (515, 288, 128), (160, 320, 384)):
         A = rng.standard_normal((M, K)).astype(np.float32)
         W = rng.standard_normal((N, K)).astype(np.float32)
         bias = rng.standard_normal(N).astype(np.float32)
         ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
         tol = 2e-6 * np.sqrt(K) * 4 + 1e-5
         for ch in skinny + tiled:
-            if ch[0] in (0, 2) and (ch[3] & 15) == 2 and N % 32:
+            if ch[0] in (0, 2) and (((ch[3] & 15) == 2 and N % 32) or ((ch[3] & 15) == 4 and N % 64)):
                 continue
             if ch[0] == 1 and ((ch[1] in (1, 4, 6, 7) and M < 128) or (ch[1] in (1, 5, 7) and N < 128)):
                 continue        # the tuner never offers tiles larger than the problem
