@@ -272,6 +272,8 @@ struct sva_batch {
 
     // graph
     hipGraphExec_t graph_exec = nullptr;
+    hipGraphExec_t pipe_graph_a[2] = {nullptr, nullptr};     // pipelined mode: the AR stage of a step, one per code-buffer parity
+    int pipe_graph_mode = 1;                                 // 0: AR stage enqueued kernel by kernel
     bool graph_ready = false;
     bool graph_step = false;       // last step ran through the graph (no per-stage events)
     bool forced_now = false;

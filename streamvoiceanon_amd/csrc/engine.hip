@@ -1361,6 +1361,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     }
     b->out_stream = b->stream;
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
+    if (const char* ev = getenv("SVA_PIPE_GRAPH")) b->pipe_graph_mode = atoi(ev);
     if (const char* ev = getenv("SVA_CONCURRENCY")) b->concurrency = atoi(ev) != 0;
     if (const char* ev = getenv("SVA_FUSED_DECODE")) b->fused_decode = atoi(ev) != 0;
     // SVA_CONCURRENCY=0: single stream (PMC profiling)
@@ -1561,6 +1562,7 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     if (b->sa) (void)hipStreamSynchronize(b->sa);
     if (b->sv) (void)hipStreamSynchronize(b->sv);
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
+    for (auto& ge : b->pipe_graph_a) if (ge) (void)hipGraphExecDestroy(ge);
     for (void* p : b->allocs.chunks) (void)hipFree(p);
     if (b->hp_in) (void)hipHostFree(b->hp_in);
     if (b->hp_out) (void)hipHostFree(b->hp_out);
@@ -1842,7 +1844,25 @@ int steady_pipelined(sva_batch* b) {
     if (b->pipe_evVc) SVA_HIP(hipStreamWaitEvent(sa, b->pipe_evVc, 0));
     b->stream = sa;
     int rc = 0;
-    for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
+    if (b->pipe_graph_mode) {
+        // The AR stage is ~210 launches on ONE stream whose arguments never change (positions, frame counters, noise keys
+        // and teacher-forcing flags live in device memory; the code buffer alternates, hence one graph per parity): replaying
+        // it as a hipGraph takes those launches off the enqueueing thread, whose launch rate is otherwise as tight a bound
+        // on a single-stream step as the GPU (1.0-2.1 ms per step depending on the host core, vs 1.75 ms of GPU time).
+        if (!b->pipe_graph_a[par]) {
+            hipGraph_t graph = nullptr;
+            SVA_HIP(hipStreamBeginCapture(sa, hipStreamCaptureModeThreadLocal));
+            for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
+            const hipError_t ce = hipStreamEndCapture(sa, &graph);
+            if (rc) { b->stream = se; return rc; }
+            SVA_HIP(ce);
+            SVA_HIP(hipGraphInstantiate(&b->pipe_graph_a[par], graph, nullptr, nullptr, 0));
+            SVA_HIP(hipGraphDestroy(graph));
+        }
+        SVA_HIP(hipGraphLaunch(b->pipe_graph_a[par], sa));
+    } else {
+        for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
+    }
     if (rc) { b->stream = se; return rc; }
     SVA_HIP(hipEventRecord(b->ev[2], sa));
     hipEvent_t evA = next_event(b);
