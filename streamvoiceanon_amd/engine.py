@@ -401,7 +401,7 @@ def host_launch_cost(device=0, iters=300):
     return float(us[0])
 
 
-def pin_enqueue_thread(device=0, group=8, iters=300):
+def pin_enqueue_thread(device=0, group=8, iters=120):
     """Place the calling (enqueueing) thread on the group of `group` consecutive CPUs from which kernel launches to `device`
     are cheapest, among the CPUs the thread may run on now.  One streaming step is ~430 kernel launches; at 1-8 streams the
     enqueue rate of this thread is as tight a bound as the GPU's dependent-kernel chains, and it varies by ~30 % between
@@ -419,8 +419,7 @@ def pin_enqueue_thread(device=0, group=8, iters=300):
     try:
         for g, cpus in sorted(groups.items()):
             os.sched_setaffinity(0, {cpus[0]})
-            host_launch_cost(device, 64)                       # settle on the core
-            table[cpus[0]] = min(host_launch_cost(device, iters), host_launch_cost(device, iters))
+            table[cpus[0]] = host_launch_cost(device, iters)   # (the call itself starts with 32 untimed launches: the thread has settled)
         best = min(table, key=table.get)
         chosen = groups[best // group]
     except Exception:
