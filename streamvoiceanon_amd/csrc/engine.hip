@@ -1317,7 +1317,10 @@ int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSe
             if (!partitioned || n <= 0 || n >= 256) { SVA_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking)); return 0; }
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = lo; i < lo + n && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
-            SVA_HIP(hipExtStreamCreateWithCUMask(st, 8, mask));
+            if (hipExtStreamCreateWithCUMask(st, 8, mask) != hipSuccess) {      // (a runtime without CU masking: plain stream, no partition)
+                (void)hipGetLastError();
+                SVA_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+            }
             return 0;
         };
         SVA_TRY(make(&s.main, part[2], part[3]));
@@ -1855,11 +1858,15 @@ int steady_pipelined(sva_batch* b) {
             for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
             const hipError_t ce = hipStreamEndCapture(sa, &graph);
             if (rc) { b->stream = se; return rc; }
-            SVA_HIP(ce);
-            SVA_HIP(hipGraphInstantiate(&b->pipe_graph_a[par], graph, nullptr, nullptr, 0));
-            SVA_HIP(hipGraphDestroy(graph));
+            if (ce != hipSuccess || hipGraphInstantiate(&b->pipe_graph_a[par], graph, nullptr, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();                   // capture unavailable: enqueue this and every later AR stage kernel by kernel
+                b->pipe_graph_a[par] = nullptr;
+                b->pipe_graph_mode = 0;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
         }
-        SVA_HIP(hipGraphLaunch(b->pipe_graph_a[par], sa));
+        if (b->pipe_graph_a[par]) SVA_HIP(hipGraphLaunch(b->pipe_graph_a[par], sa));
+        else for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
     } else {
         for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
     }

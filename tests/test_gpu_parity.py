@@ -818,3 +818,77 @@ def test_sampler_implementations_vs_oracle_and_each_other(V):
         for var in variants[1:]:
             got = E.test_sampler(T, Q, var, temperature=temp, top_p=tp)
             assert (got == base).all(), (V, tp, temp, var, np.nonzero(got != base)[0][:8])
+
+
+@pytest.mark.gpu
+def test_enqueue_thread_placement_moves_only_the_calling_thread():
+    """engine.pin_enqueue_thread: the launch-cost probe returns sane numbers, the calling thread ends up on one group of CPUs it
+    was allowed on before, and other threads keep their affinity."""
+    import os
+    import threading
+    from streamvoiceanon_amd import engine as E
+    before = os.sched_getaffinity(0)
+    us = E.host_launch_cost(0, 200)
+    assert 0.3 < us < 200.0, us
+    other = {}
+    gate, done = threading.Event(), threading.Event()
+
+    def side():
+        other["before"] = os.sched_getaffinity(0)
+        gate.wait()
+        other["after"] = os.sched_getaffinity(0)
+        done.set()
+    t = threading.Thread(target=side)
+    t.start()
+    try:
+        cpus, table = E.pin_enqueue_thread(0)
+        now = os.sched_getaffinity(0)
+        assert now == set(cpus) and now <= before
+        if len(before) > 8:
+            assert len(now) <= 8 and len(table) >= 2 and all(0.3 < v < 200.0 for v in table.values())
+    finally:
+        gate.set(); done.wait(); t.join()
+        os.sched_setaffinity(0, before)
+    assert other["before"] == other["after"]
+
+
+@pytest.mark.gpu
+def test_realtime_custom_infer_lazy_reprefill(weights0):
+    """real-time-gui.py:32-49 -- the audio-callback entry: the prompt and the stream caches are rebuilt only when the reference
+    name or the block size changes, and the converted blocks equal an explicit prefill_prompt / setup_stream_caches /
+    process_one_chunk sequence with the GUI's settings (encode window 64, prompt <= 64 frames)."""
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.realtime import RealtimeSession
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    _, _, style, timbre = synth_prompt(2500, 8)
+    refs = {"a.wav": synth_utterance(7300, 2048 * 70 + 100), "b.wav": synth_utterance(7301, 2048 * 66)}
+    src = synth_utterance(7302, 2048 * 12)
+
+    def make():
+        w = InferenceWrapper(weights=weights0)
+        w.style_encoder = lambda wav: style          # stand-ins for the CAM++ / SparkTTS encoders (N1 iii/iv)
+        w.timbre_encoder = lambda wav: timbre
+        return w
+
+    w, sess = make(), RealtimeSession()
+    got = [sess.custom_infer(w, refs["a.wav"], "a.wav", torch.from_numpy(src[i * 2048:(i + 1) * 2048]), n_frame_delay=2, alpha=1.0)
+           for i in range(5)]
+    assert sess.prefills == 1 and all(isinstance(g, torch.Tensor) and g.shape == (2048,) for g in got)
+    assert float(got[0].abs().max()) == 0.0 and float(got[1].abs().max()) == 0.0          # the decoder delay fills first
+    assert float(got[4].abs().max()) > 0.0
+    # explicit sequence on a second wrapper
+    w2 = make()
+    w2.prefill_prompt(refs["a.wav"], max_prompt_frames=64, delay=2, alpha=1.0)
+    w2.setup_stream_caches(encode_window_frames=64, decode_window_frames=64, max_seq_frames=768, buffer_frames=32, decode_chunk_frames=1)
+    for i in range(5):
+        want = np.asarray(w2.process_one_chunk(src[i * 2048:(i + 1) * 2048])).reshape(-1)
+        np.testing.assert_array_equal(got[i].numpy(), want)
+    # new reference name -> new prompt; same name, new block size (2 frames) -> caches rebuilt; same again -> nothing
+    sess.custom_infer(w, refs["b.wav"], "b.wav", src[5 * 2048:6 * 2048], alpha=1.0)
+    assert sess.prefills == 2
+    out2 = sess.custom_infer(w, refs["b.wav"], "b.wav", src[6 * 2048:8 * 2048], alpha=1.0)
+    assert sess.prefills == 3 and isinstance(out2, np.ndarray) and out2.shape == (4096,)
+    sess.custom_infer(w, refs["b.wav"], "b.wav", src[8 * 2048:10 * 2048], alpha=1.0)
+    assert sess.prefills == 3
+    w.engine.close(); w2.engine.close()
