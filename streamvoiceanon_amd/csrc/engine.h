@@ -147,6 +147,10 @@ struct sva_batch {
     hipStream_t aux[2] = {nullptr, nullptr};   // side streams for independent sub-chains (fork / join by events)
     // stage pipelining over consecutive chunk-steps (sva_step_device, p.pipeline): AR and vocoder streams, hand-off events
     hipStream_t sa = nullptr, sv = nullptr;
+    hipEvent_t pipe_evD2C = nullptr;       // recorded once the transformer of a step no longer reads the token cache
+    hipEvent_t tr_l0_event = nullptr;      // enc_transformer records this after its first layer's output projection
+    int pipe_split_e = 1;                  // 0: encoder as one in-order stage
+    int* d_step_x = nullptr;               // the side chain's copy of the chunk counter (pipelined encoder)
     hipStream_t out_stream = nullptr;      // stream that holds the PCM of the last step
     bool allow_pipe = false, pipe_dirty = false;
     hipEvent_t pipe_evVc = nullptr, pipe_evR = nullptr, pipe_evA[2] = {nullptr, nullptr};

@@ -730,6 +730,7 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows) {
         po.gamma = L.ls_attn;
         po.res = xr; po.r_bstride = xr_bs; po.r_off = xr_off + (long)r0 * D; po.ldr = D;
         SVA_TRY(gemm_call(b, b->tr_att, (long)T2 * D, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.wo, xw, xw_bs, (long)r0 * D, D, po));
+        if (li == 0 && b->tr_l0_event) SVA_HIP(hipEventRecord(b->tr_l0_event, st));     // `xin` is not read past this point
         xr = xw; xr_bs = xw_bs; xr_off = 0;
         ConvGemm pg;
         pg.w13 = 1;
@@ -764,7 +765,7 @@ int encode(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
 // 160 mel frames = 40 tokens); every later token is the true causal feature of its absolute time, computed once by
 // the streaming pass when it entered the window and kept in d2c, which slides by c tokens per chunk.  The 8-layer
 // transformer + BSQ always run on all T2 tokens.  Same values as the window pass up to fp32 summation order.
-int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
+int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add, bool transformer_too = true) {
     const int D = b->e->cfg.tr_dim, c = b->p.chunk_frames;
     hipStream_t st = b->stream;
     SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, b->B, st));                   // steady tokens slide down by c
@@ -780,7 +781,8 @@ int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add) 
     SVA_TRY(enc_frontend_window(b, step_ptr, n_chunk, add, 4 * b->Ht, nullptr, &b->d2c));   // head pass -> d2c rows [0, Ht) directly
     if (par) SVA_TRY(stream_fork(b, b->aux[0], st));                             // join
     (void)c;
-    return enc_transformer(b, b->d2c, b->p.chunk_frames);
+    if (transformer_too) return enc_transformer(b, b->d2c, b->p.chunk_frames);
+    return 0;
 }
 
 // ---- A: slow / fast transformer passes ------------------------------------------------------------
@@ -1365,6 +1367,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     b->out_stream = b->stream;
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
     if (const char* ev = getenv("SVA_PIPE_GRAPH")) b->pipe_graph_mode = atoi(ev);
+    if (const char* ev = getenv("SVA_PIPE_SPLIT_E")) b->pipe_split_e = atoi(ev);
     if (const char* ev = getenv("SVA_CONCURRENCY")) b->concurrency = atoi(ev) != 0;
     if (const char* ev = getenv("SVA_FUSED_DECODE")) b->fused_decode = atoi(ev) != 0;
     // SVA_CONCURRENCY=0: single stream (PMC profiling)
@@ -1372,6 +1375,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     const int chunk = p->chunk_frames;
     // control block
     SVA_TRY(dev_alloc(A, &b->d_step, 1));
+    SVA_TRY(dev_alloc(A, &b->d_step_x, 1));
     SVA_TRY(dev_alloc(A, &b->d_last_pos, B));
     SVA_TRY(dev_alloc(A, &b->d_nframes, B));
     SVA_TRY(dev_alloc(A, &b->d_ncontent, B));
@@ -1825,23 +1829,68 @@ int steady_pipelined(sva_batch* b) {
         SVA_HIP(hipEventRecord(ev, se));
         SVA_HIP(hipStreamWaitEvent(sa, ev, 0));
         SVA_HIP(hipStreamWaitEvent(sv, ev, 0));
-        b->pipe_evVc = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr;
+        SVA_HIP(hipMemcpyAsync(b->d_step_x, b->d_step, sizeof(int), hipMemcpyDeviceToDevice, se));      // the side chain's chunk counter
+        b->pipe_evVc = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr; b->pipe_evD2C = nullptr;
     }
     const int par = b->pipe_parity;
     b->d_codes = b->d_codes_buf[par];
     b->pipe_parity ^= 1;
-    // back-pressure: this step's encoder overwrites the code buffer that A(n-2) read, so E may lead A by at most two steps
-    if (b->pipe_evA[par]) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evA[par], 0));
-    if (b->pipe_evR) { SVA_HIP(hipStreamWaitEvent(se, b->pipe_evR, 0)); b->pipe_evR = nullptr; }
-    b->stream = se;
-    SVA_HIP(hipEventRecord(b->ev[0], se));
-    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
-    SVA_TRY(b->enc_incremental ? encode_incremental(b, b->d_step, n, 1) : encode(b, b->d_step, n, 1));
-    hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, se, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
-                       b->d_ncontent, b->d_step_content, B, b->d_step);
-    SVA_HIP(hipEventRecord(b->ev[1], se));
-    hipEvent_t evE = next_event(b);
-    SVA_HIP(hipEventRecord(evE, se));
+    hipEvent_t evE = nullptr;
+    if (b->pipe_split_e && b->enc_incremental && b->concurrency && b->aux[0]) {
+        // The encoder is three chains -- head pass (main), streaming pass (side stream sx) and the 8-layer transformer + BSQ,
+        // which needs both -- and as one in-order stage its latency (1.7 ms) was the period of the whole pipeline.  The
+        // transformer therefore moves to the side stream behind the streaming pass:
+        //   main: slide d2c, head pass(n)                         -> evHead
+        //   sx:   streaming pass(n), [evHead] transformer + BSQ(n) -> evE
+        // so head pass(n+1) overlaps transformer(n) and the encoder's period is the side stream's chain.  Hazards: the token
+        // cache d2c (written by the slide, the head rows and the tail rows; read by the transformer in its FIRST layer only --
+        // QKV operand and the residual of the output projection): main(n+1) waits for an event the transformer records
+        // after that layer, and sx is in order; the chunk counter (ring position) is read by the first kernel of each
+        // front-end chain, so each chain advances its own copy when it is done (the append no longer does).
+        hipStream_t sx = b->aux[0];
+        if (b->pipe_evD2C) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evD2C, 0));
+        b->stream = se;
+        SVA_HIP(hipEventRecord(b->ev[0], se));
+        SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
+        SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se));                       // steady tokens slide down by c
+        SVA_TRY(stream_fork(b, se, sx));
+        b->stream = sx;
+        int erc = enc_frontend_stream(b, b->d_step_x, n, 1);                          // c newest tokens -> d2c tail
+        if (!erc) erc = launch_add_i32(b->d_step_x, 1, sx);
+        b->stream = se;
+        if (erc) return erc;
+        SVA_TRY(enc_frontend_window(b, b->d_step, n, 1, 4 * b->Ht, nullptr, &b->d2c));     // head pass -> d2c rows [0, Ht)
+        SVA_TRY(launch_add_i32(b->d_step, 1, se));
+        SVA_TRY(stream_fork(b, se, sx));                                              // transformer(n) needs head pass(n)
+        // back-pressure: this step's BSQ overwrites the code buffer that A(n-2) read, so E may lead A by at most two steps
+        if (b->pipe_evA[par]) SVA_HIP(hipStreamWaitEvent(sx, b->pipe_evA[par], 0));
+        if (b->pipe_evR) { SVA_HIP(hipStreamWaitEvent(sx, b->pipe_evR, 0)); b->pipe_evR = nullptr; }
+        b->stream = sx;
+        b->pipe_evD2C = next_event(b);
+        b->tr_l0_event = b->pipe_evD2C;
+        const int trc = enc_transformer(b, b->d2c, chunk);
+        b->tr_l0_event = nullptr;
+        b->stream = se;
+        if (trc) return trc;
+        hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, sx, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
+                           b->d_ncontent, b->d_step_content, B, (int*)nullptr);
+        SVA_HIP(hipEventRecord(b->ev[1], sx));
+        evE = next_event(b);
+        SVA_HIP(hipEventRecord(evE, sx));
+    } else {
+        // back-pressure: this step's encoder overwrites the code buffer that A(n-2) read, so E may lead A by at most two steps
+        if (b->pipe_evA[par]) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evA[par], 0));
+        if (b->pipe_evR) { SVA_HIP(hipStreamWaitEvent(se, b->pipe_evR, 0)); b->pipe_evR = nullptr; }
+        b->stream = se;
+        SVA_HIP(hipEventRecord(b->ev[0], se));
+        SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
+        SVA_TRY(b->enc_incremental ? encode_incremental(b, b->d_step, n, 1) : encode(b, b->d_step, n, 1));
+        hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, se, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
+                           b->d_ncontent, b->d_step_content, B, b->d_step);
+        SVA_HIP(hipEventRecord(b->ev[1], se));
+        evE = next_event(b);
+        SVA_HIP(hipEventRecord(evE, se));
+    }
     // A(n)
     SVA_HIP(hipStreamWaitEvent(sa, evE, 0));
     if (b->pipe_evVc) SVA_HIP(hipStreamWaitEvent(sa, b->pipe_evVc, 0));
@@ -1899,8 +1948,13 @@ int quiesce(sva_batch* b) {
     SVA_HIP(hipEventRecord(e2, b->sv));
     SVA_HIP(hipStreamWaitEvent(se, e1, 0));
     SVA_HIP(hipStreamWaitEvent(se, e2, 0));
+    if (b->aux[0]) {                       // (carries the encoder's transformer in the pipelined regime)
+        hipEvent_t e3 = next_event(b);
+        SVA_HIP(hipEventRecord(e3, b->aux[0]));
+        SVA_HIP(hipStreamWaitEvent(se, e3, 0));
+    }
     b->pipe_dirty = false;
-    b->pipe_evVc = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr;
+    b->pipe_evVc = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr; b->pipe_evD2C = nullptr;
     b->out_stream = se;
     return 0;
 }

@@ -91,6 +91,7 @@ int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStrea
 
 // small helpers
 int launch_fill_i32(int* p, int n, int v, hipStream_t st);
+int launch_add_i32(int* p, int v, hipStream_t st);
 int launch_ring_write(float* ring, int* step, int B, int N, const float* chunk, int n, hipStream_t st);
 
 }  // namespace sva

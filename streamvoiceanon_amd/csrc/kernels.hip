@@ -79,6 +79,12 @@ __global__ void fill_i32_kernel(int* p, int n, int v) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+__global__ void add_i32_kernel(int* p, int v) { *p += v; }
+int launch_add_i32(int* p, int v, hipStream_t st) {
+    hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, st, p, v);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
 int launch_fill_i32(int* p, int n, int v, hipStream_t st) {
     hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, n, v);
     SVA_HIP(hipGetLastError());
