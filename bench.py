@@ -40,7 +40,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md "Pea
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (B)")
     ap.add_argument("--chunk", type=int, default=1, help="decode_chunk_frames")

@@ -33,6 +33,7 @@ for nb in [int(x) for x in os.environ.get('NB', '1,2,3,4').split(',')]:
             b.step_device(audio[i, k].data_ptr(), out[i].data_ptr())
         k += 1
     for b in bs: b.sync()
+    if os.environ.get('PIN', '0') == '1': print('pinned to', E.pin_enqueue_thread(0)[0][:1], flush=True)
     t0 = time.perf_counter()
     for _ in range(steps):
         for i, b in enumerate(bs):
