@@ -150,10 +150,14 @@ struct sva_batch {
     hipEvent_t pipe_evD2C = nullptr;       // recorded once the transformer of a step no longer reads the token cache
     hipEvent_t tr_l0_event = nullptr;      // enc_transformer records this after its first layer's output projection
     int pipe_split_e = 1;                  // 0: encoder as one in-order stage
+    std::vector<hipEvent_t> trace_ev;     // SVA_PIPE_TRACE=N: timestamps of the stage chains of the last N pipelined steps (debug)
+    long trace_steps = 0;
+    int trace_n = 0;
     int* d_step_x = nullptr;               // the side chain's copy of the chunk counter (pipelined encoder)
     hipStream_t out_stream = nullptr;      // stream that holds the PCM of the last step
     bool allow_pipe = false, pipe_dirty = false;
-    hipEvent_t pipe_evVc = nullptr, pipe_evR = nullptr, pipe_evA[2] = {nullptr, nullptr};
+    hipEvent_t pipe_evVc[2] = {nullptr, nullptr}, pipe_evR = nullptr, pipe_evA[2] = {nullptr, nullptr};
+    int* d_step_audio_buf[2] = {nullptr, nullptr};
     long long* d_codes_buf[2] = {nullptr, nullptr};
     int pipe_parity = 0;
     hipEvent_t evpool[64];

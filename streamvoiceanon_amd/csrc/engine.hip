@@ -1368,6 +1368,11 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
     if (const char* ev = getenv("SVA_PIPE_GRAPH")) b->pipe_graph_mode = atoi(ev);
     if (const char* ev = getenv("SVA_PIPE_SPLIT_E")) b->pipe_split_e = atoi(ev);
+    if (const char* ev = getenv("SVA_PIPE_TRACE")) {
+        b->trace_n = atoi(ev);
+        b->trace_ev.resize((size_t)b->trace_n * 9);
+        for (auto& t : b->trace_ev) SVA_HIP(hipEventCreate(&t));
+    }
     if (const char* ev = getenv("SVA_CONCURRENCY")) b->concurrency = atoi(ev) != 0;
     if (const char* ev = getenv("SVA_FUSED_DECODE")) b->fused_decode = atoi(ev) != 0;
     // SVA_CONCURRENCY=0: single stream (PMC profiling)
@@ -1505,7 +1510,9 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     SVA_TRY(dev_alloc(A, &b->d_content_hist, (size_t)B * b->hist_cap));
     SVA_TRY(dev_alloc(A, &b->d_pred_hist, (size_t)B * ncb * b->hist_cap));
     SVA_TRY(dev_alloc(A, &b->d_step_content, (size_t)B * chunk));
-    SVA_TRY(dev_alloc(A, &b->d_step_audio, (size_t)B * ncb * chunk));
+    SVA_TRY(dev_alloc(A, &b->d_step_audio_buf[0], (size_t)B * ncb * chunk));
+    SVA_TRY(dev_alloc(A, &b->d_step_audio_buf[1], (size_t)B * ncb * chunk));
+    b->d_step_audio = b->d_step_audio_buf[0];
     b->Pmax = S;
     SVA_TRY(dev_alloc(A, &b->d_prompt_cc, b->Pmax));
     SVA_TRY(dev_alloc(A, &b->d_prompt_ac, (size_t)ncb * b->Pmax));
@@ -1568,6 +1575,18 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     for (int i = 0; i < 2; ++i) if (b->aux[i]) (void)hipStreamSynchronize(b->aux[i]);
     if (b->sa) (void)hipStreamSynchronize(b->sa);
     if (b->sv) (void)hipStreamSynchronize(b->sv);
+    if (b->trace_n && b->trace_steps >= b->trace_n) {       // SVA_PIPE_TRACE: when each chain of the last steps could start / ended (us)
+        const long s0 = b->trace_steps - b->trace_n;
+        hipEvent_t base = b->trace_ev[(size_t)(s0 % b->trace_n) * 9];
+        fprintf(stderr, "[sva pipe trace] step: main[start end] side[start] transformer[start end] ar[start end] vocoder[start end]  (us from the first row)\n");
+        for (long q = s0; q < b->trace_steps; ++q) {
+            float t[9];
+            for (int k = 0; k < 9; ++k) { t[k] = 0.f; (void)hipEventElapsedTime(&t[k], base, b->trace_ev[(size_t)(q % b->trace_n) * 9 + k]); }
+            fprintf(stderr, "[sva pipe trace] %ld: main %.0f %.0f | side %.0f | tr %.0f %.0f | ar %.0f %.0f | voc %.0f %.0f\n", q, t[0] * 1e3, t[1] * 1e3,
+                    t[2] * 1e3, t[3] * 1e3, t[4] * 1e3, t[5] * 1e3, t[6] * 1e3, t[7] * 1e3, t[8] * 1e3);
+        }
+    }
+    for (auto& t : b->trace_ev) (void)hipEventDestroy(t);
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     for (auto& ge : b->pipe_graph_a) if (ge) (void)hipGraphExecDestroy(ge);
     for (void* p : b->allocs.chunks) (void)hipFree(p);
@@ -1817,7 +1836,8 @@ int steady_launches(sva_batch* b, bool timing_events) {
 //   main: E(n)   ->   sa: A(n)   ->   sv: V(n)
 // chained by events, so that E(n+1), A(n) and V(n-1) overlap on the GPU.  Hazards between consecutive steps:
 //   * d_codes (E writes, A reads to the end of its frame): double-buffered, swapped per step;
-//   * d_step_audio (A writes at the end of a frame, V copies it first thing): A(n+1) waits for V(n)'s copy;
+//   * d_step_audio (A writes at the end of a frame, V reads it first thing): double-buffered like d_codes, A(n) waits for
+//     V(n-2)'s read;
 //   * content history (E appends, a re-prefill on sa reads): E(n+1) waits for the re-prefill of step n.
 // Every other buffer is private to its stage.
 int steady_pipelined(sva_batch* b) {
@@ -1830,12 +1850,19 @@ int steady_pipelined(sva_batch* b) {
         SVA_HIP(hipStreamWaitEvent(sa, ev, 0));
         SVA_HIP(hipStreamWaitEvent(sv, ev, 0));
         SVA_HIP(hipMemcpyAsync(b->d_step_x, b->d_step, sizeof(int), hipMemcpyDeviceToDevice, se));      // the side chain's chunk counter
-        b->pipe_evVc = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr; b->pipe_evD2C = nullptr;
+        b->pipe_evVc[0] = b->pipe_evVc[1] = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr; b->pipe_evD2C = nullptr;
     }
     const int par = b->pipe_parity;
     b->d_codes = b->d_codes_buf[par];
+    b->d_step_audio = b->d_step_audio_buf[par];      // the frame's audio codes: A(n) writes them last, V(n) reads them first
     b->pipe_parity ^= 1;
     hipEvent_t evE = nullptr;
+    // debug trace: k = 0 main start, 1 main end, 2 side start, 3 transformer start, 4 transformer end, 5 AR start, 6 AR end,
+    // 7 vocoder start, 8 vocoder end (each recorded behind the waits of its chain, i.e. when the chain could really start)
+    auto mark = [&](int k, hipStream_t st_) -> int {
+        if (b->trace_n) SVA_HIP(hipEventRecord(b->trace_ev[(size_t)(b->trace_steps % b->trace_n) * 9 + k], st_));
+        return 0;
+    };
     if (b->pipe_split_e && b->enc_incremental && b->concurrency && b->aux[0]) {
         // The encoder is three chains -- head pass (main), streaming pass (side stream sx) and the 8-layer transformer + BSQ,
         // which needs both -- and as one in-order stage its latency (1.7 ms) was the period of the whole pipeline.  The
@@ -1851,21 +1878,25 @@ int steady_pipelined(sva_batch* b) {
         if (b->pipe_evD2C) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evD2C, 0));
         b->stream = se;
         SVA_HIP(hipEventRecord(b->ev[0], se));
+        SVA_TRY(mark(0, se));
         SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
         SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se));                       // steady tokens slide down by c
         SVA_TRY(stream_fork(b, se, sx));
         b->stream = sx;
+        SVA_TRY(mark(2, sx));
         int erc = enc_frontend_stream(b, b->d_step_x, n, 1);                          // c newest tokens -> d2c tail
         if (!erc) erc = launch_add_i32(b->d_step_x, 1, sx);
         b->stream = se;
         if (erc) return erc;
         SVA_TRY(enc_frontend_window(b, b->d_step, n, 1, 4 * b->Ht, nullptr, &b->d2c));     // head pass -> d2c rows [0, Ht)
         SVA_TRY(launch_add_i32(b->d_step, 1, se));
+        SVA_TRY(mark(1, se));
         SVA_TRY(stream_fork(b, se, sx));                                              // transformer(n) needs head pass(n)
         // back-pressure: this step's BSQ overwrites the code buffer that A(n-2) read, so E may lead A by at most two steps
         if (b->pipe_evA[par]) SVA_HIP(hipStreamWaitEvent(sx, b->pipe_evA[par], 0));
         if (b->pipe_evR) { SVA_HIP(hipStreamWaitEvent(sx, b->pipe_evR, 0)); b->pipe_evR = nullptr; }
         b->stream = sx;
+        SVA_TRY(mark(3, sx));
         b->pipe_evD2C = next_event(b);
         b->tr_l0_event = b->pipe_evD2C;
         const int trc = enc_transformer(b, b->d2c, chunk);
@@ -1875,6 +1906,7 @@ int steady_pipelined(sva_batch* b) {
         hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, sx, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
                            b->d_ncontent, b->d_step_content, B, (int*)nullptr);
         SVA_HIP(hipEventRecord(b->ev[1], sx));
+        SVA_TRY(mark(4, sx));
         evE = next_event(b);
         SVA_HIP(hipEventRecord(evE, sx));
     } else {
@@ -1893,8 +1925,9 @@ int steady_pipelined(sva_batch* b) {
     }
     // A(n)
     SVA_HIP(hipStreamWaitEvent(sa, evE, 0));
-    if (b->pipe_evVc) SVA_HIP(hipStreamWaitEvent(sa, b->pipe_evVc, 0));
+    if (b->pipe_evVc[par]) SVA_HIP(hipStreamWaitEvent(sa, b->pipe_evVc[par], 0));     // V(n-2) has read this buffer (long since)
     b->stream = sa;
+    SVA_TRY(mark(5, sa));
     int rc = 0;
     if (b->pipe_graph_mode) {
         // The AR stage is ~210 launches on ONE stream whose arguments never change (positions, frame counters, noise keys
@@ -1921,20 +1954,24 @@ int steady_pipelined(sva_batch* b) {
     }
     if (rc) { b->stream = se; return rc; }
     SVA_HIP(hipEventRecord(b->ev[2], sa));
+    SVA_TRY(mark(6, sa));
     hipEvent_t evA = next_event(b);
     SVA_HIP(hipEventRecord(evA, sa));
     b->pipe_evA[par] = evA;
     // V(n)
     SVA_HIP(hipStreamWaitEvent(sv, evA, 0));
     b->stream = sv;
+    SVA_TRY(mark(7, sv));
     b->voc_codes = b->d_step_audio; b->voc_codes_bstride = (long)ncb * chunk; b->voc_codes_gstride = chunk;      // read in place ...
-    b->pipe_evVc = next_event(b);
-    b->voc_codes_event = b->pipe_evVc;       // ... and A(n+1) may overwrite them once the FSQ decode has run
+    b->pipe_evVc[par] = next_event(b);
+    b->voc_codes_event = b->pipe_evVc[par];       // ... and A(n+1) may overwrite them once the FSQ decode has run
     rc = vocode(b, chunk, true);
     b->voc_codes = nullptr; b->voc_codes_event = nullptr;
     b->stream = se;
     if (rc) return rc;
     SVA_HIP(hipEventRecord(b->ev[3], sv));
+    SVA_TRY(mark(8, sv));
+    b->trace_steps += 1;
     b->pipe_dirty = true;
     b->out_stream = sv;
     return 0;
@@ -1954,7 +1991,7 @@ int quiesce(sva_batch* b) {
         SVA_HIP(hipStreamWaitEvent(se, e3, 0));
     }
     b->pipe_dirty = false;
-    b->pipe_evVc = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr; b->pipe_evD2C = nullptr;
+    b->pipe_evVc[0] = b->pipe_evVc[1] = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr; b->pipe_evD2C = nullptr;
     b->out_stream = se;
     return 0;
 }

@@ -17,7 +17,8 @@ PIPE = os.environ.get('PIPE', '0') == '1'
 for nb in [int(x) for x in os.environ.get('NB', '1,2,3,4').split(',')]:
     bs = []
     for i in range(nb):
-        b = E.Batch(eng, n_streams=S, pipeline=PIPE, skip_semantic=os.environ.get('SKIP_SEM', '0') == '1')
+        b = E.Batch(eng, n_streams=S, pipeline=PIPE, skip_semantic=os.environ.get('SKIP_SEM', '0') == '1',
+                    encode_window_frames=int(os.environ.get('ENC_WIN', '128')))
         for j in range(S):
             ac, cc, st, tm = synth_prompt(2000 + i * S + j, 107)
             b.prefill_prompt(j, cc, ac, st, tm, noise_seed=i * S + j)
