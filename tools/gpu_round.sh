@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -8 gpurun_out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
-SVA_GEMM_TABLE=gpurun_out/gemm_table_b1.csv python bench.py --steps 30 --warmup 5 > gpurun_out/bench_b1.json 2> gpurun_out/bench_b1.err; tail -1 gpurun_out/bench_b1.json
+SVA_GEMM_TABLE=gpurun_out/gemm_table_b1.csv python bench.py > gpurun_out/bench_b1.json 2> gpurun_out/bench_b1.err; tail -1 gpurun_out/bench_b1.json
 SVA_GEMM_TABLE=gpurun_out/gemm_table_b64.csv python bench.py --steps 10 --warmup 3 --streams 64 --no-cpu-baseline --no-batched > gpurun_out/bench_b64.json 2> gpurun_out/bench_b64.err; tail -1 gpurun_out/bench_b64.json
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_${TAG}
