@@ -79,3 +79,37 @@ def test_wav_round_trips(tmp_path):
     with pytest.raises(ValueError):
         open(str(tmp_path / "bad.wav"), "wb").write(b"not a wav file at all")
         A.read_wav(str(tmp_path / "bad.wav"))
+
+
+def test_realtime_session_lazy_reprefill_logic():
+    """streamvoiceanon_amd.realtime (real-time-gui.py:32-49): host logic only -- prompt and caches are rebuilt iff the reference
+    name or the block size changed; the block goes through process_one_chunk unchanged in kind and length."""
+    from streamvoiceanon_amd.realtime import RealtimeSession
+
+    calls = []
+
+    class Stub:
+        def prefill_prompt(self, ref, max_prompt_frames, delay, alpha):
+            calls.append(("prefill", ref.shape, max_prompt_frames, delay, alpha))
+
+        def setup_stream_caches(self, **kw):
+            calls.append(("setup", kw["encode_window_frames"], kw["decode_window_frames"], kw["max_seq_frames"], kw["buffer_frames"],
+                          kw["decode_chunk_frames"]))
+
+        def process_one_chunk(self, block):
+            calls.append(("chunk", block.shape))
+            return block * 0.5
+
+    s, m = RealtimeSession(), Stub()
+    ref = np.zeros(5000, np.float32)
+    x = np.ones(2048, np.float32)
+    y = s.custom_infer(m, ref, "a", x, n_frame_delay=3, alpha=0.7)
+    assert y.shape == (2048,) and np.allclose(y, 0.5)
+    assert calls == [("prefill", (5000,), 64, 3, 0.7), ("setup", 64, 64, 768, 32, 1), ("chunk", (1, 2048))]
+    s.custom_infer(m, ref, "a", x)
+    assert [c[0] for c in calls] == ["prefill", "setup", "chunk", "chunk"] and s.prefills == 1
+    s.custom_infer(m, ref, "b", x)
+    s.custom_infer(m, ref, "b", np.ones(4096, np.float32))
+    assert s.prefills == 3 and calls[-2] == ("setup", 64, 64, 768, 32, 2)
+    with pytest.raises(AssertionError):
+        s.custom_infer(m, ref, "b", np.ones(1000, np.float32))
