@@ -201,7 +201,12 @@ def main():
             allowed = sorted(os.sched_getaffinity(0))
             tried = [("os placement", set(allowed), enq_ms())]
             _, table = E.pin_enqueue_thread(local_rank)
-            for first in sorted(table, key=table.get)[:2]:
+            ranked = sorted(table, key=table.get)
+            near = [g_ for g_ in ranked if table[g_] <= 1.1 * table[ranked[0]]] if ranked else []
+            if world > 1 and near:          # ranks of one node spread over the near-best groups instead of piling onto the best one
+                k0 = local_rank % len(near)
+                ranked = near[k0:] + near[:k0] + [g_ for g_ in ranked if g_ not in near]
+            for first in ranked[:2]:
                 cpus = {c_ for c_ in allowed if first <= c_ < first + 8}
                 os.sched_setaffinity(0, cpus)
                 tried.append((f"cpus {first}-{first + 7}", cpus, enq_ms()))
