@@ -1296,13 +1296,14 @@ std::map<int, StreamSet> g_streams;          // per device, process lifetime
 // the GEMMs want the whole chip.  SVA_CU_PART="alo,an,elo,en,vlo,vn" overrides the ranges, SVA_CU_PART=off disables.
 int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSet* out) {
     std::lock_guard<std::mutex> lk(g_streams_mu);
-    // variant 1 (one stream): AR 96 CUs | encoder 136 | vocoder 24 -- 2.11 -> 1.75 ms per step; the vocoder needs >= 24 CUs and
-    // the landscape is not smooth (96/138/22 and 92/140/24 lose everything again).  variant 2 (2..8 streams): AR 96 | encoder
+    // variant 1 (one stream): AR 96 CUs | encoder 128 | vocoder 32 (12 / 16 / 4 per XCD) -- 2.11 -> 1.75 ms per step, 1.60 with the
+    // encoder split; 96/136/24 measures the same but leaves the vocoder no slack (96/138/22 and 92/140/24 lose the whole gain:
+    // the AR GEMV grids are multiples of 96 workgroups, the vocoder is throughput-bound on its share).  variant 2 (2..8 streams): AR 96 | encoder
     // and vocoder share the other 160 (+23 % at 2 and 4 streams, +11 % at 8; the three-way split is worse there).
     bool partitioned = n_streams_if_pipelined >= 1 && n_streams_if_pipelined <= 8;
     int variant = !partitioned ? 0 : n_streams_if_pipelined == 1 ? 1 : 2;
     int part[6] = {0, 96, 96, 160, 96, 160};
-    if (variant == 1) { part[3] = 136; part[4] = 232; part[5] = 24; }
+    if (variant == 1) { part[3] = 128; part[4] = 224; part[5] = 32; }
     if (const char* e = getenv("SVA_CU_PART")) {
         if (!strcmp(e, "off")) partitioned = false;
         else if (partitioned) { sscanf(e, "%d,%d,%d,%d,%d,%d", part, part + 1, part + 2, part + 3, part + 4, part + 5); variant = 3; }
