@@ -56,8 +56,8 @@ def parse():
     ap.add_argument("--no-pin", dest="pin", action="store_false",
                     help="leave the enqueueing thread where the OS put it (default: move it to the core group with the cheapest launches)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the captured hipGraph of the steady step (measured slower than eager multi-stream launches on this "
-                         "stack: 5.6 vs 4.8 ms at B=1, the step is GPU-bound, see DESIGN.md)")
+                    help="replay the captured single-stream hipGraph of the whole steady step (3.8 ms at B=1 against 3.6 ms for eager "
+                         "serial stepping and 1.6 ms for the pipelined default, see DESIGN.md)")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
     return ap.parse_args()
 

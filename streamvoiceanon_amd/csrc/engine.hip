@@ -1374,6 +1374,9 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
         b->trace_ev.resize((size_t)b->trace_n * 9);
         for (auto& t : b->trace_ev) SVA_HIP(hipEventCreate(&t));
     }
+    // a whole-step graph is captured from ONE stream: a capture that forks to the side stream replays at 14 ms per step on this
+    // runtime, the single-stream one at 3.8 (eager multi-stream: 3.6)
+    if (b->p.use_graph) b->concurrency = false;
     if (const char* ev = getenv("SVA_CONCURRENCY")) b->concurrency = atoi(ev) != 0;
     if (const char* ev = getenv("SVA_FUSED_DECODE")) b->fused_decode = atoi(ev) != 0;
     // SVA_CONCURRENCY=0: single stream (PMC profiling)
