@@ -184,7 +184,7 @@ int sva_host_launch_cost(int device, int iters, float* us_per_launch);
 
 /* kernel unit-test hook: the nucleus sampler of decode_one (modules/dual_ar_stream.py:1092-1132) over logits[rows][V] with
  * explicit Exp(1) draws noise[rows][V], through one implementation: 1 LDS bitonic sort, 2 register sort, 3/4/5 threshold
- * bisection (workgroup shapes).  us_out (may be NULL) = average microseconds per launch over `iters` launches */
+ * bisection (workgroup shapes), 6/7 bisection with interpolated, key-snapped probes.  us_out (may be NULL) = average microseconds per launch over `iters` launches */
 int sva_test_sampler(int device, int variant, int rows, int V, const float* logits, const float* noise, float temperature,
                      float top_p, int* tok_out, int iters, float* us_out);
 

@@ -799,7 +799,7 @@ def test_sampler_implementations_vs_oracle_and_each_other(V):
     rows = 48
     L = (rng.standard_normal((rows, V)) * rng.uniform(0.5, 8.0, (rows, 1))).astype(np.float32)
     Q = (rng.exponential(1.0, (rows, V)) + 1e-9).astype(np.float32)
-    variants = (1, 2, 3, 4) if V > 1024 else (1, 2, 3, 4, 5)
+    variants = (1, 2, 3, 4, 6, 7) if V > 1024 else (1, 2, 3, 4, 5, 6, 7)
     for tp, temp in ((0.7, 0.7), (0.9, 1.0), (0.05, 0.7), (1.0, 0.7)):
         want = np.array([O.sample_token(torch.from_numpy(L[r]), torch.from_numpy(Q[r]), temp, tp) for r in range(rows)])
         for var in variants:
