@@ -149,6 +149,7 @@ struct sva_batch {
     hipStream_t sa = nullptr, sv = nullptr;
     hipEvent_t pipe_evD2C = nullptr;       // recorded once the transformer of a step no longer reads the token cache
     hipEvent_t tr_l0_event = nullptr;      // enc_transformer records this after its first layer's output projection
+    int stream_cut = 1;                    // pipelined encoder: stages of the streaming pass that run on the main stream (0..3)
     int pipe_split_e = 1;                  // 0: encoder as one in-order stage
     std::vector<hipEvent_t> trace_ev;     // SVA_PIPE_TRACE=N: timestamps of the stage chains of the last N pipelined steps (debug)
     long trace_steps = 0;

@@ -651,13 +651,17 @@ int enc_frontend_window(sva_batch* b, const int* step_ptr, int n_chunk, int add,
 // Streaming pass of the exact-incremental formulation: the nm = 4c NEWEST mel frames of the window through the same
 // conv front-end on per-layer 6-row histories (every tensor that feeds a k7 conv keeps its own history; ConvNeXt
 // blocks are therefore out-of-place).  The resulting c token rows land in d2c[T2-c, T2).
-int enc_frontend_stream(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
+// part 0: the whole pass; 1: front (mel, stem, the first kStreamCut stages and the transition out of them); 2: the rest.  The
+// pipelined step runs the front on the main stream ahead of the head pass and the back on the side stream ahead of the
+// transformer, which evens out the two encoder chains.
+int enc_frontend_stream(sva_batch* b, const int* step_ptr, int n_chunk, int add, int part = 0) {
     sva_engine* e = b->e;
     const EncFront& F = e->tokf;
     const sva_config& c = e->cfg;
     const int B = b->B, nm = 4 * b->p.chunk_frames;
     hipStream_t st = b->stream;
     EncStream& S = b->es;
+    if (part != 2) {
     SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, S.mag, 1088, (long)nm * 1088, b->T0 - nm, nm, st));
     {
         ConvGemm p;
@@ -668,7 +672,11 @@ int enc_frontend_stream(sva_batch* b, const int* step_ptr, int n_chunk, int add)
     SVA_TRY(conv_act(b, S.mel, nm, 1, 1, 7, F.stem, S.tmp0));
     SVA_TRY(launch_layernorm_rows(S.tmp0.p, S.tmp0.bstride, 0, c.enc_dims[0], B, nm, c.enc_dims[0], F.stem_lnw, F.stem_lnb, 1e-6f,
                                   S.x[0][0].p, S.x[0][0].bstride, (long)S.x[0][0].H * c.enc_dims[0], c.enc_dims[0], st));
+    }
+    const int cut = b->stream_cut;
     for (int i = 0; i < 4; ++i) {
+        if (part == 1 && i >= cut) return 0;
+        if (part == 2 && i < cut) continue;
         const int C = c.enc_dims[i];
         const int nb = (int)F.stages[i].size();
         for (int j = 0; j < nb; ++j) {
@@ -1369,6 +1377,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
     if (const char* ev = getenv("SVA_PIPE_GRAPH")) b->pipe_graph_mode = atoi(ev);
     if (const char* ev = getenv("SVA_PIPE_SPLIT_E")) b->pipe_split_e = atoi(ev);
+    if (const char* ev = getenv("SVA_STREAM_CUT")) b->stream_cut = atoi(ev);
     if (const char* ev = getenv("SVA_PIPE_TRACE")) {
         b->trace_n = atoi(ev);
         b->trace_ev.resize((size_t)b->trace_n * 9);
@@ -1885,11 +1894,21 @@ int steady_pipelined(sva_batch* b) {
         SVA_TRY(mark(0, se));
         SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
         SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se));                       // steady tokens slide down by c
-        SVA_TRY(stream_fork(b, se, sx));
-        b->stream = sx;
-        SVA_TRY(mark(2, sx));
-        int erc = enc_frontend_stream(b, b->d_step_x, n, 1);                          // c newest tokens -> d2c tail
-        if (!erc) erc = launch_add_i32(b->d_step_x, 1, sx);
+        int erc = 0;
+        if (b->stream_cut > 0) {          // the first stages of the streaming pass run on main (its chunk counter), the rest on sx
+            SVA_TRY(enc_frontend_stream(b, b->d_step, n, 1, 1));
+            SVA_TRY(stream_fork(b, se, sx));
+            b->stream = sx;
+            SVA_TRY(mark(2, sx));
+            erc = enc_frontend_stream(b, b->d_step, n, 1, 2);
+            if (!erc) erc = launch_add_i32(b->d_step_x, 1, sx);                       // (kept in step although this layout does not read it)
+        } else {
+            SVA_TRY(stream_fork(b, se, sx));
+            b->stream = sx;
+            SVA_TRY(mark(2, sx));
+            erc = enc_frontend_stream(b, b->d_step_x, n, 1);                          // c newest tokens -> d2c tail
+            if (!erc) erc = launch_add_i32(b->d_step_x, 1, sx);
+        }
         b->stream = se;
         if (erc) return erc;
         SVA_TRY(enc_frontend_window(b, b->d_step, n, 1, 4 * b->Ht, nullptr, &b->d2c));     // head pass -> d2c rows [0, Ht)
