@@ -1,0 +1,902 @@
+// Persistent batch-1 decode kernel of the dual AR: ONE launch per frame instead of ~210 dependent launches.
+//
+// decode_one_token_ar (modules/dual_ar_stream.py:1168-1219) at batch 1 is a chain of ~200 tiny matrix-vector products
+// (12 slow layers on 2 tokens, then 8 x [4 fast layers + codebook head + nucleus sample]); every one needs the whole
+// output vector of its predecessor, so as separate kernels each costs a launch boundary plus a cold start of its weight
+// stream (5-9 us per kernel measured, 1.5 ms per frame) although the frame only moves 0.5 GB (fp32) / 0.26 GB (fp16).
+// Here 96 workgroups (one per CU of the AR stream's partition) stay resident for the whole frame and hand the
+// activation vectors to each other in-launch:
+//   * every wave owns fixed output rows of every weight matrix and keeps the whole K extent of its rows in registers
+//     (lane l holds elements 4l + 256j of an fp32 row / 8l + 512j of an fp16 row: whole-wave 1 KiB loads);
+//   * the weight rows of a phase are requested BEFORE the wave waits for that phase's input vector, so the HBM latency
+//     of the weight stream overlaps the hand-off of the previous phase's output (the one thing launches cannot do);
+//   * hand-off = 8-byte {tag = phase epoch, value} granules written with agent-scope (sc1, write-through) stores and
+//     polled with agent-scope loads until every tag matches (cdna_hip_programming.md Guideline 16, form R2: the data is
+//     the flag -- no fences, no counters, nothing depends on workgroup placement).  Measured 2.7 us per all-to-all
+//     edge at 96 workgroups (tools/micro/ar_edge.hip);  a buffer read in phase p is rewritten no earlier than phase
+//     p + 1, when every workgroup has provably finished reading it (it published its phase-p output after the read);
+//   * the nucleus sampler of a codebook runs redundantly in every wave (one wave, 16 logits per lane, sort-free
+//     threshold search with DPP reductions only), so the sampled token needs no broadcast edge;
+//   * fast-AR K/V of the 8 codebook positions go through a small global scratch with agent-scope stores / loads.
+// All spins are bounded (a timeout sets *fail and lets the kernel run to its end with garbage instead of hanging).
+#include "ar_decode.h"
+#include "device_util.h"
+#include "sva_common.h"
+
+#include <type_traits>
+
+namespace sva {
+namespace {
+
+typedef unsigned long long u64;
+constexpr int D = 768, I = 2304, H = 12, NCB = 8;
+constexpr int GX = 2 * D, GBIG = 2 * I, GATT = AR_WGS * 66, GLOG = 1024, GA = 2 * D;
+constexpr int KVF_LD = 1540;                      // LDS row stride of the fast K/V stash (bank rotation)
+constexpr int SPIN_LIMIT = 1 << 18;
+
+__device__ __forceinline__ void store_granule(u64* g, unsigned ep, float v) {
+    __hip_atomic_store(g, ((u64)ep << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// all 256 threads: wait for the n granules of a published vector (tags == ep) and unpack them into LDS
+template <int PER>
+__device__ __forceinline__ void gather(const u64* g, int n, unsigned ep, float* dst, int* fail, int code) {
+    const int tid = threadIdx.x;
+    unsigned pending = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (tid + k * 256 < n) pending |= 1u << k;
+    int spins = 0;
+    while (pending) {
+        u64 x[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (pending & (1u << k)) x[k] = __hip_atomic_load(g + tid + k * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if ((pending & (1u << k)) && (unsigned)(x[k] >> 32) == ep) {
+                dst[tid + k * 256] = __uint_as_float((unsigned)x[k]);
+                pending &= ~(1u << k);
+            }
+        if (pending && ++spins > SPIN_LIMIT) { *fail = code; break; }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float h_lo(unsigned u) { return __half2float(__ushort_as_half((unsigned short)(u & 0xffffu))); }
+__device__ __forceinline__ float h_hi(unsigned u) { return __half2float(__ushort_as_half((unsigned short)(u >> 16))); }
+
+// one weight row, spread over the 64 lanes of a wave
+template <typename WT, int K> struct WFrag;
+template <int K> struct WFrag<float, K> {
+    float4 v[K / 256];
+    __device__ __forceinline__ void load(const void* base, long row, int lane) {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + row * K);
+#pragma unroll
+        for (int j = 0; j < K / 256; ++j) v[j] = p[lane + 64 * j];
+    }
+    __device__ __forceinline__ float dot(const float (&x)[K / 64]) const {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < K / 256; ++j) {
+            a = fmaf(x[4 * j], v[j].x, a);
+            a = fmaf(x[4 * j + 1], v[j].y, a);
+            a = fmaf(x[4 * j + 2], v[j].z, a);
+            a = fmaf(x[4 * j + 3], v[j].w, a);
+        }
+        return a;
+    }
+};
+template <int K> struct WFrag<__half, K> {
+    static constexpr int NC = K / 512;          // 8-element chunks per lane, then a 4-element tail (K % 512 == 256)
+    uint4 v[NC];
+    uint2 t;
+    __device__ __forceinline__ void load(const void* base, long row, int lane) {
+        const __half* r = reinterpret_cast<const __half*>(base) + row * K;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) v[j] = reinterpret_cast<const uint4*>(r)[lane + 64 * j];
+        t = reinterpret_cast<const uint2*>(r + 512 * NC)[lane];
+    }
+    __device__ __forceinline__ float dot(const float (&x)[K / 64]) const {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            a = fmaf(x[8 * j], h_lo(v[j].x), a);
+            a = fmaf(x[8 * j + 1], h_hi(v[j].x), a);
+            a = fmaf(x[8 * j + 2], h_lo(v[j].y), a);
+            a = fmaf(x[8 * j + 3], h_hi(v[j].y), a);
+            a = fmaf(x[8 * j + 4], h_lo(v[j].z), a);
+            a = fmaf(x[8 * j + 5], h_hi(v[j].z), a);
+            a = fmaf(x[8 * j + 6], h_lo(v[j].w), a);
+            a = fmaf(x[8 * j + 7], h_hi(v[j].w), a);
+        }
+        a = fmaf(x[8 * NC], h_lo(t.x), a);
+        a = fmaf(x[8 * NC + 1], h_hi(t.x), a);
+        a = fmaf(x[8 * NC + 2], h_lo(t.y), a);
+        a = fmaf(x[8 * NC + 3], h_hi(t.y), a);
+        return a;
+    }
+};
+static_assert(D % 512 == 256 && I % 512 == 256, "fp16 fragment layout needs K % 512 == 256");
+
+// the lane's elements of an activation / norm-weight row, in the order WFrag<WT, K>::dot consumes them
+template <typename WT, int K>
+__device__ __forceinline__ void load_x(const float* xl, int lane, float (&x)[K / 64]) {
+    if constexpr (std::is_same<WT, float>::value) {
+#pragma unroll
+        for (int j = 0; j < K / 256; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(xl + 256 * j + 4 * lane);
+            x[4 * j] = t.x; x[4 * j + 1] = t.y; x[4 * j + 2] = t.z; x[4 * j + 3] = t.w;
+        }
+    } else {
+        constexpr int NC = K / 512;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const float4 t0 = *reinterpret_cast<const float4*>(xl + 512 * j + 8 * lane);
+            const float4 t1 = *reinterpret_cast<const float4*>(xl + 512 * j + 8 * lane + 4);
+            x[8 * j] = t0.x; x[8 * j + 1] = t0.y; x[8 * j + 2] = t0.z; x[8 * j + 3] = t0.w;
+            x[8 * j + 4] = t1.x; x[8 * j + 5] = t1.y; x[8 * j + 6] = t1.z; x[8 * j + 7] = t1.w;
+        }
+        const float4 tt = *reinterpret_cast<const float4*>(xl + 512 * NC + 4 * lane);
+        x[8 * NC] = tt.x; x[8 * NC + 1] = tt.y; x[8 * NC + 2] = tt.z; x[8 * NC + 3] = tt.w;
+    }
+}
+
+// out[m][r] = (NORM ? rsqrt(mean(x_m^2) + eps) : 1) * sum_k W_r[k] * x_m[k] * (NORM ? nw[k] : 1); every lane gets every value
+// (RMSNorm: modules/dual_ar_stream.py:985-990, folded into the projection like gemv_kernel does)
+template <typename WT, int K, int ROWS, int M, bool NORM>
+__device__ __forceinline__ void gemv(const WFrag<WT, K> (&w)[ROWS], const float* xl, int ldx, const float* nw, float eps, int lane,
+                                     float (&out)[M][ROWS]) {
+    float nwv[K / 64];
+    if constexpr (NORM) load_x<WT, K>(nw, lane, nwv);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        float x[K / 64];
+        load_x<WT, K>(xl + m * ldx, lane, x);
+        float s = 1.f;
+        if constexpr (NORM) {
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < K / 64; ++i) ss = fmaf(x[i], x[i], ss);
+            s = 1.f / sqrtf(wave_sum(ss) / (float)K + eps);
+#pragma unroll
+            for (int i = 0; i < K / 64; ++i) x[i] *= nwv[i];
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) out[m][r] = wave_sum(w[r].dot(x)) * s;
+    }
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + expf(-x)); }
+
+template <typename KVT> __device__ __forceinline__ float4 ld_kv4(const KVT* p);
+template <> __device__ __forceinline__ float4 ld_kv4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld_kv4<__half>(const __half* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(h_lo(u.x), h_hi(u.x), h_lo(u.y), h_hi(u.y));
+}
+template <typename KVT> __device__ __forceinline__ void st_kv(KVT* p, float v);
+template <> __device__ __forceinline__ void st_kv<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_kv<__half>(__half* p, float v) { *p = __float2half(v); }
+
+__device__ __forceinline__ float row16_sum(float v) {        // sum over the 16 lanes of a DPP row, in every lane of the row
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+
+__device__ __forceinline__ unsigned umax_wave(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Nucleus sampler of logits_to_probs + multinomial_sample_one_no_sync (modules/dual_ar_stream.py:1092-1132) over PER
+// logits per thread of NW waves (element of slot r: e0 + r * NW * 64); the sort-free threshold search of
+// sampler_bisect_kernel (kernels.hip) with interpolated, key-snapped probes.  NW == 1: no barrier at all.  Returns the
+// token in every participating thread.  red: LDS scratch of >= 64 doubles (NW > 1 only).
+template <int NW, int PER>
+__device__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float* noise, unsigned long long seed, int frame, int kind,
+                              int noise_elem_off, float inv_temp, float top_p, double* red) {
+    constexpr int ES = NW * 64;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % NW;
+    int slot = 0;
+    double* dred = red;                                     // [2][NW]
+    unsigned* ured = reinterpret_cast<unsigned*>(red + 2 * NW);       // [2][2][NW]
+    float* fred = reinterpret_cast<float*>(ured + 4 * NW);  // [2][NW]
+    int* ired = reinterpret_cast<int*>(fred + 2 * NW);      // [NW]
+    auto block_sum_d = [&](double x) {
+        x = wave_sum_d(x);
+        if constexpr (NW == 1) return x;
+        if (lane == 0) dred[slot * NW + wave] = x;
+        __syncthreads();
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += dred[slot * NW + w];
+        slot ^= 1;
+        return t;
+    };
+    auto block_sum_f = [&](float x) {
+        x = wave_sum(x);
+        if constexpr (NW == 1) return x;
+        if (lane == 0) fred[slot * NW + wave] = x;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += fred[slot * NW + w];
+        slot ^= 1;
+        return t;
+    };
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) m = fmaxf(m, l[r]);
+    m = wave_max(m);
+    float mx = m;
+    if constexpr (NW > 1) {
+        if (lane == 0) fred[slot * NW + wave] = m;
+        __syncthreads();
+        mx = fred[slot * NW];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mx = fmaxf(mx, fred[slot * NW + w]);
+        slot ^= 1;
+    }
+    float p[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        p[r] = (e0 + r * ES) < V ? expf(l[r] - mx) : 0.f;
+        s += p[r];
+    }
+    const float denom = block_sum_f(s);
+    unsigned key[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        p[r] = p[r] / denom;
+        key[r] = __builtin_bit_cast(unsigned, p[r]);
+    }
+    bool keep[PER];
+    double all = 0.0;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) all += (double)p[r];
+    if (!((float)block_sum_d(all) > top_p)) {
+#pragma unroll
+        for (int r = 0; r < PER; ++r) keep[r] = (e0 + r * ES) < V;
+    } else {
+        unsigned lo = 0u, hi = __builtin_bit_cast(unsigned, 1.0f / denom) + 2u;
+        if (hi > 0x3F800001u) hi = 0x3F800001u;
+        double f_lo = 1.0, f_hi = 0.0;
+        int it = 0;
+        while (hi - lo > 1u) {
+            unsigned mid = lo + ((hi - lo) >> 1);
+            if ((it % 3) != 2) {       // (placement only: any probe sequence keeps the bracket invariant, so float arithmetic is enough here)
+                const float t = (float)(f_lo - (double)top_p) / (float)(f_lo - f_hi);
+                const float off = (float)(hi - lo) * (t < 0.f ? 0.f : (t > 1.f ? 1.f : t));
+                unsigned m2 = lo + (unsigned)off;
+                if (m2 <= lo) m2 = lo + 1u;
+                if (m2 >= hi) m2 = hi - 1u;
+                mid = m2;
+            }
+            ++it;
+            double t = 0.0;
+            unsigned below = 0u, above_inv = 0u;
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const bool ge = key[r] >= mid;
+                t += ge ? (double)p[r] : 0.0;
+                above_inv = max(above_inv, ge ? ~key[r] : 0u);
+                below = max(below, ge ? 0u : key[r]);
+            }
+            t = wave_sum_d(t);
+            below = umax_wave(below);
+            above_inv = umax_wave(above_inv);
+            double fm = t;
+            unsigned kl = below, kgi = above_inv;
+            if constexpr (NW > 1) {
+                if (lane == 0) { dred[slot * NW + wave] = t; ured[(slot * 2) * NW + wave] = below; ured[(slot * 2 + 1) * NW + wave] = above_inv; }
+                __syncthreads();
+                fm = 0.0; kl = 0u; kgi = 0u;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    fm += dred[slot * NW + w];
+                    kl = max(kl, ured[(slot * 2) * NW + w]);
+                    kgi = max(kgi, ured[(slot * 2 + 1) * NW + w]);
+                }
+                slot ^= 1;
+            }
+            if ((float)fm > top_p) { lo = ~kgi; f_lo = fm; }
+            else { hi = kl + 1u; f_hi = fm; }
+        }
+        const unsigned kb = lo;
+        const float pb = __builtin_bit_cast(float, kb);
+        double above = 0.0;
+        float ties = 0.f;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            above += key[r] > kb ? (double)p[r] : 0.0;
+            ties += (key[r] == kb && (e0 + r * ES) < V) ? 1.f : 0.f;
+        }
+        const double base = block_sum_d(above);
+        const int cnt = (int)block_sum_f(ties);
+        int nk = 0;
+        double run = base;
+        for (int j = 0; j < cnt; ++j) {
+            run += (double)pb;
+            if ((float)run > top_p) break;
+            ++nk;
+        }
+        if (base == 0.0 && nk == 0) nk = 1;
+        int id_cut = -1;
+        if (nk >= cnt) id_cut = 0x7fffffff;
+        else if (nk > 0) {
+            int ilo = -1, ihi = V - 1;
+            while (ihi - ilo > 1) {
+                const int mid = ilo + ((ihi - ilo) >> 1);
+                float c = 0.f;
+#pragma unroll
+                for (int r = 0; r < PER; ++r) c += (key[r] == kb && (e0 + r * ES) <= mid) ? 1.f : 0.f;
+                if ((int)block_sum_f(c) >= nk) ihi = mid; else ilo = mid;
+            }
+            id_cut = ihi;
+        }
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int e = e0 + r * ES;
+            keep[r] = e < V && (key[r] > kb || (key[r] == kb && e <= id_cut));
+        }
+    }
+    const float m2 = mx * inv_temp;
+    float e2[PER];
+    float s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        e2[r] = keep[r] ? expf(l[r] * inv_temp - m2) : 0.f;
+        s2 += e2[r];
+    }
+    const float denom2 = block_sum_f(s2);
+    float best = -1.f;
+    int best_id = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        if (!keep[r]) continue;
+        const int e = e0 + r * ES;
+        const float pr = e2[r] / denom2;
+        const float q = noise ? noise[e] : exp1_noise_dev(seed, frame, kind, (unsigned)(noise_elem_off + e));
+        const float rr = pr / q;
+        if (rr > best || (rr == best && e < best_id)) { best = rr; best_id = e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_id, o, 64);
+        if (ob > best || (ob == best && oi < best_id)) { best = ob; best_id = oi; }
+    }
+    if constexpr (NW > 1) {
+        if (lane == 0) { fred[slot * NW + wave] = best; ired[wave] = best_id; }
+        __syncthreads();
+        best = fred[slot * NW]; best_id = ired[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+            if (fred[slot * NW + w] > best || (fred[slot * NW + w] == best && ired[w] < best_id)) { best = fred[slot * NW + w]; best_id = ired[w]; }
+        __syncthreads();
+    }
+    return best_id;
+}
+
+// SVA_AR_TIMING=1: workgroup 0 records wall_clock64() (100 MHz) at every phase boundary -- [2k] = input gathered, [2k + 1] = output published
+#define AR_MARK() do { if (a.dbg && wg == 0 && tid == 0) { a.dbg[nmark] = wall_clock64(); } ++nmark; } while (0)
+
+template <typename WT, typename KVT>
+__global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                          // [2][768] residual stream (fast AR: row 0)
+    float* big = xs + GX;                     // [2][2304] qkv / SwiGLU output
+    float* attp = big + GBIG;                 // [96][66] split-key attention partials
+    float* av = attp + GATT;                  // [2][768] attention output
+    float* kvf = av + GX;                     // [8][KVF_LD] fast-AR K|V rows of one layer
+    float* lg = kvf + NCB * KVF_LD;           // [1024] codebook logits
+    float* scr = lg + GLOG;                   // [16][68] group partials | sampler scratch | scores
+    float* sc = scr + 16 * 68;                // [12][8] scores -> probabilities
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, gw = wg * 4 + wave;
+    unsigned ep = *a.epoch;
+    int nmark = 0;
+    const int p0 = *a.last_pos + 1;           // positions of the two new tokens (dual_ar_stream.py:821-824)
+    const int frame = *a.nframes;
+    const unsigned long long seed = *a.seed;
+    const int code = (int)a.codes[a.code_off];
+    const int use_forced = *a.use_forced;
+    KVT* kv = reinterpret_cast<KVT*>(a.kv_slow);
+    const long SH = (long)a.S * 64;           // one head of the cache
+
+    // tokens [cached_new_audio_emb, src_cond] (decode_one, :817-837)
+    for (int i = tid; i < D; i += 256) {
+        xs[i] = a.cached_audio_emb[i];
+        xs[D + i] = a.content_emb[(long)code * D + i];
+    }
+    __syncthreads();
+
+    // ======================================= slow AR: 12 layers on M = 2 rows =======================================
+    for (int l = 0; l < AR_SLOW_LAYERS; ++l) {
+        const ArLayerW& L = a.slow[l];
+        KVT* kl = kv + (long)l * a.kv_layer_stride;
+        {   // ---- A: RMSNorm + wqkv + RoPE + KV write ----
+            WFrag<WT, D> w[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) w[r].load(L.wqkv, 6L * gw + r, lane);
+            asm volatile("" ::: "memory");
+            if (l > 0) gather<6>(a.gx, GX, ep, xs, a.fail, 1);
+            AR_MARK();
+            float o[2][6];
+            gemv<WT, D, 6, 2, true>(w, xs, D, L.attn_norm, 1e-5f, lane, o);
+            const int n0 = 6 * gw, region = gw >> 7;               // 0 q, 1 k, 2 v  (128 waves each)
+            if (region < 2) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        const int d = (n0 + 2 * pr) & 63;
+                        const float c = a.rope_slow[((long)(p0 + m) * 32 + (d >> 1)) * 2], sn = a.rope_slow[((long)(p0 + m) * 32 + (d >> 1)) * 2 + 1];
+                        const float x0 = o[m][2 * pr], x1 = o[m][2 * pr + 1];
+                        o[m][2 * pr] = x0 * c - x1 * sn;
+                        o[m][2 * pr + 1] = x1 * c + x0 * sn;
+                    }
+            }
+            AR_MARK();
+            ++ep;
+            float mine = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+                    if (lane == m * 6 + r) mine = o[m][r];
+            if (lane < 12) {
+                const int m = lane / 6, r = lane - m * 6;
+                store_granule(a.gbig + m * I + n0 + r, ep, mine);
+                if (region >= 1) {
+                    const int nn = n0 + r - D * region, h = nn >> 6, d = nn & 63;
+                    st_kv<KVT>(kl + ((long)(region - 1) * H + h) * SH + (long)(p0 + m) * 64 + d, mine);
+                }
+            }
+        }
+        {   // ---- B1: attention of (row, head, quarter of the keys) per workgroup ----
+            const int r = wg / 48, h = (wg % 48) >> 2, qtr = wg & 3;
+            const int Lk = p0 + r + 1;                              // keys 0 .. p_r
+            const int seg = qtr * 4 + wave;
+            const int lo = (int)((long)seg * Lk / 16), hi = (int)((long)(seg + 1) * Lk / 16);
+            const int grp = lane >> 4, li = lane & 15;
+            const KVT* kc = kl + (long)h * SH + li * 4;
+            const KVT* vc = kc + (long)H * SH;
+            const int hc = hi < p0 ? hi : p0;                       // cached keys of this segment: [lo, hc)
+            // the cached K / V rows do not depend on this step: request the first 8 keys of every 16-lane group before waiting
+            // for q (covers contexts up to 512 positions entirely)
+            float4 pkk[8], pvv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int t = lo + grp + 4 * i;
+                if (t > hc - 1) t = hc - 1;
+                if (t < 0) t = 0;
+                pkk[i] = ld_kv4<KVT>(kc + (long)t * 64);
+                pvv[i] = ld_kv4<KVT>(vc + (long)t * 64);
+            }
+            asm volatile("" ::: "memory");
+            gather<18>(a.gbig, GBIG, ep, big, a.fail, 2);
+            AR_MARK();
+            float4 q = *reinterpret_cast<const float4*>(big + r * I + h * 64 + li * 4);
+            q.x *= 0.125f; q.y *= 0.125f; q.z *= 0.125f; q.w *= 0.125f;
+            float mrun = -INFINITY, lsum = 0.f;
+            float4 oacc = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto step = [&](const float4& kk, const float4& vv) {
+                float s = q.x * kk.x + q.y * kk.y + q.z * kk.z + q.w * kk.w;
+                s = row16_sum(s);
+                const float mn = fmaxf(mrun, s);
+                const float corr = expf(mrun - mn), p = expf(s - mn);
+                lsum = lsum * corr + p;
+                oacc.x = oacc.x * corr + p * vv.x; oacc.y = oacc.y * corr + p * vv.y;
+                oacc.z = oacc.z * corr + p * vv.z; oacc.w = oacc.w * corr + p * vv.w;
+                mrun = mn;
+            };
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (lo + grp + 4 * i < hc) step(pkk[i], pvv[i]);
+            int t = lo + grp + 32;
+#pragma unroll 4
+            for (; t < hc; t += 4) {
+                const float4 kk = ld_kv4<KVT>(kc + (long)t * 64), vv = ld_kv4<KVT>(vc + (long)t * 64);
+                step(kk, vv);
+            }
+            t = lo + grp;
+            while (t < hc) t += 4;                                  // first key of this group at or beyond the cached range
+            for (; t < hi; t += 4) {                                // the one or two keys written in this launch: from the gathered rows
+                const float* cur = big + (t - p0) * I + h * 64 + li * 4;
+                step(*reinterpret_cast<const float4*>(cur + D), *reinterpret_cast<const float4*>(cur + 2 * D));
+            }
+            float* pg = scr + (wave * 4 + grp) * 68;
+            *reinterpret_cast<float4*>(pg + li * 4) = oacc;
+            if (li == 0) { pg[64] = mrun; pg[65] = lsum; }
+            __syncthreads();
+            AR_MARK();
+            ++ep;
+            if (tid < 66) {
+                float M = -INFINITY;
+#pragma unroll
+                for (int g2 = 0; g2 < 16; ++g2)
+                    if (scr[g2 * 68 + 65] > 0.f) M = fmaxf(M, scr[g2 * 68 + 64]);
+                float val = 0.f, den = 0.f;
+#pragma unroll
+                for (int g2 = 0; g2 < 16; ++g2) {
+                    const float lg2 = scr[g2 * 68 + 65];
+                    const float wgt = lg2 > 0.f ? expf(scr[g2 * 68 + 64] - M) : 0.f;
+                    den = fmaf(wgt, lg2, den);
+                    if (tid < 64) val = fmaf(wgt, scr[g2 * 68 + tid], val);
+                }
+                store_granule(a.gatt + wg * 66 + tid, ep, tid < 64 ? val : (tid == 64 ? M : den));
+            }
+        }
+        {   // ---- B1m: the first workgroup of every (row, head) merges its four key quarters and publishes that head's output ----
+            // (two small edges instead of one 6336-granule gather in every workgroup)
+            if ((wg & 3) == 0) {
+                gather<2>(a.gatt + wg * 66, 4 * 66, ep, attp, a.fail, 3);
+                AR_MARK();
+                if (tid < 64) {
+                    float M = -INFINITY;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if (attp[qq * 66 + 65] > 0.f) M = fmaxf(M, attp[qq * 66 + 64]);
+                    float num = 0.f, den = 0.f;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const float lq = attp[qq * 66 + 65];
+                        const float wgt = lq > 0.f ? expf(attp[qq * 66 + 64] - M) : 0.f;
+                        den = fmaf(wgt, lq, den);
+                        num = fmaf(wgt, attp[qq * 66 + tid], num);
+                    }
+                    const int r = wg / 48, h = (wg % 48) >> 2;
+                    AR_MARK();
+                    store_granule(a.ga + r * D + h * 64 + tid, ep + 1, num / den);
+                } else { AR_MARK(); }
+            } else { AR_MARK(); AR_MARK(); }
+            ++ep;
+        }
+        {   // ---- B2: wo + residual ----
+            WFrag<WT, D> w[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) w[r].load(L.wo, 2L * gw + r, lane);
+            asm volatile("" ::: "memory");
+            gather<6>(a.ga, GA, ep, av, a.fail, 13);
+            AR_MARK();
+            float o[2][2];
+            gemv<WT, D, 2, 2, false>(w, av, D, nullptr, 0.f, lane, o);
+            AR_MARK();
+            ++ep;
+            float mine = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (lane == m * 2 + r) mine = o[m][r];
+            if (lane < 4) {
+                const int m = lane >> 1, n = 2 * gw + (lane & 1);
+                store_granule(a.gx + m * D + n, ep, xs[m * D + n] + mine);
+            }
+        }
+        {   // ---- C: RMSNorm + w1|w3 + SwiGLU ----
+            WFrag<WT, D> w[12];
+#pragma unroll
+            for (int r = 0; r < 12; ++r) w[r].load(L.w13, 12L * gw + r, lane);
+            asm volatile("" ::: "memory");
+            gather<6>(a.gx, GX, ep, xs, a.fail, 4);
+            AR_MARK();
+            float o[2][12];
+            gemv<WT, D, 12, 2, true>(w, xs, D, L.ffn_norm, 1e-5f, lane, o);
+            AR_MARK();
+            ++ep;
+            float mine = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+                    if (lane == m * 6 + r) mine = silu_f(o[m][r]) * o[m][6 + r];
+            if (lane < 12) {
+                const int m = lane / 6, r = lane - m * 6;
+                store_granule(a.gbig + m * I + 6 * gw + r, ep, mine);
+            }
+        }
+        {   // ---- D: w2 + residual ----
+            WFrag<WT, I> w[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) w[r].load(L.w2, 2L * gw + r, lane);
+            asm volatile("" ::: "memory");
+            gather<18>(a.gbig, GBIG, ep, big, a.fail, 5);
+            AR_MARK();
+            float o[2][2];
+            gemv<WT, I, 2, 2, false>(w, big, I, nullptr, 0.f, lane, o);
+            AR_MARK();
+            ++ep;
+            float mine = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (lane == m * 2 + r) mine = o[m][r];
+            if (lane < 4) {
+                const int m = lane >> 1, n = 2 * gw + (lane & 1);
+                store_granule(a.gx + m * D + n, ep, xs[m * D + n] + mine);
+            }
+        }
+    }
+    gather<6>(a.gx, GX, ep, xs, a.fail, 6);
+    AR_MARK();
+    // hidden = pre-norm state of the content token (forward_generate :340-341): tap + input of the fast AR
+    if (wg == 0)
+        for (int i = tid; i < D; i += 256) a.hidden[i] = xs[D + i];
+    for (int i = tid; i < D; i += 256) xs[i] = xs[D + i];
+    __syncthreads();
+    if (!a.skip_semantic) {
+        // semantic-token logits (dual_ar_stream.py:1181-1186; the sample is discarded by every caller, :833): rows gw + 384 j,
+        // written through (agent scope) for the sampler that workgroup 0 runs at the end of the frame
+        for (int half = 0; half < 2; ++half) {
+            WFrag<WT, D> w[11];
+#pragma unroll
+            for (int j = 0; j < 11; ++j) {
+                int row = gw + AR_WAVES * (half * 11 + j);
+                if (row > a.vocab - 1) row = a.vocab - 1;
+                w[j].load(a.out_w, row, lane);
+            }
+            float o[1][11];
+            gemv<WT, D, 11, 1, true>(w, xs, D, a.out_norm, 1e-5f, lane, o);
+            float mine = 0.f;
+#pragma unroll
+            for (int j = 0; j < 11; ++j)
+                if (lane == j) mine = o[0][j];
+            const int row = gw + AR_WAVES * (half * 11 + lane);
+            if (lane < 11 && row < a.vocab) __hip_atomic_store(a.slow_logits + row, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // ======================================= fast AR: 8 codebooks x 4 layers on M = 1 row =======================================
+    __shared__ int toks[NCB];                  // the frame's codes (every workgroup samples the same token)
+    int tprev = 0;
+    WFrag<WT, D> wq0[6];                       // wqkv rows of fast layer 0: requested a phase early (before the sampler of the previous codebook)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) wq0[r].load(a.fast[0].wqkv, 6L * gw + r, lane);
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (cb > 0) {
+            for (int i = tid; i < D; i += 256) xs[i] = a.fast_emb[(long)tprev * D + i];
+            __syncthreads();
+        }
+        for (int l = 0; l < AR_FAST_LAYERS; ++l) {
+            const ArLayerW& L = a.fast[l];
+            float* kvg = a.kv_fast + (long)l * NCB * 2 * D;             // [8][k 768 | v 768]
+            {   // ---- FA: RMSNorm + wqkv + RoPE (position = codebook index) ----
+                WFrag<WT, D> w[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    if (l > 0) w[r].load(L.wqkv, 6L * gw + r, lane);
+                    else w[r] = wq0[r];
+                }
+                asm volatile("" ::: "memory");
+                if (l > 0) gather<3>(a.gx, D, ep, xs, a.fail, 7);
+                AR_MARK();
+                float o[1][6];
+                gemv<WT, D, 6, 1, true>(w, xs, D, L.attn_norm, 1e-5f, lane, o);
+                const int n0 = 6 * gw, region = gw >> 7;
+                if (region < 2) {
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        const int d = (n0 + 2 * pr) & 63;
+                        const float c = a.rope_fast[(cb * 32 + (d >> 1)) * 2], sn = a.rope_fast[(cb * 32 + (d >> 1)) * 2 + 1];
+                        const float x0 = o[0][2 * pr], x1 = o[0][2 * pr + 1];
+                        o[0][2 * pr] = x0 * c - x1 * sn;
+                        o[0][2 * pr + 1] = x1 * c + x0 * sn;
+                    }
+                }
+                AR_MARK();
+                ++ep;
+                float mine = 0.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+                    if (lane == r) mine = o[0][r];
+                if (lane < 6) {
+                    store_granule(a.gbig + n0 + lane, ep, mine);
+                    if (region >= 1)       // K | V of this codebook position for the later positions of this frame
+                        __hip_atomic_store(kvg + (long)cb * 2 * D + (n0 + lane - D), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            {   // ---- FB: attention over <= 8 positions (every workgroup computes all heads: wave w takes heads 3w..3w+2), wo + residual ----
+                WFrag<WT, D> w[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) w[r].load(L.wo, 2L * gw + r, lane);
+                // K | V of the earlier positions, lane = head dimension: written (through) at least one whole codebook step ago
+                float pk[3][7], pv[3][7];
+#pragma unroll
+                for (int hh = 0; hh < 3; ++hh)
+#pragma unroll
+                    for (int t = 0; t < 7; ++t)
+                        if (t < cb) {
+                            const float* src = kvg + (long)t * 2 * D + (wave * 3 + hh) * 64 + lane;
+                            pk[hh][t] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            pv[hh][t] = __hip_atomic_load(src + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                asm volatile("" ::: "memory");
+                gather<9>(a.gbig, I, ep, big, a.fail, 8);
+                AR_MARK();
+#pragma unroll
+                for (int hh = 0; hh < 3; ++hh) {
+                    const int n = (wave * 3 + hh) * 64 + lane;
+                    const float qd = big[n] * 0.125f;
+                    float sc8[NCB];
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int t = 0; t < NCB; ++t) {
+                        const float kd = t < cb ? (t < 7 ? pk[hh][t < 7 ? t : 0] : 0.f) : big[D + n];
+                        sc8[t] = t <= cb ? wave_sum(qd * kd) : -INFINITY;
+                        mx = fmaxf(mx, sc8[t]);
+                    }
+                    float sum = 0.f, acc = 0.f;
+#pragma unroll
+                    for (int t = 0; t < NCB; ++t) {
+                        const float e = t <= cb ? expf(sc8[t] - mx) : 0.f;
+                        const float vd = t < cb ? (t < 7 ? pv[hh][t < 7 ? t : 0] : 0.f) : big[2 * D + n];
+                        sum += e;
+                        acc = fmaf(e, vd, acc);
+                    }
+                    av[n] = acc / sum;
+                }
+                __syncthreads();
+                float o[1][2];
+                gemv<WT, D, 2, 1, false>(w, av, D, nullptr, 0.f, lane, o);
+                AR_MARK();
+                ++ep;
+                if (lane < 2) {
+                    const int n = 2 * gw + lane;
+                    store_granule(a.gx + n, ep, xs[n] + (lane == 0 ? o[0][0] : o[0][1]));
+                }
+            }
+            {   // ---- FC ----
+                WFrag<WT, D> w[12];
+#pragma unroll
+                for (int r = 0; r < 12; ++r) w[r].load(L.w13, 12L * gw + r, lane);
+                asm volatile("" ::: "memory");
+                gather<3>(a.gx, D, ep, xs, a.fail, 9);
+                AR_MARK();
+                float o[1][12];
+                gemv<WT, D, 12, 1, true>(w, xs, D, L.ffn_norm, 1e-5f, lane, o);
+                AR_MARK();
+                ++ep;
+                float mine = 0.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+                    if (lane == r) mine = silu_f(o[0][r]) * o[0][6 + r];
+                if (lane < 6) store_granule(a.gbig + 6 * gw + lane, ep, mine);
+            }
+            {   // ---- FD ----
+                WFrag<WT, I> w[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) w[r].load(L.w2, 2L * gw + r, lane);
+                asm volatile("" ::: "memory");
+                gather<9>(a.gbig, I, ep, big, a.fail, 10);
+                AR_MARK();
+                float o[1][2];
+                gemv<WT, I, 2, 1, false>(w, big, I, nullptr, 0.f, lane, o);
+                AR_MARK();
+                ++ep;
+                if (lane < 2) {
+                    const int n = 2 * gw + lane;
+                    store_granule(a.gx + n, ep, xs[n] + (lane == 0 ? o[0][0] : o[0][1]));
+                }
+            }
+        }
+        {   // ---- FH: fast_norm + codebook head (rows gw, gw + 384, gw + 768) ----
+            WFrag<WT, D> w[3];
+            const int V = a.codebook_size;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                int row = gw + AR_WAVES * j;
+                if (row > V - 1) row = V - 1;
+                w[j].load(a.fast_out_w, row, lane);
+            }
+            asm volatile("" ::: "memory");
+            gather<3>(a.gx, D, ep, xs, a.fail, 11);
+            AR_MARK();
+            float o[1][3];
+            gemv<WT, D, 3, 1, true>(w, xs, D, a.fast_norm, 1e-5f, lane, o);
+            AR_MARK();
+            ++ep;
+            float mine = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (lane == j) mine = o[0][j];
+            const int row = gw + AR_WAVES * lane;
+            if (lane < 3 && row < V) {
+                store_granule(a.glog + row, ep, mine);
+                a.fast_logits[(long)cb * V + row] = mine;
+            }
+        }
+        {   // ---- FS: nucleus sample, redundantly in every workgroup (4 waves x 4 logits per lane) ----
+            const int V = a.codebook_size;
+            if (cb + 1 < NCB) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) wq0[r].load(a.fast[0].wqkv, 6L * gw + r, lane);
+                asm volatile("" ::: "memory");
+            }
+            gather<4>(a.glog, V, ep, lg, a.fail, 12);
+            AR_MARK();
+            float l[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) l[r] = (tid + 256 * r) < V ? lg[tid + 256 * r] : -INFINITY;
+            const int raw = nucleus_sample<4, 4>(l, V, tid, a.noise ? a.noise + a.vocab + (long)cb * V : nullptr, seed, frame, 1, cb * V, a.inv_temp,
+                                                 a.top_p, reinterpret_cast<double*>(scr));
+            int t = raw;
+            if (use_forced) t = a.forced[(long)cb * a.chunk + a.ci];
+            tprev = t;
+            if (tid == 0) toks[cb] = t;
+            if (wg == 0 && tid == 0) { a.tok_raw[cb] = raw; a.tok[cb] = t; }
+            __syncthreads();          // lg / xs are rewritten by the next codebook step
+        }
+    }
+
+    // ======================================= frame bookkeeping =======================================
+    // cached_new_audio_emb = embed(codes) (dual_ar_stream.py:834, 245-255): 8 features per workgroup, codebooks summed in order
+    if (tid < 8) {
+        const int i = wg * 8 + tid;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < NCB; ++q) acc += a.codebook_emb[((long)toks[q] + (long)q * a.codebook_size) * D + i];
+        a.cached_audio_emb[i] = acc;
+    }
+    if (wg != 0) return;
+    if (tid < NCB) {
+        a.pred_hist[(long)tid * a.hist_cap + (frame & (a.hist_cap - 1))] = toks[tid];
+        a.step_audio[tid * a.chunk + a.ci] = toks[tid];
+    }
+    if (tid == 0) {
+        a.step_content[a.ci] = code;
+        *a.nframes = frame + 1;
+        *a.last_pos = p0 + 1;
+        *a.epoch = ep;
+    }
+    if (!a.skip_semantic) {
+        float l[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int e = tid + 256 * r;
+            l[r] = e < a.vocab ? __hip_atomic_load(a.slow_logits + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+        }
+        __syncthreads();
+        const int s = nucleus_sample<4, 32>(l, a.vocab, tid, a.noise, seed, frame, 0, 0, a.inv_temp, a.top_p, reinterpret_cast<double*>(scr));
+        if (tid == 0) *a.sem = s;
+    }
+}
+
+constexpr size_t AR_LDS_FLOATS = GX + GBIG + GATT + GX + NCB * KVF_LD + GLOG + 16 * 68 + 128;
+
+}  // namespace
+
+size_t ar_decode_granule_words() { return (size_t)GX + GBIG + GATT + GLOG + GA; }
+
+int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, hipStream_t st) {
+    SVA_CHECK(a.vocab <= 22 * AR_WAVES && a.codebook_size <= 3 * AR_WAVES && a.codebook_size <= 1024 && (a.hist_cap & (a.hist_cap - 1)) == 0,
+              "ar_decode: unsupported head sizes");
+    const size_t smem = AR_LDS_FLOATS * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<__half, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<__half, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<float, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    if (wt_half && kv_half) hipLaunchKernelGGL((ar_decode_kernel<__half, __half>), dim3(AR_WGS), dim3(256), smem, st, a);
+    else if (wt_half) hipLaunchKernelGGL((ar_decode_kernel<__half, float>), dim3(AR_WGS), dim3(256), smem, st, a);
+    else if (kv_half) hipLaunchKernelGGL((ar_decode_kernel<float, __half>), dim3(AR_WGS), dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((ar_decode_kernel<float, float>), dim3(AR_WGS), dim3(256), smem, st, a);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace sva

@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/sva.h"
 #include "kernels.h"
+#include "ar_decode.h"
 
 #include <array>
 #include <map>
@@ -53,6 +54,9 @@ struct TrLayer {
     float* ls_attn = nullptr;
     float* ls_ffn = nullptr;
     Lin wqkv, wo, w13, w2;
+    // AR layers only: the persistent decode kernel's copies (fp32: wqkv / wo / w2 alias the Lin weights; fp16 with ar_dtype = 1),
+    // m_w13 in that kernel's own row order (ar_decode.h)
+    void *m_wqkv = nullptr, *m_wo = nullptr, *m_w13 = nullptr, *m_w2 = nullptr;
 };
 
 // activation tensor [B, H + Tmax, C] channel-last with H history / zero-pad rows in front
@@ -122,6 +126,8 @@ struct sva_engine {
     float *ar_norm = nullptr, *ar_fast_norm = nullptr;
     sva::Lin ar_output, ar_fast_output, context_in, style_in;
     float *rope_ar = nullptr, *rope_fast = nullptr;
+    void *m_output = nullptr, *m_fast_output = nullptr;     // heads in the persistent decode kernel's element type
+    bool mega_ok = false;                  // layer counts / sizes match what ar_decode.hip is built for
 
     // ---- vocoder ----
     float *fsq_W = nullptr, *fsq_b = nullptr;   // [8][64][4], [8][64]
@@ -165,6 +171,13 @@ struct sva_batch {
     int evi = 0;
     bool concurrency = true;
     bool fused_decode = true;              // B <= 2: GEMV path with fused norm / RoPE / KV-write / SwiGLU
+    bool use_mega = false;                 // B == 1: one persistent kernel per decoded frame (ar_decode.hip)
+    unsigned long long* d_gran = nullptr;  // its granule buffers (gx | gbig | gatt | glog)
+    unsigned* d_epoch = nullptr;           // [1] running phase counter of the granule tags
+    int* d_ar_fail = nullptr;              // [1] timeout code of the persistent kernel (0 = healthy)
+    long long* d_ar_dbg = nullptr;         // SVA_AR_TIMING=1: phase timestamps of workgroup 0
+    float* kv_fast_mega = nullptr;         // [4][8][2][768] fast-AR K/V scratch of the persistent kernel
+    bool kv_half = false;                  // slow KV cache holds __half (ar_dtype = 1)
     sva::DevPool allocs;
 
     // ---- device control block ----

@@ -100,7 +100,7 @@ extern "C" int sva_engine_create(const sva_config* cfg, int device, sva_engine**
     SVA_CHECK(cfg && out, "null argument");
     SVA_CHECK(cfg->tr_dim == cfg->enc_dims[3] && cfg->voc_dim == 512, "unsupported dims");
     SVA_CHECK(cfg->ar_dim / cfg->ar_heads == 64 && cfg->tr_dim / cfg->tr_heads == 64, "head_dim must be 64");
-    SVA_CHECK(cfg->ar_dtype == 0, "ar_dtype=1 (fp16 weights) is not built in this round");
+    SVA_CHECK(cfg->ar_dtype == 0 || cfg->ar_dtype == 1, "ar_dtype must be 0 (fp32 weights / fp32 KV) or 1 (fp16 weights / fp16 slow KV)");
     int ndev = 0;
     SVA_HIP(hipGetDeviceCount(&ndev));
     SVA_CHECK(ndev > 0 && device < ndev, "no such HIP device (the product path has no CPU fallback)");
@@ -140,9 +140,30 @@ struct Packer {
         if (it != e->host.end()) return &it->second;
         return nullptr;
     }
+    // ar_dtype = 1: the AR's matrices ("arvc." Linear weights) hold fp16 values, as under the reference's
+    // torch.autocast(fp16) decode (evaluations/infer_arvc.py:483, 493); the fp32 copies used by the batched / prefill GEMMs carry
+    // the same rounded values, so every path computes with one set of numbers
+    static float round_half(float v) { return (float)(_Float16)v; }
+    int upload_half(void** out, const std::vector<float>& v) {
+        std::vector<uint16_t> hbits(v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            const _Float16 hv = (_Float16)v[i];
+            memcpy(&hbits[i], &hv, 2);
+        }
+        uint16_t* d = nullptr;
+        SVA_TRY(dev_alloc(e->allocs, &d, hbits.size(), false));
+        SVA_HIP(hipMemcpy(d, hbits.data(), hbits.size() * 2, hipMemcpyHostToDevice));
+        *out = d;
+        return 0;
+    }
     // plain weight or folded weight-norm pair (firefly.py:105-111, 295-301: w = g * v / ||v||, norm over dims 1..)
     bool weight(const std::string& prefix, HostTensor& out) {
-        if (const HostTensor* t = find(prefix + ".weight")) { out = *t; return true; }
+        if (const HostTensor* t = find(prefix + ".weight")) {
+            out = *t;
+            if (e->cfg.ar_dtype == 1 && prefix.compare(0, 5, "arvc.") == 0)
+                for (auto& v : out.data) v = round_half(v);
+            return true;
+        }
         const HostTensor* g = find(prefix + ".parametrizations.weight.original0");
         const HostTensor* v = find(prefix + ".parametrizations.weight.original1");
         if (!g || !v) { err = "missing weight " + prefix + ".weight"; return false; }
@@ -236,7 +257,7 @@ struct Packer {
         return 0;
     }
     // w1 / w3 rows interleaved in groups of 16 -> [2*I][D]
-    int w13(const std::string& p, Lin& l, int I, int D) {
+    int w13(const std::string& p, Lin& l, int I, int D, void** mega_w13 = nullptr) {
         HostTensor w1, w3;
         SVA_CHECK(weight(p + "feed_forward.w1", w1), err.c_str());
         SVA_CHECK(weight(p + "feed_forward.w3", w3), err.c_str());
@@ -248,15 +269,39 @@ struct Packer {
                 memcpy(&out[((size_t)g * 32 + 16 + r) * D], &w3.data[((size_t)g * 16 + r) * D], sizeof(float) * D);
             }
         l.N = 2 * I; l.K = D; l.b = nullptr;
+        if (mega_w13) {
+            // the persistent decode kernel's row order: wave w owns rows [12w, 12w + 12) = w1 rows 6w..6w+5, w3 rows 6w..6w+5
+            SVA_CHECK(I % 6 == 0, "ffn size must be a multiple of 6");
+            std::vector<float> mp((size_t)2 * I * D);
+            for (int w = 0; w < I / 6; ++w)
+                for (int r = 0; r < 6; ++r) {
+                    memcpy(&mp[((size_t)w * 12 + r) * D], &w1.data[((size_t)w * 6 + r) * D], sizeof(float) * D);
+                    memcpy(&mp[((size_t)w * 12 + 6 + r) * D], &w3.data[((size_t)w * 6 + r) * D], sizeof(float) * D);
+                }
+            if (e->cfg.ar_dtype == 1) SVA_TRY(upload_half(mega_w13, mp));
+            else { float* f = nullptr; SVA_TRY(upload(e->allocs, &f, mp)); *mega_w13 = f; }
+        }
         return upload(e->allocs, &l.W, out);
     }
-    int llama(const std::string& p, TrLayer& L, int D, int I, bool layerscale) {
+    // fp16 copy of an already uploaded [N][K] matrix's host values (ar_dtype = 1) or the fp32 device pointer itself
+    int mega_copy(const std::string& prefix, const Lin& l, void** out) {
+        if (e->cfg.ar_dtype != 1) { *out = l.W; return 0; }
+        HostTensor w;
+        SVA_CHECK(weight(prefix, w), err.c_str());
+        return upload_half(out, w.data);
+    }
+    int llama(const std::string& p, TrLayer& L, int D, int I, bool layerscale, bool mega = false) {
         SVA_TRY(vec(p + "attention_norm.weight", &L.attn_norm, D));
         SVA_TRY(vec(p + "ffn_norm.weight", &L.ffn_norm, D));
         SVA_TRY(linear(p + "attention.wqkv", L.wqkv, 3 * D, D));
         SVA_TRY(linear(p + "attention.wo", L.wo, D, D));
-        SVA_TRY(w13(p, L.w13, I, D));
+        SVA_TRY(w13(p, L.w13, I, D, mega ? &L.m_w13 : nullptr));
         SVA_TRY(linear(p + "feed_forward.w2", L.w2, D, I));
+        if (mega) {
+            SVA_TRY(mega_copy(p + "attention.wqkv", L.wqkv, &L.m_wqkv));
+            SVA_TRY(mega_copy(p + "attention.wo", L.wo, &L.m_wo));
+            SVA_TRY(mega_copy(p + "feed_forward.w2", L.w2, &L.m_w2));
+        }
         if (layerscale) {
             SVA_TRY(vec(p + "attention_layer_scale.gamma", &L.ls_attn, D));
             SVA_TRY(vec(p + "ffn_layer_scale.gamma", &L.ls_ffn, D));
@@ -379,14 +424,22 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
         SVA_TRY(P.vec(m + "fast_embeddings.weight", &e->fast_emb, (long)c.codebook_size * D));
         SVA_TRY(P.vec("arvc.decoder.wait4start_embedding.weight", &e->wait4start, (long)c.max_delay * D));
         e->ar_layers.resize(c.ar_layers);
-        for (int l = 0; l < c.ar_layers; ++l) SVA_TRY(P.llama(m + "layers." + std::to_string(l) + ".", e->ar_layers[l], D, c.ar_inter, false));
+        // the persistent batch-1 decode kernel (ar_decode.hip) is built for the reference's sizes
+        e->mega_ok = c.ar_layers == AR_SLOW_LAYERS && c.ar_fast_layers == AR_FAST_LAYERS && D == 768 && c.ar_inter == 2304 && c.ar_heads == 12 &&
+                     c.num_codebooks == 8 && c.ar_vocab <= 22 * AR_WAVES && c.codebook_size <= 1024;
+        const bool mg = e->mega_ok;
+        for (int l = 0; l < c.ar_layers; ++l) SVA_TRY(P.llama(m + "layers." + std::to_string(l) + ".", e->ar_layers[l], D, c.ar_inter, false, mg));
         e->ar_fast_layers.resize(c.ar_fast_layers);
         for (int l = 0; l < c.ar_fast_layers; ++l)
-            SVA_TRY(P.llama(m + "fast_layers." + std::to_string(l) + ".", e->ar_fast_layers[l], D, c.ar_inter, false));
+            SVA_TRY(P.llama(m + "fast_layers." + std::to_string(l) + ".", e->ar_fast_layers[l], D, c.ar_inter, false, mg));
         SVA_TRY(P.vec(m + "norm.weight", &e->ar_norm, D));
         SVA_TRY(P.vec(m + "fast_norm.weight", &e->ar_fast_norm, D));
         SVA_TRY(P.linear(m + "output", e->ar_output, c.ar_vocab, D));
         SVA_TRY(P.linear(m + "fast_output", e->ar_fast_output, c.codebook_size, D));
+        if (mg) {
+            SVA_TRY(P.mega_copy(m + "output", e->ar_output, &e->m_output));
+            SVA_TRY(P.mega_copy(m + "fast_output", e->ar_fast_output, &e->m_fast_output));
+        }
         SVA_TRY(P.linear("arvc.context_in", e->context_in, D, c.timbre_dim));
         SVA_TRY(P.linear("arvc.style_in", e->style_in, D, c.style_dim));
         SVA_TRY(P.rope(m + "freqs_cis", &e->rope_ar, c.max_seq_len, 64));
@@ -800,7 +853,8 @@ int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int*
     const sva_config& c = b->e->cfg;
     const int D = c.ar_dim, I = c.ar_inter, H = c.ar_heads;
     hipStream_t st = b->stream;
-    if (M <= 4 && b->fused_decode) {
+    const bool half_kv = b->kv_half && S > 8;           // the slow cache of an ar_dtype = 1 batch (the fast cache stays fp32)
+    if (M <= 4 && b->fused_decode && !half_kv) {
         // decode at B <= 2: 5 launches per layer -- QKV GEMV (+RMSNorm, +RoPE, +KV write), attention, wo GEMV (+residual),
         // w1|w3 GEMV (+RMSNorm, +SwiGLU), w2 GEMV (+residual)
         for (size_t l = 0; l < layers.size(); ++l) {
@@ -849,6 +903,10 @@ int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int*
         }
         if (S <= 8) {
             SVA_TRY(launch_ar_fast_attention(b->aqkv, M, H, d_slot, d_pos, rope, cache, kv_slot, S, b->aatt, st));
+        } else if (half_kv) {
+            __half* ch = reinterpret_cast<__half*>(kv) + (long)l * kv_layer;
+            SVA_TRY(launch_rope_kvwrite<__half>(b->aqkv, M, H, 64, d_slot, d_pos, rope, ch, kv_slot, S, st));
+            SVA_TRY(launch_ar_attention<__half>(b->aqkv, M, H, 64, d_slot, d_pos, ch, kv_slot, S, b->aatt, st));
         } else {
             SVA_TRY(launch_rope_kvwrite<float>(b->aqkv, M, H, 64, d_slot, d_pos, rope, cache, kv_slot, S, st));
             SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
@@ -1028,17 +1086,53 @@ namespace {
 // one decoded frame for every stream (decode_one_token_ar, dual_ar_stream.py:1168-1219)
 int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const long long* codes, int codes_ld, int code_off, int last_pos_inc);
 
+int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_off);
+
 int ar_decode_frame(sva_batch* b, int ci) {
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
     const int B = b->B, D = c.ar_dim, chunk = b->p.chunk_frames;
     hipStream_t st = b->stream;
     const int code_off = b->T2 - chunk + ci;
+    if (b->use_mega) return ar_decode_frame_mega(b, ci, b->d_codes, code_off);
     hipLaunchKernelGGL(ar_prepare_step_kernel, dim3(B), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, b->d_codes, b->T2,
                        code_off, b->d_last_pos, D, b->ax, b->d_slot, b->d_pos, b->d_step_content, chunk, ci);
     SVA_TRY(ar_layers_pass(b, e->ar_layers, 2 * B, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
                            b->kv_slow_slot, c.max_seq_len, b->ax));
     return ar_frame_tail(b, ci, (long)2 * D, (long)D, b->d_codes, b->T2, code_off, 2);
+}
+
+// one decoded frame of a one-stream batch in ONE launch of the persistent kernel (ar_decode.hip)
+int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_off) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    ArDecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int l = 0; l < AR_SLOW_LAYERS; ++l) {
+        const TrLayer& L = e->ar_layers[l];
+        a.slow[l] = ArLayerW{L.m_wqkv, L.m_wo, L.m_w13, L.m_w2, L.attn_norm, L.ffn_norm};
+    }
+    for (int l = 0; l < AR_FAST_LAYERS; ++l) {
+        const TrLayer& L = e->ar_fast_layers[l];
+        a.fast[l] = ArLayerW{L.m_wqkv, L.m_wo, L.m_w13, L.m_w2, L.attn_norm, L.ffn_norm};
+    }
+    a.out_w = e->m_output; a.out_norm = e->ar_norm; a.fast_out_w = e->m_fast_output; a.fast_norm = e->ar_fast_norm;
+    a.content_emb = e->content_emb; a.codebook_emb = e->codebook_emb; a.fast_emb = e->fast_emb; a.rope_slow = e->rope_ar; a.rope_fast = e->rope_fast;
+    a.codes = codes; a.code_off = code_off;
+    a.cached_audio_emb = b->cached_audio_emb; a.last_pos = b->d_last_pos; a.nframes = b->d_nframes; a.seed = b->d_seed;
+    a.kv_slow = b->kv_slow; a.kv_layer_stride = b->kv_slow_layer; a.S = c.max_seq_len; a.kv_fast = b->kv_fast_mega;
+    a.gx = b->d_gran; a.gbig = a.gx + 2 * 768; a.gatt = a.gbig + 2 * 2304; a.glog = a.gatt + AR_WGS * 66; a.ga = a.glog + 1024;
+    a.epoch = b->d_epoch; a.fail = b->d_ar_fail; a.dbg = b->d_ar_dbg;
+    a.slow_logits = b->slow_logits; a.fast_logits = b->fast_logits; a.hidden = b->hidden;
+    a.sem = b->d_sem; a.tok_raw = b->d_tok_raw; a.tok = b->d_tok; a.step_audio = b->d_step_audio; a.pred_hist = b->d_pred_hist;
+    a.step_content = b->d_step_content; a.hist_cap = b->hist_cap; a.chunk = b->p.chunk_frames; a.ci = ci;
+    const int nstride = c.ar_vocab + c.num_codebooks * c.codebook_size;
+    a.noise = b->noise_on_device ? nullptr : b->d_noise + (long)ci * nstride;
+    a.forced = b->d_forced; a.use_forced = b->d_use_forced;
+    const float tclamp = b->p.temperature > 1e-5f ? b->p.temperature : 1e-5f;
+    a.inv_temp = 1.0f / tclamp; a.top_p = b->p.top_p; a.skip_semantic = b->p.skip_semantic;
+    a.vocab = c.ar_vocab; a.codebook_size = c.codebook_size;
+    return launch_ar_decode(a, c.ar_dtype == 1, b->kv_half, b->stream);
 }
 
 // semantic head + 8-step fast AR + bookkeeping of one frame; the slow hidden state of slot s is row
@@ -1501,11 +1595,22 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     b->kv_slow_layer = b->kv_slow_slot * B;
     b->kv_fast_slot = 2L * H * ncb * 64;
     b->kv_fast_layer = b->kv_fast_slot * B;
+    b->kv_half = c.ar_dtype == 1;              // slow KV cache in fp16 (75.5 MB per stream instead of 151), as the reference's (infer_arvc.py:55-59)
     {
-        float* p1; float* p2;
-        SVA_TRY(dev_alloc(A, &p1, (size_t)c.ar_layers * b->kv_slow_layer));
+        float* p2;
+        if (b->kv_half) { uint16_t* ph; SVA_TRY(dev_alloc(A, &ph, (size_t)c.ar_layers * b->kv_slow_layer)); b->kv_slow = ph; }
+        else { float* p1; SVA_TRY(dev_alloc(A, &p1, (size_t)c.ar_layers * b->kv_slow_layer)); b->kv_slow = p1; }
         SVA_TRY(dev_alloc(A, &p2, (size_t)c.ar_fast_layers * b->kv_fast_layer));
-        b->kv_slow = p1; b->kv_fast = p2;
+        b->kv_fast = p2;
+    }
+    // persistent batch-1 decode kernel (ar_decode.hip): granule buffers, tag epoch, timeout word, fast K/V scratch
+    b->use_mega = B == 1 && e->mega_ok && b->fused_decode && !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
+    if (b->use_mega) {
+        SVA_TRY(dev_alloc(A, &b->d_gran, ar_decode_granule_words()));
+        SVA_TRY(dev_alloc(A, &b->d_epoch, 1));
+        SVA_TRY(dev_alloc(A, &b->d_ar_fail, 1));
+        SVA_TRY(dev_alloc(A, &b->kv_fast_mega, (size_t)AR_FAST_LAYERS * 8 * 2 * D));
+        if (getenv("SVA_AR_TIMING")) SVA_TRY(dev_alloc(A, &b->d_ar_dbg, 1024));
     }
     SVA_TRY(dev_alloc(A, &b->cached_audio_emb, (size_t)B * D));
     SVA_TRY(dev_alloc(A, &b->cached_ref_emb, (size_t)B * c.max_delay * D));
@@ -2423,6 +2528,8 @@ extern "C" long sva_get_tap(sva_batch* b, const char* what, void* out, long out_
     else if (w == "feat") { src = b->feat.p; bytes = sizeof(float) * (long)B * b->feat.bstride; }
     else if (w == "mag") { src = b->mag; bytes = sizeof(float) * (long)B * b->T0 * 1088; }
     else if (w == "z") { src = b->tr_z; bytes = sizeof(float) * (long)B * b->T2 * c.tr_dim; }
+    else if (w == "ar_fail") { src = b->d_ar_fail; bytes = b->d_ar_fail ? (long)sizeof(int) : 0; if (!src) { set_error("ar_fail: the persistent decode kernel is not in use"); return -1; } }
+    else if (w == "ar_timing") { src = b->d_ar_dbg; bytes = b->d_ar_dbg ? 1024L * (long)sizeof(long long) : 0; if (!src) { set_error("ar_timing: set SVA_AR_TIMING=1"); return -1; } }
     else if (w == "voc_z") { src = b->pin.p; bytes = sizeof(float) * (long)B * b->pin.bstride; }
     else { set_error("unknown tap " + w); return -1; }
     if (out_bytes < bytes) { set_error("tap buffer too small"); return -1; }

@@ -1,0 +1,51 @@
+"""Phase timeline of the persistent AR decode kernel (SVA_AR_TIMING=1): workgroup 0 stamps wall_clock64() (100 MHz) when a
+phase's input has been gathered ("in") and when its outputs are computed ("out").  Prints the mean over a few frames."""
+import os
+import sys
+
+os.environ["SVA_AR_TIMING"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from streamvoiceanon_amd import engine as E, specs, synth_weights as sw
+from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+ar_dtype = int(os.environ.get("AR_DTYPE", "0"))
+W = {k: sw.generate(0, k, shp) for k, shp in specs.all_specs().items()}
+W = {k: v for k, v in W.items() if v is not None}
+eng = E.Engine(W, ar_dtype=ar_dtype)
+b = E.Batch(eng, n_streams=1)
+ac, cc, style, timbre = synth_prompt(2000, 107)
+b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=1000)
+b.begin()
+src = synth_utterance(1000, 2048 * 40)
+labels = []
+for l in range(12):
+    for ph in ("A", "B1", "B1m", "B2", "C", "D"):
+        labels += [f"s{l}.{ph}.in", f"s{l}.{ph}.out"]
+labels.append("hidden.in")
+for cb in range(8):
+    for l in range(4):
+        for ph in ("FA", "FB", "FC", "FD"):
+            labels += [f"f{cb}.{l}.{ph}.in", f"f{cb}.{l}.{ph}.out"]
+    labels += [f"f{cb}.FH.in", f"f{cb}.FH.out", f"f{cb}.FS.in"]
+acc = None
+n = 0
+for i in range(30):
+    b.step(src[i * 2048:(i + 1) * 2048][None])
+    if i >= 10:
+        t = b.tap("ar_timing", (1024,), np.int64)[:len(labels)].astype(np.float64) * 0.01     # us
+        d = np.diff(t)
+        acc = d if acc is None else acc + d
+        n += 1
+        total = t[-1] - t[0]
+acc /= n
+kinds = {}
+for k in range(len(acc)):
+    a, bb = labels[k].split(".")[-2:], labels[k + 1].split(".")[-2:]
+    key = f"{a[0]}.{a[1]} -> {bb[0]}.{bb[1]}"
+    kinds.setdefault(key, []).append(acc[k])
+print(f"ar_dtype={ar_dtype}  frame span (first mark -> last mark): {acc.sum():.1f} us   fail={b.tap('ar_fail', (1,), np.int32)[0]}")
+for key, v in kinds.items():
+    print(f"  {key:24s} n={len(v):3d} mean {np.mean(v):6.2f} us  min {np.min(v):6.2f}  max {np.max(v):6.2f}  sum {np.sum(v):7.1f}")
+print("timings:", b.timings())
