@@ -52,7 +52,9 @@ typedef struct sva_config {
     int timbre_tokens;     /* 32 */
     int style_dim;         /* 192 */
     int voc_dim;           /* 512 */
-    int ar_dtype;          /* 0: fp32 weights + fp32 KV (parity mode); 1: fp16 weights + fp16 KV */
+    int ar_dtype;          /* 0: fp32 AR weights + fp32 KV (parity mode); 1: fp16 AR weights (streamed as fp16 by the batch-1 decode kernel;
+                            * the batched / prefill GEMMs use the same fp16-rounded values) + fp16 slow KV cache, as the reference
+                            * decodes under torch.autocast(fp16) with fp16 caches (evaluations/infer_arvc.py:55-59, 483, 493) */
 } sva_config;
 
 /* evaluations/infer_arvc.py setup_stream_caches (:443-460) + stream_infer defaults (:598-613) */
@@ -131,6 +133,11 @@ int sva_firefly_encode(sva_batch* b, const float* audio, int32_t* codes_out);
 /* code2wav_fn (infer_arvc.py:173-176) with the reference's window semantics (zero history):
  * codes host int32[B][8][T] -> pcm float[B][2048*T];  T <= voc_max_frames */
 int sva_vocode_window(sva_batch* b, const int32_t* codes, int T, float* pcm_out);
+/* the two halves of code2wav_fn as seams of their own (infer_arvc.py:175): firefly.quantizer.decode
+ * (modules/vqgan/modules/fsq.py:112-116) codes int32[B][8][T] -> z float[B][4T][512] (channel-last; the reference tensor is
+ * [B, 512, 4T]) and firefly.head (firefly.py:280-293) z -> pcm float[B][2048*T]; window semantics, T <= voc_max_frames */
+int sva_quantizer_decode(sva_batch* b, const int32_t* codes, int T, float* z_out);
+int sva_vocoder_head(sva_batch* b, const float* z, int T, float* pcm_out);
 /* streaming-exact vocoder: continue from the ring-buffer state: codes int32[B][8][T] -> pcm[B][2048*T] */
 int sva_vocode_stream(sva_batch* b, const int32_t* codes, int T, float* pcm_out);
 int sva_vocode_reset(sva_batch* b);
@@ -173,7 +180,8 @@ int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* 
 
 /* same through one specific dispatch choice of the autotuned GEMM (kind 0: small-M K-split kernel, a = 16-row tiles per
  * workgroup, b = K-split waves, c = 16-column tiles per wave; kind 1: LDS-tiled kernel, a = tile variant 0..6; kind 2: the
- * small-M kernel with its K axis also split over c >> 4 workgroups, c & 15 = column tiles; launched twice) */
+ * small-M kernel with its K axis also split over c >> 4 workgroups, c & 15 = column tiles; launched twice; kind 3: the LDS-DMA
+ * ring kernel, a = tile variant 0..6, needs K % 64 == 0) */
 int sva_test_gemm_choice(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int kind,
                          int a, int b, int c);
 

@@ -574,7 +574,7 @@ class StreamSession:
         self.ref_content_codes = ref_content_codes[:max_prompt_frames]
         self.style, self.timbre = style, timbre
         self.ar = DualAR(W, temperature=temperature, top_p=top_p)
-        self.ar.prefill_prompt(ref_content_codes, ref_audio_codes, style, timbre, self.delay)
+        self.prefill_hidden, self.prefill_logits = self.ar.prefill_prompt(ref_content_codes, ref_audio_codes, style, timbre, self.delay)
         # setup_stream_caches (:443-460)
         self.We, self.Wd = encode_window_frames, decode_window_frames
         self.max_seq_frames, self.buffer_frames, self.chunk = max_seq_frames, buffer_frames, decode_chunk_frames
@@ -594,7 +594,7 @@ class StreamSession:
         codes = encode_window(self.window, self.W)[0, 0]                                  # :505-508
         new_codes = codes[-c:]
         self.src_content_codes = torch.cat([self.src_content_codes, new_codes])           # :518
-        rec = dict(content=new_codes.clone(), audio=None)
+        rec = dict(content=new_codes.clone(), audio=None, hidden=[], slow_logits=[], fast_logits=[])
         self.trace.append(rec)
         if self.src_content_codes.shape[0] < self.delay:                                  # :519-520
             return torch.zeros_like(chunk)
@@ -606,7 +606,8 @@ class StreamSession:
         for i in range(c):                                                                # :534-538
             ns, nf = self.noise_fn(self.frame_idx)
             forced = None if forced_codes is None else forced_codes[:, i]
-            out_codes, pos, _ = self.ar.decode_one(int(new_codes[i]), ns, nf, forced)
+            out_codes, pos, aux = self.ar.decode_one(int(new_codes[i]), ns, nf, forced)
+            rec["hidden"].append(aux["hidden"]); rec["slow_logits"].append(aux["logits"]); rec["fast_logits"].append(aux["fast_logits"])
             keep = out_codes if forced is None else forced
             self.pred_codes = torch.cat([self.pred_codes, keep.long()[:, None]], dim=-1)
             self.frame_idx += 1

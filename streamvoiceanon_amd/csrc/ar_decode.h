@@ -53,7 +53,8 @@ struct ArDecodeArgs {
 };
 
 // wt_half / kv_half: element types of the weights / the slow KV cache (0 = fp32, 1 = fp16)
-int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, hipStream_t st);
+// one_per_cu: pad the LDS request so that no two of the 96 workgroups share a CU
+int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st);
 size_t ar_decode_granule_words();     // u64 words the four granule buffers need in total (gx | gbig | gatt | glog | ga, in this order)
 
 }  // namespace sva

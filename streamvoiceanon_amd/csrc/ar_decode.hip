@@ -396,10 +396,9 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                          // [2][768] residual stream (fast AR: row 0)
     float* big = xs + GX;                     // [2][2304] qkv / SwiGLU output
-    float* attp = big + GBIG;                 // [96][66] split-key attention partials
-    float* av = attp + GATT;                  // [2][768] attention output
-    float* kvf = av + GX;                     // [8][KVF_LD] fast-AR K|V rows of one layer
-    float* lg = kvf + NCB * KVF_LD;           // [1024] codebook logits
+    float* attp = big + GBIG;                 // [4][66] split-key attention partials of one (row, head)
+    float* av = attp + 4 * 68;                // [2][768] attention output
+    float* lg = av + GX;                      // [1024] codebook logits
     float* scr = lg + GLOG;                   // [16][68] group partials | sampler scratch | scores
     float* sc = scr + 16 * 68;                // [12][8] scores -> probabilities
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, gw = wg * 4 + wave;
@@ -873,22 +872,26 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
     }
 }
 
-constexpr size_t AR_LDS_FLOATS = GX + GBIG + GATT + GX + NCB * KVF_LD + GLOG + 16 * 68 + 128;
+constexpr size_t AR_LDS_FLOATS = GX + GBIG + 4 * 68 + GX + GLOG + 16 * 68 + 128;
 
 }  // namespace
 
 size_t ar_decode_granule_words() { return (size_t)GX + GBIG + GATT + GLOG + GA; }
 
-int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, hipStream_t st) {
+int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st) {
     SVA_CHECK(a.vocab <= 22 * AR_WAVES && a.codebook_size <= 3 * AR_WAVES && a.codebook_size <= 1024 && (a.hist_cap & (a.hist_cap - 1)) == 0,
               "ar_decode: unsupported head sizes");
-    const size_t smem = AR_LDS_FLOATS * sizeof(float);
+    // one_per_cu: ask for more than half of a CU's LDS so that the 96 workgroups land on 96 different CUs (the AR stream's own
+    // partition: every CU's load bandwidth counts); otherwise the small footprint lets other kernels share the CUs
+    const size_t smem_max = (size_t)88 * 1024;
+    const size_t smem = one_per_cu ? smem_max : AR_LDS_FLOATS * sizeof(float);
+    static_assert(AR_LDS_FLOATS * sizeof(float) <= (size_t)88 * 1024, "LDS layout");
     static bool attr = false;
     if (!attr) {
-        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<__half, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<__half, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<float, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<__half, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<__half, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<float, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         attr = true;
     }
     if (wt_half && kv_half) hipLaunchKernelGGL((ar_decode_kernel<__half, __half>), dim3(AR_WGS), dim3(256), smem, st, a);

@@ -81,6 +81,24 @@ struct EncStream {
     int n_shift = 0;
 };
 
+// Merged incremental front-end pass: the newest 4c mel frames ride in the SAME launches as the head pass (they use the same
+// weights).  Every tensor that feeds a k7 conv is [B][6 zero rows | Hh head rows | 6 history rows | n new rows][C]: a GEMM over
+// Hh + 6 + n rows computes head and new rows together, its epilogue skips the 6 history rows of the destination
+// (ConvGemm::skip_lo/hi), and after the step the newest 6 rows of (history ++ new) become the next step's history.
+struct EncMerged {
+    int Hh = 0, nm = 0;                    // head rows (mel rate), new mel frames per step
+    float* mag = nullptr;                  // [B][R0][1088]                  R0 = Hh + 6 + nm
+    Act mel;                               // [B][6 + R0][160]
+    float* stem = nullptr;                 // [B][R0][128]
+    std::vector<std::vector<Act>> x;       // x[i][j] = input of block j of stage i  [B][6 + R0][C_i]
+    Act xout[4];                           // output of the last block of stage i    [B][R0][C_i]
+    Act feat;                              // [B][R0][512]
+    Act d1, d1o, d2, tok;                  // [B][6 + R1][512], [B][R1][512], [B][6 + R2][512], [B][R2][512]   R1 = Hh/2 + 6 + nm/2 ...
+    float *h1 = nullptr, *h2 = nullptr;    // ConvNeXt scratch [B][R0][512], [B][R0][2048]
+    ShiftDesc* d_shift = nullptr;
+    int n_shift = 0;
+};
+
 // ConvNeXtEncoder (firefly.py:443-520) + the quantizer's 2x (conv k2 s2 + ConvNeXtBlock) downsampler: the tokenizer
 // front-end and the vocoder's own encoder (firefly.encode, firefly.py:560-574) share this shape
 struct EncFront {
@@ -202,6 +220,8 @@ struct sva_batch {
     float* tr_x = nullptr;                 // [B][T2][512] transformer work copy
     sva::Act d2c;                          // [B][T2][512] steady token cache of the exact-incremental encoder
     sva::EncStream es;
+    sva::EncMerged em;
+    bool enc_merged = true;                // new frames folded into the head-pass launches (SVA_ENC_MERGED=0: separate streaming pass)
     sva::ShiftDesc* d_shift_d2c = nullptr;
     int Ht = 40;                           // head tokens recomputed every chunk (receptive field 38.25 tokens)
     bool enc_incremental = true;

@@ -620,7 +620,8 @@ __global__ void mean3_kernel(const float* __restrict__ y0, const float* __restri
 // ConvNeXtBlock (firefly.py:421-440) on x rows [x.H, x.H+T); result into `out` rows [out.H, out.H+T)
 // (out == nullptr: in place).  Streaming users must NOT run in place: the dwconv history of the next step is the
 // block INPUT, while downstream convs need history of the block OUTPUT.  h1 / h2 = scratch with batch strides.
-int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs, float* h2, long h2_bs, Act* out = nullptr) {
+int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs, float* h2, long h2_bs, Act* out = nullptr, int skip_lo = 0,
+                int skip_hi = 0) {
     const int C = c.C;
     SVA_CHECK(x.H >= 6 && x.C == C, "cnx_block: bad activation");
     Act& o = out ? *out : x;
@@ -639,6 +640,7 @@ int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs
     }
     ConvGemm p2;
     p2.gamma = c.gamma;
+    p2.skip_lo = skip_lo; p2.skip_hi = skip_hi;
     p2.res = x.p; p2.r_bstride = x.bstride; p2.r_off = (long)x.H * C; p2.ldr = C;
     SVA_TRY(gemm_call(b, h2, h2_bs, 0, 4 * C, b->B, T, 1, 1, 1, 4 * C, c.pw2, o.p, o.bstride, (long)o.H * C, C, p2));
     return 0;
@@ -757,6 +759,78 @@ int enc_frontend_stream(sva_batch* b, const int* step_ptr, int n_chunk, int add,
     return 0;
 }
 
+__global__ void copy_tokens_kernel(const float* __restrict__ tok, long tok_bstride, int Ht, int gap, int c, float* __restrict__ d2c, long d_bstride,
+                                   int T2, int D) {
+    // head tokens -> d2c rows [0, Ht); newest c tokens -> d2c rows [T2 - c, T2)
+    const int r = blockIdx.x, bi = blockIdx.y;
+    const int src = r < Ht ? r : Ht + gap + (r - Ht);
+    const int dst = r < Ht ? r : T2 - c + (r - Ht);
+    const float4* s = reinterpret_cast<const float4*>(tok + (long)bi * tok_bstride + (long)src * D);
+    float4* d = reinterpret_cast<float4*>(d2c + (long)bi * d_bstride + (long)dst * D);
+    for (int i = threadIdx.x; i < D / 4; i += blockDim.x) d[i] = s[i];
+}
+
+// Merged incremental front-end pass (see EncMerged): head rows (the first 4*Ht mel frames of the window, zero left padding as in
+// the reference's window pass) and the 4c newest mel frames (on per-layer 6-row histories) through ONE sequence of launches.
+// Results: token rows [0, Ht) and [T2 - c, T2) of d2c.
+int enc_frontend_merged(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
+    sva_engine* e = b->e;
+    const EncFront& F = e->tokf;
+    const sva_config& c = e->cfg;
+    EncMerged& M = b->em;
+    const int B = b->B, Hh = M.Hh, nm = M.nm, R0 = Hh + 6 + nm, ch = b->p.chunk_frames;
+    hipStream_t st = b->stream;
+    const long mag_bs = (long)R0 * 1088;
+    SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, M.mag, 1088, mag_bs, 0, Hh, st));
+    SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, M.mag + (long)(Hh + 6) * 1088, 1088, mag_bs, b->T0 - nm, nm, st));
+    {
+        ConvGemm p;
+        p.act = ACT_LOGCLAMP; p.skip_lo = Hh; p.skip_hi = Hh + 6;
+        SVA_TRY(gemm_call(b, M.mag, mag_bs, 0, 1088, B, R0, 1, 1, 1, 1088, e->mel_fb, M.mel.p, M.mel.bstride, (long)M.mel.H * c.n_mels, c.n_mels, p));
+    }
+    const int C0 = c.enc_dims[0];
+    SVA_TRY(gemm_call(b, M.mel.p, M.mel.bstride, 0, c.n_mels, B, R0, 1, 1, 7, c.n_mels, F.stem, M.stem, (long)R0 * C0, 0, C0));
+    {   // LayerNorm of the stem output into the first block's input: head rows and new rows (its history rows stay)
+        Act& X = M.x[0][0];
+        SVA_TRY(launch_layernorm_rows(M.stem, (long)R0 * C0, 0, C0, B, Hh, C0, F.stem_lnw, F.stem_lnb, 1e-6f, X.p, X.bstride, (long)X.H * C0, C0, st));
+        SVA_TRY(launch_layernorm_rows(M.stem, (long)R0 * C0, (long)(Hh + 6) * C0, C0, B, nm, C0, F.stem_lnw, F.stem_lnb, 1e-6f, X.p, X.bstride,
+                                      (long)(X.H + Hh + 6) * C0, C0, st));
+    }
+    for (int i = 0; i < 4; ++i) {
+        const int C = c.enc_dims[i];
+        const int nb = (int)F.stages[i].size();
+        for (int j = 0; j < nb; ++j) {
+            const bool last = j + 1 == nb;
+            Act& out = last ? M.xout[i] : M.x[i][j + 1];
+            SVA_TRY(cnx_block_t(b, F.stages[i][j], M.x[i][j], R0, M.h1, (long)R0 * C, M.h2, (long)R0 * 4 * C, &out, last ? 0 : Hh, last ? 0 : Hh + 6));
+        }
+        if (i < 3) {
+            const int Cn = c.enc_dims[i + 1];
+            SVA_TRY(launch_layernorm_rows(M.xout[i].p, M.xout[i].bstride, 0, C, B, R0, C, F.trans_lnw[i + 1], F.trans_lnb[i + 1], 1e-6f, M.h1, (long)R0 * C, 0, C, st));
+            ConvGemm p;
+            p.skip_lo = Hh; p.skip_hi = Hh + 6;
+            Act& X = M.x[i + 1][0];
+            SVA_TRY(gemm_call(b, M.h1, (long)R0 * C, 0, C, B, R0, 1, 1, 1, C, F.trans[i + 1], X.p, X.bstride, (long)X.H * Cn, Cn, p));
+        }
+    }
+    const int D = c.tr_dim;
+    SVA_TRY(launch_layernorm_rows(M.xout[3].p, M.xout[3].bstride, 0, D, B, R0, D, F.final_lnw, F.final_lnb, 1e-6f, M.feat.p, M.feat.bstride, 0, D, st));
+    // BSQ downsample x2 (conv k2 s2 + ConvNeXtBlock, bsq_no_upsample.py:48-61); the strided convs run per row group
+    const int R1 = Hh / 2 + 6 + nm / 2, R2 = Hh / 4 + 6 + nm / 4;
+    SVA_TRY(gemm_call(b, M.feat.p, M.feat.bstride, 0, D, B, Hh / 2, 2, 1, 2, D, F.ds_conv[0], M.d1.p, M.d1.bstride, (long)M.d1.H * D, D));
+    SVA_TRY(gemm_call(b, M.feat.p, M.feat.bstride, (long)(Hh + 6) * D, D, B, nm / 2, 2, 1, 2, D, F.ds_conv[0], M.d1.p, M.d1.bstride,
+                      (long)(M.d1.H + Hh / 2 + 6) * D, D));
+    SVA_TRY(cnx_block_t(b, F.ds_cnx[0], M.d1, R1, M.h1, (long)R1 * D, M.h2, (long)R1 * 4 * D, &M.d1o));
+    SVA_TRY(gemm_call(b, M.d1o.p, M.d1o.bstride, 0, D, B, Hh / 4, 2, 1, 2, D, F.ds_conv[1], M.d2.p, M.d2.bstride, (long)M.d2.H * D, D));
+    SVA_TRY(gemm_call(b, M.d1o.p, M.d1o.bstride, (long)(Hh / 2 + 6) * D, D, B, nm / 4, 2, 1, 2, D, F.ds_conv[1], M.d2.p, M.d2.bstride,
+                      (long)(M.d2.H + Hh / 4 + 6) * D, D));
+    SVA_TRY(cnx_block_t(b, F.ds_cnx[1], M.d2, R2, M.h1, (long)R2 * D, M.h2, (long)R2 * 4 * D, &M.tok));
+    hipLaunchKernelGGL(copy_tokens_kernel, dim3(b->Ht + ch, B), dim3(128), 0, st, M.tok.p, M.tok.bstride, b->Ht, 6, ch, b->d2c.p, b->d2c.bstride, b->T2, D);
+    SVA_TRY(launch_shift_history(M.d_shift, M.n_shift, B, st));
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
 // pre_module (8-layer causal transformer on T2 tokens, windowed_transformer.py:103-143) + BSQ.  Reads the token
 // features from `xin` without modifying them (the exact-incremental path keeps them as its steady cache).
 // need_rows > 0: only the codes of the LAST need_rows tokens are consumed by the caller (streaming keeps codes[-c:],
@@ -830,6 +904,11 @@ int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add, 
     const int D = b->e->cfg.tr_dim, c = b->p.chunk_frames;
     hipStream_t st = b->stream;
     SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, b->B, st));                   // steady tokens slide down by c
+    if (b->enc_merged) {
+        SVA_TRY(enc_frontend_merged(b, step_ptr, n_chunk, add));
+        if (transformer_too) return enc_transformer(b, b->d2c, b->p.chunk_frames);
+        return 0;
+    }
     // the head pass and the streaming pass are independent chains: run the short one on a side stream
     const bool par = b->concurrency;
     if (par) {
@@ -1132,7 +1211,8 @@ int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_
     const float tclamp = b->p.temperature > 1e-5f ? b->p.temperature : 1e-5f;
     a.inv_temp = 1.0f / tclamp; a.top_p = b->p.top_p; a.skip_semantic = b->p.skip_semantic;
     a.vocab = c.ar_vocab; a.codebook_size = c.codebook_size;
-    return launch_ar_decode(a, c.ar_dtype == 1, b->kv_half, b->stream);
+    static const bool share = getenv("SVA_AR_SHARE_CU") && atoi(getenv("SVA_AR_SHARE_CU")) != 0;
+    return launch_ar_decode(a, c.ar_dtype == 1, b->kv_half, !share, b->stream);
 }
 
 // semantic head + 8-step fast AR + bookkeeping of one frame; the slow hidden state of slot s is row
@@ -1198,7 +1278,7 @@ int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const lon
 }
 
 // prefill of ONE slot from prompt codes already staged in d_prompt_cc / d_prompt_ac (R frames)
-int ar_prefill_slot(sva_batch* b, int slot, int R) {
+int ar_prefill_slot(sva_batch* b, int slot, int R, bool tap_logits = false) {
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
     const int D = c.ar_dim, d = b->p.delay, nspk = c.timbre_tokens + 1;
@@ -1224,6 +1304,13 @@ int ar_prefill_slot(sva_batch* b, int slot, int R) {
     // cached_ref_emb = embed(ref_audio_codes)[-d:]  (:775)
     SVA_TRY(launch_audio_embed(e->codebook_emb, b->d_prompt_ac + (R - d), 1, b->Pmax, d, c.num_codebooks, c.codebook_size, D,
                                b->cached_ref_emb + (long)slot * c.max_delay * D, D, st));
+    // logits / pre-norm hidden state of the last prompt token, as forward_generate returns them for a prefill
+    // (dual_ar_stream.py:338-356); nobody consumes them downstream, they are taps for the parity tests ("slow_logits", "hidden")
+    if (tap_logits) {       // (the initial prefill only: a re-prefill inside a stream must not overwrite the frame's taps)
+        hipLaunchKernelGGL(copy_rows_kernel, dim3(1), dim3(256), 0, st, b->ax, (long)D, (long)(M - 1) * D, b->hidden + (long)slot * D, D);
+        SVA_TRY(launch_rmsnorm_rows(b->hidden + (long)slot * D, D, 0, D, 1, 1, D, e->ar_norm, 1e-5f, b->ahn, D, 0, D, st));
+        SVA_TRY(gemm_call(b, b->ahn, D, 0, D, 1, 1, 1, 1, 1, D, e->ar_output, b->slow_logits + (long)slot * c.ar_vocab, c.ar_vocab, 0, c.ar_vocab));
+    }
     const int lp = M - 1;
     SVA_HIP(hipMemcpyAsync(b->d_last_pos + slot, &lp, sizeof(int), hipMemcpyHostToDevice, st));
     SVA_HIP(hipStreamSynchronize(st));
@@ -1257,12 +1344,15 @@ int ar_delay_fill(sva_batch* b) {
 }
 
 // ---- V: streaming vocoder on T new code frames held in d_vcodes [B][8][Tv] -------------------------------
-int vocode(sva_batch* b, int T, bool shift) {
+// part 0: the whole vocoder; 1: firefly.quantizer.decode only (FSQ decode + upsampler, output = rows [pin.H, pin.H + 4T) of
+// b->pin); 2: firefly.head only (HiFiGAN on those rows)
+int vocode(sva_batch* b, int T, bool shift, int part = 0) {
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
     const int B = b->B, V = c.voc_dim, G = c.num_codebooks;
     hipStream_t st = b->stream;
     SVA_CHECK(T >= 1 && T <= b->Tv, "vocode: T out of range");
+    if (part != 2) {
     if (b->voc_codes) SVA_TRY(launch_fsq_decode(b->voc_codes, b->voc_codes_bstride, b->voc_codes_gstride, B, T, G, V / G, e->fsq_W, e->fsq_b, b->zq.p, b->zq.bstride, 0, V, st));
     else SVA_TRY(launch_fsq_decode(b->d_vcodes, (long)G * b->Tv, b->Tv, B, T, G, V / G, e->fsq_W, e->fsq_b, b->zq.p, b->zq.bstride, 0, V, st));
     if (b->voc_codes_event) SVA_HIP(hipEventRecord(b->voc_codes_event, st));
@@ -1272,6 +1362,8 @@ int vocode(sva_batch* b, int T, bool shift) {
     SVA_TRY(gemm_call(b, b->v0.p, b->v0.bstride, 0, V, B, 2 * T, 1, 1, 1, V, e->up_conv[1], b->u1.p, b->u1.bstride,
                       (long)b->u1.H * V, 2 * V));
     SVA_TRY(cnx_block(b, e->up_cnx[1], b->u1, 4 * T, b->vh1, b->vh2, &b->pin));
+    }
+    if (part == 1) return 0;
     // conv_pre k13 (reads the upsampler output with 12 history rows) -> S[0]
     SVA_TRY(conv_act(b, b->pin, 4 * T, 1, 1, e->pre_k, e->conv_pre, b->S[0]));
     long Tl = 4L * T;
@@ -1561,6 +1653,43 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
         SVA_TRY(dev_alloc(A, &b->d_shift_d2c, 1));
         SVA_HIP(hipMemcpy(b->d_shift_d2c, &dc, sizeof(ShiftDesc), hipMemcpyHostToDevice));
     }
+    if (const char* ev = getenv("SVA_ENC_MERGED")) b->enc_merged = atoi(ev) != 0;
+    if (b->enc_incremental && b->enc_merged) {
+        EncMerged& M = b->em;
+        M.Hh = 4 * b->Ht; M.nm = 4 * chunk;
+        const int Hh = M.Hh, nm = M.nm, R0 = Hh + 6 + nm, R1 = Hh / 2 + 6 + nm / 2, R2 = Hh / 4 + 6 + nm / 4;
+        std::vector<ShiftDesc> sd;
+        auto reg = [&](Act& a, int head_rows, int new_rows) {      // history rows sit right behind the head rows
+            ShiftDesc d;
+            d.ptr = a.p + (long)(a.H + head_rows) * a.C; d.bstride = a.bstride; d.H = 6; d.T = new_rows; d.C = a.C; d.pad = 0;
+            sd.push_back(d);
+        };
+        SVA_TRY(dev_alloc(A, &M.mag, (size_t)B * R0 * 1088));
+        SVA_TRY(alloc_act(A, M.mel, B, 6, R0, c.n_mels));
+        reg(M.mel, Hh, nm);
+        SVA_TRY(dev_alloc(A, &M.stem, (size_t)B * R0 * c.enc_dims[0]));
+        M.x.resize(4);
+        for (int i = 0; i < 4; ++i) {
+            M.x[i].resize(c.enc_depths[i]);
+            for (int j = 0; j < c.enc_depths[i]; ++j) {
+                SVA_TRY(alloc_act(A, M.x[i][j], B, 6, R0, c.enc_dims[i]));
+                reg(M.x[i][j], Hh, nm);
+            }
+            SVA_TRY(alloc_act(A, M.xout[i], B, 0, R0, c.enc_dims[i]));
+        }
+        SVA_TRY(alloc_act(A, M.feat, B, 0, R0, Dm));
+        SVA_TRY(alloc_act(A, M.d1, B, 6, R1, Dm));
+        reg(M.d1, Hh / 2, nm / 2);
+        SVA_TRY(alloc_act(A, M.d1o, B, 0, R1, Dm));
+        SVA_TRY(alloc_act(A, M.d2, B, 6, R2, Dm));
+        reg(M.d2, Hh / 4, nm / 4);
+        SVA_TRY(alloc_act(A, M.tok, B, 0, R2, Dm));
+        SVA_TRY(dev_alloc(A, &M.h1, (size_t)B * R0 * Dm));
+        SVA_TRY(dev_alloc(A, &M.h2, (size_t)B * R0 * 4 * Dm));
+        M.n_shift = (int)sd.size();
+        SVA_TRY(dev_alloc(A, &M.d_shift, sd.size()));
+        SVA_HIP(hipMemcpy(M.d_shift, sd.data(), sizeof(ShiftDesc) * sd.size(), hipMemcpyHostToDevice));
+    }
     SVA_TRY(dev_alloc(A, &b->aatt_part, (size_t)4 * c.ar_heads * 8 * 68));
     SVA_TRY(dev_alloc(A, &b->d_codes_buf[0], (size_t)B * T2));
     SVA_TRY(dev_alloc(A, &b->d_codes_buf[1], (size_t)B * T2));
@@ -1759,7 +1888,7 @@ extern "C" int sva_prefill_prompt(sva_batch* b, int slot, const int64_t* ref_con
     SVA_TRY(h2d(b, b->d_seed + slot, &sd, sizeof(sd)));
     // quirk (iv): the KV prefill uses the UNTRUNCATED prompt (infer_arvc.py:484-489) ...
     SVA_TRY(stage_prompt(b, cc, ac, R));
-    SVA_TRY(ar_prefill_slot(b, slot, R));
+    SVA_TRY(ar_prefill_slot(b, slot, R, true));
     // ... while the stored prompt (re-prefill, vocoder fill) is truncated to max_prompt_frames (:469-470)
     const int Rt = std::min(R, b->p.max_prompt_frames);
     b->ref_content[slot].assign(cc.begin(), cc.begin() + Rt);
@@ -1829,6 +1958,34 @@ extern "C" int sva_vocode_window(sva_batch* b, const int32_t* codes, int T, floa
     return sva_vocode_reset(b);
 }
 
+// firefly.quantizer.decode (modules/vqgan/modules/fsq.py:112-116) as a seam of its own: codes int32[B][8][T] -> z float[B][4T][512]
+// (channel-last; the reference tensor is [B, 512, 4T]), window semantics (zero history) like sva_vocode_window
+extern "C" int sva_quantizer_decode(sva_batch* b, const int32_t* codes, int T, float* z_out) {
+    SVA_CHECK(b && codes && z_out, "null argument");
+    SVA_CHECK(T >= 1 && T <= b->Tv, "quantizer_decode: T out of range (1 .. voc_max_frames)");
+    SVA_TRY(sva_vocode_reset(b));
+    SVA_TRY(upload_vcodes(b, codes, T));
+    SVA_TRY(vocode(b, T, false, 1));
+    const int V = b->e->cfg.voc_dim;
+    SVA_HIP(hipMemcpy2DAsync(z_out, sizeof(float) * 4 * T * V, b->pin.p + (long)b->pin.H * V, sizeof(float) * b->pin.bstride, sizeof(float) * 4 * T * V, b->B,
+                             hipMemcpyDeviceToHost, b->stream));
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    return sva_vocode_reset(b);
+}
+
+// firefly.head (HiFiGANGenerator.forward, firefly.py:280-293) as a seam of its own: z float[B][4T][512] -> pcm float[B][2048 T]
+extern "C" int sva_vocoder_head(sva_batch* b, const float* z, int T, float* pcm_out) {
+    SVA_CHECK(b && z && pcm_out, "null argument");
+    SVA_CHECK(T >= 1 && T <= b->Tv, "vocoder_head: T out of range (1 .. voc_max_frames)");
+    SVA_TRY(sva_vocode_reset(b));
+    const int V = b->e->cfg.voc_dim;
+    SVA_HIP(hipMemcpy2DAsync(b->pin.p + (long)b->pin.H * V, sizeof(float) * b->pin.bstride, z, sizeof(float) * 4 * T * V, sizeof(float) * 4 * T * V, b->B,
+                             hipMemcpyHostToDevice, b->stream));
+    SVA_TRY(vocode(b, T, false, 2));
+    SVA_TRY(download_pcm(b, T, pcm_out));
+    return sva_vocode_reset(b);
+}
+
 extern "C" int sva_streams_begin(sva_batch* b) {
     SVA_CHECK(b, "null batch");
     SVA_HIP(hipSetDevice(b->e->device));
@@ -1852,10 +2009,18 @@ extern "C" int sva_streams_begin(sva_batch* b) {
             return 0;
         };
         EncStream& S = b->es;
-        SVA_TRY(zero(S.mel)); SVA_TRY(zero(S.d1)); SVA_TRY(zero(S.d2)); SVA_TRY(zero(b->d2c));
-        for (auto& st_ : S.x) for (auto& a : st_) SVA_TRY(zero(a));
+        SVA_TRY(zero(b->d2c));
         const int warm = 48 / c + 2;             // > receptive field (117 mel frames = 30 tokens) -> histories are steady
-        for (int i = 0; i < warm; ++i) SVA_TRY(enc_frontend_stream(b, nullptr, 0, 0));
+        if (b->enc_merged) {
+            EncMerged& M = b->em;
+            SVA_TRY(zero(M.mel)); SVA_TRY(zero(M.d1)); SVA_TRY(zero(M.d2));
+            for (auto& st_ : M.x) for (auto& a : st_) SVA_TRY(zero(a));
+            for (int i = 0; i < warm; ++i) SVA_TRY(enc_frontend_merged(b, nullptr, 0, 0));     // (the ring is all zeros here)
+        } else {
+            SVA_TRY(zero(S.mel)); SVA_TRY(zero(S.d1)); SVA_TRY(zero(S.d2));
+            for (auto& st_ : S.x) for (auto& a : st_) SVA_TRY(zero(a));
+            for (int i = 0; i < warm; ++i) SVA_TRY(enc_frontend_stream(b, nullptr, 0, 0));
+        }
         // every cached token of a silent window is that same steady response
         hipLaunchKernelGGL(broadcast_row_kernel, dim3(b->T2, B), dim3(256), 0, b->stream, b->d2c.p, b->d2c.bstride, b->T2 - 1, 0, b->T2,
                            b->e->cfg.tr_dim);
@@ -2000,7 +2165,11 @@ int steady_pipelined(sva_batch* b) {
         SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
         SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se));                       // steady tokens slide down by c
         int erc = 0;
-        if (b->stream_cut > 0) {          // the first stages of the streaming pass run on main (its chunk counter), the rest on sx
+        if (b->enc_merged) {
+            // one front-end chain on the main stream (the new frames ride in the head-pass launches); the side stream only carries
+            // the transformer, which overlaps the next step's front-end
+            SVA_TRY(mark(2, sx));
+        } else if (b->stream_cut > 0) {          // the first stages of the streaming pass run on main (its chunk counter), the rest on sx
             SVA_TRY(enc_frontend_stream(b, b->d_step, n, 1, 1));
             SVA_TRY(stream_fork(b, se, sx));
             b->stream = sx;
@@ -2016,7 +2185,8 @@ int steady_pipelined(sva_batch* b) {
         }
         b->stream = se;
         if (erc) return erc;
-        SVA_TRY(enc_frontend_window(b, b->d_step, n, 1, 4 * b->Ht, nullptr, &b->d2c));     // head pass -> d2c rows [0, Ht)
+        if (b->enc_merged) SVA_TRY(enc_frontend_merged(b, b->d_step, n, 1));
+        else SVA_TRY(enc_frontend_window(b, b->d_step, n, 1, 4 * b->Ht, nullptr, &b->d2c));     // head pass -> d2c rows [0, Ht)
         SVA_TRY(launch_add_i32(b->d_step, 1, se));
         SVA_TRY(mark(1, se));
         SVA_TRY(stream_fork(b, se, sx));                                              // transformer(n) needs head pass(n)

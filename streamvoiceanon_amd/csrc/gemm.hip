@@ -181,6 +181,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvGemmG
             const int n = bn0 + grp * 32 + c4;              // w1 column
             if (m >= g.M || n >= g.N) continue;
             const int b = m / g.T, t = m - b * g.T;
+            if (t >= g.skip_lo && t < g.skip_hi) continue;
             const float4 a = *reinterpret_cast<const float4*>(&Cs[row * CS + grp * 32 + c4]);
             const float4 w = *reinterpret_cast<const float4*>(&Cs[row * CS + grp * 32 + 16 + c4]);
             float4 o;
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvGemmG
         const int m = bm0 + row, n = bn0 + c4;
         if (m >= g.M || n >= g.N) continue;
         const int b = m / g.T, t = m - b * g.T;
+        if (t >= g.skip_lo && t < g.skip_hi) continue;
         float4 v = *reinterpret_cast<const float4*>(&Cs[row * CS + c4]);
         if (g.bias) {
             const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
             const int m = m_base + i * 16 + rq + r;
             if (m >= g.M) continue;
             const int b = m / g.T, tt = m - b * g.T;
+            if (tt >= g.skip_lo && tt < g.skip_hi) continue;
             float* crow = g.C + (long)b * g.c_bstride + g.c_off + (long)tt * g.ldc;
             const float* rrow = g.res ? g.res + (long)b * g.r_bstride + g.r_off + (long)tt * g.ldr : nullptr;
             if (g.w13) {
@@ -639,6 +642,11 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
 struct Choice { int kind, a, b, c; int z = 1; };      // z: grid-level K split of the small-M kernel
 
 static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
+    if (ch.kind == 2) {                 // LDS-DMA ring kernel (gemm_pipe.hip), a = tile variant
+        ConvGemmGroup gg;
+        if (t_group) gg = *t_group; else gg.g[0] = g;
+        return launch_pipe_gemm(gg, ch.a, st);
+    }
     if (ch.kind == 0) {
         t_ksplit = ch.z;
         const int rc = ch.c == 4 ? launch_cfg<4>(g, st, ch.a, ch.b) : ch.c == 2 ? launch_cfg<2>(g, st, ch.a, ch.b) : launch_cfg<1>(g, st, ch.a, ch.b);
@@ -666,7 +674,27 @@ static bool ksplit_enabled() {
     return on;
 }
 
+static bool pipe_enabled() {
+    static const bool on = !(getenv("SVA_GEMM_PIPE") && atoi(getenv("SVA_GEMM_PIPE")) == 0);
+    return on;
+}
+// tile variant of the ring kernel for an under-filled grid: the largest tile that still gives every CU of a partition work
+static int pipe_variant(const ConvGemm& g) {
+    static const char* force = getenv("SVA_PIPE_VARIANT");        // A/B switch
+    if (force) return atoi(force);
+    auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
+    if (tiles(128, 64) >= 192) return 2;
+    if (tiles(64, 64) >= 160) return 1;
+    if (tiles(32, 64) >= 96 || g.N % 64 == 0) return 0;
+    return 6;
+}
+
 static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
+    {
+        const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+        static const bool force_all = getenv("SVA_PIPE_VARIANT") != nullptr;
+        if (pipe_enabled() && c_vec && pipe_gemm_supported(g) && g.M >= 32 && g.N >= 32 && (t64 < 1024 || force_all)) return Choice{2, pipe_variant(g), 0, 0};
+    }
     // the K tile is as deep as Cin allows (bytes in flight per workgroup hide the L2/HBM latency of the register-staged
     // pipeline); 128x128 tiles only when they still fill the 256 CUs
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
@@ -700,6 +728,38 @@ static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
 
 static std::mutex g_tune_mu;
 static std::map<std::array<int, 6>, Choice> g_tune;      // (M, N, K, taps, epilogue / prologue flags, stride)
+// compiled-in per-shape choices: the outcome of an offline tuning run (tools/make_tune_table.py -> tune_table.inc), so the
+// default dispatch is a pure function of the problem shape
+struct TuneRow { int key[6]; int kind, a, b, c, z; };
+static const TuneRow kTuneTable[] = {
+#include "tune_table.inc"
+    {{0, 0, 0, 0, 0, 0}, -1, 0, 0, 0, 1}};
+static const std::map<std::array<int, 6>, Choice>& static_table() {
+    static const std::map<std::array<int, 6>, Choice> m = [] {
+        std::map<std::array<int, 6>, Choice> t;
+        if (getenv("SVA_TUNE_TABLE") && atoi(getenv("SVA_TUNE_TABLE")) == 0) return t;
+        for (const TuneRow& r : kTuneTable) {
+            if (r.kind < 0) continue;
+            Choice c{r.kind, r.a, r.b, r.c};
+            c.z = r.z;
+            t[{r.key[0], r.key[1], r.key[2], r.key[3], r.key[4], r.key[5]}] = c;
+        }
+        return t;
+    }();
+    return m;
+}
+// SVA_TUNE_DUMP=<file>: the shapes tuned by this process (SVA_AUTOTUNE=1) are appended as table rows when the library unloads
+static void dump_tune_table() {
+    const char* path = getenv("SVA_TUNE_DUMP");
+    if (!path) return;
+    FILE* f = fopen(path, "a");
+    if (!f) return;
+    for (const auto& kv : g_tune)
+        fprintf(f, "{{%d, %d, %d, %d, %d, %d}, %d, %d, %d, %d, %d},\n", kv.first[0], kv.first[1], kv.first[2], kv.first[3], kv.first[4], kv.first[5],
+                kv.second.kind, kv.second.a, kv.second.b, kv.second.c, kv.second.z);
+    fclose(f);
+}
+static const int g_tune_dump_registered = (atexit(dump_tune_table), 0);
 static float* g_tune_c = nullptr;
 static size_t g_tune_elems = 0;
 
@@ -742,7 +802,17 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
     if (g.dw_wT) SVA_CHECK(g.taps == 1 && g.M <= 16 && g.Cin <= 512 && !g.a_silu && !g.rms_w && !g.w13 && group_n == 1 && g.dw_b && g.ln_w && g.ln_b,
                            "conv_gemm: the fused ConvNeXt prologue needs taps == 1, M <= 16, Cin <= 512");
     Choice ch = heuristic_choice(g, c_vec);
-    static const bool tune = !(getenv("SVA_SKINNY_MT") || getenv("SVA_SKINNY_KW")) && !(getenv("SVA_AUTOTUNE") && atoi(getenv("SVA_AUTOTUNE")) == 0);
+    const unsigned long long key_flags = (unsigned long long)(g.a_silu ? 1 : 0) | (g.rms_w ? 2 : 0) | (g.w13 ? 4 : 0) | (c_vec ? 8 : 0) | (g.accumulate ? 16 : 0) |
+                                         (group_n > 1 ? 32 : 0) | (g.dw_wT ? 64 : 0);
+    {
+        const auto& tab = static_table();
+        auto it = tab.find({g.M, g.N, g.taps * g.Cin, g.taps, (int)key_flags, g.stride});
+        if (it != tab.end()) ch = it->second;
+    }
+    // Deterministic by default: the kernel / configuration of a problem shape comes from the compiled-in table (tune_table.inc,
+    // generated offline from a logged tuning run) or the heuristic -- never from wall-clock measurements of this process, so two
+    // processes, ranks or runs sum in the same order.  SVA_AUTOTUNE=1 re-enables the timed search (tools/make_tune_table.py uses it).
+    static const bool tune = !(getenv("SVA_SKINNY_MT") || getenv("SVA_SKINNY_KW")) && (getenv("SVA_AUTOTUNE") && atoi(getenv("SVA_AUTOTUNE")) != 0);
     if (tune) {
         // Shape-keyed autotune: the first eager launch of a problem shape times the candidate kernels / configurations on
         // the real operands with the output redirected to scratch, and keeps a candidate only if it beats the heuristic
@@ -828,6 +898,12 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                     if (g.N <= 64) cand.push_back(Choice{1, 2, 0, 0});
                     if (g.N <= 16 && !g.w13) cand.push_back(Choice{1, 3, 0, 0});
                 }
+                if (c_vec && pipe_gemm_supported(g) && g.M >= 32 && g.N >= 32 && pipe_enabled())
+                    for (int v = 0; v <= 6; ++v) {
+                        if (v == 4 && (g.M < 128 || g.N < 128)) continue;
+                        if ((v == 2 && g.M < 128) || ((v == 3 || v == 5) && g.N < 128)) continue;
+                        cand.push_back(Choice{2, v, 0, 0});
+                    }
                 float base = 0.f;
                 SVA_TRY_RC(time_choice(ch, &base));
                 float best = base * 0.93f;
@@ -855,6 +931,12 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
 // test hook: run one specific dispatch choice (kind 0: a = rows/16, b = K split, c = column tiles; kind 1: a = tile variant)
 int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, int b, int c) {
     SVA_CHECK(g.Cin % 16 == 0 && g.lda % 4 == 0, "conv_gemm_choice: alignment");
+    if (kind == 2) {
+        SVA_CHECK(pipe_gemm_supported(g) && a >= 0 && a <= 6, "conv_gemm_choice: the ring kernel needs Cin % 64 == 0 and 16-byte aligned operands");
+        SVA_TRY_RC(launch_choice(g, st, Choice{2, a, 0, 0}));
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
     SVA_CHECK(kind == 0 || kind == 1, "conv_gemm_choice: kind");
     if (kind == 0) SVA_CHECK((a == 1 || a == 2 || a == 3 || a == 4) && (b == 4 || b == 8 || (b == 16 && a == 1)) &&
                                  (c == 1 || (c == 2 && g.N % 32 == 0) || (c == 4 && g.N % 64 == 0 && a != 3 && b != 16)),

@@ -59,6 +59,8 @@ struct ConvGemm {
     long c_off = 0;
     int ldc = 0;
     float scale = 1.f;
+    int skip_lo = 0, skip_hi = 0;   // output rows t (within a batch item) in [skip_lo, skip_hi) are computed but not stored: the history
+                                    // rows that sit between the head rows and the newest rows of the merged incremental encoder pass
     int act = ACT_NONE;
     int accumulate = 0;         // C += value   (ParallelBlock mean of three ResBlock branches)
     int a_silu = 0;             // apply SiLU to A on load (HiFiGAN: silu precedes every conv)
@@ -84,6 +86,9 @@ struct ConvGemmGroup {
     int n = 1;
 };
 
+// gemm_pipe.hip: LDS-DMA ring kernel (Cin % 64 == 0); variant = tile shape, see launch_pipe_gemm
+bool pipe_gemm_supported(const ConvGemm& g);
+int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
 int launch_conv_gemm_group(const ConvGemm* gs, int n, hipStream_t st);
 // true when launch_conv_gemm would route this (M, N) problem to the K-split small-M kernel, which can normalise its A rows

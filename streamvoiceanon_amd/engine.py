@@ -14,10 +14,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # The engine overlaps its stages on four HIP streams (plus the process's default stream).  The runtime multiplexes streams
-# onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise, so ask for more queues --
-# effective only if the HIP runtime has not been initialised yet (import this module, or set the variable, before the
-# first torch.cuda / HIP call).  Measured: 382 -> 465 frames/s single-stream, 4175 -> 4250 at 64 streams.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise; a host application that wants
+# the pipelined throughput mode at its best exports GPU_MAX_HW_QUEUES=8 BEFORE the HIP runtime starts (bench.py does; see
+# INTEGRATION.md).  This module does not touch the process environment.  Measured: 382 -> 465 frames/s single-stream.
+RECOMMENDED_ENV = {"GPU_MAX_HW_QUEUES": "8"}
 
 LIB_PATH = os.environ.get("SVA_LIB_PATH") or os.path.join(_HERE, "libsva_hip.so")      # override: A/B builds of the kernels
 
@@ -75,6 +75,8 @@ def load_library():
     lib.sva_encode_window.argtypes = [vp, vp, vp, vp]
     lib.sva_vocode_window.argtypes = [vp, vp, i32, vp]
     lib.sva_vocode_stream.argtypes = [vp, vp, i32, vp]
+    lib.sva_quantizer_decode.argtypes = [vp, vp, i32, vp]
+    lib.sva_vocoder_head.argtypes = [vp, vp, i32, vp]
     lib.sva_vocode_reset.argtypes = [vp]
     lib.sva_ar_delay_fill.argtypes = [vp, vp]
     lib.sva_ar_decode_one.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -102,7 +104,7 @@ EXPORTED_SYMBOLS = [
     "sva_last_error", "sva_config_default", "sva_stream_params_default", "sva_engine_create",
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
     "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_stream_chunks", "sva_encode_window", "sva_firefly_encode",
-    "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
+    "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_quantizer_decode", "sva_vocoder_head", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
     "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
 ]
 
@@ -284,6 +286,22 @@ class Batch:
         out = np.empty((self.B, 2048 * T), dtype=np.float32)
         _check(self.lib.sva_vocode_window(self.h, _ptr(c), T, _ptr(out)), "sva_vocode_window")
         return out
+
+    def quantizer_decode(self, codes):
+        """firefly.quantizer.decode: codes [B, 8, T] -> z float32 [B, 512, 4T] (the reference's channel-first layout)."""
+        c = np.ascontiguousarray(codes, dtype=np.int32).reshape(self.B, 8, -1)
+        T = c.shape[2]
+        z = np.empty((self.B, 4 * T, self.engine.cfg.voc_dim), dtype=np.float32)
+        _check(self.lib.sva_quantizer_decode(self.h, _ptr(c), T, _ptr(z)), "sva_quantizer_decode")
+        return np.ascontiguousarray(z.transpose(0, 2, 1))
+
+    def vocoder_head(self, z):
+        """firefly.head: z [B, 512, 4T] -> pcm float32 [B, 1, 2048 T]."""
+        zz = np.ascontiguousarray(np.asarray(z, dtype=np.float32).reshape(self.B, self.engine.cfg.voc_dim, -1).transpose(0, 2, 1))
+        T = zz.shape[1] // 4
+        out = np.empty((self.B, 2048 * T), dtype=np.float32)
+        _check(self.lib.sva_vocoder_head(self.h, _ptr(zz), T, _ptr(out)), "sva_vocoder_head")
+        return out[:, None, :]
 
     def vocode_stream(self, codes):
         c = np.ascontiguousarray(codes, dtype=np.int32).reshape(self.B, 8, -1)

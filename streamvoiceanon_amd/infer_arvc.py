@@ -1,13 +1,14 @@
 """Host-side mirror of ``InferenceWrapper`` (evaluations/infer_arvc.py:26-689) on top of the HIP engine:
-the chunk-by-chunk streaming surface -- ``prefill_prompt`` / ``setup_stream_caches`` /
-``process_one_chunk`` / ``stream_infer`` -- with the reference's names, defaults and quirks, so callers
-such as the CLI (__main__, :691-743) or the GUI's ``custom_infer`` (real-time-gui.py:32-49) can switch
-by changing one import.
+``infer`` / ``stream_infer`` / ``prefill_prompt`` / ``setup_stream_caches`` / ``process_one_chunk`` / ``calculate_prompt`` with the
+reference's names, defaults and quirks, the module seams the hot loop crosses (``.speech_tokenizer.encode``,
+``.model.decode_one``, ``.firefly.quantizer.decode``, ``.firefly.head``, :506-508, 535-537, 175) as attributes, and the
+reference's command line (``python -m streamvoiceanon_amd.infer_arvc --src_path ... --ref_path ... [--simulate_streaming]``,
+:691-743) -- so callers such as the CLI or the GUI's ``custom_infer`` (real-time-gui.py:32-49) switch by changing one import.
 
-Not built in this round: the wav -> prompt encoders (CAM++ style vector,
-SparkTTS timbre latents, ``firefly.encode`` audio codes).  ``prefill_prompt`` therefore also accepts
-the prompt as codes/embeddings via ``prompt=`` (what ``calculate_prompt`` returns, :382-441); calling it
-with raw reference audio raises NotImplementedError naming the missing rows.
+The prompt's two code streams (``firefly.encode`` audio codes, speech-tokenizer content codes) are computed on the device.  The
+two speaker-embedding encoders (CAM++ style vector, SparkTTS timbre latents; SURVEY.md 8f N1 iii/iv) run on the device when
+their weights are loaded (``style.*`` / ``timbre.*`` tensors); otherwise ``calculate_prompt`` takes ``style_vectors=`` /
+``timbre_latents=`` (or installable callables) and raises NotImplementedError naming the row.
 """
 from __future__ import annotations
 
@@ -16,6 +17,92 @@ import os
 import numpy as np
 
 from . import engine as E
+
+
+def _np(x, dtype=None):
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    x = np.asarray(x)
+    return x.astype(dtype) if dtype is not None else x
+
+
+def _like(ref, arr):
+    """numpy result -> torch tensor on ref's device when the caller passed torch (the reference's seams are torch in / torch out)"""
+    if hasattr(ref, "detach"):
+        import torch
+
+        return torch.from_numpy(np.ascontiguousarray(arr)).to(ref.device)
+    return arr
+
+
+class _SpeechTokenizerSeam:
+    """`speech_tokenizer.encode(audios, audio_lengths)` (modules/vqgan/modules/firefly_encoder.py:553-566):
+    float [B, N] (+ lengths [B]) -> (codes int64 [1, B, N // 2048], lengths // 2048)."""
+
+    def __init__(self, wrapper):
+        self._w = wrapper
+
+    def encode(self, audios, audio_lengths=None):
+        x = _np(audios, np.float32)
+        x = x.reshape(1, -1) if x.ndim == 1 else x.reshape(x.shape[0], -1)
+        B, N = x.shape
+        T = N // 2048
+        lens = np.full(B, N, np.int64) if audio_lengths is None else _np(audio_lengths, np.int64).reshape(B)
+        codes = np.zeros((1, B, T), np.int64)
+        for i in range(B):
+            # the reference masks the mel frames beyond a row's length (:558-559) = encoding the zero-padded row (causal net)
+            row = x[i].copy()
+            row[int(lens[i]):] = 0.0
+            codes[0, i] = self._w.encode_content(row[:T * 2048])
+        return _like(audios, codes), _like(audios, lens // 2048)
+
+    __call__ = encode
+
+
+class _QuantizerSeam:
+    def __init__(self, wrapper):
+        self._w = wrapper
+
+    def decode(self, codes):
+        """firefly.quantizer.decode (modules/vqgan/modules/fsq.py:112-116): int [B, 8, T] -> float32 [B, 512, 4T]."""
+        c = _np(codes, np.int32)
+        c = c.reshape(-1, 8, c.shape[-1])
+        b = E.Batch(self._w.engine, n_streams=c.shape[0], voc_max_frames=c.shape[2])
+        try:
+            return _like(codes, b.quantizer_decode(c))
+        finally:
+            b.close()
+
+
+class _FireflySeam:
+    """`firefly.quantizer.decode` / `firefly.head` (code2wav_fn, evaluations/infer_arvc.py:173-176) and `firefly.encode`
+    (wav2target_fn, :168-171)."""
+
+    def __init__(self, wrapper):
+        self._w = wrapper
+        self.quantizer = _QuantizerSeam(wrapper)
+
+    def head(self, z):
+        """HiFiGANGenerator.forward (modules/vqgan/modules/firefly.py:280-293): float [B, 512, 4T] -> [B, 1, 2048 T]."""
+        zz = _np(z, np.float32)
+        zz = zz.reshape(-1, zz.shape[-2], zz.shape[-1])
+        b = E.Batch(self._w.engine, n_streams=zz.shape[0], voc_max_frames=zz.shape[2] // 4)
+        try:
+            return _like(z, b.vocoder_head(zz))
+        finally:
+            b.close()
+
+    def encode(self, audios, audio_lengths=None):
+        """FireflyArchitecture.encode (firefly.py:560-574) -> ((indices int [B, 8, T], None), feature lengths); the quantised
+        latent the reference returns beside the indices is not produced (no caller on the path reads it, :168-171, 431-434)."""
+        x = _np(audios, np.float32)
+        x = x.reshape(1, -1) if x.ndim == 1 else x.reshape(x.shape[0], -1)
+        lens = np.full(x.shape[0], x.shape[1], np.int64) if audio_lengths is None else _np(audio_lengths, np.int64).reshape(-1)
+        out = np.concatenate([self._w.wav2target_fn(np.where(np.arange(x.shape[1]) < lens[i], x[i], 0.0)) for i in range(x.shape[0])])
+        return (_like(audios, out), None), _like(audios, lens // 2048)
+
+    def remove_parametrizations(self):
+        return self          # weight-norm pairs are folded when the engine packs its weights
 
 
 class InferenceWrapper:
@@ -32,10 +119,21 @@ class InferenceWrapper:
             weights = self.load_checkpoints(config_path, checkpoint_path)
         self.sr = 44100
         self.device = f"cuda:{device}"
-        self.engine = E.Engine(weights, device=device, ar_dtype=0)
+        # fp16: the reference's `self.model.half()` (:62-63) -> fp16 AR weights + fp16 KV cache (sva_config.ar_dtype = 1)
+        self.engine = E.Engine(weights, device=device, ar_dtype=1 if fp16 else 0)
         self.use_graph = bool(compile_ar or compile_decoder or compile_encoder)   # the reference's --compile
         self.batch = None
         self._prompt = None
+        # the module seams the reference's hot loop crosses (:506-508, 535-537, 175)
+        from .arvc_wrapper import ARVCWrapper
+
+        self.model = ARVCWrapper(self.engine)
+        self.speech_tokenizer = _SpeechTokenizerSeam(self)
+        self.firefly = _FireflySeam(self)
+
+    def code2wav_fn(self, code):
+        """:173-176 firefly.head(firefly.quantizer.decode(code))"""
+        return self.firefly.head(self.firefly.quantizer.decode(code))
 
     @staticmethod
     def load_checkpoints(config_path, checkpoint_path):
@@ -196,7 +294,7 @@ class InferenceWrapper:
         return codes
 
     def infer(self, src, ref_path=None, out_dir=None, output_path=None, delay=None, ref_crop_lengths=None, alpha=1.0,
-              spk_emb_collate_type="concat_mel", save_result=False, prompt=None, noise_seed=0, **sampling_kwargs):
+              spk_emb_collate_type="concat_mel", save_result=True, prompt=None, noise_seed=0, **sampling_kwargs):
         """:261-380 offline conversion: encode the source, ARVCWrapper.generate, code2wav.  `src` is a 44.1 kHz mono float
         array and the prompt is given as codes/embeddings (file I/O, resampling and the wav -> prompt encoders are rows
         N1/N2).  Returns the converted waveform as a numpy array like the reference."""
@@ -219,7 +317,7 @@ class InferenceWrapper:
             wav = b.vocode_window(codes[None])[0]
         finally:
             b.close()
-        if save_result:
+        if save_result and (src_path or out_dir or output_path):      # (array input with nowhere to write: an extension of this mirror)
             self._save(wav, src_path, ref_path, out_dir, output_path)
         return wav
 
@@ -237,7 +335,7 @@ class InferenceWrapper:
 
     def stream_infer(self, src, ref_path=None, out_dir=None, encode_window_frames=128, decode_window_frames=64, max_prompt_frames=256,
                      max_seq_frames=768, buffer_frames=32, decode_chunk_frames=1, delay=None, ref_crop_lengths=None, alpha=1.0,
-                     spk_emb_collate_type="concat_mel", save_result=False, prompt=None, noise_seed=0, style_vectors=None,
+                     spk_emb_collate_type="concat_mel", save_result=True, prompt=None, noise_seed=0, style_vectors=None,
                      timbre_latents=None):
         """:598-689.  `src` / `ref_path`: wav paths (loaded and resampled to 44.1 kHz, audio_io.py) or float arrays already at
         44.1 kHz; `style_vectors` / `timbre_latents` stand in for the CAM++ / SparkTTS encoders (N1 iii/iv) unless the
@@ -258,6 +356,53 @@ class InferenceWrapper:
         # the chunk loop (:650-675) in one engine call: the whole file is known, so the stages of consecutive chunks
         # overlap on the GPU; chunk by chunk through process_one_chunk gives the same samples
         pred = self.batch.stream_chunks(src[None])[0]
-        if save_result:
+        if save_result and (src_path or out_dir):
             self._save(pred, src_path, ref_path, out_dir)
         return pred
+
+
+def main(argv=None, weights=None, style_vectors=None, timbre_latents=None):
+    """The reference's command line (evaluations/infer_arvc.py:691-743), flag for flag.  `weights` / `style_vectors` /
+    `timbre_latents` exist for tests and for deployments without the speaker-encoder checkpoints."""
+    import argparse
+    from pathlib import Path
+
+    parser = argparse.ArgumentParser(description="Inference Wrapper")
+    parser.add_argument("--config_path", type=str, default="configs/config_firefly_arvcasr_8192_delay0_8.yaml")
+    parser.add_argument("--checkpoint_path", type=str, default="pretrained_checkpoints/dual_ar_delay_0_8.pth")
+    parser.add_argument("--src_path", type=str, default="./test_waves/azuma_0.wav")
+    parser.add_argument("--ref_path", type=str, nargs="+", default="./test_waves/trump_0.wav", help="One or more reference audio paths")
+    parser.add_argument("--out_dir", type=str, default="./audio_outputs/")
+    parser.add_argument("--compile", action="store_true", help="Compile the model (here: replay the captured hipGraph of the steady step)")
+    parser.add_argument("--delay", type=int, default=2, help="Delay for the decoder (in frames), 0 means no delay")
+    parser.add_argument("--ref_crop_lengths", type=float, nargs="+", default=None, help="Crop lengths in seconds for each reference audio")
+    parser.add_argument("--alpha", type=float, default=1.0, help="Noise mixing coefficient for speaker embeddings (1.0 = no noise, lower = more anonymization)")
+    parser.add_argument("--simulate_streaming", action="store_true", help="Simulate streaming inference")
+    parser.add_argument("--encode_window_frames", type=int, default=128, help="Encoder context window size in frames")
+    parser.add_argument("--decode_window_frames", type=int, default=64, help="Vocoder context window size in frames")
+    parser.add_argument("--max_prompt_frames", type=int, default=256, help="Maximum prompt length in frames")
+    parser.add_argument("--max_seq_frames", type=int, default=768, help="Maximum sequence length in frames")
+    parser.add_argument("--buffer_frames", type=int, default=32, help="Buffer frames when refilling prompt")
+    parser.add_argument("--decode_chunk_frames", type=int, default=1, help="Decode chunk size in frames")
+    args = parser.parse_args(argv)
+    infer_wrapper = InferenceWrapper(
+        args.config_path, args.checkpoint_path, compile_ar=args.compile,
+        compile_decoder=args.compile if args.simulate_streaming else False,
+        compile_encoder=args.compile if args.simulate_streaming else False, weights=weights)
+    ref_path = args.ref_path if isinstance(args.ref_path, list) and len(args.ref_path) > 1 else args.ref_path[0] if isinstance(args.ref_path, list) else args.ref_path
+    Path(args.out_dir).mkdir(parents=True, exist_ok=True)
+    extra = {k: v for k, v in (("style_vectors", style_vectors), ("timbre_latents", timbre_latents)) if v is not None}
+    if args.simulate_streaming:
+        vc_wav = infer_wrapper.stream_infer(
+            args.src_path, ref_path, args.out_dir, encode_window_frames=args.encode_window_frames,
+            decode_window_frames=args.decode_window_frames, max_prompt_frames=args.max_prompt_frames, max_seq_frames=args.max_seq_frames,
+            buffer_frames=args.buffer_frames, decode_chunk_frames=args.decode_chunk_frames, delay=args.delay,
+            ref_crop_lengths=args.ref_crop_lengths, alpha=args.alpha, **extra)
+    else:
+        vc_wav = infer_wrapper.infer(args.src_path, ref_path, args.out_dir, delay=args.delay, ref_crop_lengths=args.ref_crop_lengths,
+                                     alpha=args.alpha, **extra)
+    return vc_wav
+
+
+if __name__ == "__main__":
+    main()

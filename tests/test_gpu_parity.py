@@ -126,6 +126,8 @@ def _stream_vs_golden(eng, W, name, forced=False, device_rng=False, n_limit=None
     b = E.Batch(eng, n_streams=1, chunk_frames=chunk, delay=delay, max_seq_frames=int(g["max_seq_frames"]),
                 buffer_frames=int(g["buffer_frames"]), use_graph=use_graph)
     b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=useed)
+    extra = dict(prefill_logits=b.tap("slow_logits", (1, 8192))[0].copy(), prefill_hidden=b.tap("hidden", (1, 768))[0].copy(), hidden=[])
+    _stream_vs_golden.last = extra
     b.begin()
     n = 2048 * chunk
     src = synth_utterance(useed, n * int(g["n_chunks"]))
@@ -150,6 +152,7 @@ def _stream_vs_golden(eng, W, name, forced=False, device_rng=False, n_limit=None
             slow.append(b.tap("slow_logits", (1, 8192))[0])
             fast.append(b.tap("fast_logits", (1, 8, 1000))[0])
             frame += chunk
+            extra["hidden"].append((frame - 1, b.tap("hidden", (1, 768))[0][:16].copy()))     # of the chunk's last frame
     last_pos = int(b.tap("last_pos", (1,), np.int32)[0])
     b.close()
     return g, outs, np.concatenate(content), (np.concatenate(audio, axis=1) if audio else None), slow, fast, last_pos
@@ -165,6 +168,14 @@ def test_stream_vs_reference_golden(eng, weights0, name):
         np.testing.assert_allclose(outs[int(idx)], g["pcm_full"][k], atol=PCM_TOL)
     sums = np.array([float(o.astype(np.float64).sum()) for o in outs])
     np.testing.assert_allclose(sums, g["pcm_sum"], atol=5e-2)
+    # seams inside the reference's forward passes: last-token logits of the prompt prefill (dual_ar_stream.py:764-796 ->
+    # forward_generate :338-356) and the pre-norm hidden state of every decoded frame
+    ex = _stream_vs_golden.last
+    assert np.abs(ex["prefill_logits"][g["prefill_top_i"]] - g["prefill_top_v"]).max() <= LOGIT_TOL
+    assert int(np.argmax(ex["prefill_logits"])) == int(g["prefill_top_i"][0])
+    assert len(ex["hidden"]) > 0
+    for f, h16 in ex["hidden"]:
+        assert np.abs(h16 - g["hidden16"][f]).max() <= LOGIT_TOL, f
 
 
 def test_teacher_forced_logits(eng, weights0):
@@ -449,12 +460,30 @@ def test_inference_wrapper_offline_infer(weights0):
     w.engine.close()
 
 
+def _report_flips(record_property, name, got, ref, safe):
+    """FSQ index disagreements are a MEASURED count, not a tolerance: report it (pytest property + gpurun_out/fsq_flips.jsonl)."""
+    import json
+    import os
+
+    n_flip, n_unsafe = int((got != ref).sum()), int((~safe).sum())
+    rec = dict(test=name, indices=int(got.size), flips=n_flip, flips_with_safe_margin=int(((got != ref) & safe).sum()), margin_unsafe=n_unsafe)
+    record_property("fsq_flips", rec)
+    print("FSQ boundary flips:", rec)
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "fsq_flips.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    return rec
+
+
 def _fsq_digits(idx):
     idx = np.asarray(idx, dtype=np.int64)
     return np.stack([idx % 8, (idx // 8) % 5, (idx // 40) % 5, (idx // 200) % 5], -1)
 
 
-def test_firefly_encode_vs_reference_golden(eng, weights0):
+def test_firefly_encode_vs_reference_golden(eng, weights0, record_property):
     """Prompt path (SURVEY.md §8f N1 i): sva_firefly_encode against the codes the reference's wav2target_fn produced.
     FSQ rounds tanh-bounded fp32 values, so a frame whose pre-round value sits within 2e-3 of a rounding boundary (per
     the oracle's margin) may legitimately land on the neighbouring level; everything else must be identical, and a
@@ -478,13 +507,14 @@ def test_firefly_encode_vs_reference_golden(eng, weights0):
     assert safe.mean() > 0.9
     np.testing.assert_array_equal(codes[0][safe], ref[safe])
     bad = codes[0] != ref
-    assert bad.mean() <= 0.02
+    rec = _report_flips(record_property, "firefly_encode_vs_reference_golden", codes[0], ref, safe)
+    assert rec["flips_with_safe_margin"] == 0 and rec["flips"] <= rec["margin_unsafe"]
     if bad.any():
         d = np.abs(_fsq_digits(codes[0][bad]) - _fsq_digits(ref[bad]))
         assert (d.sum(-1) == 1).all()
 
 
-def test_firefly_encode_batched_vs_oracle(eng, weights0):
+def test_firefly_encode_batched_vs_oracle(eng, weights0, record_property):
     """B = 3 prompts of 20 frames in one call against the oracle (same margin rule)."""
     from oracle import sva_oracle as O
     from streamvoiceanon_amd import engine as E
@@ -497,7 +527,8 @@ def test_firefly_encode_batched_vs_oracle(eng, weights0):
     ref, margin = O.firefly_encode(torch.from_numpy(x), weights0, return_margin=True)
     safe = margin.numpy() > 2e-3
     np.testing.assert_array_equal(codes[safe], ref.numpy()[safe])
-    assert (codes != ref.numpy()).mean() <= 0.02
+    rec = _report_flips(record_property, "firefly_encode_batched_vs_oracle", codes, ref.numpy(), safe)
+    assert rec["flips_with_safe_margin"] == 0 and rec["flips"] <= rec["margin_unsafe"]
 
 
 def test_calculate_prompt_mirror_feeds_stream(weights0):
@@ -582,7 +613,8 @@ def test_every_gemm_dispatch_choice_vs_fp64():
         bias = rng.standard_normal(N).astype(np.float32)
         ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
         tol = 2e-6 * np.sqrt(K) * 4 + 1e-5
-        for ch in skinny + tiled:
+        ring = [(3, v, 0, 0) for v in range(7)]            # kind 3: the LDS-DMA ring kernel (gemm_pipe.hip), all tile variants
+        for ch in skinny + tiled + ring:
             if ch[0] in (0, 2) and (((ch[3] & 15) == 2 and N % 32) or ((ch[3] & 15) == 4 and N % 64)):
                 continue
             if ch[0] == 1 and ((ch[1] in (1, 4, 6, 7) and M < 128) or (ch[1] in (1, 5, 7) and N < 128)):
@@ -631,6 +663,158 @@ def test_config5_anonymisation_prompt_and_chunk4(weights0):
         ref = sess.process_one_chunk(torch.from_numpy(ch)[None])[0].numpy()
         out = np.asarray(w.process_one_chunk(ch[None])).reshape(-1)
         assert np.abs(out - ref).max() <= PCM_TOL, i
+    w.engine.close()
+
+
+def test_config5_batched_chunk4_per_gpu_shape(eng, weights0):
+    """BASELINE.json configs[4] at its per-GPU shape: 32 concurrent streams, decode_chunk_frames = 4 (four AR decodes per
+    step, evaluations/infer_arvc.py:534-538), alpha = 0.7 noise-mixed speaker embeddings of a 3-reference prompt (R = 3 x 22
+    frames, concat_mel semantics :413-424).  Two slots are checked against the oracle (codes identical under shared noise,
+    PCM within tolerance) and every copy of an utterance must equal its first copy bit for bit (slot independence) -- the
+    batched chunk-4 route runs the MFMA small-M GEMMs and the fused fast-AR attention, not the B = 1 decode kernel."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    B, c, n_steps, n_utt, alpha = 32, 4, 4, 4, 0.7
+    prompts = []
+    for k in range(n_utt):
+        parts = [synth_prompt(2800 + 10 * k + j, 22) for j in range(3)]                       # three references, concatenated
+        ac = np.concatenate([p_[0] for p_ in parts], axis=1)
+        cc = np.concatenate([p_[1] for p_ in parts])
+        gen = torch.Generator().manual_seed(500 + k)
+        style = O.apply_noise_mixing(torch.from_numpy(parts[0][2]), alpha, torch.randn(parts[0][2].shape, generator=gen)).numpy()
+        timbre = O.apply_noise_mixing(torch.from_numpy(parts[0][3]), alpha, torch.randn(parts[0][3].shape, generator=gen)).numpy()
+        prompts.append((ac, cc, style, timbre))
+    b = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2)
+    for s in range(B):
+        ac, cc, style, timbre = prompts[s % n_utt]
+        b.prefill_prompt(s, cc, ac, style, timbre, noise_seed=7600 + s % n_utt)
+    b.begin()
+    n = 2048 * c
+    src = np.stack([synth_utterance(7600 + s % n_utt, n * n_steps) for s in range(B)])
+    outs, codes = [], []
+    for i in range(n_steps):
+        outs.append(b.step(src[:, i * n:(i + 1) * n]))
+        codes.append(b.tap("audio_codes", (B, 8, c), np.int32))
+    b.close()
+    outs = np.concatenate(outs, axis=1)
+    codes = np.concatenate(codes[1:], axis=2)                       # step 0 only fills the delay
+    for s in range(n_utt, B):
+        np.testing.assert_array_equal(codes[s], codes[s % n_utt])
+        np.testing.assert_array_equal(outs[s], outs[s % n_utt])
+    for k in (0, 3):                                                # two slots against the oracle
+        ac, cc, style, timbre = prompts[k]
+        useed = 7600 + k
+        sess = O.StreamSession(weights0, torch.from_numpy(cc), torch.from_numpy(ac), torch.from_numpy(style), torch.from_numpy(timbre),
+                               noise_fn=lambda f: tuple(torch.from_numpy(a) for a in frame_noise(useed, f)), delay=2, decode_chunk_frames=c)
+        ref = np.concatenate([sess.process_one_chunk(torch.from_numpy(src[k, i * n:(i + 1) * n])[None])[0].numpy() for i in range(n_steps)])
+        np.testing.assert_array_equal(codes[k], sess.pred_codes.numpy())
+        assert np.abs(outs[k] - ref).max() <= PCM_TOL, k
+    assert np.abs(outs[0]).max() > 0.01 and not np.array_equal(outs[0], outs[1])
+
+
+def test_weight_norm_folding_and_checkpoint_files(eng, weights0, tmp_path):
+    """The only route real weights take: `.pth` files -> InferenceWrapper(config_path, checkpoint_path) ->
+    engine.  The vocoder head's convs are stored as weight-norm pairs (parametrizations.weight.original0/1 = g, v with
+    w = g v / ||v||, firefly.py:105-111, 295-301) and folded inside the engine (engine.hip Packer::weight); the tokenizer file
+    is wrapped like a DDP training checkpoint ({'net': {'module.<key>': ...}}, evaluations/infer_arvc.py:70-78).  The engine
+    built from the files must reproduce the engine built from the plain tensors."""
+    import yaml
+
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.synth_audio import synth_utterance
+
+    rng = np.random.RandomState(5)
+    arvc, tok, voc, n_pairs = {}, {}, {}, 0
+    for k, v in weights0.items():
+        net, key = k.split(".", 1)
+        t = v if hasattr(v, "detach") else torch.from_numpy(np.asarray(v))
+        if net == "arvc":
+            arvc[key] = t
+        elif net == "tok":
+            tok["module." + key] = t
+        elif key.startswith("head.") and key.endswith(".conv.weight"):
+            w = t.double()
+            rows = w.shape[0]
+            scale = torch.from_numpy(rng.uniform(0.5, 2.0, size=rows)).reshape(rows, 1, 1)
+            vv = (w * scale).float()
+            gg = w.reshape(rows, -1).norm(dim=1).reshape(rows, 1, 1).float()
+            base = key[:-len("weight")]
+            voc[base + "parametrizations.weight.original0"] = gg
+            voc[base + "parametrizations.weight.original1"] = vv
+            n_pairs += 1
+        else:
+            voc[key] = t
+    assert n_pairs == 1 + 5 + 5 * 3 * 6 + 1            # conv_pre, ups, resblock convs1/2, conv_post
+    torch.save(arvc, tmp_path / "arvc.pth")
+    torch.save({"net": tok}, tmp_path / "tok.pth")
+    torch.save(voc, tmp_path / "voc.pth")
+    yaml.safe_dump({"speech_tokenizer": {"checkpoint_path": str(tmp_path / "tok.pth")}, "firefly": {"checkpoint_path": str(tmp_path / "voc.pth")}},
+                   open(tmp_path / "config.yaml", "w"))
+    w = InferenceWrapper(str(tmp_path / "config.yaml"), str(tmp_path / "arvc.pth"))
+    codes = (np.arange(8 * 20).reshape(1, 8, 20) * 37 % 1000).astype(np.int32)
+    x = synth_utterance(7700, 64 * 2048)[None]
+    b0 = E.Batch(eng, n_streams=1, voc_max_frames=20, encode_window_frames=64)
+    b1 = E.Batch(w.engine, n_streams=1, voc_max_frames=20, encode_window_frames=64)
+    pcm0, pcm1 = b0.vocode_window(codes), b1.vocode_window(codes)
+    assert np.abs(pcm0).max() > 0.01
+    assert np.abs(pcm0 - pcm1).max() <= 1e-5           # folding differs from the stored tensor by fp32 rounding only
+    np.testing.assert_array_equal(b0.encode_window(x), b1.encode_window(x))
+    b0.close(); b1.close()
+    w.engine.close()
+
+
+def test_reference_main_call_sequence_and_module_seams(weights0, tmp_path):
+    """Drop-in surface: the reference's `__main__` (evaluations/infer_arvc.py:691-743) executed against the mirror
+    -- same flags, `InferenceWrapper(config_path, checkpoint_path, compile_*=...)`, `stream_infer(src_path, ref_path, out_dir,
+    ...)` / `infer(...)` with save_result defaulting to True -- and the four module seams the hot loop crosses
+    (`speech_tokenizer.encode`, `model.decode_one`, `firefly.quantizer.decode`, `firefly.head`, :506-508, 535-537, 175) as
+    attributes with the reference's argument / return conventions.  Style / timbre vectors are injected (N1 iii/iv)."""
+    import os
+
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import audio_io
+    from streamvoiceanon_amd import infer_arvc as IA
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    src = synth_utterance(7800, 2048 * 9 + 300)
+    ref = synth_utterance(7801, 2048 * 70)                 # >= 64 frames: fills the vocoder window
+    audio_io.write_wav(str(tmp_path / "azuma_0.wav"), src, 44100)
+    audio_io.write_wav(str(tmp_path / "trump_0.wav"), ref, 44100)
+    _, _, style, timbre = synth_prompt(2900, 8)
+    out_dir = tmp_path / "audio_outputs"
+    argv = ["--src_path", str(tmp_path / "azuma_0.wav"), "--ref_path", str(tmp_path / "trump_0.wav"), "--out_dir", str(out_dir), "--delay", "2"]
+    wav_stream = IA.main(argv + ["--simulate_streaming", "--decode_chunk_frames", "1"], weights=weights0, style_vectors=style, timbre_latents=timbre)
+    saved = out_dir / "azuma_0_trump_0.wav"
+    assert saved.exists()                                   # save_result defaults to True like the reference (:271, :612)
+    back, sr = audio_io.load(str(saved), 44100)
+    assert sr == 44100 and back.shape == wav_stream.shape and np.abs(back - wav_stream).max() <= 1e-6
+    assert wav_stream.shape[0] == (src.shape[0] // 2048 + 1) * 2048 and np.abs(wav_stream[2 * 2048:]).max() > 0.01
+    os.remove(saved)
+    wav_off = IA.main(argv, weights=weights0, style_vectors=style, timbre_latents=timbre)
+    assert saved.exists() and wav_off.shape[0] == (src.shape[0] // 2048) * 2048
+    # ---- module seams ----
+    w = IA.InferenceWrapper(weights=weights0)
+    assert w.sr == 44100 and w.device.startswith("cuda")
+    x = torch.from_numpy(synth_utterance(7802, 2048 * 8))[None]
+    codes, lens = w.speech_tokenizer.encode(x, torch.tensor([x.shape[1]]))
+    assert isinstance(codes, torch.Tensor) and tuple(codes.shape) == (1, 1, 8) and codes.dtype == torch.int64 and int(lens[0]) == 8
+    np.testing.assert_array_equal(codes[0, 0].numpy(), O.encode_window(x, weights0)[0, 0].numpy())
+    ac = torch.from_numpy((np.arange(8 * 6).reshape(1, 8, 6) * 53 % 1000).astype(np.int64))
+    z = w.firefly.quantizer.decode(ac)
+    assert tuple(z.shape) == (1, 512, 24)
+    z_ref = O.fsq_upsample(O.fsq_decode(ac, weights0), weights0)
+    assert np.abs(z.numpy() - z_ref.numpy()).max() <= 1e-4
+    pcm = w.firefly.head(z)
+    assert tuple(pcm.shape) == (1, 1, 6 * 2048)
+    assert np.abs(pcm.numpy() - O.vocode_window(ac, weights0).numpy()).max() <= PCM_TOL
+    assert np.abs(w.code2wav_fn(ac).numpy() - pcm.numpy()).max() == 0.0
+    (idx, _), flen = w.firefly.encode(x, torch.tensor([x.shape[1]]))
+    assert tuple(idx.shape) == (1, 8, 8) and int(flen[0]) == 8
+    # model seam: the ARVCWrapper mirror (decode_one is exercised against the fixtures in test_arvc_wrapper_seams)
+    assert all(hasattr(w.model, m) for m in ("prefill_prompt", "prefill_src_condition4delay", "decode_one", "generate", "set_delay", "setup_caches"))
     w.engine.close()
 
 

@@ -76,3 +76,36 @@ def test_synth_audio_is_deterministic_and_bounded():
     assert ac.shape == (8, 107) and ac.dtype == np.int32 and 0 <= ac.min() and ac.max() < 1000
     assert cc.shape == (107,) and cc.dtype == np.int64 and cc.max() < 8192
     assert style.shape == (192,) and timbre.shape == (32, 128)
+
+
+def test_load_checkpoints_unwraps_like_the_reference(tmp_path):
+    """InferenceWrapper.load_checkpoints mirrors evaluations/infer_arvc.py:67-94, 160-165: the main checkpoint is a plain state
+    dict, the speech tokenizer's may be wrapped in {'net': ...} with 'module.'-prefixed keys (DDP), the vocoder's is plain
+    (weight-norm pairs included, folded later by the engine); non-float entries are dropped."""
+    import numpy as np
+    import torch
+    import yaml
+
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+
+    g = torch.Generator().manual_seed(0)
+    arvc = {"embedding.weight": torch.randn(5, 3, generator=g), "decoder.model.norm.weight": torch.randn(3, generator=g)}
+    tok = {"backbone.norm.weight": torch.randn(4, generator=g), "quantizer.pre_module.layers.0.attention.wo.weight": torch.randn(2, 2, generator=g)}
+    voc = {"head.conv_pre.conv.parametrizations.weight.original0": torch.rand(3, 1, 1, generator=g),
+           "head.conv_pre.conv.parametrizations.weight.original1": torch.randn(3, 2, 5, generator=g),
+           "head.conv_pre.conv.bias": torch.randn(3, generator=g), "backbone.bn.num_batches_tracked": torch.tensor(7)}
+    torch.save(arvc, tmp_path / "arvc.pth")
+    torch.save({"net": {"module." + k: v for k, v in tok.items()}, "iters": 123}, tmp_path / "tok.pth")
+    torch.save(voc, tmp_path / "voc.pth")
+    cfg = {"speech_tokenizer": {"checkpoint_path": str(tmp_path / "tok.pth")}, "firefly": {"checkpoint_path": str(tmp_path / "voc.pth")}}
+    yaml.safe_dump(cfg, open(tmp_path / "config.yaml", "w"))
+    W = InferenceWrapper.load_checkpoints(str(tmp_path / "config.yaml"), str(tmp_path / "arvc.pth"))
+    want = {**{"arvc." + k: v for k, v in arvc.items()}, **{"tok." + k: v for k, v in tok.items()},
+            **{"voc." + k: v for k, v in voc.items() if v.dtype.is_floating_point}}
+    assert set(W) == set(want)
+    for k in want:
+        np.testing.assert_array_equal(np.asarray(W[k]), want[k].numpy())
+    # a tokenizer checkpoint that is already a bare state dict loads the same way
+    torch.save(tok, tmp_path / "tok.pth")
+    W2 = InferenceWrapper.load_checkpoints(str(tmp_path / "config.yaml"), str(tmp_path / "arvc.pth"))
+    assert set(W2) == set(want)

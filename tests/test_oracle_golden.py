@@ -78,6 +78,19 @@ def test_stream_matches_reference(name, weights0):
     np.testing.assert_allclose(sums, g["pcm_sum"], atol=1e-3)
     if name == "stream_reprefill":
         assert sess.n_reprefill > 0
+    # seam fixtures captured inside the reference's forward passes: last-token logits of the prompt prefill, the pre-norm hidden
+    # state and the top-32 slow / fast logits of every decoded frame (sampled, not teacher-forced: same codes => same inputs)
+    np.testing.assert_allclose(sess.prefill_logits.numpy()[g["prefill_top_i"]], g["prefill_top_v"], atol=2e-4)
+    assert int(sess.prefill_logits.argmax()) == int(g["prefill_top_i"][0])
+    hid = [h for r in sess.trace for h in r["hidden"]]
+    slow = [x for r in sess.trace for x in r["slow_logits"]]
+    fast = [x for r in sess.trace for x in r["fast_logits"]]
+    assert len(hid) == g["hidden16"].shape[0] == g["slow_top_v"].shape[0]
+    for f in range(len(hid)):
+        np.testing.assert_allclose(hid[f][:16].numpy(), g["hidden16"][f], atol=2e-4)
+        np.testing.assert_allclose(slow[f].numpy()[g["slow_top_i"][f]], g["slow_top_v"][f], atol=2e-4)
+        for cb in range(8):
+            np.testing.assert_allclose(fast[f][cb].numpy()[g["fast_top_i"][f, cb]], g["fast_top_v"][f, cb], atol=2e-4)
 
 
 def test_offline_generate_matches_reference(weights0):
