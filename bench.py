@@ -35,6 +35,10 @@ sys.path.insert(0, ROOT)
 
 FRAME_S = 2048 / 44100.0
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0              # HBM3E ~8 TB/s (same guide)
+# unique weight elements per chunk-step: encoder 52.0 M, AR slow 92.03 + head 6.29 + fast 30.68 + fast_out 0.77 M,
+# vocoder 22.35 M
+ENC_PARAMS, AR_PARAMS, VOC_PARAMS = 52.0e6, 129.77e6, 22.35e6
 
 
 def parse():
@@ -45,6 +49,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (B)")
     ap.add_argument("--chunk", type=int, default=1, help="decode_chunk_frames")
     ap.add_argument("--prompt-frames", type=int, default=107)
+    ap.add_argument("--ar-dtype", type=int, default=0, choices=(0, 1),
+                    help="0: fp32 AR weights + fp32 KV (parity mode, the headline); 1: fp16 AR weights + fp16 slow KV cache, as the "
+                         "reference decodes under torch.autocast(fp16) (evaluations/infer_arvc.py:55-59, 483)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=60, help="CPU-baseline sample size (chunk-steps)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -146,15 +153,14 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
-    from oracle import sva_oracle as O            # only to regenerate the synthetic weights + cpu_baseline leg
-    from streamvoiceanon_amd import engine as E, specs
+    from streamvoiceanon_amd import engine as E, specs, synth_weights
     from streamvoiceanon_amd.sharding import gather_results, shard_utterances
     from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
 
     B, c = args.streams, args.chunk
     n = 2048 * c
-    W = O.load_synth_weights(0, specs.all_specs())
-    eng = E.Engine(W, device=local_rank)
+    W = synth_weights.generate_all(0, specs.all_specs())
+    eng = E.Engine(W, device=local_rank, ar_dtype=args.ar_dtype)
     pin_info = {}
     cpus_at_start = os.sched_getaffinity(0)
 
@@ -259,7 +265,9 @@ def main():
             run(k); k += 1
             batch.sync()
             flops, launches = batch.gemm_stats()
+            alg_bytes = batch.gemm_bytes()
             tot_ms, nl = batch.gemm_profile()
+            tm_prof = batch.timings()          # stage times of this serial, event-bracketed step
             if os.environ.get("SVA_GEMM_TABLE"):
                 tab = batch.gemm_profile_table()
                 agg = {}
@@ -282,12 +290,18 @@ def main():
                 pj = json.load(open(cands[-1]))
                 traffic = round(pj["hbm_bytes_per_launch"], 1)
                 mfma_util = round(pj["gemm_mfma_util"], 4) if pj.get("gemm_mfma_util") is not None else None
-            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32)", "achieved": round(ach, 3),
+            alg_per_launch = alg_bytes / max(nl, 1)
+            roof = {"bound": "mfma", "kernel": "conv-GEMM family: pipe_gemm_kernel / conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32)",
+                    "achieved": round(ach, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
+                    "mode": "one serial step, every conv-GEMM launch bracketed by hipEvents on its launch stream (launches do not overlap)",
                     "traffic": traffic, "traffic_source": os.path.basename(cands[-1]) if traffic is not None else None,
+                    "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
+                    "traffic_over_algorithmic": round(traffic / alg_per_launch, 3) if traffic else None,
                     "mfma_util_pmc": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024) over the same kernels (tools/pmc.sh)
                     "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
-                    "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4)}
+                    "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4),
+                    "stage_ms_profiled_step": {k_: round(v, 4) for k_, v in tm_prof.items()}}
         batch.close()
         return dt, tm, (int(gathered.shape[0]) if gathered is not None else B), roof, extra
 
@@ -302,7 +316,7 @@ def main():
         "metric": "aggregate converted frames/s (2048-sample frames @44.1 kHz), chunk-by-chunk streaming infer_arvc",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if not args.ar_dtype else "f32 (encoder, vocoder) / f16 weights + f16 KV, f32 accumulate (AR)", "data": "synthetic",
         "config": {"workload": f"infer_arvc --simulate_streaming --decode_chunk_frames {c}, delay=2, {B} stream(s) per GPU, "
                                f"encode window 128 / vocoder window 64 frames, synthetic 44.1 kHz speech-like audio, "
                                f"synthetic prompt R={args.prompt_frames}, random-init weights of the reference architecture",
@@ -314,7 +328,33 @@ def main():
         "gathered_utterances": n_gathered,
     }
     out.update(extra)
+
+    def stage_rates(B_, ms_step, tm_, gflop_step):
+        """Rates of the TIMED (pipelined) configuration and of the stages of a synchronised step: the conv-GEMM FLOPs of a step
+        are the encoder's and the vocoder's (+ the AR's at B > 2); the AR at B <= 2 is weight streaming."""
+        wb = 2 if args.ar_dtype else 4
+        p_tok = 33 + 2 * args.prompt_frames + 3 + 2 * 60                     # a typical slow-AR position during the timed region
+        kv_bytes = 2 * 12 * (p_tok + 2) * 768 * wb * 2 * c                   # K and V of 12 layers, read once per decoded frame (two query rows share it)
+        ar_bytes = AR_PARAMS * wb * c + B_ * kv_bytes
+        weight_bytes = ENC_PARAMS * 4 + VOC_PARAMS * 4 + AR_PARAMS * wb * c
+        enc_gflop = 13.9 * B_                                                # merged incremental pass: head 160 + 6 + 4c rows, 128-token transformer
+        voc_gflop = 2.646 * c * B_
+        r = {"timed": {"ms_per_step": round(ms_step, 4), "algorithmic_gflop_per_step": round(gflop_step, 3),
+                       "tflops": round(gflop_step / ms_step, 3), "frac_f32_mfma": round(gflop_step / ms_step / PEAK_F32_MFMA_TFLOPS, 5),
+                       "unique_weight_bytes_per_step": int(weight_bytes), "weight_stream_GBs": round(weight_bytes / ms_step / 1e6, 1),
+                       "frac_hbm": round(weight_bytes / ms_step / 1e6 / PEAK_HBM_GBS, 5)},
+             "stages_synchronised_step": {
+                 "encoder": {"ms": round(tm_["encoder"], 4), "gflop": round(enc_gflop, 2), "tflops": round(enc_gflop / max(tm_["encoder"], 1e-9), 2),
+                             "frac_f32_mfma": round(enc_gflop / max(tm_["encoder"], 1e-9) / PEAK_F32_MFMA_TFLOPS, 5)},
+                 "ar": {"ms": round(tm_["ar"], 4), "bytes": int(ar_bytes), "GBs": round(ar_bytes / max(tm_["ar"], 1e-9) / 1e6, 1),
+                        "frac_hbm": round(ar_bytes / max(tm_["ar"], 1e-9) / 1e6 / PEAK_HBM_GBS, 5),
+                        "note": "unique AR weight bytes (fast layers counted once per codebook pass: 8 x 30.7 M elements stream from L2 / MALL) + slow KV read"},
+                 "vocoder": {"ms": round(tm_["vocoder"], 4), "gflop": round(voc_gflop, 2), "tflops": round(voc_gflop / max(tm_["vocoder"], 1e-9), 2),
+                             "frac_f32_mfma": round(voc_gflop / max(tm_["vocoder"], 1e-9) / PEAK_F32_MFMA_TFLOPS, 5)}}}
+        return r
+
     if roof:
+        roof.update(stage_rates(B, ms, tm, roof["algorithmic_gflop_per_step"]))
         out["roofline"] = roof
     if world == 1 and B == 1 and not args.no_batched:
         # BASELINE.json configs[2] next to the headline single-stream workload: 64 concurrent streams on the same GPU
@@ -324,10 +364,12 @@ def main():
         out["batched_64_streams"] = {"workload": "BASELINE.json configs[2]: 64 concurrent streams, chunk=1, 1 GPU", "ms_per_step": round(ms2, 4),
                                      "value": round(64 * c * 10 / dt2, 3), "unit": "frames/s", "rtf": round(ms2 * 1e-3 / (c * FRAME_S), 5),
                                      "x_realtime": round(64 * c * 10 / dt2 * FRAME_S, 2),
-                                     "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm2.items()}, "roofline": roof2, **extra2}
+                                     "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm2.items()},
+                                     "roofline": ({**roof2, **stage_rates(64, ms2, tm2, roof2["algorithmic_gflop_per_step"])} if roof2 else None), **extra2}
     if world == 1 and not args.no_cpu_baseline:
         os.sched_setaffinity(0, cpus_at_start)      # the CPU leg uses all host cores again
-        out["cpu_baseline"] = cpu_baseline(args, W)
+        import torch as _t
+        out["cpu_baseline"] = cpu_baseline(args, {k: _t.from_numpy(v) for k, v in W.items()})
     print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -167,6 +167,8 @@ int sva_get_timings(sva_batch* b, float ms[4]);
 /* dominant-kernel bookkeeping for bench.py: number of conv-GEMM launches and their summed
  * algorithmic FLOPs in the last step */
 int sva_get_gemm_stats(sva_batch* b, double* flops, long* launches);
+/* ... and their summed ALGORITHMIC bytes (every operand element once: input rows incl. the tap halo, weights, outputs, residual) */
+int sva_get_gemm_bytes(sva_batch* b, double* bytes);
 
 /* roofline leg of bench.py: bracket every conv-GEMM launch of the following steps with hipEvents on the
  * engine stream; sva_get_gemm_profile returns the summed kernel time and the launch count since enabling */

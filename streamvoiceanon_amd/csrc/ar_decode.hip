@@ -32,7 +32,7 @@ typedef unsigned long long u64;
 constexpr int D = 768, I = 2304, H = 12, NCB = 8;
 constexpr int GX = 2 * D, GBIG = 2 * I, GATT = AR_WGS * 66, GLOG = 1024, GA = 2 * D;
 constexpr int KVF_LD = 1540;                      // LDS row stride of the fast K/V stash (bank rotation)
-constexpr int SPIN_LIMIT = 1 << 18;
+constexpr int SPIN_LIMIT = 1 << 16;                // polls before a gather gives up (~50 ms); a healthy edge takes a handful
 
 __device__ __forceinline__ void store_granule(u64* g, unsigned ep, float v) {
     __hip_atomic_store(g, ((u64)ep << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -47,6 +47,7 @@ __device__ __forceinline__ void gather(const u64* g, int n, unsigned ep, float* 
     for (int k = 0; k < PER; ++k)
         if (tid + k * 256 < n) pending |= 1u << k;
     int spins = 0;
+    if (*reinterpret_cast<volatile int*>(fail)) pending = 0;       // an earlier gather timed out (e.g. not all 96 workgroups resident): run through
     while (pending) {
         u64 x[PER];
 #pragma unroll
@@ -400,8 +401,10 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
     float* av = attp + 4 * 68;                // [2][768] attention output
     float* lg = av + GX;                      // [1024] codebook logits
     float* scr = lg + GLOG;                   // [16][68] group partials | sampler scratch | scores
-    float* sc = scr + 16 * 68;                // [12][8] scores -> probabilities
+    float* ropef = scr + 16 * 68;             // [8][32][2] RoPE table of the codebook positions
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, gw = wg * 4 + wave;
+    // this kernel is a latency chain that shares its CUs with the encoder's / vocoder's throughput kernels: its waves go first
+    __builtin_amdgcn_s_setprio(3);
     unsigned ep = *a.epoch;
     int nmark = 0;
     const int p0 = *a.last_pos + 1;           // positions of the two new tokens (dual_ar_stream.py:821-824)
@@ -412,6 +415,20 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
     KVT* kv = reinterpret_cast<KVT*>(a.kv_slow);
     const long SH = (long)a.S * 64;           // one head of the cache
 
+    // RoPE factors of this wave's three (even, odd) pairs: the two slow positions in registers, the 8 codebook positions in LDS
+    float rc[2][3], rsn[2][3];
+    {
+        const int n0 = 6 * gw;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {
+                const int d = (n0 + 2 * pr) & 63;
+                rc[m][pr] = a.rope_slow[((long)(p0 + m) * 32 + (d >> 1)) * 2];
+                rsn[m][pr] = a.rope_slow[((long)(p0 + m) * 32 + (d >> 1)) * 2 + 1];
+            }
+        for (int i = tid; i < NCB * 64; i += 256) ropef[i] = a.rope_fast[i];
+    }
     // tokens [cached_new_audio_emb, src_cond] (decode_one, :817-837)
     for (int i = tid; i < D; i += 256) {
         xs[i] = a.cached_audio_emb[i];
@@ -438,8 +455,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int pr = 0; pr < 3; ++pr) {
-                        const int d = (n0 + 2 * pr) & 63;
-                        const float c = a.rope_slow[((long)(p0 + m) * 32 + (d >> 1)) * 2], sn = a.rope_slow[((long)(p0 + m) * 32 + (d >> 1)) * 2 + 1];
+                        const float c = rc[m][pr], sn = rsn[m][pr];
                         const float x0 = o[m][2 * pr], x1 = o[m][2 * pr + 1];
                         o[m][2 * pr] = x0 * c - x1 * sn;
                         o[m][2 * pr + 1] = x1 * c + x0 * sn;
@@ -688,7 +704,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
 #pragma unroll
                     for (int pr = 0; pr < 3; ++pr) {
                         const int d = (n0 + 2 * pr) & 63;
-                        const float c = a.rope_fast[(cb * 32 + (d >> 1)) * 2], sn = a.rope_fast[(cb * 32 + (d >> 1)) * 2 + 1];
+                        const float c = ropef[(cb * 32 + (d >> 1)) * 2], sn = ropef[(cb * 32 + (d >> 1)) * 2 + 1];
                         const float x0 = o[0][2 * pr], x1 = o[0][2 * pr + 1];
                         o[0][2 * pr] = x0 * c - x1 * sn;
                         o[0][2 * pr + 1] = x1 * c + x0 * sn;
@@ -710,41 +726,61 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                 WFrag<WT, D> w[2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) w[r].load(L.wo, 2L * gw + r, lane);
-                // K | V of the earlier positions, lane = head dimension: written (through) at least one whole codebook step ago
-                float pk[3][7], pv[3][7];
+                // K | V of the earlier positions (written through at least one whole codebook step ago).  Scores: one key per 16-lane
+                // row, 4 dimensions per lane (two rounds cover the 8 positions: 2 row reductions per head instead of 8 wave reductions);
+                // P.V: lane = head dimension
+                const int kg = lane >> 4, kli = lane & 15;
+                u64 pk[3][2][2];
+                float pv[3][7];
 #pragma unroll
-                for (int hh = 0; hh < 3; ++hh)
+                for (int hh = 0; hh < 3; ++hh) {
+                    const int hb = (wave * 3 + hh) * 64;
+#pragma unroll
+                    for (int rnd = 0; rnd < 2; ++rnd) {
+                        const int t = kg + 4 * rnd;
+                        if (t < cb) {
+                            const u64* src = reinterpret_cast<const u64*>(kvg + (long)t * 2 * D + hb + 4 * kli);
+                            pk[hh][rnd][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            pk[hh][rnd][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
 #pragma unroll
                     for (int t = 0; t < 7; ++t)
-                        if (t < cb) {
-                            const float* src = kvg + (long)t * 2 * D + (wave * 3 + hh) * 64 + lane;
-                            pk[hh][t] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            pv[hh][t] = __hip_atomic_load(src + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
+                        if (t < cb) pv[hh][t] = __hip_atomic_load(kvg + (long)t * 2 * D + D + hb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 asm volatile("" ::: "memory");
                 gather<9>(a.gbig, I, ep, big, a.fail, 8);
                 AR_MARK();
 #pragma unroll
                 for (int hh = 0; hh < 3; ++hh) {
-                    const int n = (wave * 3 + hh) * 64 + lane;
-                    const float qd = big[n] * 0.125f;
-                    float sc8[NCB];
-                    float mx = -INFINITY;
+                    const int hb = (wave * 3 + hh) * 64;
+                    const float4 q4 = *reinterpret_cast<const float4*>(big + hb + 4 * kli);
+                    float sc2[2];
+#pragma unroll
+                    for (int rnd = 0; rnd < 2; ++rnd) {
+                        const int t = kg + 4 * rnd;
+                        float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (t < cb) {
+                            k4 = make_float4(__uint_as_float((unsigned)pk[hh][rnd][0]), __uint_as_float((unsigned)(pk[hh][rnd][0] >> 32)),
+                                             __uint_as_float((unsigned)pk[hh][rnd][1]), __uint_as_float((unsigned)(pk[hh][rnd][1] >> 32)));
+                        } else if (t == cb) {
+                            k4 = *reinterpret_cast<const float4*>(big + D + hb + 4 * kli);
+                        }
+                        const float dot = row16_sum(q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w) * 0.125f;
+                        sc2[rnd] = t <= cb ? dot : -INFINITY;
+                    }
+                    const float mx = wave_max(fmaxf(sc2[0], sc2[1]));
+                    const float e0 = sc2[0] > -INFINITY ? expf(sc2[0] - mx) : 0.f, e1 = sc2[1] > -INFINITY ? expf(sc2[1] - mx) : 0.f;
+                    const float inv = 16.f / wave_sum(e0 + e1);                  // every row holds its value 16 times
+                    float acc = 0.f;
 #pragma unroll
                     for (int t = 0; t < NCB; ++t) {
-                        const float kd = t < cb ? (t < 7 ? pk[hh][t < 7 ? t : 0] : 0.f) : big[D + n];
-                        sc8[t] = t <= cb ? wave_sum(qd * kd) : -INFINITY;
-                        mx = fmaxf(mx, sc8[t]);
+                        // probability of position t: held by row t & 3 in round t >> 2
+                        const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (t >> 2) ? e1 : e0), (t & 3) * 16));
+                        const float vd = t < cb ? (t < 7 ? pv[hh][t < 7 ? t : 0] : 0.f) : big[2 * D + hb + lane];
+                        if (t <= cb) acc = fmaf(e, vd, acc);
                     }
-                    float sum = 0.f, acc = 0.f;
-#pragma unroll
-                    for (int t = 0; t < NCB; ++t) {
-                        const float e = t <= cb ? expf(sc8[t] - mx) : 0.f;
-                        const float vd = t < cb ? (t < 7 ? pv[hh][t < 7 ? t : 0] : 0.f) : big[2 * D + n];
-                        sum += e;
-                        acc = fmaf(e, vd, acc);
-                    }
-                    av[n] = acc / sum;
+                    av[hb + lane] = acc * inv;
                 }
                 __syncthreads();
                 float o[1][2];
@@ -872,7 +908,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
     }
 }
 
-constexpr size_t AR_LDS_FLOATS = GX + GBIG + 4 * 68 + GX + GLOG + 16 * 68 + 128;
+constexpr size_t AR_LDS_FLOATS = GX + GBIG + 4 * 68 + GX + GLOG + 16 * 68 + NCB * 64;
 
 }  // namespace
 

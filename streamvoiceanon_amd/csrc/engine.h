@@ -146,6 +146,11 @@ struct sva_engine {
     float *rope_ar = nullptr, *rope_fast = nullptr;
     void *m_output = nullptr, *m_fast_output = nullptr;     // heads in the persistent decode kernel's element type
     bool mega_ok = false;                  // layer counts / sizes match what ar_decode.hip is built for
+    // the front-end's steady response to silence (what sva_streams_begin initialises the per-layer histories and the token cache
+    // with), computed once per (streams, chunk) configuration by streaming zeros and reused by later batches: one row per history
+    // buffer (in steady state every row of a layer is the same vector) + the token row
+    struct SilenceState { std::vector<float*> rows; float* tok = nullptr; };
+    std::map<std::pair<int, int>, SilenceState> silence;
 
     // ---- vocoder ----
     float *fsq_W = nullptr, *fsq_b = nullptr;   // [8][64][4], [8][64]
@@ -190,6 +195,7 @@ struct sva_batch {
     bool concurrency = true;
     bool fused_decode = true;              // B <= 2: GEMV path with fused norm / RoPE / KV-write / SwiGLU
     bool use_mega = false;                 // B == 1: one persistent kernel per decoded frame (ar_decode.hip)
+    bool ar_partitioned = false;           // the AR stream has a CU partition of its own
     unsigned long long* d_gran = nullptr;  // its granule buffers (gx | gbig | gatt | glog)
     unsigned* d_epoch = nullptr;           // [1] running phase counter of the granule tags
     int* d_ar_fail = nullptr;              // [1] timeout code of the persistent kernel (0 = healthy)
@@ -305,7 +311,7 @@ struct sva_batch {
     hipEvent_t ev[5];
     bool ev_ok = false;
     float last_ms[4] = {0, 0, 0, 0};
-    double gemm_flops = 0;
+    double gemm_flops = 0, gemm_bytes = 0;
     long gemm_launches = 0;
     bool prof_on = false;
     int prof_n = 0;
@@ -316,6 +322,11 @@ struct sva_batch {
     hipGraphExec_t graph_exec = nullptr;
     hipGraphExec_t pipe_graph_a[2] = {nullptr, nullptr};     // pipelined mode: the AR stage of a step, one per code-buffer parity
     int pipe_graph_mode = 1;                                 // 0: AR stage enqueued kernel by kernel
+    // pipelined mode: the front-end chain, the transformer (cut after its first layer, where it releases the token cache) and the
+    // vocoder (behind the FSQ decode, where it releases the step's codes) replayed as hipGraphs: ~135 launches per step off the
+    // enqueueing thread, which is otherwise the bound once the GPU side of a single-stream step drops to ~1 ms
+    bool stage_graphs = true;
+    hipGraphExec_t gE = nullptr, gT0 = nullptr, gT1[2] = {nullptr, nullptr}, gV = nullptr;
     bool graph_ready = false;
     bool graph_step = false;       // last step ran through the graph (no per-stage events)
     bool forced_now = false;

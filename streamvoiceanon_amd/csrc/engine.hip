@@ -529,6 +529,9 @@ int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda,
     SVA_CHECK(w.K == taps * Cin, "gemm_call: weight K mismatch");
     b->gemm_flops += 2.0 * g.M * (double)g.N * w.K;
     b->gemm_launches += 1;
+    // algorithmic bytes: every operand element once (input rows incl. the tap halo, weights, outputs, residual)
+    b->gemm_bytes += 4.0 * ((double)nb * ((double)(T - 1) * stride + (taps - 1) * dil + 1) * Cin + (double)g.N * w.K +
+                            (double)g.M * (g.w13 ? g.N / 2 : g.N) * (g.res ? 2 : 1));
     if (b->prof_on) {        // bench.py roofline leg: bracket every conv-GEMM launch with hipEvents on the launch stream
         if (b->prof_n + 2 > (int)b->prof_ev.size()) {
             const size_t old = b->prof_ev.size();
@@ -584,6 +587,9 @@ int gemm_group_call(sva_batch* b, const ConvGemm* gs, int n) {
     }
     b->gemm_flops += fl;
     b->gemm_launches += 1;
+    for (int i = 0; i < n; ++i)
+        b->gemm_bytes += 4.0 * ((double)(gs[i].M / gs[i].T) * ((double)(gs[i].T - 1) + (gs[i].taps - 1) * gs[i].dil + 1) * gs[i].Cin +
+                                (double)gs[i].N * gs[i].taps * gs[i].Cin + (double)gs[i].M * gs[i].N * (gs[i].res ? 2 : 1));
     if (b->prof_on) {
         if (b->prof_n + 2 > (int)b->prof_ev.size()) {
             const size_t old = b->prof_ev.size();
@@ -836,7 +842,7 @@ int enc_frontend_merged(sva_batch* b, const int* step_ptr, int n_chunk, int add)
 // need_rows > 0: only the codes of the LAST need_rows tokens are consumed by the caller (streaming keeps codes[-c:],
 // infer_arvc.py:518), so the last layer runs its query / output / FFN rows, the final norm and BSQ for those rows
 // only (its K and V are still computed for every token).  need_rows = 0: all T2 codes (seam API).
-int enc_transformer(sva_batch* b, const Act& xin, int need_rows) {
+int enc_transformer(sva_batch* b, const Act& xin, int need_rows, int part = 0) {
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
     const int B = b->B, T2 = b->T2, D = c.tr_dim, I = c.tr_inter;
@@ -846,7 +852,10 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows) {
     float* xw = b->tr_x;                     // work copy [B][T2][D]
     const long xw_bs = (long)T2 * D;
     const int nl = (int)e->tr.size();
-    for (int li = 0; li < nl; ++li) {
+    // part 1 = layer 0 only, part 2 = layers 1.. + final norm + BSQ (the pipelined stage graphs are cut where `xin` is released)
+    const int l_lo = part == 2 ? 1 : 0, l_hi = part == 1 ? 1 : nl;
+    if (part == 2) { xr = xw; xr_bs = xw_bs; xr_off = 0; }
+    for (int li = l_lo; li < l_hi; ++li) {
         TrLayer& L = e->tr[li];
         const bool tail = need_rows > 0 && li == nl - 1;
         const int Tr = tail ? need_rows : T2;             // rows of this layer's output that are needed
@@ -881,6 +890,7 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows) {
         pd.res = xw; pd.r_bstride = xw_bs; pd.r_off = (long)r0 * D; pd.ldr = D;
         SVA_TRY(gemm_call(b, b->tr_g, (long)T2 * I, (long)r0 * I, I, B, Tr, 1, 1, 1, I, L.w2, xw, xw_bs, (long)r0 * D, D, pd));
     }
+    if (part == 1) return 0;
     const int Tr = need_rows > 0 ? need_rows : T2, r0 = T2 - Tr;
     // final RMSNorm fused into the BSQ projection (normalised rows still land in tr_z for the "z" tap)
     SVA_CHECK(xw_bs == (long)T2 * D, "enc_transformer: work copy layout");
@@ -1093,6 +1103,12 @@ __global__ void broadcast_row_kernel(float* p, long bstride, int src_row, int lo
     for (int i = threadIdx.x; i < C; i += blockDim.x) base[(long)r * C + i] = base[(long)src_row * C + i];
 }
 
+// rows [0, gridDim.x) of every batch item <- one source row
+__global__ void fill_rows_kernel(float* p, long bstride, int C, const float* __restrict__ src) {
+    float* dst = p + (long)blockIdx.y * bstride + (long)blockIdx.x * C;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) dst[i] = src[i];
+}
+
 __global__ void inc_kernel(int* p, int v) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *p += v;
 }
@@ -1211,7 +1227,10 @@ int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_
     const float tclamp = b->p.temperature > 1e-5f ? b->p.temperature : 1e-5f;
     a.inv_temp = 1.0f / tclamp; a.top_p = b->p.top_p; a.skip_semantic = b->p.skip_semantic;
     a.vocab = c.ar_vocab; a.codebook_size = c.codebook_size;
-    static const bool share = getenv("SVA_AR_SHARE_CU") && atoi(getenv("SVA_AR_SHARE_CU")) != 0;
+    // on its own CU partition the kernel pads its LDS request so that the 96 workgroups land on 96 different CUs; on shared CUs it
+    // keeps its small footprint so that the other stages' GEMM workgroups fit beside it
+    static const char* share_env = getenv("SVA_AR_SHARE_CU");
+    const bool share = share_env ? atoi(share_env) != 0 : !b->ar_partitioned;
     return launch_ar_decode(a, c.ar_dtype == 1, b->kv_half, !share, b->stream);
 }
 
@@ -1352,10 +1371,14 @@ int vocode(sva_batch* b, int T, bool shift, int part = 0) {
     const int B = b->B, V = c.voc_dim, G = c.num_codebooks;
     hipStream_t st = b->stream;
     SVA_CHECK(T >= 1 && T <= b->Tv, "vocode: T out of range");
+    // parts 3 / 4: the FSQ decode alone / everything behind it (the pipelined stage graphs are cut where the step's codes are released)
     if (part != 2) {
+    if (part != 4) {
     if (b->voc_codes) SVA_TRY(launch_fsq_decode(b->voc_codes, b->voc_codes_bstride, b->voc_codes_gstride, B, T, G, V / G, e->fsq_W, e->fsq_b, b->zq.p, b->zq.bstride, 0, V, st));
     else SVA_TRY(launch_fsq_decode(b->d_vcodes, (long)G * b->Tv, b->Tv, B, T, G, V / G, e->fsq_W, e->fsq_b, b->zq.p, b->zq.bstride, 0, V, st));
     if (b->voc_codes_event) SVA_HIP(hipEventRecord(b->voc_codes_event, st));
+    }
+    if (part == 3) return 0;
     // upsample.0/1: ConvTranspose k=s=2 (stateless) + ConvNeXtBlock  (fsq.py:61-74)
     SVA_TRY(gemm_call(b, b->zq.p, b->zq.bstride, 0, V, B, T, 1, 1, 1, V, e->up_conv[0], b->u0.p, b->u0.bstride, (long)b->u0.H * V, 2 * V));
     SVA_TRY(cnx_block(b, e->up_cnx[0], b->u0, 2 * T, b->vh1, b->vh2, &b->v0));
@@ -1553,7 +1576,14 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     if (b->p.pipeline) SVA_CHECK(b->voc_grouped, "stage pipelining needs the grouped vocoder launches");
     {
         StreamSet ss;
-        SVA_TRY(get_streams(e->device, !b->voc_grouped, b->p.pipeline ? B : 0, &ss));
+        // one stream with the persistent AR decode kernel: no CU partition -- that kernel is a single launch of 96 workgroups that
+        // mostly wait on hand-offs, so the AR chain no longer queues behind the other stages' workgroups, and the encoder /
+        // vocoder GEMMs want the whole chip (measured 1.41 ms per step with the 96 | 128 | 32 split, 1.13 without)
+        const bool will_mega = B == 1 && e->mega_ok && !(getenv("SVA_FUSED_DECODE") && atoi(getenv("SVA_FUSED_DECODE")) == 0) &&
+                               !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
+        const int part_streams = b->p.pipeline ? (will_mega && !getenv("SVA_CU_PART") ? 0 : B) : 0;
+        SVA_TRY(get_streams(e->device, !b->voc_grouped, part_streams, &ss));
+        b->ar_partitioned = part_streams >= 1 && part_streams <= 8 && !(getenv("SVA_CU_PART") && !strcmp(getenv("SVA_CU_PART"), "off"));
         b->stream = b->main_stream = ss.main;
         b->aux[0] = ss.aux0;
         b->aux[1] = b->voc_grouped ? nullptr : ss.aux1;
@@ -1562,6 +1592,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     b->out_stream = b->stream;
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
     if (const char* ev = getenv("SVA_PIPE_GRAPH")) b->pipe_graph_mode = atoi(ev);
+    if (const char* ev = getenv("SVA_STAGE_GRAPHS")) b->stage_graphs = atoi(ev) != 0;
     if (const char* ev = getenv("SVA_PIPE_SPLIT_E")) b->pipe_split_e = atoi(ev);
     if (const char* ev = getenv("SVA_STREAM_CUT")) b->stream_cut = atoi(ev);
     if (const char* ev = getenv("SVA_PIPE_TRACE")) {
@@ -1836,6 +1867,7 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     for (auto& t : b->trace_ev) (void)hipEventDestroy(t);
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     for (auto& ge : b->pipe_graph_a) if (ge) (void)hipGraphExecDestroy(ge);
+    for (hipGraphExec_t ge : {b->gE, b->gT0, b->gT1[0], b->gT1[1], b->gV}) if (ge) (void)hipGraphExecDestroy(ge);
     for (void* p : b->allocs.chunks) (void)hipFree(p);
     if (b->hp_in) (void)hipHostFree(b->hp_in);
     if (b->hp_out) (void)hipHostFree(b->hp_out);
@@ -2015,7 +2047,33 @@ extern "C" int sva_streams_begin(sva_batch* b) {
             EncMerged& M = b->em;
             SVA_TRY(zero(M.mel)); SVA_TRY(zero(M.d1)); SVA_TRY(zero(M.d2));
             for (auto& st_ : M.x) for (auto& a : st_) SVA_TRY(zero(a));
-            for (int i = 0; i < warm; ++i) SVA_TRY(enc_frontend_merged(b, nullptr, 0, 0));     // (the ring is all zeros here)
+            sva_engine* e = b->e;
+            std::vector<ShiftDesc> sd(M.n_shift);
+            SVA_HIP(hipMemcpy(sd.data(), M.d_shift, sizeof(ShiftDesc) * M.n_shift, hipMemcpyDeviceToHost));
+            const auto key = std::make_pair(B, c);
+            auto it = e->silence.find(key);
+            if (it == e->silence.end()) {
+                for (int i = 0; i < warm; ++i) SVA_TRY(enc_frontend_merged(b, nullptr, 0, 0));     // (the ring is all zeros here)
+                sva_engine::SilenceState ss;
+                for (const ShiftDesc& d : sd) {          // keep the newest history row of item 0 per buffer, and the token row
+                    float* r = nullptr;
+                    SVA_TRY(dev_alloc(e->allocs, &r, (size_t)d.C, false));
+                    SVA_HIP(hipMemcpyAsync(r, d.ptr + (long)(d.H - 1) * d.C, sizeof(float) * d.C, hipMemcpyDeviceToDevice, b->stream));
+                    ss.rows.push_back(r);
+                }
+                SVA_TRY(dev_alloc(e->allocs, &ss.tok, (size_t)b->e->cfg.tr_dim, false));
+                SVA_HIP(hipMemcpyAsync(ss.tok, b->d2c.p + (long)(b->T2 - 1) * b->e->cfg.tr_dim, sizeof(float) * b->e->cfg.tr_dim, hipMemcpyDeviceToDevice, b->stream));
+                e->silence[key] = ss;
+            } else {
+                const sva_engine::SilenceState& ss = it->second;
+                for (size_t i = 0; i < sd.size(); ++i) {
+                    const ShiftDesc& d = sd[i];
+                    hipLaunchKernelGGL(fill_rows_kernel, dim3(d.H, B), dim3(128), 0, b->stream, d.ptr, d.bstride, d.C, ss.rows[i]);
+                }
+                hipLaunchKernelGGL(fill_rows_kernel, dim3(1, B), dim3(128), 0, b->stream, b->d2c.p + (long)(b->T2 - 1) * b->e->cfg.tr_dim, b->d2c.bstride,
+                                   b->e->cfg.tr_dim, ss.tok);
+                SVA_HIP(hipGetLastError());
+            }
         } else {
             SVA_TRY(zero(S.mel)); SVA_TRY(zero(S.d1)); SVA_TRY(zero(S.d2));
             for (auto& st_ : S.x) for (auto& a : st_) SVA_TRY(zero(a));
@@ -2115,6 +2173,30 @@ int steady_launches(sva_batch* b, bool timing_events) {
     return 0;
 }
 
+// Replays `body` (launches on stream st only, all arguments fixed device pointers / constants) as a hipGraph captured on first
+// use; falls back to eager launches for good if the runtime cannot capture.
+template <class F>
+int stage_graph(sva_batch* b, hipGraphExec_t* slot, hipStream_t st, F&& body) {
+    if (!b->stage_graphs) return body();
+    if (!*slot) {
+        hipGraph_t graph = nullptr;
+        SVA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = body();
+        const hipError_t ce = hipStreamEndCapture(st, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ce != hipSuccess || hipGraphInstantiate(slot, graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            *slot = nullptr;
+            b->stage_graphs = false;
+            if (graph) (void)hipGraphDestroy(graph);
+            return body();
+        }
+        (void)hipGraphDestroy(graph);
+    }
+    SVA_HIP(hipGraphLaunch(*slot, st));
+    return 0;
+}
+
 // Pipelined steady step (sva_step_device with p.pipeline): the three stages of chunk-step n go to three streams,
 //   main: E(n)   ->   sa: A(n)   ->   sv: V(n)
 // chained by events, so that E(n+1), A(n) and V(n-1) overlap on the GPU.  Hazards between consecutive steps:
@@ -2162,14 +2244,45 @@ int steady_pipelined(sva_batch* b) {
         b->stream = se;
         SVA_HIP(hipEventRecord(b->ev[0], se));
         SVA_TRY(mark(0, se));
+        if (b->enc_merged) {
+            // ONE front-end chain on the main stream (the new frames ride in the head-pass launches); the side stream only carries
+            // the transformer, which overlaps the next step's front-end.  Both chains replay as hipGraphs (stage_graph).
+            SVA_TRY(stage_graph(b, &b->gE, se, [&]() -> int {
+                b->stream = se;
+                SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
+                SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se));                   // steady tokens slide down by c
+                SVA_TRY(enc_frontend_merged(b, b->d_step, n, 1));
+                return launch_add_i32(b->d_step, 1, se);
+            }));
+            SVA_TRY(mark(1, se));
+            SVA_TRY(mark(2, sx));
+            SVA_TRY(stream_fork(b, se, sx));                                              // transformer(n) needs the front-end of step n
+            if (b->pipe_evA[par]) SVA_HIP(hipStreamWaitEvent(sx, b->pipe_evA[par], 0));  // back-pressure: BSQ overwrites the codes A(n-2) read
+            if (b->pipe_evR) { SVA_HIP(hipStreamWaitEvent(sx, b->pipe_evR, 0)); b->pipe_evR = nullptr; }
+            SVA_TRY(mark(3, sx));
+            b->tr_l0_event = nullptr;
+            int trc = stage_graph(b, &b->gT0, sx, [&]() -> int { b->stream = sx; return enc_transformer(b, b->d2c, chunk, 1); });
+            b->stream = se;
+            if (trc) return trc;
+            b->pipe_evD2C = next_event(b);                                                // the token cache is not read past the first layer
+            SVA_HIP(hipEventRecord(b->pipe_evD2C, sx));
+            trc = stage_graph(b, &b->gT1[par], sx, [&]() -> int {
+                b->stream = sx;
+                SVA_TRY(enc_transformer(b, b->d2c, chunk, 2));
+                hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, sx, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
+                                   b->d_ncontent, b->d_step_content, B, (int*)nullptr);
+                SVA_HIP(hipGetLastError());
+                return 0;
+            });
+            b->stream = se;
+            if (trc) return trc;
+            SVA_HIP(hipEventRecord(b->ev[1], sx));
+            SVA_TRY(mark(4, sx));
+        } else {
         SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
         SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se));                       // steady tokens slide down by c
         int erc = 0;
-        if (b->enc_merged) {
-            // one front-end chain on the main stream (the new frames ride in the head-pass launches); the side stream only carries
-            // the transformer, which overlaps the next step's front-end
-            SVA_TRY(mark(2, sx));
-        } else if (b->stream_cut > 0) {          // the first stages of the streaming pass run on main (its chunk counter), the rest on sx
+        if (b->stream_cut > 0) {          // the first stages of the streaming pass run on main (its chunk counter), the rest on sx
             SVA_TRY(enc_frontend_stream(b, b->d_step, n, 1, 1));
             SVA_TRY(stream_fork(b, se, sx));
             b->stream = sx;
@@ -2185,8 +2298,7 @@ int steady_pipelined(sva_batch* b) {
         }
         b->stream = se;
         if (erc) return erc;
-        if (b->enc_merged) SVA_TRY(enc_frontend_merged(b, b->d_step, n, 1));
-        else SVA_TRY(enc_frontend_window(b, b->d_step, n, 1, 4 * b->Ht, nullptr, &b->d2c));     // head pass -> d2c rows [0, Ht)
+        SVA_TRY(enc_frontend_window(b, b->d_step, n, 1, 4 * b->Ht, nullptr, &b->d2c));     // head pass -> d2c rows [0, Ht)
         SVA_TRY(launch_add_i32(b->d_step, 1, se));
         SVA_TRY(mark(1, se));
         SVA_TRY(stream_fork(b, se, sx));                                              // transformer(n) needs head pass(n)
@@ -2205,6 +2317,7 @@ int steady_pipelined(sva_batch* b) {
                            b->d_ncontent, b->d_step_content, B, (int*)nullptr);
         SVA_HIP(hipEventRecord(b->ev[1], sx));
         SVA_TRY(mark(4, sx));
+        }
         evE = next_event(b);
         SVA_HIP(hipEventRecord(evE, sx));
     } else {
@@ -2263,7 +2376,13 @@ int steady_pipelined(sva_batch* b) {
     b->voc_codes = b->d_step_audio; b->voc_codes_bstride = (long)ncb * chunk; b->voc_codes_gstride = chunk;      // read in place ...
     b->pipe_evVc[par] = next_event(b);
     b->voc_codes_event = b->pipe_evVc[par];       // ... and A(n+1) may overwrite them once the FSQ decode has run
-    rc = vocode(b, chunk, true);
+    if (b->stage_graphs && !b->pcm_dst) {
+        rc = vocode(b, chunk, true, 3);           // FSQ decode (reads this parity's code buffer) + the release event, eagerly
+        b->voc_codes_event = nullptr;
+        if (!rc) rc = stage_graph(b, &b->gV, sv, [&]() -> int { b->stream = sv; return vocode(b, chunk, true, 4); });
+    } else {
+        rc = vocode(b, chunk, true);
+    }
     b->voc_codes = nullptr; b->voc_codes_event = nullptr;
     b->stream = se;
     if (rc) return rc;
@@ -2394,7 +2513,7 @@ extern "C" int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const
     b->h_use_forced = uf;
     if (forced_codes) SVA_HIP(hipMemcpyAsync(b->d_forced, forced_codes, sizeof(int) * (size_t)B * ncb * chunk, hipMemcpyHostToDevice, st));
     SVA_HIP(hipStreamSynchronize(st));
-    b->gemm_flops = 0; b->gemm_launches = 0;
+    b->gemm_flops = 0; b->gemm_launches = 0; b->gemm_bytes = 0;
     SVA_TRY(step_body(b));
     SVA_HIP(hipMemcpy2DAsync(b->hp_out, sizeof(float) * n, b->d_pcm, sizeof(float) * 2048 * b->Tv, sizeof(float) * n, B, hipMemcpyDeviceToHost, st));
     SVA_HIP(hipStreamSynchronize(st));
@@ -2418,13 +2537,13 @@ extern "C" int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm
     // no staging: the ring write reads the caller's chunk, the vocoder's last kernel writes the caller's PCM buffer and
     // the FSQ decode reads the step's codes in place (each staging copy was a kernel of its own in a chain whose length is
     // what bounds the step)
-    const bool direct = !b->p.use_graph;       // a captured graph bakes its pointers: it keeps the fixed staging buffers
+    const bool direct = !b->p.use_graph && !(b->p.pipeline && b->stage_graphs);       // a captured graph bakes its pointers: it keeps the fixed staging buffers
     if (direct) b->step_src = d_pcm_in;
     else SVA_HIP(hipMemcpyAsync(b->d_chunk, d_pcm_in, sizeof(float) * (size_t)B * n, hipMemcpyDeviceToDevice, st));
     b->noise_on_device = true;
     b->forced_now = false;
     if (b->h_use_forced != 0) { SVA_HIP(hipMemsetAsync(b->d_use_forced, 0, sizeof(int), st)); b->h_use_forced = 0; }
-    b->gemm_flops = 0; b->gemm_launches = 0;
+    b->gemm_flops = 0; b->gemm_launches = 0; b->gemm_bytes = 0;
     b->allow_pipe = true;
     b->out_stream = st;
     b->pcm_dst = direct ? d_pcm_out : nullptr; b->pcm_dst_bstride = n; b->pcm_direct_done = false;
@@ -2637,7 +2756,7 @@ extern "C" int sva_encode_window(sva_batch* b, const float* audio, int64_t* code
     SVA_TRY(quiesce(b));
     hipStream_t st = b->stream;
     SVA_HIP(hipMemcpyAsync(b->ring, audio, sizeof(float) * (size_t)b->B * b->N, hipMemcpyHostToDevice, st));
-    b->gemm_flops = 0; b->gemm_launches = 0;
+    b->gemm_flops = 0; b->gemm_launches = 0; b->gemm_bytes = 0;
     SVA_HIP(hipEventRecord(b->ev[0], st));
     SVA_TRY(encode(b, nullptr, 0, 0));
     SVA_HIP(hipEventRecord(b->ev[1], st));
@@ -2661,7 +2780,7 @@ extern "C" int sva_firefly_encode(sva_batch* b, const float* audio, int32_t* cod
     hipStream_t st = b->stream;
     const sva_config& c = e->cfg;
     SVA_HIP(hipMemcpyAsync(b->ring, audio, sizeof(float) * (size_t)b->B * b->N, hipMemcpyHostToDevice, st));
-    b->gemm_flops = 0; b->gemm_launches = 0;
+    b->gemm_flops = 0; b->gemm_launches = 0; b->gemm_bytes = 0;
     SVA_HIP(hipEventRecord(b->ev[0], st));
     SVA_TRY(enc_frontend_window(b, nullptr, 0, 0, b->T0, &e->vocf));
     SVA_TRY(launch_fsq_encode(b->d2.p, b->d2.bstride, (long)b->d2.H * c.voc_dim, c.voc_dim, b->B, b->T2, c.num_codebooks,
@@ -2757,6 +2876,11 @@ extern "C" long sva_get_gemm_profile_table(sva_batch* b, double* out, long max_r
         out[i * 6 + 5] = t * 1e3;
     }
     return n;
+}
+extern "C" int sva_get_gemm_bytes(sva_batch* b, double* bytes) {
+    SVA_CHECK(b && bytes, "null argument");
+    *bytes = b->gemm_bytes;
+    return 0;
 }
 extern "C" int sva_get_gemm_stats(sva_batch* b, double* flops, long* launches) {
     SVA_CHECK(b && flops && launches, "null argument");

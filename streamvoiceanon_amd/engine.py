@@ -87,6 +87,7 @@ def load_library():
     lib.sva_get_tap.restype = C.c_long
     lib.sva_get_timings.argtypes = [vp, f32p]
     lib.sva_get_gemm_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    lib.sva_get_gemm_bytes.argtypes = [vp, C.POINTER(C.c_double)]
     lib.sva_profile_gemm.argtypes = [vp, i32]
     lib.sva_get_gemm_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.sva_get_gemm_profile_table.argtypes = [vp, vp, C.c_long]
@@ -105,7 +106,7 @@ EXPORTED_SYMBOLS = [
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
     "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_stream_chunks", "sva_encode_window", "sva_firefly_encode",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_quantizer_decode", "sva_vocoder_head", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
-    "sva_get_gemm_stats", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
+    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
 ]
 
 
@@ -380,6 +381,11 @@ class Batch:
 
     def sync(self):
         _check(self.lib.sva_sync(self.h), "sva_sync")
+
+    def gemm_bytes(self):
+        v = C.c_double()
+        _check(self.lib.sva_get_gemm_bytes(self.h, C.byref(v)), "sva_get_gemm_bytes")
+        return v.value
 
     def gemm_stats(self):
         f, n = C.c_double(), C.c_long()

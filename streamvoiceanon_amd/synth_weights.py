@@ -168,3 +168,13 @@ def exp1_noise(utt_seed: int, frame: int, kind: int, n: int) -> np.ndarray:
     k = u24_from_key(noise_key(utt_seed, frame, kind), n).astype(np.float64)
     u = np.maximum(k, 0.5) * (1.0 / 16777216.0)
     return (-np.log(u)).astype(np.float32)
+
+
+def generate_all(seed: int, specs: dict) -> dict:
+    """name -> float32 array for every (prefixed state-dict name, shape) of `specs` (tensors the hot path never touches are skipped)."""
+    out = {}
+    for name, shape in specs.items():
+        arr = generate(seed, name, shape)
+        if arr is not None:
+            out[name] = arr
+    return out
