@@ -177,6 +177,39 @@ int sva_get_gemm_profile(sva_batch* b, double* total_ms, long* launches);
 /* per-launch rows (M, N, K, taps, mode bits, microseconds) of the profiled steps; returns the number of rows */
 long sva_get_gemm_profile_table(sva_batch* b, double* out, long max_rows);
 
+/* ---- prompt path: device primitives of the two speaker-embedding encoders (SURVEY.md 8f N1 iii / iv) --------------------------
+ * calculate_style_vec (evaluations/infer_arvc.py:179-211: Kaldi fbank -> CAM++, modules/campplus/DTDNN.py:50-137) and
+ * calculate_timbre_latent (:213-223: MelSpectrogram -> ECAPA-TDNN -> PerceiverResampler -> FSQ,
+ * modules/bicodec_speaker_encoder/speaker_encoder.py:136-144) run once per utterance; the host mirror
+ * (streamvoiceanon_amd/prompt_encoders.py) owns the activation buffers and the topology, these entry points do the arithmetic
+ * on device arrays (channel-last rows [T][C], row strides in floats; every pointer below is a DEVICE pointer from sva_dev_alloc
+ * unless it says host).  All of them run on the device's default stream, in call order. */
+int sva_dev_alloc(sva_engine* e, long n_floats, float** out);            /* zero-initialised */
+int sva_dev_free(sva_engine* e, float* p);
+int sva_dev_upload(sva_engine* e, float* dst, const float* host_src, long n_floats);
+int sva_dev_download(sva_engine* e, float* host_dst, const float* src, long n_floats);
+/* nn.Conv1d / nn.Linear: y[t][n] = bias[n] + sum_{tap,c} x[(t*stride + tap*dil)*ldx + c] * W[n][tap*Cin + c]; x points at tap 0 of
+ * output row 0 (the caller pads); f32-MFMA conv-GEMM when Cin % 16 == 0, a plain kernel otherwise */
+int sva_op_conv(sva_engine* e, const float* x, long ldx, int T, int stride, int dil, int taps, int Cin, const float* W, const float* bias, int N,
+                float* y, long ldy);
+/* y = post(scale[c] * pre(x) + shift[c]); relu_mode 0 none, 1 ReLU after (batchnorm-relu), 2 ReLU before (Conv1dReluBn); eval-mode
+ * BatchNorm arrives folded into scale / shift (either may be NULL) */
+int sva_op_affine(sva_engine* e, const float* x, long ldx, int T, int C, const float* scale, const float* shift, int relu_mode, float* y, long ldy);
+int sva_op_unary(sva_engine* e, float* x, long n, int op /* 1 log(max(x, p0)), 2 FSQ level-4 quantise, 3 sigmoid */, float p0);
+int sva_op_colstats(sva_engine* e, const float* x, long ldx, int T, int C, float* mean, float* std_or_null, int unbiased);
+int sva_op_cam_context(sva_engine* e, const float* y, long ldy, int T, int C, int seg_len, const float* mean, float* ctx, long ldc);   /* layers.py:103-119 */
+int sva_op_mul(sva_engine* e, float* y, long ldy, const float* m, long ldm /* 0 = broadcast one row */, int T, int C, int sigmoid);
+int sva_op_add(sva_engine* e, float* y, long ldy, const float* x, long ldx, int T, int C);
+/* Conv2d k x k (k = 1 or 3, padding k/2, stride (stride_f, 1)) + folded BatchNorm (+ residual) (+ ReLU) on channel-first [C][F][T] */
+int sva_op_conv2d(sva_engine* e, const float* x, int Cin, int F, int T, const float* W, int Cout, int k, int stride_f, const float* scale,
+                  const float* shift, const float* res_or_null, int relu, float* y);
+int sva_op_cf_to_rows(sva_engine* e, const float* x, int CF, int T, float* y, long ldy);
+int sva_op_fbank_power(sva_engine* e, const float* wave, long n, float* frames_scratch /* [m][512] */, float* out, int ldo, int* frames_out /* host */);
+int sva_op_stft_mag(sva_engine* e, const float* wave, long n, int n_fft, int win, int hop, float* frames_scratch, float* out, int ldo, int* frames_out /* host */);
+int sva_op_attention(sva_engine* e, const float* q, const float* kv, int Lq, int Lk, int n_valid, int H, float* out, float* scratch /* [Lq][H][Lk] */);
+int sva_op_geglu(sva_engine* e, const float* h, long ldh, int T, int Dh, float* out, long ldo);
+int sva_op_l2norm(sva_engine* e, const float* x, int T, int C, const float* gamma, float scale, float* y);
+
 /* kernel unit-test hook: C = A[M,K] * W[N,K]^T (+bias) through the conv-GEMM kernel (host arrays) */
 int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C);
 

@@ -130,6 +130,37 @@ class InferenceWrapper:
         self.model = ARVCWrapper(self.engine)
         self.speech_tokenizer = _SpeechTokenizerSeam(self)
         self.firefly = _FireflySeam(self)
+        # the two speaker-embedding encoders of the prompt path (:96-125, 179-223) run on the device when their weights are given
+        # ("style.*" = CAM++, "timbre.*" = SparkTTS SpeakerEncoder); a caller may also install any callable wav16k -> embedding
+        self.style_encoder = self.timbre_encoder = None
+        if any(k.startswith("style.") for k in weights):
+            from .prompt_encoders import StyleEncoder
+
+            self.style_encoder = StyleEncoder(self.engine, weights)
+        if any(k.startswith("timbre.") for k in weights):
+            from .prompt_encoders import TimbreEncoder
+
+            self.timbre_encoder = TimbreEncoder(self.engine, weights)
+
+    def calculate_style_vec(self, audio_16k_tensor, wave_lens=None):
+        """:179-211 Kaldi fbank (80 bins, mean-subtracted) -> CAM++ -> [1, 192] (batch 1 like every call site)"""
+        if self.style_encoder is None:
+            raise NotImplementedError("CAM++ style encoder weights ('style.*', SURVEY.md 8f N1 iii) were not loaded: pass style_vectors= "
+                                      "or set InferenceWrapper.style_encoder to a callable wav16k -> [1, 192]")
+        x = _np(audio_16k_tensor, np.float32).reshape(-1)
+        if wave_lens is not None:
+            x = x[:int(_np(wave_lens).reshape(-1)[0])]
+        return _like(audio_16k_tensor, np.asarray(self.style_encoder(x), np.float32).reshape(1, -1))
+
+    def calculate_timbre_latent(self, audio_16k_tensor, wave_lens=None):
+        """:213-223 SpeakerEncoder.tokenize_wav -> zq.mT [1, 32, 128]"""
+        if self.timbre_encoder is None:
+            raise NotImplementedError("SparkTTS timbre encoder weights ('timbre.*', SURVEY.md 8f N1 iv) were not loaded: pass timbre_latents= "
+                                      "or set InferenceWrapper.timbre_encoder to a callable wav16k -> [1, 32, 128]")
+        x = _np(audio_16k_tensor, np.float32).reshape(-1)
+        if wave_lens is not None:
+            x = x[:int(_np(wave_lens).reshape(-1)[0])]
+        return _like(audio_16k_tensor, np.asarray(self.timbre_encoder(x), np.float32).reshape(1, 32, -1))
 
     def code2wav_fn(self, code):
         """:173-176 firefly.head(firefly.quantizer.decode(code))"""
@@ -151,6 +182,18 @@ class InferenceWrapper:
         out.update({"tok." + (k[7:] if k.startswith("module.") else k): v for k, v in tok.items()})
         voc = torch.load(cfg["firefly"]["checkpoint_path"], map_location="cpu")
         out.update({"voc." + k: v for k, v in voc.items()})     # weight-norm pairs are folded by the engine
+        # speaker-embedding encoders (:96-125); CAM++ checkpoints of an older layout keep `stats` / `dense` under `xvector.`
+        # (modules/campplus/DTDNN.py:107-124)
+        for net, prefix in (("style_encoder", "style."), ("timbre_encoder", "timbre.")):
+            path = (cfg.get(net) or {}).get("checkpoint_path")
+            if path and os.path.exists(path):
+                sd = torch.load(path, map_location="cpu")
+                for k, v in sd.items():
+                    if k.startswith("xvector.stats"):
+                        k = k.replace("xvector.stats", "stats")
+                    elif k.startswith("xvector.dense"):
+                        k = k.replace("xvector.dense", "dense")
+                    out[prefix + k] = v
         return {k: v for k, v in out.items() if hasattr(v, "dtype") and v.dtype.is_floating_point}
 
     # ---- prompt ------------------------------------------------------------------------------------------
@@ -179,16 +222,18 @@ class InferenceWrapper:
         ref_list = ref_wav_tensors if isinstance(ref_wav_tensors, (list, tuple)) else [ref_wav_tensors]
         ref = np.concatenate([np.asarray(r.detach().cpu().numpy() if hasattr(r, "detach") else r, dtype=np.float32).reshape(-1)
                               for r in ref_list])            # :411 / :415 torch.cat(ref_wav_list, dim=-1)
-        if style_vectors is None:
-            if getattr(self, "style_encoder", None) is None:
-                raise NotImplementedError("CAM++ style encoder (SURVEY.md §8f N1 iii) is not built: pass style_vectors= or set "
-                                          "InferenceWrapper.style_encoder to a callable wav -> [1, 192]")
-            style_vectors = self.style_encoder(ref)
-        if timbre_latents is None:
-            if getattr(self, "timbre_encoder", None) is None:
-                raise NotImplementedError("SparkTTS timbre encoder (SURVEY.md §8f N1 iv) is not built: pass timbre_latents= or set "
-                                          "InferenceWrapper.timbre_encoder to a callable wav -> [1, 32, 128]")
-            timbre_latents = self.timbre_encoder(ref)
+        if spk_emb_collate_type == "avg" and len(ref_list) > 1:
+            # reference quirk (vi): the 'avg' branch falls through to an undefined variable (:389-424) -- only 'concat_mel' works upstream
+            raise NotImplementedError("spk_emb_collate_type='avg' with several references raises NameError in the reference "
+                                      "(evaluations/infer_arvc.py:389-424); use 'concat_mel'")
+        if style_vectors is None or timbre_latents is None:
+            from . import audio_io
+
+            ref16 = audio_io.resample(ref, self.sr, self.RESAMPLE_FREQ)                    # :415-417
+            if style_vectors is None:
+                style_vectors = self.calculate_style_vec(ref16)
+            if timbre_latents is None:
+                timbre_latents = self.calculate_timbre_latent(ref16)
         style_vectors = self.apply_noise_mixing(torch.as_tensor(np.asarray(style_vectors), dtype=torch.float32), alpha)
         timbre_latents = self.apply_noise_mixing(torch.as_tensor(np.asarray(timbre_latents), dtype=torch.float32), alpha)
         ref_audio_codes = self.wav2target_fn(ref)                       # :431-434

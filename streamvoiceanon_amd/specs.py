@@ -167,6 +167,112 @@ def vocoder_specs(c: ModelConfig = ModelConfig(), prompt_path: bool = False) -> 
     return out
 
 
+def _bn_spec(p, n, out, affine=True):
+    if affine:
+        out[p + "weight"] = (n,)
+        out[p + "bias"] = (n,)
+    out[p + "running_mean"] = (n,)
+    out[p + "running_var"] = (n,)
+
+
+def style_specs() -> dict:
+    """CAMPPlus(feat_dim=80, embedding_size=192) (modules/campplus/DTDNN.py:50-117, configs/hydra_arcs/sv/campplus.yaml): the
+    style encoder of the prompt path (SURVEY.md 8f N1 iii), keys prefixed 'style.'"""
+    out = {}
+    h = "style.head."
+    out[h + "conv1.weight"] = (32, 1, 3, 3)
+    _bn_spec(h + "bn1.", 32, out)
+    for layer in ("layer1.", "layer2."):
+        for b in range(2):
+            q = h + layer + f"{b}."
+            out[q + "conv1.weight"] = (32, 32, 3, 3)
+            _bn_spec(q + "bn1.", 32, out)
+            out[q + "conv2.weight"] = (32, 32, 3, 3)
+            _bn_spec(q + "bn2.", 32, out)
+            if b == 0:                                  # stride 2: projection shortcut
+                out[q + "shortcut.0.weight"] = (32, 32, 1, 1)
+                _bn_spec(q + "shortcut.1.", 32, out)
+    out[h + "conv2.weight"] = (32, 32, 3, 3)
+    _bn_spec(h + "bn2.", 32, out)
+    xv = "style.xvector."
+    out[xv + "tdnn.linear.weight"] = (128, 320, 5)
+    _bn_spec(xv + "tdnn.nonlinear.batchnorm.", 128, out)
+    ch = 128
+    for bi, nl in enumerate((12, 24, 16)):
+        for li in range(nl):
+            q = xv + f"block{bi + 1}.tdnnd{li + 1}."
+            cin = ch + 32 * li
+            _bn_spec(q + "nonlinear1.batchnorm.", cin, out)
+            out[q + "linear1.weight"] = (128, cin, 1)
+            _bn_spec(q + "nonlinear2.batchnorm.", 128, out)
+            out[q + "cam_layer.linear_local.weight"] = (32, 128, 3)
+            out[q + "cam_layer.linear1.weight"] = (64, 128, 1)
+            out[q + "cam_layer.linear1.bias"] = (64,)
+            out[q + "cam_layer.linear2.weight"] = (32, 64, 1)
+            out[q + "cam_layer.linear2.bias"] = (32,)
+        ch += 32 * nl
+        q = xv + f"transit{bi + 1}."
+        _bn_spec(q + "nonlinear.batchnorm.", ch, out)
+        out[q + "linear.weight"] = (ch // 2, ch, 1)
+        ch //= 2
+    _bn_spec(xv + "out_nonlinear.batchnorm.", ch, out)
+    out["style.dense.linear.weight"] = (192, 2 * ch, 1)
+    _bn_spec("style.dense.nonlinear.batchnorm.", 192, out, affine=False)
+    return out
+
+
+def timbre_specs() -> dict:
+    """SpeakerEncoder(input_dim=128, out_dim=1024, latent_dim=128, token_num=32, fsq_levels=[4]*6)
+    (modules/bicodec_speaker_encoder/speaker_encoder.py:36-63, configs/hydra_arcs/sv/sparktts_speaker_encoder.yaml): the tensors
+    tokenize_wav touches (:136-144 -- the x-vector head, `project` and the pooling layer are not on the path), prefixed 'timbre.'"""
+    out = {}
+    se = "timbre.speaker_encoder."
+    out[se + "layer1.conv.weight"] = (512, 128, 5)
+    out[se + "layer1.conv.bias"] = (512,)
+    _bn_spec(se + "layer1.bn.", 512, out)
+    for li in (2, 3, 4):
+        q = se + f"layer{li}.se_res2block."
+        for j in (0, 2):
+            out[q + f"{j}.conv.weight"] = (512, 512, 1)
+            out[q + f"{j}.conv.bias"] = (512,)
+            _bn_spec(q + f"{j}.bn.", 512, out)
+        for i in range(7):
+            out[q + f"1.convs.{i}.weight"] = (64, 64, 3)
+            out[q + f"1.convs.{i}.bias"] = (64,)
+            _bn_spec(q + f"1.bns.{i}.", 64, out)
+        out[q + "3.linear1.weight"] = (128, 512)
+        out[q + "3.linear1.bias"] = (128,)
+        out[q + "3.linear2.weight"] = (512, 128)
+        out[q + "3.linear2.bias"] = (512,)
+    out[se + "conv.weight"] = (1536, 1536, 1)
+    out[se + "conv.bias"] = (1536,)
+    ps = "timbre.perceiver_sampler."
+    out[ps + "latents"] = (32, 128)
+    out[ps + "proj_context.weight"] = (128, 1536)
+    out[ps + "proj_context.bias"] = (128,)
+    for l in range(2):
+        q = ps + f"layers.{l}."
+        out[q + "0.to_q.weight"] = (512, 128)
+        out[q + "0.to_kv.weight"] = (1024, 128)
+        out[q + "0.to_out.weight"] = (128, 512)
+        out[q + "1.0.weight"] = (682, 128)
+        out[q + "1.0.bias"] = (682,)
+        out[q + "1.2.weight"] = (128, 341)
+        out[q + "1.2.bias"] = (128,)
+    out[ps + "norm.gamma"] = (128,)
+    out["timbre.quantizer.project_in.weight"] = (6, 128)
+    out["timbre.quantizer.project_in.bias"] = (6,)
+    out["timbre.quantizer.project_out.weight"] = (128, 6)
+    out["timbre.quantizer.project_out.bias"] = (128,)
+    return out
+
+
+def prompt_encoder_specs() -> dict:
+    out = style_specs()
+    out.update(timbre_specs())
+    return out
+
+
 def all_specs(c: ModelConfig = ModelConfig(), prompt_path: bool = False) -> dict:
     out = {}
     out.update(arvc_specs(c))

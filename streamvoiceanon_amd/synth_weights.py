@@ -107,6 +107,14 @@ def generate(seed: int, name: str, shape) -> np.ndarray | None:
     if not is_hot(name):
         return None
     leaf = name.rsplit(".", 1)[-1]
+    if leaf == "running_var":                 # BatchNorm statistics of the speaker encoders (prompt path)
+        return _rng(seed, name, shape, 0.6, 1.4)
+    if leaf == "running_mean":
+        return _sym(seed, name, shape, 0.1)
+    if leaf == "latents":                     # PerceiverResampler latents (init std 0.02; O(1) here so that they matter)
+        return _sym(seed, name, shape, 0.5)
+    if leaf == "gamma" and name.startswith("timbre."):
+        return _rng(seed, name, shape, 0.8, 1.2)
     if leaf == "gamma":                       # ConvNeXt / LayerScale gammas
         return _rng(seed, name, shape, 0.1, 0.5)
     if "embedding" in name and len(shape) == 2:

@@ -818,6 +818,72 @@ def test_reference_main_call_sequence_and_module_seams(weights0, tmp_path):
     w.engine.close()
 
 
+def test_prompt_speaker_encoders_vs_reference_golden(eng, record_property):
+    """SURVEY.md 8f N1 iii / iv on the device: Kaldi fbank -> CAM++ style vector and MelSpectrogram -> ECAPA -> Perceiver -> FSQ timbre
+    latents (csrc/prompt_ops.hip driven by streamvoiceanon_amd/prompt_encoders.py) against the outputs of the reference's own
+    modules (tests/golden/prompt_encoders_s0.npz) and the oracle.  The timbre latents are FSQ-quantised: a disagreement can only
+    be a level flip at a rounding boundary, reported as a count."""
+    from oracle import prompt_oracle as PO
+    from streamvoiceanon_amd import specs, synth_weights as sw
+    from streamvoiceanon_amd.prompt_encoders import StyleEncoder, TimbreEncoder
+    from streamvoiceanon_amd.synth_audio import synth_utterance
+
+    g = load_golden("prompt_encoders_s0")
+    Wn = sw.generate_all(int(g["weight_seed"]), specs.prompt_encoder_specs())
+    se, te = StyleEncoder(eng, Wn), TimbreEncoder(eng, Wn)
+    Wt = {k: torch.from_numpy(v) for k, v in Wn.items()}
+    for tag in ("a", "b"):
+        wav = synth_utterance(int(g[f"{tag}_audio_seed"]), int(g[f"{tag}_n"]))
+        style = se(wav)
+        assert style.shape == (1, 192)
+        ref = g[f"{tag}_style"]
+        assert np.abs(style[0] - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), np.abs(style[0] - ref).max()
+        timbre = te(wav)
+        assert timbre.shape == (1, 32, 128)
+        reft = g[f"{tag}_timbre"]
+        bad_rows = int((np.abs(timbre[0] - reft).max(axis=1) > 1e-4).sum())          # a flipped FSQ level changes a whole latent row
+        rec = dict(test="timbre_latents_" + tag, latent_rows=32, rows_with_a_flipped_level=bad_rows)
+        record_property("fsq_flips", rec)
+        print("FSQ boundary flips (timbre):", rec)
+        assert bad_rows <= 1
+        assert np.abs(timbre[0] - PO.timbre_latents(torch.from_numpy(wav)[None], Wt)[0].numpy()).max() <= 1e-4 or bad_rows == 1
+    se.close(); te.close()
+
+
+def test_stream_infer_from_wav_files_without_injected_embeddings(weights0, tmp_path):
+    """The reference's call shape end to end (evaluations/infer_arvc.py:724-743): stream_infer(src.wav, ref.wav, out_dir) with NO
+    injected tensors -- style vector and timbre latents come from the device encoders, audio codes and content codes from the
+    device prompt path -- equals the same stream fed the oracle's prompt embeddings."""
+    from oracle import prompt_oracle as PO
+    from streamvoiceanon_amd import audio_io, specs, synth_weights as sw
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.synth_audio import synth_utterance
+
+    src = synth_utterance(7950, 2048 * 8 + 500)
+    ref = synth_utterance(7951, 2048 * 66)
+    audio_io.write_wav(str(tmp_path / "src.wav"), src, 44100)
+    audio_io.write_wav(str(tmp_path / "ref.wav"), ref, 44100)
+    W = dict(weights0)
+    Wp = sw.generate_all(0, specs.prompt_encoder_specs())
+    W.update(Wp)
+    w = InferenceWrapper(weights=W)
+    assert w.style_encoder is not None and w.timbre_encoder is not None
+    out = w.stream_infer(str(tmp_path / "src.wav"), str(tmp_path / "ref.wav"), str(tmp_path), delay=2, noise_seed=5)
+    assert (tmp_path / "src_ref.wav").exists() and np.abs(out[2 * 2048:]).max() > 0.01
+    # the same stream with the ORACLE's embeddings of the same 16 kHz audio
+    ref44, _ = audio_io.load(str(tmp_path / "ref.wav"), 44100)
+    ref16 = audio_io.resample(ref44, 44100, 16000)
+    Wt = {k: torch.from_numpy(v) for k, v in Wp.items()}
+    st_o = PO.style_vector(torch.from_numpy(ref16)[None], Wt).numpy()
+    tm_o = PO.timbre_latents(torch.from_numpy(ref16)[None], Wt).numpy()
+    st_d = np.asarray(w.calculate_style_vec(ref16))
+    assert np.abs(st_d - st_o).max() <= 2e-4 * max(1.0, np.abs(st_o).max())
+    out2 = w.stream_infer(str(tmp_path / "src.wav"), str(tmp_path / "ref.wav"), None, delay=2, noise_seed=5, style_vectors=st_d,
+                          timbre_latents=np.asarray(w.calculate_timbre_latent(ref16)), save_result=False)
+    np.testing.assert_array_equal(out, out2)
+    w.engine.close()
+
+
 def test_stream_infer_from_wav_files(weights0, tmp_path):
     """File-level drop-in: 24 kHz source and reference wavs on disk -> load + polyphase resample to 44.1 kHz
     -> device prompt codes -> streaming conversion -> wav written; equals the array-level path fed the same resampled audio."""

@@ -129,3 +129,28 @@ def test_sampler_rules():
     noise = torch.tensor([100.0, 1e-3, 1.0, 1.0])                # would pick 1 if it survived
     assert O.sample_token(logits, noise, 1.0, 0.7) == 0
     assert O.sample_token(logits, noise, 1.0, 0.85) == 1         # cum=.5,.8 kept
+
+
+def test_prompt_encoders_match_reference():
+    """Style (CAM++) and timbre (SparkTTS) encoders of the prompt path (SURVEY.md 8f N1 iii / iv): the oracle's restatement against
+    outputs of the reference's own modules (tools/make_golden.py prompt_encoders; torchaudio's two front-ends are restatements on
+    both sides -- parity unpinned for kaldi.fbank / MelSpectrogram themselves)."""
+    from oracle import prompt_oracle as PO
+    from streamvoiceanon_amd import specs
+
+    g = load_golden("prompt_encoders_s0")
+    W = {k: torch.from_numpy(sw.generate(int(g["weight_seed"]), k, shp)) for k, shp in specs.prompt_encoder_specs().items()}
+    for tag in ("a", "b"):
+        wav = torch.from_numpy(synth_utterance(int(g[f"{tag}_audio_seed"]), int(g[f"{tag}_n"])))[None]
+        feat = PO.kaldi_fbank(wav)
+        feat = feat - feat.mean(dim=0, keepdim=True)
+        np.testing.assert_allclose(feat[7].numpy(), g[f"{tag}_feat_row7"], atol=1e-5)
+        style = PO.style_vector(wav, W)
+        assert tuple(style.shape) == (1, 192)
+        np.testing.assert_allclose(style[0].numpy(), g[f"{tag}_style"], atol=1e-5)
+        timbre = PO.timbre_latents(wav, W)
+        assert tuple(timbre.shape) == (1, 32, 128)
+        np.testing.assert_allclose(timbre[0].numpy(), g[f"{tag}_timbre"], atol=1e-5)
+    # Kaldi mel banks: triangular, unit peak spacing, last (Nyquist) column empty
+    banks = PO.kaldi_mel_banks()
+    assert banks.shape == (80, 257) and float(banks[:, -1].abs().max()) == 0.0 and float(banks.max()) <= 1.0 + 1e-6

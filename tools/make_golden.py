@@ -240,6 +240,50 @@ def prompt_fixture(w, wseed, useed, frames=48):
     print("prompt fixture", tuple(ac.shape), tuple(cc.shape), "distinct audio codes", len(set(ac.flatten().tolist())))
 
 
+def prompt_encoder_fixture(wseed=0):
+    """The reference's CAM++ and SparkTTS SpeakerEncoder modules (modules/campplus/DTDNN.py, modules/bicodec_speaker_encoder/*) with
+    synthetic weights, driven as calculate_style_vec / calculate_timbre_latent drive them (evaluations/infer_arvc.py:179-223).
+    torchaudio is not installed: its two front-ends (kaldi.fbank, transforms.MelSpectrogram) are the restatements of
+    oracle/prompt_oracle.py (parity unpinned for those two functions); everything behind them is the reference's own code."""
+    from modules.bicodec_speaker_encoder.speaker_encoder import SpeakerEncoder
+    from modules.campplus.DTDNN import CAMPPlus
+    from oracle import prompt_oracle as PO
+    from streamvoiceanon_amd import specs
+
+    class Mel(torch.nn.Module):
+        hop_length = 320
+
+        def forward(self, wav):
+            return torch.stack([PO.mel_spectrogram_16k(w) for w in wav])
+
+    W = {k: torch.from_numpy(sw.generate(wseed, k, shp)) for k, shp in specs.prompt_encoder_specs().items()}
+    cam = CAMPPlus(feat_dim=80, embedding_size=192).eval()
+    sd = cam.state_dict()
+    spec_s = specs.style_specs()
+    assert {("style." + k) for k in sd if not k.endswith("num_batches_tracked")} == set(spec_s)
+    for k, v in sd.items():
+        if not k.endswith("num_batches_tracked"):
+            assert tuple(v.shape) == spec_s["style." + k], k
+    cam.load_state_dict({k[6:]: v for k, v in W.items() if k.startswith("style.")}, strict=False)
+    spk = SpeakerEncoder(mel_fn=Mel(), input_dim=128, out_dim=1024, latent_dim=128, token_num=32, fsq_levels=[4] * 6, fsq_num_quantizers=1).eval()
+    sd = spk.state_dict()
+    for k, shp in specs.timbre_specs().items():
+        assert tuple(sd[k[7:]].shape) == shp, k
+    missing, unexpected = spk.load_state_dict({k[7:]: v for k, v in W.items() if k.startswith("timbre.")}, strict=False)
+    assert not unexpected
+    out = dict(weight_seed=wseed)
+    for tag, useed, n in (("a", 7900, 16000 * 3), ("b", 7901, 16000 * 2 + 3333)):       # 298 (even) / 219 (odd) fbank frames
+        wav = torch.from_numpy(synth_utterance(useed, n))[None]
+        feat = PO.kaldi_fbank(wav)
+        feat = feat - feat.mean(dim=0, keepdim=True)
+        style = cam(feat[None], torch.tensor([feat.shape[0] // 2]))          # evaluations/infer_arvc.py:196-210
+        zq, idx = spk.tokenize_wav(wav, torch.tensor([wav.shape[1]]))          # :218-222
+        out.update({f"{tag}_audio_seed": useed, f"{tag}_n": n, f"{tag}_style": style[0].numpy(), f"{tag}_timbre": zq.mT[0].numpy(),
+                    f"{tag}_fsq_idx": idx[0].numpy(), f"{tag}_feat_sum": feat.double().sum(0).numpy(), f"{tag}_feat_row7": feat[7].numpy()})
+    np.savez_compressed(os.path.join(OUT, "prompt_encoders_s0.npz"), **out)
+    print("prompt encoder fixture", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rh.install_stubs()
@@ -251,6 +295,10 @@ def main():
     np.savez_compressed(os.path.join(OUT, "melfb.npz"), col_sum=fb.sum(0).numpy(), row_sum=fb.sum(1).numpy(),
                         peak=fb.max(0).values.numpy(), argpeak=fb.argmax(0).numpy())
     only = sys.argv[1] if len(sys.argv) > 1 else None     # e.g. `make_golden.py prompt` adds one fixture without rewriting the rest
+    if only in (None, "prompt_encoders"):
+        prompt_encoder_fixture(0)
+        if only:
+            return
     for wseed in (0, 1):
         w = rh.build_wrapper(seed=wseed)
         if only == "prompt":
