@@ -162,13 +162,17 @@ def convnext_encoder(x: torch.Tensor, W: dict, p: str, depths=(3, 3, 9, 3)) -> t
 
 
 def window_transformer(x: torch.Tensor, W: dict, p: str, n_layer=8, n_head=8) -> torch.Tensor:
-    """WindowLimitedTransformer.forward (causal, window 512 >= T so the mask is plain causal),
-    modules/vqgan/windowed_transformer.py:337-354, 103-120, 134-143, 163-194.
+    """WindowLimitedTransformer.forward (causal, window_size 512: keys max(0, r - 511) .. r, make_window_limited_mask :291-304 --
+    plain causal while T <= 512), modules/vqgan/windowed_transformer.py:337-354, 103-120, 134-143, 163-194.
     x [B, C, T] -> [B, C, T]."""
     x = x.transpose(1, 2)
     B, T, C = x.shape
     hd = C // n_head
     tab = rope_table(2048, hd)[:T]
+    win_mask = None
+    if T > 512:
+        r = torch.arange(T)
+        win_mask = (r[None, :] <= r[:, None]) & (r[None, :] >= (r[:, None] - 511).clamp(min=0))
     for l in range(n_layer):
         q = f"{p}layers.{l}."
         h = rms_norm(x, W[q + "attention_norm.weight"])
@@ -177,7 +181,10 @@ def window_transformer(x: torch.Tensor, W: dict, p: str, n_layer=8, n_head=8) ->
         qq = apply_rope(qq.view(B, T, n_head, hd), tab).transpose(1, 2)
         kk = apply_rope(kk.view(B, T, n_head, hd), tab).transpose(1, 2)
         vv = vv.view(B, T, n_head, hd).transpose(1, 2)
-        y = F.scaled_dot_product_attention(qq, kk, vv, is_causal=True)
+        if win_mask is None:
+            y = F.scaled_dot_product_attention(qq, kk, vv, is_causal=True)
+        else:
+            y = F.scaled_dot_product_attention(qq, kk, vv, attn_mask=win_mask)
         y = y.transpose(1, 2).reshape(B, T, C)
         y = F.linear(y, W[q + "attention.wo.weight"])
         x = x + y * W[q + "attention_layer_scale.gamma"]
@@ -413,7 +420,13 @@ class DualAR:
         remaining = torch.cat([src_cond[d:], W["arvc.decoder.wait4end_embedding.weight"][:d]], dim=0)
         seq = torch.cat([seq, remaining[:1]], dim=0)
         pos = torch.arange(seq.shape[0])
-        out = self.decode_tokens(seq, pos, *noise_fn(0))
+        # the prefill's decode_one_token_ar call passes no sampling_kwargs (dual_ar_stream.py:722): defaults 0.7 / 0.7
+        user = (self.temperature, self.top_p)
+        self.temperature, self.top_p = 0.7, 0.7
+        try:
+            out = self.decode_tokens(seq, pos, *noise_fn(0))
+        finally:
+            self.temperature, self.top_p = user
         codes = [out["codes"]]
         last = int(pos[-1])
         for i in range(remaining.shape[0] - 1):

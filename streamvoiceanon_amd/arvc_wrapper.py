@@ -50,7 +50,9 @@ class ARVCWrapper:
         import torch
 
         kw = dict(self._kw)
-        kw.update({k: sampling_kwargs[k] for k in ("temperature", "top_p") if k in sampling_kwargs})
+        from .infer_arvc import check_sampling_kwargs
+
+        kw.update(check_sampling_kwargs(sampling_kwargs))
         batch = E.Batch(self.engine, n_streams=1, delay=self.delay, **kw)
         try:
             codes = batch.generate(_np(ref_content_codes, np.int64), _np(ref_audio_codes, np.int32), _np(src_content_codes, np.int64),

@@ -1554,13 +1554,29 @@ int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSe
 }
 }  // namespace
 
+static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batch* b);
+
 extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_batch** out) {
     SVA_CHECK(e && p && out && e->finalized, "engine not finalized");
     SVA_HIP(hipSetDevice(e->device));
     (void)hipGetLastError();
-    const sva_config& c = e->cfg;
     sva_batch* b = new sva_batch();
+    for (auto& ev : b->evpool) ev = nullptr;
+    for (auto& ev : b->ev) ev = nullptr;
     b->e = e;
+    const int rc = batch_create_impl(e, p, b);
+    if (rc) {                      // nothing of a half-built batch survives (events, arena chunks, pinned buffers)
+        const std::string msg = sva_last_error();
+        sva_batch_destroy(b);
+        set_error(msg);
+        return rc;
+    }
+    *out = b;
+    return 0;
+}
+
+static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batch* b) {
+    const sva_config& c = e->cfg;
     b->p = *p;
     const int B = b->B = p->n_streams;
     SVA_CHECK(B >= 1 && p->chunk_frames >= 1 && p->delay >= 1 && p->delay <= c.max_delay, "bad stream params (delay 0 is broken upstream too)");
@@ -1621,7 +1637,7 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     b->N = b->We * 2048;
     b->T0 = b->N / 512;
     b->T2 = b->T0 / 4;
-    SVA_CHECK(b->T2 % 4 == 0 && b->T2 <= 256, "encode_window_frames must be a multiple of 4 and <= 256");
+    SVA_CHECK(b->T2 % 4 == 0 && b->T2 <= 2048, "encode_window_frames must be a multiple of 4 and <= 2048 (the RoPE table of the tokenizer's transformer)");
     const int T0 = b->T0;
     SVA_TRY(dev_alloc(A, &b->ring, (size_t)B * b->N));
     SVA_TRY(dev_alloc(A, &b->d_chunk, (size_t)B * 2048 * chunk));
@@ -1841,7 +1857,6 @@ extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_b
     for (int i = 0; i < 5; ++i) SVA_HIP(hipEventCreate(&b->ev[i]));
     b->ev_ok = true;
     SVA_HIP(hipDeviceSynchronize());
-    *out = b;
     return 0;
 }
 
@@ -1849,7 +1864,7 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->e->device);
     (void)quiesce(b);
-    (void)hipStreamSynchronize(b->main_stream);
+    if (b->main_stream) (void)hipStreamSynchronize(b->main_stream);
     for (int i = 0; i < 2; ++i) if (b->aux[i]) (void)hipStreamSynchronize(b->aux[i]);
     if (b->sa) (void)hipStreamSynchronize(b->sa);
     if (b->sv) (void)hipStreamSynchronize(b->sv);
@@ -1871,10 +1886,9 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     for (void* p : b->allocs.chunks) (void)hipFree(p);
     if (b->hp_in) (void)hipHostFree(b->hp_in);
     if (b->hp_out) (void)hipHostFree(b->hp_out);
-    if (b->ev_ok)
-        for (int i = 0; i < 5; ++i) (void)hipEventDestroy(b->ev[i]);
+    for (int i = 0; i < 5; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
     for (auto& ev : b->prof_ev) (void)hipEventDestroy(ev);
-    for (int i = 0; i < 64; ++i) (void)hipEventDestroy(b->evpool[i]);
+    for (int i = 0; i < 64; ++i) if (b->evpool[i]) (void)hipEventDestroy(b->evpool[i]);
     (void)hipGetLastError();          // the streams belong to the process-wide set and stay
     delete b;
 }
@@ -2702,8 +2716,9 @@ extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* 
     // remaining_cond = [src_cond[d:], wait4end[:d]]  (:716), wait4end_j addressed as vocab + j in the extended table
     std::vector<int64_t> rem(S);
     for (int i = 0; i < S; ++i) rem[i] = i < S - d ? src_cc[d + i] : (int64_t)c.ar_vocab + (i - (S - d));
-    long long* d_remq = nullptr;
-    SVA_HIP(hipMalloc((void**)&d_remq, sizeof(long long) * (size_t)S));
+    struct DevGuard { long long* p = nullptr; ~DevGuard() { if (p) (void)hipFree(p); } } remq_guard;      // freed on every return path
+    SVA_HIP(hipMalloc((void**)&remq_guard.p, sizeof(long long) * (size_t)S));
+    long long* d_remq = remq_guard.p;
     SVA_HIP(hipMemcpyAsync(d_remq, rem.data(), sizeof(long long) * (size_t)S, hipMemcpyHostToDevice, st));
     SVA_HIP(hipStreamSynchronize(st));
     // speaker prefix + prompt rows, then remaining_cond[0] as the last row
@@ -2731,7 +2746,13 @@ extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* 
     for (int i = 0; i < S; ++i) {
         if (noise) SVA_TRY(h2d(b, b->d_noise, noise + (size_t)i * nstride, sizeof(float) * nstride));
         if (i == 0) {
-            SVA_TRY(ar_frame_tail(b, 0, 0, (long)(M - 1) * D, d_remq, S, 0, 0));
+            // the prefill's decode ignores the caller's sampling_kwargs: generate() calls decode_one_token_ar without them
+            // (dual_ar_stream.py:722), i.e. with temperature = top_p = 0.7
+            const float t_user = b->p.temperature, p_user = b->p.top_p;
+            b->p.temperature = 0.7f; b->p.top_p = 0.7f;
+            const int rc0 = ar_frame_tail(b, 0, 0, (long)(M - 1) * D, d_remq, S, 0, 0);
+            b->p.temperature = t_user; b->p.top_p = p_user;
+            SVA_TRY(rc0);
         } else {
             hipLaunchKernelGGL(prepare_offline_step_kernel, dim3(1), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, d_remq, i, b->d_last_pos, D,
                                b->ax, b->d_slot, b->d_pos);
@@ -2745,7 +2766,6 @@ extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* 
     SVA_HIP(hipStreamSynchronize(st));
     for (int q = 0; q < ncb; ++q)
         SVA_HIP(hipMemcpy(codes_out + (size_t)q * S, b->d_pred_hist + (size_t)q * b->hist_cap, sizeof(int) * (size_t)S, hipMemcpyDeviceToHost));
-    (void)hipFree(d_remq);
     return 0;
 }
 
@@ -2777,6 +2797,7 @@ extern "C" int sva_firefly_encode(sva_batch* b, const float* audio, int32_t* cod
     SVA_CHECK(e->vocf.loaded, "firefly.encode weights (voc.backbone.*, voc.quantizer.downsample.*, ...project_in) were not loaded");
     SVA_HIP(hipSetDevice(e->device));
     (void)hipGetLastError();
+    SVA_TRY(quiesce(b));
     hipStream_t st = b->stream;
     const sva_config& c = e->cfg;
     SVA_HIP(hipMemcpyAsync(b->ring, audio, sizeof(float) * (size_t)b->B * b->N, hipMemcpyHostToDevice, st));

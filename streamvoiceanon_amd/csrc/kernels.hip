@@ -456,6 +456,71 @@ __global__ __launch_bounds__(256) void enc_attention_mfma_kernel(const float* __
     }
 }
 
+// Tiled (flash-style) formulation for whole-utterance encodes: any T, keys visited in blocks of 64 with an online softmax, so
+// LDS holds one K / V block instead of the whole sequence.  Causal + window-limited exactly as WindowLimitedTransformer builds
+// its mask (modules/vqgan/windowed_transformer.py:291-304: keys max(0, r - window + 1) .. r; window_size 512 in the tokenizer's
+// YAML -- irrelevant for the <= 256-token streaming windows, binding for utterances beyond 512 tokens = 23.8 s).  One workgroup =
+// 4 consecutive query rows (one per wave) of one (head, stream); lane = key inside a block for the scores, lane = head
+// dimension for P.V.  Exact fp32 (the BSQ bits downstream need it).
+__global__ __launch_bounds__(256) void enc_attention_flash_kernel(const float* __restrict__ qkv, const float* __restrict__ rope, int T, int H, int window,
+                                                                  float* __restrict__ out, int row0) {
+    constexpr int HD = 64, LDK = HD + 1;
+    __shared__ float Ks[64 * LDK], Vs[64 * LDK], qs[4 * HD], ps[4 * 64];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = H * HD;
+    const float* base = qkv + (long)b * T * 3 * D;
+    const int r0 = row0 + blockIdx.z * 4;
+    const int r = min(r0 + wave, T - 1);
+    if (lane < HD / 2) {
+        const float* row = base + (long)r * 3 * D + h * HD;
+        const float q0 = row[2 * lane], q1 = row[2 * lane + 1];
+        const float c = rope[(r * (HD / 2) + lane) * 2], sn = rope[(r * (HD / 2) + lane) * 2 + 1];
+        qs[wave * HD + 2 * lane] = (q0 * c - q1 * sn) * 0.125f;
+        qs[wave * HD + 2 * lane + 1] = (q1 * c + q0 * sn) * 0.125f;
+    }
+    const int klo = max(0, r - window + 1);                       // this row's first key
+    const int rmax = min(r0 + 3, T - 1);
+    const int blk_lo = max(0, r0 - window + 1) / 64 * 64;
+    float m = -INFINITY, l = 0.f, o = 0.f;
+    for (int j0 = blk_lo; j0 <= rmax; j0 += 64) {
+        __syncthreads();                                          // the previous block is consumed (and qs is written, first pass)
+        for (int idx = tid; idx < 64 * (HD / 2); idx += 256) {
+            const int jj = idx / (HD / 2), p = idx - jj * (HD / 2);
+            const int t = min(j0 + jj, T - 1);
+            const float* row = base + (long)t * 3 * D;
+            const float k0 = row[D + h * HD + 2 * p], k1 = row[D + h * HD + 2 * p + 1];
+            const float c = rope[(t * (HD / 2) + p) * 2], sn = rope[(t * (HD / 2) + p) * 2 + 1];
+            Ks[jj * LDK + 2 * p] = k0 * c - k1 * sn;
+            Ks[jj * LDK + 2 * p + 1] = k1 * c + k0 * sn;
+            Vs[jj * LDK + 2 * p] = row[2 * D + h * HD + 2 * p];
+            Vs[jj * LDK + 2 * p + 1] = row[2 * D + h * HD + 2 * p + 1];
+        }
+        __syncthreads();
+        const int j = j0 + lane;
+        const bool valid = j >= klo && j <= r;
+        float sc = -INFINITY;
+        if (valid) {
+            float acc = 0.f;
+#pragma unroll 16
+            for (int d = 0; d < HD; ++d) acc = fmaf(qs[wave * HD + d], Ks[lane * LDK + d], acc);
+            sc = acc;
+        }
+        const float bm = wave_max(sc);
+        if (bm > -INFINITY) {                                     // (uniform per wave) at least one key of the block is visible to this row
+            const float mn = fmaxf(m, bm);
+            const float corr = expf(m - mn), pj = valid ? expf(sc - mn) : 0.f;
+            ps[wave * 64 + lane] = pj;
+            l = l * corr + wave_sum(pj);
+            float acc = 0.f;
+#pragma unroll 16
+            for (int jj = 0; jj < 64; ++jj) acc = fmaf(ps[wave * 64 + jj], Vs[jj * LDK + lane], acc);
+            o = o * corr + acc;
+            m = mn;
+        }
+    }
+    if (r0 + wave < T) out[((long)b * T + r) * D + h * HD + lane] = o / l;
+}
+
 int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out, int row0, hipStream_t st) {
     SVA_CHECK(hd == 64 && T % 4 == 0, "enc_attention: head_dim must be 64 and T a multiple of 4");
     static const bool valu_only = getenv("SVA_ENC_ATTN_VALU") != nullptr;          // A/B switch
@@ -474,7 +539,11 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
         return 0;
     }
     const size_t smem = ((size_t)T * 65 * 2 + 4 * 64 + 4 * (size_t)T) * sizeof(float);
-    SVA_CHECK(smem <= 160 * 1024, "enc_attention: window too long for the LDS-resident kernel");
+    if (smem > 160 * 1024 || T > 512) {      // whole-utterance encodes: tiled kernel with the transformer's 512-key causal window
+        hipLaunchKernelGGL(enc_attention_flash_kernel, dim3(H, B, (T - row0 + 3) / 4), dim3(256), 0, st, qkv, rope, T, H, 512, out, row0);
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         SVA_HIP(hipFuncSetAttribute((const void*)enc_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import weakref
 
 import numpy as np
 
@@ -199,9 +200,12 @@ class Engine:
             _check(self.lib.sva_engine_load_weight(self.h, name.encode(), max(a.ndim, 1), shape, _ptr(a)),
                    f"sva_engine_load_weight({name})")
         _check(self.lib.sva_engine_finalize(self.h), "sva_engine_finalize")
+        self._batches = weakref.WeakSet()
 
     def close(self):
         if self.h:
+            for b in list(getattr(self, "_batches", ())):      # a batch must not outlive its engine (its destroy touches the engine)
+                b.close()
             self.lib.sva_engine_destroy(self.h)
             self.h = None
 
@@ -232,6 +236,7 @@ class Batch:
         self.B, self.chunk = n_streams, chunk_frames
         self.h = C.c_void_p()
         _check(self.lib.sva_batch_create(engine.h, C.byref(p), C.byref(self.h)), "sva_batch_create")
+        engine._batches.add(self)
         cfg = engine.cfg
         self.noise_stride = cfg.ar_vocab + cfg.num_codebooks * cfg.codebook_size
 

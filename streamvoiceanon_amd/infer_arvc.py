@@ -35,6 +35,23 @@ def _like(ref, arr):
     return arr
 
 
+def check_sampling_kwargs(sampling_kwargs: dict) -> dict:
+    """`sample(logits, previous_tokens=None, temperature=0.7, top_p=0.7, repetition_penalty=1.0)` (modules/dual_ar_stream.py:1081-1132):
+    temperature / top_p go to the engine; a repetition penalty needs previous_tokens, which no caller on the path passes (:1088) --
+    anything the engine would silently ignore is refused instead."""
+    out = {}
+    for k, v in sampling_kwargs.items():
+        if k in ("temperature", "top_p"):
+            out[k] = float(v)
+        elif k == "repetition_penalty" and float(v) == 1.0:
+            continue
+        elif k == "previous_tokens" and v is None:
+            continue
+        else:
+            raise NotImplementedError(f"sampling argument {k}={v!r} is not supported by the engine's sampler (temperature, top_p only)")
+    return out
+
+
 class _SpeechTokenizerSeam:
     """`speech_tokenizer.encode(audios, audio_lengths)` (modules/vqgan/modules/firefly_encoder.py:553-566):
     float [B, N] (+ lengths [B]) -> (codes int64 [1, B, N // 2048], lengths // 2048)."""
@@ -322,13 +339,14 @@ class InferenceWrapper:
     # ---- offline -----------------------------------------------------------------------------------------
     def encode_content(self, wav):
         """speech_tokenizer.encode on a whole utterance (:334-339) -> int64 codes [S], S = len // 2048.  The utterance is
-        right-padded with zeros to a multiple of 4 frames (causal encoder: earlier codes are unaffected); limited to 256
-        frames by the LDS-resident encoder attention (longer inputs are row N3 follow-up work)."""
+        right-padded with zeros to a multiple of 4 frames (causal encoder: earlier codes are unaffected).  Beyond 256 frames the
+        transformer runs the tiled attention kernel with the 512-token causal window of WindowLimitedTransformer
+        (modules/vqgan/windowed_transformer.py:291-304)."""
         wav = np.asarray(wav, dtype=np.float32).reshape(-1)
         S = wav.shape[0] // self.SAMPLES_PER_FRAME
         Wp = ((S + 3) // 4) * 4
-        if Wp > 256:
-            raise NotImplementedError("offline encode of more than 256 frames (11.9 s) needs the tiled attention kernel (N3 follow-up)")
+        if Wp > 2048:
+            raise ValueError(f"utterance of {S} frames: the tokenizer's transformer has rotary tables for 2048 positions (95 s)")
         buf = np.zeros(Wp * self.SAMPLES_PER_FRAME, np.float32)
         buf[:S * self.SAMPLES_PER_FRAME] = wav[:S * self.SAMPLES_PER_FRAME]
         b = E.Batch(self.engine, n_streams=1, encode_window_frames=Wp)
@@ -354,7 +372,7 @@ class InferenceWrapper:
         src_codes = self.encode_content(src)
         S = src_codes.shape[0]
         d = 2 if delay is None else int(delay)
-        kw = {k: sampling_kwargs[k] for k in ("temperature", "top_p") if k in sampling_kwargs}
+        kw = check_sampling_kwargs(sampling_kwargs)
         b = E.Batch(self.engine, n_streams=1, delay=d, voc_max_frames=S, **kw)
         try:
             codes = b.generate(ref_content_codes.reshape(-1), ref_audio_codes.reshape(8, -1), src_codes, style_vectors.reshape(-1),

@@ -436,6 +436,32 @@ def test_offline_generate_vs_reference_golden(eng, weights0):
     b.close()
 
 
+def test_offline_generate_sampling_kwargs_frame0_defaults(eng, weights0):
+    """generate(**sampling_kwargs): the prefill's decode ignores them (dual_ar_stream.py:722 -> temperature = top_p = 0.7),
+    every later frame uses them (:742-748); unsupported sampler arguments are refused, not dropped."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd.arvc_wrapper import ARVCWrapper
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt
+
+    useed, S = 881, 10
+    ac, cc, style, timbre = synth_prompt(2301, 24)
+    src_codes = (np.arange(S, dtype=np.int64) * 2654435761 % 8192).astype(np.int64)
+    noise = np.stack([np.concatenate([frame_noise(useed, s)[0], frame_noise(useed, s)[1].reshape(-1)]) for s in range(S)])
+    m = ARVCWrapper(eng, delay=2)
+    args = (torch.from_numpy(cc)[None], torch.from_numpy(ac)[None], torch.from_numpy(src_codes)[None],
+            torch.from_numpy(style)[None], torch.from_numpy(timbre)[None])
+    codes = m.generate(*args, noise=noise, temperature=1.3, top_p=0.95)
+    ar = O.DualAR(weights0, temperature=1.3, top_p=0.95)
+    ref = ar.generate(torch.from_numpy(cc), torch.from_numpy(ac), torch.from_numpy(src_codes), torch.from_numpy(style),
+                      torch.from_numpy(timbre), 2, noise_fn=lambda s_: tuple(torch.from_numpy(a) for a in frame_noise(useed, s_)))
+    np.testing.assert_array_equal(codes.numpy(), ref.numpy())
+    dflt = m.generate(*args, noise=noise)
+    np.testing.assert_array_equal(dflt.numpy()[..., 0], codes.numpy()[..., 0])       # frame 0 does not see the kwargs
+    assert (dflt.numpy() != codes.numpy()).any()                                     # later frames do
+    with pytest.raises(NotImplementedError):
+        m.generate(*args, noise=noise, repetition_penalty=1.2)
+
+
 def test_inference_wrapper_offline_infer(weights0):
     """InferenceWrapper.infer mirror (offline): encode whole utterance -> generate -> code2wav, against the CPU oracle
     (codes identical with the device RNG seeded like the oracle's noise, PCM within tol)."""
@@ -881,6 +907,30 @@ def test_stream_infer_from_wav_files_without_injected_embeddings(weights0, tmp_p
     out2 = w.stream_infer(str(tmp_path / "src.wav"), str(tmp_path / "ref.wav"), None, delay=2, noise_seed=5, style_vectors=st_d,
                           timbre_latents=np.asarray(w.calculate_timbre_latent(ref16)), save_result=False)
     np.testing.assert_array_equal(out, out2)
+    w.engine.close()
+
+
+def test_long_offline_encode_beyond_256_frames(eng, weights0):
+    """whole-utterance encoding (evaluations/infer_arvc.py:334-339) of 560 frames = 26 s -- past the old 256-frame
+    limit and past the 512-token causal window of the tokenizer's transformer (tiled attention kernel, kernels.hip
+    enc_attention_flash_kernel): BSQ indices bit-exact against the reference's, through both the seam and the wrapper."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.synth_audio import synth_utterance
+
+    g = load_golden("encoder_long_s0")
+    n = int(g["n_samples"])
+    x = synth_utterance(int(g["audio_seed"]), n)
+    assert float(g["min_abs_u"].min()) > 1e-5
+    b = E.Batch(eng, n_streams=1, encode_window_frames=n // 2048)
+    codes = b.encode_window(x[None])
+    b.close()
+    np.testing.assert_array_equal(codes[0], g["codes"])
+    w = InferenceWrapper(weights=weights0)
+    np.testing.assert_array_equal(w.encode_content(x), g["codes"])
+    # a 300-frame reference (> max_prompt_frames = 256) goes through calculate_prompt untruncated, as in the reference
+    ac = w.wav2target_fn(x[:300 * 2048])
+    assert ac.shape == (1, 8, 300)
     w.engine.close()
 
 

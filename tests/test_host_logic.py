@@ -2,6 +2,8 @@
 box must reproduce), the streaming left-pad rule, the spec table, and the wrapper surfaces."""
 import inspect
 
+import pytest
+
 import numpy as np
 
 
@@ -109,3 +111,15 @@ def test_load_checkpoints_unwraps_like_the_reference(tmp_path):
     torch.save(tok, tmp_path / "tok.pth")
     W2 = InferenceWrapper.load_checkpoints(str(tmp_path / "config.yaml"), str(tmp_path / "arvc.pth"))
     assert set(W2) == set(want)
+
+
+def test_sampling_kwargs_are_validated_not_dropped():
+    """sample()'s arguments (modules/dual_ar_stream.py:1081-1132): temperature/top_p pass through, the no-op values of the
+    others are accepted, anything the engine cannot honour raises."""
+    from streamvoiceanon_amd.infer_arvc import check_sampling_kwargs
+
+    assert check_sampling_kwargs({}) == {}
+    assert check_sampling_kwargs({"temperature": 1, "top_p": 0.9, "repetition_penalty": 1.0, "previous_tokens": None}) == {"temperature": 1.0, "top_p": 0.9}
+    for bad in ({"repetition_penalty": 1.5}, {"previous_tokens": [1]}, {"top_k": 5}):
+        with pytest.raises(NotImplementedError):
+            check_sampling_kwargs(bad)

@@ -154,3 +154,12 @@ def test_prompt_encoders_match_reference():
     # Kaldi mel banks: triangular, unit peak spacing, last (Nyquist) column empty
     banks = PO.kaldi_mel_banks()
     assert banks.shape == (80, 257) and float(banks[:, -1].abs().max()) == 0.0 and float(banks.max()) <= 1.0 + 1e-6
+
+
+def test_long_encode_window_limited_attention(weights0):
+    """Whole-utterance encode of 560 frames: beyond 512 tokens the tokenizer's transformer attends to the newest 512 keys only
+    (WindowLimitedTransformer, windowed_transformer.py:291-304); codes bit-exact against the reference's."""
+    g = load_golden("encoder_long_s0")
+    x = torch.from_numpy(synth_utterance(int(g["audio_seed"]), int(g["n_samples"])))[None]
+    codes = O.encode_window(x, weights0)
+    np.testing.assert_array_equal(codes[0, 0].numpy(), g["codes"])

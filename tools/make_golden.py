@@ -91,6 +91,20 @@ def encoder_fixture(w, wseed, useed):
           "min|u| q01", float(np.quantile(u.abs().min(-1).values.numpy(), 0.01)))
 
 
+def encoder_long_fixture(w, wseed=0, useed=1005, frames=560):
+    """Whole-utterance encode beyond the transformer's 512-token causal window (WindowLimitedTransformer,
+    modules/vqgan/windowed_transformer.py:291-304): the offline `infer` path encodes the entire source at once (:334-339)."""
+    n = frames * 2048
+    x = torch.from_numpy(synth_utterance(useed, n))[None]
+    codes, lens = w.speech_tokenizer.encode(x, torch.LongTensor([n]))
+    q = w.speech_tokenizer.quantizer
+    z = q.pre_module(q.downsample(w.speech_tokenizer.backbone(w.speech_tokenizer.spec_transform(x))))
+    u = torch.nn.functional.normalize(q.residual_bsq.rvqs[0].project_in(z.mT).float(), dim=-1)
+    np.savez_compressed(os.path.join(OUT, f"encoder_long_s{wseed}.npz"), weight_seed=wseed, audio_seed=useed, n_samples=n,
+                        codes=codes[0, 0].numpy(), min_abs_u=u[0].abs().min(-1).values.numpy())
+    print("long encoder fixture", codes.shape, "distinct", len(set(codes.flatten().tolist())), "min|u|", float(u.abs().min()))
+
+
 def vocoder_fixture(w, wseed):
     cseed = 77
     codes = np.floor(sw.uniform01(cseed, "voc.codes", 8 * 64).astype(np.float64) * 1000).astype(np.int64).reshape(1, 8, 64)
@@ -295,6 +309,9 @@ def main():
     np.savez_compressed(os.path.join(OUT, "melfb.npz"), col_sum=fb.sum(0).numpy(), row_sum=fb.sum(1).numpy(),
                         peak=fb.max(0).values.numpy(), argpeak=fb.argmax(0).numpy())
     only = sys.argv[1] if len(sys.argv) > 1 else None     # e.g. `make_golden.py prompt` adds one fixture without rewriting the rest
+    if only == "encoder_long":
+        encoder_long_fixture(rh.build_wrapper(seed=0))
+        return
     if only in (None, "prompt_encoders"):
         prompt_encoder_fixture(0)
         if only:
@@ -315,6 +332,7 @@ def main():
             stream_fixture(w, feed, "stream_chunk4", 0, useed=1002, pseed=2002, n_chunks=6, chunk=4,
                            full_pcm_frames=(-1,))
             offline_fixture(w, feed, 0, useed=1003, pseed=2003)
+            encoder_long_fixture(w)
             prompt_fixture(w, 0, useed=1004)
 
 
