@@ -66,6 +66,8 @@ def parse():
                     help="replay the captured single-stream hipGraph of the whole steady step (3.8 ms at B=1 against 3.6 ms for eager "
                          "serial stepping and 1.6 ms for the pipelined default, see DESIGN.md)")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
+    ap.add_argument("--torch-gpu-baseline", action="store_true",
+                    help="also time the reference's formulation under eager PyTorch-ROCm on this GPU (second baseline, N=1 only)")
     return ap.parse_args()
 
 
@@ -113,6 +115,41 @@ def cpu_baseline(args, W):
                   f"({', '.join(f'{t}: {v:.2f} s' for t, v in probe.items())})",
         "rtf": round(dt / args.cpu_steps / (args.chunk * FRAME_S), 3),
     }
+
+
+def torch_gpu_baseline(args, W, steps=20):
+    """Second baseline: the reference's FORMULATION run by PyTorch-ROCm eager on the same MI355X -- the oracle
+    (the reference itself cannot travel to the GPU box) with its tensors on cuda:0, i.e. sliding-window recompute of encoder
+    and vocoder, one aten kernel per op, fp32, no torch.compile.  Reported, never the target."""
+    import torch
+
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    dev = torch.device("cuda")
+    Wd = {k: v.to(dev) for k, v in W.items()}
+    useed = 1000
+    ac, cc, style, timbre = synth_prompt(2000, args.prompt_frames)
+    n = 2048 * args.chunk
+    warm = 5
+    with dev:                       # factory calls inside the oracle (arange, zeros, windows, masks) land on the GPU
+        sess = O.StreamSession(Wd, torch.from_numpy(cc).to(dev), torch.from_numpy(ac).to(dev), torch.from_numpy(style).to(dev),
+                               torch.from_numpy(timbre).to(dev),
+                               noise_fn=lambda f: tuple(torch.from_numpy(a).to(dev) for a in frame_noise(useed, f)), delay=2,
+                               decode_chunk_frames=args.chunk)
+        src = torch.from_numpy(synth_utterance(useed, n * (warm + steps))).to(dev)[None]
+        for i in range(warm):
+            sess.process_one_chunk(src[:, i * n:(i + 1) * n])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warm, warm + steps):
+            sess.process_one_chunk(src[:, i * n:(i + 1) * n])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"value": round(steps * args.chunk / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "kind": "port",
+            "sample": f"{steps} steady chunk-steps, B=1, chunk={args.chunk}: the oracle's torch restatement of the reference's window-recompute "
+                      f"formulation, eager PyTorch {torch.__version__} on cuda:0 (fp32, no torch.compile, synchronised at the ends only)",
+            "rtf": round(dt / steps / (args.chunk * FRAME_S), 4)}
 
 
 def main():
@@ -254,9 +291,16 @@ def main():
             t = torch.tensor([dt], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        # the trivial gather of per-utterance results (codes of the last step) to rank 0
-        codes = batch.tap("audio_codes", (B, 8, c), np.int32)
+        # the trivial gather of the per-utterance RESULTS to rank 0 (north_star configs[3]/[4]; SURVEY.md 8e: codes [8, T] per utterance):
+        # every frame each utterance decoded since begin() -- delay fill, warm-up, timed and latency-sample steps
+        n_res = min(batch.frames_decoded(s_) for s_ in range(B))
+        if world > 1 or force_dist:           # ranks may have run a different number of placement-probe steps: gather the common length
+            t = torch.tensor([n_res], device="cuda", dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            n_res = int(t.item())
+        codes = np.stack([batch.pred_codes(s_, n_res) for s_ in range(B)])               # [B, 8, T]
         gathered = gather_results(torch.from_numpy(codes).cuda(), world, rank, force=force_dist)
+        n_gathered_frames = int(gathered.shape[0] * gathered.shape[2]) if gathered is not None else 0
         roof = None
         if rank == 0 and want_roofline:
             # dominant kernel = conv_gemm_kernel (f32 MFMA): algorithmic FLOPs of all its launches in one step /
@@ -303,6 +347,7 @@ def main():
                     "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4),
                     "stage_ms_profiled_step": {k_: round(v, 4) for k_, v in tm_prof.items()}}
         batch.close()
+        extra["gathered_frames"] = n_gathered_frames
         return dt, tm, (int(gathered.shape[0]) if gathered is not None else B), roof, extra
 
     dt, tm, n_gathered, roof, extra = run_workload(B, args.steps, args.warmup, not args.no_roofline)
@@ -366,6 +411,13 @@ def main():
                                      "x_realtime": round(64 * c * 10 / dt2 * FRAME_S, 2),
                                      "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm2.items()},
                                      "roofline": ({**roof2, **stage_rates(64, ms2, tm2, roof2["algorithmic_gflop_per_step"])} if roof2 else None), **extra2}
+    if world == 1 and args.torch_gpu_baseline:
+        import torch as _t
+        eng.close()
+        try:
+            out["torch_gpu_baseline"] = torch_gpu_baseline(args, {k: _t.from_numpy(v) for k, v in W.items()})
+        except Exception as ex:          # a reported extra, never a reason to lose the bench line
+            out["torch_gpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if world == 1 and not args.no_cpu_baseline:
         os.sched_setaffinity(0, cpus_at_start)      # the CPU leg uses all host cores again
         import torch as _t

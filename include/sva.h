@@ -162,6 +162,10 @@ int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* ref_ac, int
  * "slow_logits" float[B][vocab], "fast_logits" float[B][8][codebook_size], "hidden" float[B][dim],
  * "semantic" int32[B], "last_pos" int32[B], "mel" float[B][T][160] ... ; returns #bytes or <0 */
 long sva_get_tap(sva_batch* b, const char* what, void* out, long out_bytes);
+/* the stream state `pred_codes[..., -n:]` of evaluations/infer_arvc.py:520-523 for one slot: the last n predicted frames
+ * (n <= frames decoded so far, n <= 4096 = the device ring), int32 codes_out[8][n].  Drains the batch's streams first.
+ * *n_frames_total (optional) receives the number of frames the slot has decoded since sva_streams_begin. */
+int sva_stream_codes(sva_batch* b, int slot, int n, int32_t* codes_out, long* n_frames_total);
 /* per-stage device time of the last sva_step in ms: [encoder, ar, vocoder, total] (hipEvents) */
 int sva_get_timings(sva_batch* b, float ms[4]);
 /* dominant-kernel bookkeeping for bench.py: number of conv-GEMM launches and their summed

@@ -2898,6 +2898,23 @@ extern "C" long sva_get_gemm_profile_table(sva_batch* b, double* out, long max_r
     }
     return n;
 }
+extern "C" int sva_stream_codes(sva_batch* b, int slot, int n, int32_t* codes_out, long* n_frames_total) {
+    SVA_CHECK(b && slot >= 0 && slot < b->B, "bad slot");
+    const int nf = b->h_nframes[slot], cap = b->hist_cap, ncb = b->e->cfg.num_codebooks;
+    if (n_frames_total) *n_frames_total = nf;
+    SVA_CHECK(n >= 0 && n <= nf && n <= cap, "more frames requested than the stream has decoded (or than the 4096-frame ring holds)");
+    if (!n) return 0;
+    SVA_CHECK(codes_out, "null argument");
+    SVA_HIP(hipSetDevice(b->e->device));
+    SVA_TRY(quiesce(b));
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    std::vector<int> ring(cap);
+    for (int q = 0; q < ncb; ++q) {
+        SVA_HIP(hipMemcpy(ring.data(), b->d_pred_hist + ((long)slot * ncb + q) * cap, sizeof(int) * cap, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) codes_out[(size_t)q * n + i] = ring[(nf - n + i) & (cap - 1)];
+    }
+    return 0;
+}
 extern "C" int sva_get_gemm_bytes(sva_batch* b, double* bytes) {
     SVA_CHECK(b && bytes, "null argument");
     *bytes = b->gemm_bytes;

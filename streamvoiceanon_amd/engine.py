@@ -89,6 +89,7 @@ def load_library():
     lib.sva_get_timings.argtypes = [vp, f32p]
     lib.sva_get_gemm_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.sva_get_gemm_bytes.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.sva_stream_codes.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_long)]
     lib.sva_profile_gemm.argtypes = [vp, i32]
     lib.sva_get_gemm_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.sva_get_gemm_profile_table.argtypes = [vp, vp, C.c_long]
@@ -110,7 +111,7 @@ EXPORTED_SYMBOLS = [
     "sva_dev_alloc", "sva_dev_free", "sva_dev_upload", "sva_dev_download", "sva_op_conv", "sva_op_affine", "sva_op_unary", "sva_op_colstats",
     "sva_op_cam_context", "sva_op_mul", "sva_op_add", "sva_op_conv2d", "sva_op_cf_to_rows", "sva_op_fbank_power", "sva_op_stft_mag", "sva_op_attention",
     "sva_op_geglu", "sva_op_l2norm",
-    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
+    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
 ]
 
 
@@ -389,6 +390,20 @@ class Batch:
 
     def sync(self):
         _check(self.lib.sva_sync(self.h), "sva_sync")
+
+    def frames_decoded(self, slot=0):
+        n = C.c_long()
+        _check(self.lib.sva_stream_codes(self.h, slot, 0, None, C.byref(n)), "sva_stream_codes")
+        return int(n.value)
+
+    def pred_codes(self, slot=0, n=None):
+        """`pred_codes[..., -n:]` of the slot's stream state (evaluations/infer_arvc.py:520-523): int32 [8, n]; n=None -> every
+        frame decoded since begin() (at most the 4096-frame device ring)."""
+        if n is None:
+            n = min(self.frames_decoded(slot), 4096)
+        out = np.empty((8, n), np.int32)
+        _check(self.lib.sva_stream_codes(self.h, slot, n, _ptr(out) if n else None, None), "sva_stream_codes")
+        return out
 
     def gemm_bytes(self):
         v = C.c_double()

@@ -409,6 +409,10 @@ def test_stream_configs_vs_oracle(eng, weights0, cfg):
             frame += c
         assert np.abs(out[0] - ref).max() <= PCM_TOL, i
     assert int(b.tap("last_pos", (1,), np.int32)[0]) == sess.ar.last_pos
+    # the stream state the reference keeps as self.pred_codes (infer_arvc.py:520-523): what the multi-GPU result gather ships
+    assert b.frames_decoded(0) == sess.pred_codes.shape[1]
+    np.testing.assert_array_equal(b.pred_codes(0), sess.pred_codes.numpy())
+    np.testing.assert_array_equal(b.pred_codes(0, 3), sess.pred_codes[:, -3:].numpy())
     b.close()
 
 
