@@ -93,6 +93,8 @@ struct EncMerged {
     std::vector<std::vector<Act>> x;       // x[i][j] = input of block j of stage i  [B][6 + R0][C_i]
     Act xout[4];                           // output of the last block of stage i    [B][R0][C_i]
     Act feat;                              // [B][R0][512]
+    Act feat2;                             // second copy: the pipelined step alternates (main chain writes, side chain reads)
+    float *h1b = nullptr, *h2b = nullptr;  // ConvNeXt scratch of the downsampler when it runs on the side chain [B][R1][512], [B][R1][2048]
     Act d1, d1o, d2, tok;                  // [B][6 + R1][512], [B][R1][512], [B][6 + R2][512], [B][R2][512]   R1 = Hh/2 + 6 + nm/2 ...
     float *h1 = nullptr, *h2 = nullptr;    // ConvNeXt scratch [B][R0][512], [B][R0][2048]
     ShiftDesc* d_shift = nullptr;
@@ -326,7 +328,10 @@ struct sva_batch {
     // vocoder (behind the FSQ decode, where it releases the step's codes) replayed as hipGraphs: ~135 launches per step off the
     // enqueueing thread, which is otherwise the bound once the GPU side of a single-stream step drops to ~1 ms
     bool stage_graphs = true;
-    hipGraphExec_t gE = nullptr, gT0 = nullptr, gT1[2] = {nullptr, nullptr}, gV = nullptr;
+    hipGraphExec_t gEm[2] = {nullptr, nullptr}, gEs[2] = {nullptr, nullptr};      // front-end cut behind the backbone: main part / side part, per parity
+    hipEvent_t pipe_evFeat[2] = {nullptr, nullptr};
+    int enc_cut = 1;
+    hipGraphExec_t gE = nullptr, gE2 = nullptr, gT0 = nullptr, gT1[2] = {nullptr, nullptr}, gV = nullptr;
     bool graph_ready = false;
     bool graph_step = false;       // last step ran through the graph (no per-stage events)
     bool forced_now = false;

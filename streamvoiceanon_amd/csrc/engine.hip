@@ -779,13 +779,44 @@ __global__ void copy_tokens_kernel(const float* __restrict__ tok, long tok_bstri
 // Merged incremental front-end pass (see EncMerged): head rows (the first 4*Ht mel frames of the window, zero left padding as in
 // the reference's window pass) and the 4c newest mel frames (on per-layer 6-row histories) through ONE sequence of launches.
 // Results: token rows [0, Ht) and [T2 - c, T2) of d2c.
-int enc_frontend_merged(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
+// part 0 = everything; part 1 = up to the token features (does not touch the token cache d2c); part 2 = the hand-over: head and
+// new tokens -> d2c, then the layers' history rows slide (the pipelined step waits for transformer(n-1)'s first layer only here).
+// part 3 / 4 = the cut the balanced pipeline uses: 3 = STFT .. backbone .. final LayerNorm -> feat[fpar] + the history shift of
+// those layers; 4 = quantizer downsampler (2 x (conv k2 s2 + ConvNeXt block)) from feat[fpar] with its own scratch, tokens -> d2c,
+// its two history shifts (runs on the side stream in front of the transformer)
+int enc_frontend_merged(sva_batch* b, const int* step_ptr, int n_chunk, int add, int part = 0, int fpar = 0) {
     sva_engine* e = b->e;
     const EncFront& F = e->tokf;
     const sva_config& c = e->cfg;
     EncMerged& M = b->em;
     const int B = b->B, Hh = M.Hh, nm = M.nm, R0 = Hh + 6 + nm, ch = b->p.chunk_frames;
     hipStream_t st = b->stream;
+    const int D = c.tr_dim;
+    Act& feat = fpar ? M.feat2 : M.feat;
+    float* h1 = part == 4 ? M.h1b : M.h1;
+    float* h2 = part == 4 ? M.h2b : M.h2;
+    const int R1 = Hh / 2 + 6 + nm / 2, R2 = Hh / 4 + 6 + nm / 4;
+    const int n_shift_ds = 2;                       // the last two descriptors are the downsampler's (d1, d2)
+    if (part == 2) {
+        hipLaunchKernelGGL(copy_tokens_kernel, dim3(b->Ht + ch, B), dim3(128), 0, st, M.tok.p, M.tok.bstride, b->Ht, 6, ch, b->d2c.p, b->d2c.bstride, b->T2, D);
+        SVA_TRY(launch_shift_history(M.d_shift, M.n_shift, B, st));
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
+    if (part == 4) {
+        SVA_TRY(gemm_call(b, feat.p, feat.bstride, 0, D, B, Hh / 2, 2, 1, 2, D, F.ds_conv[0], M.d1.p, M.d1.bstride, (long)M.d1.H * D, D));
+        SVA_TRY(gemm_call(b, feat.p, feat.bstride, (long)(Hh + 6) * D, D, B, nm / 2, 2, 1, 2, D, F.ds_conv[0], M.d1.p, M.d1.bstride,
+                          (long)(M.d1.H + Hh / 2 + 6) * D, D));
+        SVA_TRY(cnx_block_t(b, F.ds_cnx[0], M.d1, R1, h1, (long)R1 * D, h2, (long)R1 * 4 * D, &M.d1o));
+        SVA_TRY(gemm_call(b, M.d1o.p, M.d1o.bstride, 0, D, B, Hh / 4, 2, 1, 2, D, F.ds_conv[1], M.d2.p, M.d2.bstride, (long)M.d2.H * D, D));
+        SVA_TRY(gemm_call(b, M.d1o.p, M.d1o.bstride, (long)(Hh / 2 + 6) * D, D, B, nm / 4, 2, 1, 2, D, F.ds_conv[1], M.d2.p, M.d2.bstride,
+                          (long)(M.d2.H + Hh / 4 + 6) * D, D));
+        SVA_TRY(cnx_block_t(b, F.ds_cnx[1], M.d2, R2, h1, (long)R2 * D, h2, (long)R2 * 4 * D, &M.tok));
+        hipLaunchKernelGGL(copy_tokens_kernel, dim3(b->Ht + ch, B), dim3(128), 0, st, M.tok.p, M.tok.bstride, b->Ht, 6, ch, b->d2c.p, b->d2c.bstride, b->T2, D);
+        SVA_TRY(launch_shift_history(M.d_shift + (M.n_shift - n_shift_ds), n_shift_ds, B, st));
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
     const long mag_bs = (long)R0 * 1088;
     SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, M.mag, 1088, mag_bs, 0, Hh, st));
     SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, M.mag + (long)(Hh + 6) * 1088, 1088, mag_bs, b->T0 - nm, nm, st));
@@ -819,22 +850,19 @@ int enc_frontend_merged(sva_batch* b, const int* step_ptr, int n_chunk, int add)
             SVA_TRY(gemm_call(b, M.h1, (long)R0 * C, 0, C, B, R0, 1, 1, 1, C, F.trans[i + 1], X.p, X.bstride, (long)X.H * Cn, Cn, p));
         }
     }
-    const int D = c.tr_dim;
-    SVA_TRY(launch_layernorm_rows(M.xout[3].p, M.xout[3].bstride, 0, D, B, R0, D, F.final_lnw, F.final_lnb, 1e-6f, M.feat.p, M.feat.bstride, 0, D, st));
+    SVA_TRY(launch_layernorm_rows(M.xout[3].p, M.xout[3].bstride, 0, D, B, R0, D, F.final_lnw, F.final_lnb, 1e-6f, feat.p, feat.bstride, 0, D, st));
+    if (part == 3) return launch_shift_history(M.d_shift, M.n_shift - n_shift_ds, B, st);
     // BSQ downsample x2 (conv k2 s2 + ConvNeXtBlock, bsq_no_upsample.py:48-61); the strided convs run per row group
-    const int R1 = Hh / 2 + 6 + nm / 2, R2 = Hh / 4 + 6 + nm / 4;
-    SVA_TRY(gemm_call(b, M.feat.p, M.feat.bstride, 0, D, B, Hh / 2, 2, 1, 2, D, F.ds_conv[0], M.d1.p, M.d1.bstride, (long)M.d1.H * D, D));
-    SVA_TRY(gemm_call(b, M.feat.p, M.feat.bstride, (long)(Hh + 6) * D, D, B, nm / 2, 2, 1, 2, D, F.ds_conv[0], M.d1.p, M.d1.bstride,
+    SVA_TRY(gemm_call(b, feat.p, feat.bstride, 0, D, B, Hh / 2, 2, 1, 2, D, F.ds_conv[0], M.d1.p, M.d1.bstride, (long)M.d1.H * D, D));
+    SVA_TRY(gemm_call(b, feat.p, feat.bstride, (long)(Hh + 6) * D, D, B, nm / 2, 2, 1, 2, D, F.ds_conv[0], M.d1.p, M.d1.bstride,
                       (long)(M.d1.H + Hh / 2 + 6) * D, D));
     SVA_TRY(cnx_block_t(b, F.ds_cnx[0], M.d1, R1, M.h1, (long)R1 * D, M.h2, (long)R1 * 4 * D, &M.d1o));
     SVA_TRY(gemm_call(b, M.d1o.p, M.d1o.bstride, 0, D, B, Hh / 4, 2, 1, 2, D, F.ds_conv[1], M.d2.p, M.d2.bstride, (long)M.d2.H * D, D));
     SVA_TRY(gemm_call(b, M.d1o.p, M.d1o.bstride, (long)(Hh / 2 + 6) * D, D, B, nm / 4, 2, 1, 2, D, F.ds_conv[1], M.d2.p, M.d2.bstride,
                       (long)(M.d2.H + Hh / 4 + 6) * D, D));
     SVA_TRY(cnx_block_t(b, F.ds_cnx[1], M.d2, R2, M.h1, (long)R2 * D, M.h2, (long)R2 * 4 * D, &M.tok));
-    hipLaunchKernelGGL(copy_tokens_kernel, dim3(b->Ht + ch, B), dim3(128), 0, st, M.tok.p, M.tok.bstride, b->Ht, 6, ch, b->d2c.p, b->d2c.bstride, b->T2, D);
-    SVA_TRY(launch_shift_history(M.d_shift, M.n_shift, B, st));
-    SVA_HIP(hipGetLastError());
-    return 0;
+    if (part == 1) return 0;
+    return enc_frontend_merged(b, step_ptr, n_chunk, add, 2);
 }
 
 // pre_module (8-layer causal transformer on T2 tokens, windowed_transformer.py:103-143) + BSQ.  Reads the token
@@ -1609,6 +1637,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
     if (const char* ev = getenv("SVA_PIPE_GRAPH")) b->pipe_graph_mode = atoi(ev);
     if (const char* ev = getenv("SVA_STAGE_GRAPHS")) b->stage_graphs = atoi(ev) != 0;
+    if (const char* ev = getenv("SVA_ENC_CUT")) b->enc_cut = atoi(ev);
     if (const char* ev = getenv("SVA_PIPE_SPLIT_E")) b->pipe_split_e = atoi(ev);
     if (const char* ev = getenv("SVA_STREAM_CUT")) b->stream_cut = atoi(ev);
     if (const char* ev = getenv("SVA_PIPE_TRACE")) {
@@ -1725,6 +1754,9 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
             SVA_TRY(alloc_act(A, M.xout[i], B, 0, R0, c.enc_dims[i]));
         }
         SVA_TRY(alloc_act(A, M.feat, B, 0, R0, Dm));
+        SVA_TRY(alloc_act(A, M.feat2, B, 0, R0, Dm));
+        SVA_TRY(dev_alloc(A, &M.h1b, (size_t)B * R1 * Dm));
+        SVA_TRY(dev_alloc(A, &M.h2b, (size_t)B * R1 * 4 * Dm));
         SVA_TRY(alloc_act(A, M.d1, B, 6, R1, Dm));
         reg(M.d1, Hh / 2, nm / 2);
         SVA_TRY(alloc_act(A, M.d1o, B, 0, R1, Dm));
@@ -1882,7 +1914,7 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     for (auto& t : b->trace_ev) (void)hipEventDestroy(t);
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     for (auto& ge : b->pipe_graph_a) if (ge) (void)hipGraphExecDestroy(ge);
-    for (hipGraphExec_t ge : {b->gE, b->gT0, b->gT1[0], b->gT1[1], b->gV}) if (ge) (void)hipGraphExecDestroy(ge);
+    for (hipGraphExec_t ge : {b->gEm[0], b->gEm[1], b->gEs[0], b->gEs[1], b->gE, b->gE2, b->gT0, b->gT1[0], b->gT1[1], b->gV}) if (ge) (void)hipGraphExecDestroy(ge);
     for (void* p : b->allocs.chunks) (void)hipFree(p);
     if (b->hp_in) (void)hipHostFree(b->hp_in);
     if (b->hp_out) (void)hipHostFree(b->hp_out);
@@ -2230,6 +2262,7 @@ int steady_pipelined(sva_batch* b) {
         SVA_HIP(hipStreamWaitEvent(sv, ev, 0));
         SVA_HIP(hipMemcpyAsync(b->d_step_x, b->d_step, sizeof(int), hipMemcpyDeviceToDevice, se));      // the side chain's chunk counter
         b->pipe_evVc[0] = b->pipe_evVc[1] = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr; b->pipe_evD2C = nullptr;
+        b->pipe_evFeat[0] = b->pipe_evFeat[1] = nullptr;
     }
     const int par = b->pipe_parity;
     b->d_codes = b->d_codes_buf[par];
@@ -2254,23 +2287,55 @@ int steady_pipelined(sva_batch* b) {
         // after that layer, and sx is in order; the chunk counter (ring position) is read by the first kernel of each
         // front-end chain, so each chain advances its own copy when it is done (the append no longer does).
         hipStream_t sx = b->aux[0];
-        if (b->pipe_evD2C) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evD2C, 0));
+        if (b->pipe_evD2C && !b->enc_merged) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evD2C, 0));
         b->stream = se;
         SVA_HIP(hipEventRecord(b->ev[0], se));
         SVA_TRY(mark(0, se));
         if (b->enc_merged) {
             // ONE front-end chain on the main stream (the new frames ride in the head-pass launches); the side stream only carries
             // the transformer, which overlaps the next step's front-end.  Both chains replay as hipGraphs (stage_graph).
+            if (b->enc_cut) {
+                // Balanced cut: the backbone (STFT .. final LayerNorm) is the main chain, the quantizer's downsampler joins the
+                // transformer on the side chain -- both near the AR frame time, and the token cache d2c is then written and read on
+                // ONE in-order stream.  The hand-over buffer feat[] alternates; main(n+2) waits until side(n) has read it.
+                if (b->pipe_evFeat[par]) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evFeat[par], 0));
+                SVA_TRY(stage_graph(b, &b->gEm[par], se, [&]() -> int {
+                    b->stream = se;
+                    SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
+                    SVA_TRY(enc_frontend_merged(b, b->d_step, n, 1, 3, par));
+                    return launch_add_i32(b->d_step, 1, se);
+                }));
+                SVA_TRY(mark(1, se));
+                SVA_TRY(mark(2, sx));
+                SVA_TRY(stream_fork(b, se, sx));
+                int src_ = stage_graph(b, &b->gEs[par], sx, [&]() -> int {
+                    b->stream = sx;
+                    SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, sx));               // steady tokens slide down by c
+                    return enc_frontend_merged(b, nullptr, n, 1, 4, par);
+                });
+                b->stream = se;
+                if (src_) return src_;
+                b->pipe_evFeat[par] = next_event(b);
+                SVA_HIP(hipEventRecord(b->pipe_evFeat[par], sx));
+            } else {
+            // the token cache d2c is only touched by the last three kernels of the front-end (slide, head + new tokens in, history
+            // shift): only they wait for transformer(n-1)'s first layer -- the front-end of step n itself starts at once
             SVA_TRY(stage_graph(b, &b->gE, se, [&]() -> int {
                 b->stream = se;
                 SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
+                return enc_frontend_merged(b, b->d_step, n, 1, 1);
+            }));
+            if (b->pipe_evD2C) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evD2C, 0));
+            SVA_TRY(stage_graph(b, &b->gE2, se, [&]() -> int {
+                b->stream = se;
                 SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se));                   // steady tokens slide down by c
-                SVA_TRY(enc_frontend_merged(b, b->d_step, n, 1));
+                SVA_TRY(enc_frontend_merged(b, b->d_step, n, 1, 2));
                 return launch_add_i32(b->d_step, 1, se);
             }));
             SVA_TRY(mark(1, se));
             SVA_TRY(mark(2, sx));
             SVA_TRY(stream_fork(b, se, sx));                                              // transformer(n) needs the front-end of step n
+            }
             if (b->pipe_evA[par]) SVA_HIP(hipStreamWaitEvent(sx, b->pipe_evA[par], 0));  // back-pressure: BSQ overwrites the codes A(n-2) read
             if (b->pipe_evR) { SVA_HIP(hipStreamWaitEvent(sx, b->pipe_evR, 0)); b->pipe_evR = nullptr; }
             SVA_TRY(mark(3, sx));
@@ -2423,6 +2488,7 @@ int quiesce(sva_batch* b) {
     }
     b->pipe_dirty = false;
     b->pipe_evVc[0] = b->pipe_evVc[1] = nullptr; b->pipe_evR = nullptr; b->pipe_evA[0] = b->pipe_evA[1] = nullptr; b->pipe_evD2C = nullptr;
+        b->pipe_evFeat[0] = b->pipe_evFeat[1] = nullptr;
     b->out_stream = se;
     return 0;
 }

@@ -113,3 +113,24 @@ def test_realtime_session_lazy_reprefill_logic():
     assert s.prefills == 3 and calls[-2] == ("setup", 64, 64, 768, 32, 2)
     with pytest.raises(AssertionError):
         s.custom_infer(m, ref, "b", np.ones(1000, np.float32))
+
+
+def test_gui_presets_schema_and_apply(tmp_path):
+    """configs/presets.json schema of the reference GUI (real-time-gui.py:629-662): name -> {description, alpha, block_frame,
+    n_frame_delay}; unknown names and "Custom" leave the settings alone, missing keys keep their value, unreadable file -> {}."""
+    import json
+
+    from streamvoiceanon_amd.realtime import GuiSettings, apply_preset, load_presets
+
+    assert load_presets(str(tmp_path / "missing.json")) == {}
+    f = tmp_path / "presets.json"
+    f.write_text(json.dumps({"Max Quality": {"description": "d", "alpha": 1.0, "block_frame": 1, "n_frame_delay": 4},
+                             "Only Alpha": {"alpha": 0.25}}))
+    presets = load_presets(str(f))
+    s0 = GuiSettings()
+    assert (s0.alpha, s0.block_frame, s0.n_frame_delay) == (0.7, 1, 2)
+    assert apply_preset(s0, "Custom", presets) == s0 and apply_preset(s0, "nope", presets) == s0
+    s1 = apply_preset(s0, "Max Quality", presets)
+    assert (s1.alpha, s1.block_frame, s1.n_frame_delay) == (1.0, 1, 4) and s0.n_frame_delay == 2
+    s2 = apply_preset(s1, "Only Alpha", presets)
+    assert (s2.alpha, s2.block_frame, s2.n_frame_delay) == (0.25, 1, 4)

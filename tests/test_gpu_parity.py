@@ -1196,3 +1196,49 @@ def test_realtime_custom_infer_lazy_reprefill(weights0):
     sess.custom_infer(w, refs["b.wav"], "b.wav", src[8 * 2048:10 * 2048], alpha=1.0)
     assert sess.prefills == 3
     w.engine.close(); w2.engine.close()
+
+
+@pytest.mark.gpu
+def test_realtime_gui_presets_vs_oracle(weights0, tmp_path):
+    """the GUI's quick presets (configs/presets.json of the reference: Max Privacy / Balanced / Max Quality /
+    Low Latency = alpha 0 / 0.5 / 1 / 0.7, block_frame 1, n_frame_delay 2 / 2 / 4 / 1) through the audio-callback entry; every
+    converted block against the CPU oracle driven with the prompt the wrapper built (noise-mixed embeddings included)."""
+    import json
+
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.realtime import GuiSettings, RealtimeSession, apply_preset, load_presets
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    f = tmp_path / "presets.json"
+    f.write_text(json.dumps({"Max Privacy": {"description": "", "alpha": 0.0, "block_frame": 1, "n_frame_delay": 2},
+                             "Balanced": {"description": "", "alpha": 0.5, "block_frame": 1, "n_frame_delay": 2},
+                             "Max Quality": {"description": "", "alpha": 1.0, "block_frame": 1, "n_frame_delay": 4},
+                             "Low Latency": {"description": "", "alpha": 0.7, "block_frame": 1, "n_frame_delay": 1}}))
+    presets = load_presets(str(f))
+    _, _, style, timbre = synth_prompt(2510, 8)
+    ref = synth_utterance(7400, 2048 * 70 + 100)
+    src = synth_utterance(7401, 2048 * 9)
+    w = InferenceWrapper(weights=weights0)
+    w.style_encoder = lambda wav: style
+    w.timbre_encoder = lambda wav: timbre
+    for k, name in enumerate(presets):
+        st = apply_preset(GuiSettings(), name, presets)
+        sess = RealtimeSession()
+        torch.manual_seed(100 + k)                       # apply_noise_mixing draws from torch's global generator (:228-232)
+        got = [sess.run_block(w, ref, f"ref{k}.wav", src[i * 2048:(i + 1) * 2048], st) for i in range(9)]
+        assert sess.prefills == 1 and w.delay == st.n_frame_delay
+        ac, cc, sv, tl = w._prompt
+        if st.alpha == 1.0:
+            np.testing.assert_array_equal(sv.reshape(-1), style.reshape(-1))
+        else:
+            assert np.abs(sv.reshape(-1) - style.reshape(-1)).max() > 1e-3
+        osess = O.StreamSession(weights0, torch.from_numpy(cc.reshape(-1)), torch.from_numpy(ac.reshape(8, -1)), torch.from_numpy(sv.reshape(-1)),
+                                torch.from_numpy(tl.reshape(32, -1)), delay=st.n_frame_delay, encode_window_frames=64, decode_window_frames=64,
+                                max_prompt_frames=64, noise_fn=lambda fr: tuple(torch.from_numpy(a) for a in frame_noise(w._noise_seed, fr)))
+        for i in range(9):
+            want = osess.process_one_chunk(torch.from_numpy(src[i * 2048:(i + 1) * 2048])[None])[0].numpy()
+            assert np.abs(got[i] - want).max() <= PCM_TOL, (name, i)
+            if i < st.n_frame_delay:
+                assert np.abs(got[i]).max() == 0.0
+    w.engine.close()
