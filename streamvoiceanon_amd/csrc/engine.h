@@ -331,6 +331,10 @@ struct sva_batch {
     hipGraphExec_t gEm[2] = {nullptr, nullptr}, gEs[2] = {nullptr, nullptr};      // front-end cut behind the backbone: main part / side part, per parity
     hipEvent_t pipe_evFeat[2] = {nullptr, nullptr};
     int enc_cut = 1;
+    int voc_fused_mask = -1;               // -1: default policy; else bit 0: the C = 16 level, bit 1: the C = 32 level
+    bool voc_fused = true;                 // narrow vocoder levels (C <= 32) as one fused launch (voc_fused.hip)
+    int* d_voc_frames = nullptr;           // code frames the streaming vocoder has consumed since its last reset
+    int voc_rpf[5] = {0, 0, 0, 0, 0};      // rows of level i per code frame
     hipGraphExec_t gE = nullptr, gE2 = nullptr, gT0 = nullptr, gT1[2] = {nullptr, nullptr}, gV = nullptr;
     bool graph_ready = false;
     bool graph_step = false;       // last step ran through the graph (no per-stage events)

@@ -1390,6 +1390,17 @@ int ar_delay_fill(sva_batch* b) {
     return ar_delay_fill(b, all);
 }
 
+// Which HiFiGAN levels run as the fused LDS-resident kernel (voc_fused.hip).  Measured on MI355X (profiles/r02_voc_fused.txt): the
+// C = 16 level takes 27-33 us fused against 7 launches / ~70 us at one stream and breaks even around 4-8 streams; from there on,
+// and for C = 32 at any batch, the tap-split GEMM formulation is faster (the fused kernel recomputes an 18 (k - 1)-row halo per
+// tile and runs one workgroup per CU), so the default fuses C = 16 for <= 4 streams.  SVA_VOC_FUSED_MASK (bit 0: C = 16,
+// bit 1: C = 32) / SVA_VOC_FUSED=0 override.
+bool voc_level_is_fused(const sva_batch* b, int C) {
+    if (!b->voc_fused || !voc_level_supported(C)) return false;
+    if (b->voc_fused_mask >= 0) return (b->voc_fused_mask & (C == 16 ? 1 : 2)) != 0;
+    return C == 16 && b->B <= 4;
+}
+
 // ---- V: streaming vocoder on T new code frames held in d_vcodes [B][8][Tv] -------------------------------
 // part 0: the whole vocoder; 1: firefly.quantizer.decode only (FSQ decode + upsampler, output = rows [pin.H, pin.H + 4T) of
 // b->pin); 2: firefly.head only (HiFiGAN on those rows)
@@ -1434,6 +1445,33 @@ int vocode(sva_batch* b, int T, bool shift, int part = 0) {
         // chains of 6 convs: branch 0 stays on the main stream, branches 1/2 run on side streams; the last conv of each
         // branch accumulates (x 1/3) into the level output in the fixed order 0, 1, 2 (event chain => deterministic sum).
         Act& out = b->S[i + 1];
+        if (voc_level_is_fused(b, Cout)) {
+            // narrow levels: the whole ParallelBlock in one launch (three branches x time tiles x streams), intermediates in LDS,
+            // the level input's history (18 (k - 1) rows) as the only streaming state
+            const float* W[3][6]; const float* bs[3][6]; float* y3[3];
+            for (int br = 0; br < 3; ++br) {
+                for (int j = 0; j < 3; ++j) {
+                    const ResConv& rcv = e->res[i][br][j];
+                    SVA_CHECK(rcv.k == kResK[br] && rcv.dil == kResD[j], "voc_level: unexpected ResBlock geometry");
+                    W[br][2 * j] = rcv.c1.W; bs[br][2 * j] = rcv.c1.b; W[br][2 * j + 1] = rcv.c2.W; bs[br][2 * j + 1] = rcv.c2.b;
+                }
+                y3[br] = b->y3[i][br].p;
+            }
+            SVA_TRY(launch_voc_level(b->X[i].p, b->X[i].bstride, b->X[i].H, Cout, B, (int)Tl, W, bs, kResD, y3, b->y3[i][0].bstride, b->d_voc_frames,
+                                     b->voc_rpf[i], st));
+            {   // bookkeeping as one conv-GEMM launch: algorithmic FLOPs of the 18 convs, bytes = input (+ history) + weights + output
+                double kk = 0;
+                for (int br = 0; br < 3; ++br) kk += 6.0 * kResK[br];
+                b->gemm_flops += 2.0 * B * (double)Tl * Cout * Cout * kk;
+                b->gemm_launches += 1;
+                b->gemm_bytes += 4.0 * ((double)B * (Tl + b->X[i].H) * Cout + kk * Cout * Cout + 3.0 * B * (double)Tl * Cout);
+            }
+            const long n4 = Tl * Cout / 4;
+            hipLaunchKernelGGL(mean3_kernel, dim3((unsigned)((n4 + 255) / 256), B), dim3(256), 0, st, b->y3[i][0].p, b->y3[i][1].p, b->y3[i][2].p,
+                               b->y3[i][0].bstride, out.p, out.bstride, (long)out.H * Cout, n4);
+            SVA_HIP(hipGetLastError());
+            continue;
+        }
         if (b->voc_grouped) {
             // one launch per conv stage for the three branches (same M, N, Cin; k = 3 / 7 / 11 taps): 12 launches + the
             // mean per level instead of 18 on three streams -- at small B the step is bound by the number of kernels
@@ -1516,6 +1554,7 @@ int vocode(sva_batch* b, int T, bool shift, int part = 0) {
             SVA_HIP(hipStreamSynchronize(st));
         }
         SVA_TRY(launch_shift_history(b->d_shift, (int)b->shift_host.size(), B, st));
+        SVA_TRY(launch_add_i32(b->d_voc_frames, T, st));      // (the fused levels ask whether their halo lies inside the stream)
     }
     return 0;
 }
@@ -1847,6 +1886,10 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     // vocoder
     const int Tv = b->Tv = b->p.voc_max_frames;
     const int V = c.voc_dim;
+    if (const char* ev = getenv("SVA_VOC_FUSED")) b->voc_fused = atoi(ev) != 0;
+    if (const char* ev = getenv("SVA_VOC_FUSED_MASK")) b->voc_fused_mask = atoi(ev);
+    SVA_TRY(dev_alloc(A, &b->d_voc_frames, 1));
+    SVA_HIP(hipMemset(b->d_voc_frames, 0, sizeof(int)));
     SVA_TRY(alloc_act(A, b->zq, B, 0, Tv, V));
     SVA_TRY(alloc_act(A, b->u0, B, 6, 2L * Tv, V));
     SVA_TRY(alloc_act(A, b->v0, B, 0, 2L * Tv, V));
@@ -1866,7 +1909,10 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         rows *= e->ups_s[i];
         rpf *= e->ups_s[i];
         ch /= 2;
-        SVA_TRY(alloc_act(A, b->X[i], B, (kResK[2] - 1) * kResD[0], rows, ch));
+        b->voc_rpf[i] = rpf;
+        const bool fused_level = voc_level_is_fused(b, ch);
+        // fused levels keep the receptive field of the whole six-conv chain as input history (their only streaming state)
+        SVA_TRY(alloc_act(A, b->X[i], B, fused_level ? (kResK[2] - 1) * 2 * (kResD[0] + kResD[1] + kResD[2]) : (kResK[2] - 1) * kResD[0], rows, ch));
         SVA_TRY(register_shift(b, b->X[i], rpf));
         for (int br = 0; br < 3; ++br)
             for (int j = 0; j < 3; ++j) {
@@ -1988,6 +2034,7 @@ extern "C" int sva_vocode_reset(sva_batch* b) {
         return 0;
     };
     SVA_TRY(zero(b->u0)); SVA_TRY(zero(b->u1)); SVA_TRY(zero(b->pin));
+    SVA_HIP(hipMemsetAsync(b->d_voc_frames, 0, sizeof(int), b->stream));
     for (int i = 0; i < 6; ++i) SVA_TRY(zero(b->S[i]));
     for (int i = 0; i < 5; ++i) {
         SVA_TRY(zero(b->X[i]));

@@ -87,6 +87,10 @@ struct ConvGemmGroup {
 };
 
 // gemm_pipe.hip: LDS-DMA ring kernel (Cin % 64 == 0); variant = tile shape, see launch_pipe_gemm
+// fused HiFiGAN ParallelBlock level for C = 16 / 32 (voc_fused.hip)
+bool voc_level_supported(int C);
+int launch_voc_level(const float* X, long x_bstride, int xH, int C, int B, int Tl, const float* const W[3][6], const float* const bias[3][6],
+                     const int dil[3], float* const y3[3], long y_bstride, const int* frames_done, int rows_per_frame, hipStream_t st);
 bool pipe_gemm_supported(const ConvGemm& g);
 int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);

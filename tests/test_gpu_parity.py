@@ -88,10 +88,15 @@ def test_encoder_window_64(eng, weights0):
     b.close()
 
 
-def test_vocoder_window_and_stream(eng, weights0):
+@pytest.mark.parametrize("fused_mask", [None, 0, 3])
+def test_vocoder_window_and_stream(eng, weights0, fused_mask, monkeypatch):
+    """fused_mask: None = the default policy (C = 16 level fused at this batch size), 0 = every level as tap-split GEMMs,
+    3 = both narrow levels (C = 16 and C = 32) through the fused LDS-resident kernel (voc_fused.hip)."""
     from oracle import sva_oracle as O
     from streamvoiceanon_amd import engine as E
 
+    if fused_mask is not None:
+        monkeypatch.setenv("SVA_VOC_FUSED_MASK", str(fused_mask))
     g = load_golden("vocoder_s0")
     codes = g["codes"].astype(np.int32)
     b = E.Batch(eng, n_streams=1, voc_max_frames=64)
