@@ -411,17 +411,20 @@ def main():
                                      "x_realtime": round(64 * c * 10 / dt2 * FRAME_S, 2),
                                      "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm2.items()},
                                      "roofline": ({**roof2, **stage_rates(64, ms2, tm2, roof2["algorithmic_gflop_per_step"])} if roof2 else None), **extra2}
-    if world == 1 and args.torch_gpu_baseline:
-        import torch as _t
-        eng.close()
-        try:
-            out["torch_gpu_baseline"] = torch_gpu_baseline(args, {k: _t.from_numpy(v) for k, v in W.items()})
-        except Exception as ex:          # a reported extra, never a reason to lose the bench line
-            out["torch_gpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if world == 1 and not args.no_cpu_baseline:
         os.sched_setaffinity(0, cpus_at_start)      # the CPU leg uses all host cores again
         import torch as _t
         out["cpu_baseline"] = cpu_baseline(args, {k: _t.from_numpy(v) for k, v in W.items()})
+    if world == 1 and args.torch_gpu_baseline:
+        import torch as _t
+        eng.close()
+        try:
+            from oracle import sva_oracle as _O
+            _O._FB_CACHE.clear()             # (the oracle caches its mel filterbank on the device it was first built on)
+            out["torch_gpu_baseline"] = torch_gpu_baseline(args, {k: _t.from_numpy(v) for k, v in W.items()})
+            _O._FB_CACHE.clear()
+        except Exception as ex:          # a reported extra, never a reason to lose the bench line
+            out["torch_gpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()

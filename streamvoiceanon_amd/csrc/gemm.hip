@@ -52,7 +52,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvGemmG
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    int tbx = blockIdx.x, tby = blockIdx.y;
+    xcd_tile(gg.xcd_swz, gridDim.x, gridDim.y, tbx, tby);
+    const int bm0 = tby * BM, bn0 = tbx * BN;
     const int kq = tid % F4R;                     // which float4 of the BK-wide k tile
     const int lrow = tid / F4R;
 
@@ -632,6 +634,7 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
     ConvGemmGroup gg;
     if (t_group) gg = *t_group; else gg.g[0] = g;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, gg.n);
+    gg.xcd_swz = xcd_swizzle_for(grid.x, grid.y);
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK>), grid, dim3(64 * WM * WN), smem, st, gg);
     return 0;
 }

@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) void pipe_gemm_kernel(const ConvGemmGroup gg) 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    int tbx = blockIdx.x, tby = blockIdx.y;
+    xcd_tile(gg.xcd_swz, gridDim.x, gridDim.y, tbx, tby);
+    const int bm0 = tby * BM, bn0 = tbx * BN;
     const long Kt = (long)g.taps * g.Cin;
 
     // chunk q = tid + 256 j of a tile: row q >> 4, chunk q & 15 (16 consecutive lanes = one 256-byte row: coalesced)
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(256) void pipe_gemm_kernel(const ConvGemmGroup gg) 
 }
 
 template <int BM, int BN, int RS, int PRO>
-int launch_pipe_p(const ConvGemmGroup& gg, hipStream_t st) {
+int launch_pipe_p(const ConvGemmGroup& gg_in, hipStream_t st) {
+    ConvGemmGroup gg = gg_in;
     constexpr size_t ring = (size_t)2 * (BM + BN) * 64 * sizeof(float) + 2048 * sizeof(float);
     constexpr size_t epi = ((size_t)BM * (BN + 4) + BM) * sizeof(float);
     constexpr size_t smem = ring > epi ? ring : epi;
@@ -265,6 +268,7 @@ int launch_pipe_p(const ConvGemmGroup& gg, hipStream_t st) {
     }
     const ConvGemm& g = gg.g[0];
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, gg.n);
+    gg.xcd_swz = xcd_swizzle_for(grid.x, grid.y);
     hipLaunchKernelGGL((pipe_gemm_kernel<BM, BN, RS, PRO>), grid, dim3(256), smem, st, gg);
     return 0;
 }

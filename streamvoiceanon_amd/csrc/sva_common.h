@@ -1,5 +1,6 @@
 // Common declarations of the sva HIP engine (gfx950 / MI355X only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -84,7 +85,25 @@ struct ConvGemm {
 struct ConvGemmGroup {
     ConvGemm g[3];
     int n = 1;
+    int xcd_swz = 0;            // tiled kernels: remap the workgroup id so that each XCD owns a contiguous band of M tiles
 };
+
+// Workgroup b runs on XCD b % 8 (observed placement; a speed assumption only).  With the default N-fastest tile order the eight
+// workgroups that share an A row panel sit on eight XCDs and each of the eight private L2s fetches the panel from the fabric;
+// this bijective remap gives XCD k the k-th contiguous eighth of the tile sequence, i.e. a band of M tiles with all its N
+// tiles -- the panel is fetched once and re-read from that XCD's L2 (cdna_hip_programming.md, "XCD swizzle must be bijective").
+// host side: remap only grids that give every XCD several M bands' worth of tiles (SVA_XCD_SWIZZLE=0 disables)
+inline int xcd_swizzle_for(unsigned nx, unsigned ny) {
+    static const int on = getenv("SVA_XCD_SWIZZLE") ? atoi(getenv("SVA_XCD_SWIZZLE")) : 1;
+    return on && nx >= 2 && ny >= 16 ? 1 : 0;
+}
+__device__ __forceinline__ void xcd_tile(int swz, int nx, int ny, int& bx, int& by) {
+    if (!swz) return;
+    const int T = nx * ny, L = by * nx + bx;
+    const int xcd = L & 7, idx = L >> 3, q = T >> 3, r = T & 7;
+    const int V = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    by = V / nx; bx = V - by * nx;
+}
 
 // gemm_pipe.hip: LDS-DMA ring kernel (Cin % 64 == 0); variant = tile shape, see launch_pipe_gemm
 // fused HiFiGAN ParallelBlock level for C = 16 / 32 (voc_fused.hip)

@@ -7,9 +7,21 @@ import sys
 
 tag = sys.argv[1]
 per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+# steady state only: the dispatches of steps [SKIP, SKIP + STEPS) -- every (non-pipelined) step starts with one ring_write_kernel;
+# prompt prefill, delay fill, warm-up and the trailing latency-sample steps of bench.py stay outside the window
+SKIP, STEPS = 10, 100
+window_note = None
 for name in ("RD", "WR", "MFMA", "MOPS"):
     for f in glob.glob(f"gpurun_out/pmc_{tag}_{name}/*counter_collection.csv"):
-        for row in csv.DictReader(open(f)):
+        rows = list(csv.DictReader(open(f)))
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows if "ring_write" in r["Kernel_Name"]})
+        lo, hi = None, None
+        if len(ids) >= SKIP + 2:
+            lo, hi = ids[SKIP], ids[min(SKIP + STEPS, len(ids) - 1)]
+            window_note = f"dispatches of {min(SKIP + STEPS, len(ids) - 1) - SKIP} steady steps (after {SKIP} start-up steps)"
+        for row in rows:
+            if lo is not None and not (lo <= int(row["Dispatch_Id"]) < hi):
+                continue
             a = per[row["Kernel_Name"]][row["Counter_Name"]]
             a[0] += 1
             a[1] += float(row["Counter_Value"])
@@ -42,7 +54,8 @@ busy = sum(per[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1] for k in gemm if "SQ_VALU_MFMA_
 act = sum(per[k]["GRBM_GUI_ACTIVE"][1] for k in gemm if "GRBM_GUI_ACTIVE" in per[k])
 summary = {
     "tag": tag,
-    "note": "per-launch averages over every conv-GEMM dispatch (tiled + skinny kernels) of the profiled bench run incl. prompt prefill; "
+    "window": window_note or "whole run (no step marker found)",
+    "note": "per-launch averages over every conv-GEMM dispatch (pipe / tiled / skinny kernels) inside the window; "
             "reads = 32 B x RDREQ_32B + 2 x 64 B x (RDREQ - RDREQ_32B) (FETCH_SIZE definition + gfx950 x2 correction of "
             "MI355X_MICROARCH.md); writes = WRITE_SIZE KiB x 1024 (uncalibrated)",
     "gemm_mfma_util": (busy / (act * 128.0)) if act > 0 else None,
