@@ -2621,6 +2621,8 @@ int step_body(sva_batch* b) {
 
 }  // namespace
 
+static int check_ar_fail(sva_batch* b);
+
 extern "C" int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const float* noise, const int32_t* forced_codes) {
     SVA_CHECK(b && pcm_in && pcm_out && b->begun, "sva_step: bad argument or sva_streams_begin not called");
     SVA_HIP(hipSetDevice(b->e->device));
@@ -2644,6 +2646,7 @@ extern "C" int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const
     SVA_TRY(step_body(b));
     SVA_HIP(hipMemcpy2DAsync(b->hp_out, sizeof(float) * n, b->d_pcm, sizeof(float) * 2048 * b->Tv, sizeof(float) * n, B, hipMemcpyDeviceToHost, st));
     SVA_HIP(hipStreamSynchronize(st));
+    SVA_TRY(check_ar_fail(b));
     memcpy(pcm_out, b->hp_out, sizeof(float) * (size_t)B * n);
     float t;
     if (!b->graph_step)
@@ -2711,12 +2714,24 @@ extern "C" int sva_stream_chunks(sva_batch* b, const float* pcm_in, float* pcm_o
     return rc;
 }
 
+// the persistent decode kernel gives up on a hand-off that does not arrive (bounded spin) and records where: surface it at the
+// next synchronisation instead of returning garbage codes
+static int check_ar_fail(sva_batch* b) {
+    if (!b->use_mega || !b->d_ar_fail) return 0;
+    int f = 0;
+    SVA_HIP(hipMemcpy(&f, b->d_ar_fail, sizeof(int), hipMemcpyDeviceToHost));
+    SVA_CHECK(f == 0, "persistent AR decode kernel timed out waiting for a workgroup hand-off (code " + std::to_string(f) +
+                      "): are all 96 workgroups resident? (SVA_AR_MEGA=0 selects the multi-launch decode)");
+    return 0;
+}
+
 extern "C" int sva_sync(sva_batch* b) {
     SVA_CHECK(b, "null batch");
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
     SVA_TRY(quiesce(b));
     SVA_HIP(hipStreamSynchronize(b->stream));
+    SVA_TRY(check_ar_fail(b));
     float t;
     if (!b->graph_step)
         for (int i = 0; i < 3; ++i)
