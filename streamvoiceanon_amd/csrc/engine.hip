@@ -941,7 +941,7 @@ int encode(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
 int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add, bool transformer_too = true) {
     const int D = b->e->cfg.tr_dim, c = b->p.chunk_frames;
     hipStream_t st = b->stream;
-    SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, b->B, st));                   // steady tokens slide down by c
+    SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, b->B, st, 16));                   // steady tokens slide down by c
     if (b->enc_merged) {
         SVA_TRY(enc_frontend_merged(b, step_ptr, n_chunk, add));
         if (transformer_too) return enc_transformer(b, b->d2c, b->p.chunk_frames);
@@ -1553,7 +1553,7 @@ int vocode(sva_batch* b, int T, bool shift, int part = 0) {
             SVA_HIP(hipMemcpyAsync(b->d_shift, b->shift_host.data(), sizeof(ShiftDesc) * b->shift_host.size(), hipMemcpyHostToDevice, st));
             SVA_HIP(hipStreamSynchronize(st));
         }
-        SVA_TRY(launch_shift_history(b->d_shift, (int)b->shift_host.size(), B, st));
+        SVA_TRY(launch_shift_history(b->d_shift, (int)b->shift_host.size(), B, st, b->B <= 8 ? 4 : 1));
         SVA_TRY(launch_add_i32(b->d_voc_frames, T, st));      // (the fused levels ask whether their halo lies inside the stream)
     }
     return 0;
@@ -2357,7 +2357,7 @@ int steady_pipelined(sva_batch* b) {
                 SVA_TRY(stream_fork(b, se, sx));
                 int src_ = stage_graph(b, &b->gEs[par], sx, [&]() -> int {
                     b->stream = sx;
-                    SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, sx));               // steady tokens slide down by c
+                    SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, sx, 16));               // steady tokens slide down by c
                     return enc_frontend_merged(b, nullptr, n, 1, 4, par);
                 });
                 b->stream = se;
@@ -2375,7 +2375,7 @@ int steady_pipelined(sva_batch* b) {
             if (b->pipe_evD2C) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evD2C, 0));
             SVA_TRY(stage_graph(b, &b->gE2, se, [&]() -> int {
                 b->stream = se;
-                SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se));                   // steady tokens slide down by c
+                SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se, 16));                   // steady tokens slide down by c
                 SVA_TRY(enc_frontend_merged(b, b->d_step, n, 1, 2));
                 return launch_add_i32(b->d_step, 1, se);
             }));
@@ -2406,7 +2406,7 @@ int steady_pipelined(sva_batch* b) {
             SVA_TRY(mark(4, sx));
         } else {
         SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
-        SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se));                       // steady tokens slide down by c
+        SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, B, se, 16));                       // steady tokens slide down by c
         int erc = 0;
         if (b->stream_cut > 0) {          // the first stages of the streaming pass run on main (its chunk counter), the rest on sx
             SVA_TRY(enc_frontend_stream(b, b->d_step, n, 1, 1));

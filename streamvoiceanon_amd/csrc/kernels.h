@@ -87,7 +87,7 @@ struct ShiftDesc {      // one history buffer: rows [T, T+H) move to [0, H) afte
     int H, T, C;
     int pad;
 };
-int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStream_t st);
+int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStream_t st, int col_slices = 1);
 
 // small helpers
 int launch_fill_i32(int* p, int n, int v, hipStream_t st);

@@ -1555,22 +1555,25 @@ __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
     const int nrows = min(256, T - t0) + k - 1;
+    const int LD = C + 1;                // odd row stride: thread t reads row t + j, so a stride of C = 16 would put 64 lanes on 2 banks
     const float* xb = x + (long)b * x_bstride + x_off + (long)t0 * C;
-    for (int i = tid; i < nrows * C; i += 256) smem[i] = silu_acc(xb[i]);
-    float* ws = smem + (256 + k - 1) * C;
+    for (int i = tid; i < nrows * C; i += 256) smem[(i / C) * LD + (i % C)] = silu_acc(xb[i]);
+    float* ws = smem + (256 + k - 1) * LD;
     for (int i = tid; i < k * C; i += 256) ws[i] = w[i];
     __syncthreads();
     const int t = t0 + tid;
     if (t < T) {
         float acc = bias[0];
-        const float* r = smem + tid * C;
-        for (int i = 0; i < k * C; ++i) acc = fmaf(ws[i], r[i], acc);
+        for (int j = 0; j < k; ++j) {    // same accumulation order as before: taps outer, channels inner
+            const float* r = smem + (tid + j) * LD;
+            for (int c = 0; c < C; ++c) acc = fmaf(ws[j * C + c], r[c], acc);
+        }
         pcm[(long)b * p_bstride + p_off + t] = tanhf(acc);
     }
 }
 int launch_conv_post_tanh(const float* x, long x_bstride, long x_off, int B, int T, int C, int k, const float* w,
                           const float* bias, float* pcm, long p_bstride, long p_off, hipStream_t st) {
-    const size_t smem = ((size_t)(256 + k - 1) * C + (size_t)k * C) * sizeof(float);
+    const size_t smem = ((size_t)(256 + k - 1) * (C + 1) + (size_t)k * C) * sizeof(float);
     SVA_CHECK(smem <= 64 * 1024, "conv_post: tile too large");
     hipLaunchKernelGGL(conv_post_tanh_kernel, dim3((T + 255) / 256, B), dim3(256), smem, st, x, x_bstride, x_off, T, C, k, w,
                        bias, pcm, p_bstride, p_off);
@@ -1584,29 +1587,37 @@ int launch_conv_post_tanh(const float* x, long x_bstride, long x_off, int B, int
 // (tensor, stream) walks the rows in increasing address order (dst < src always), staging
 // each 256-element chunk in registers across a barrier so overlapping ranges are safe.
 // ------------------------------------------------------------------------------------------
+// gridDim.z column slices per tensor: element (r, c) moves to (r - T, c), so slices of the channel axis are independent and a long
+// tensor (the encoder's token cache: 88 rows x 512) is not one workgroup's serial loop
 __global__ __launch_bounds__(256) void shift_history_kernel(const ShiftDesc* __restrict__ descs) {
     const ShiftDesc d = descs[blockIdx.x];
     float* base = d.ptr + (long)blockIdx.y * d.bstride;
-    const long n = (long)d.H * d.C, delta = (long)d.T * d.C;
+    const int zs = gridDim.z;
+    const int cs = (d.C % (4 * zs) == 0) ? d.C / zs : d.C;           // slice width (whole tensor in slice 0 if C does not split)
+    if (cs == d.C && blockIdx.z > 0) return;
+    const int c0 = cs == d.C ? 0 : (int)blockIdx.z * cs;
+    const long n = (long)d.H * cs, delta = (long)d.T * d.C;
     for (long i0 = 0; i0 < n; i0 += 4096) {
         float v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const long i = i0 + threadIdx.x + e * 256;
-            v[e] = i < n ? base[i + delta] : 0.f;
+            const long r = i / cs, c = i - r * cs;
+            v[e] = i < n ? base[r * d.C + c0 + c + delta] : 0.f;
         }
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const long i = i0 + threadIdx.x + e * 256;
-            if (i < n) base[i] = v[e];
+            const long r = i / cs, c = i - r * cs;
+            if (i < n) base[r * d.C + c0 + c] = v[e];
         }
         __syncthreads();
     }
 }
-int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStream_t st) {
+int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStream_t st, int col_slices) {
     if (n_desc == 0) return 0;
-    hipLaunchKernelGGL(shift_history_kernel, dim3(n_desc, B), dim3(256), 0, st, descs_dev);
+    hipLaunchKernelGGL(shift_history_kernel, dim3(n_desc, B, col_slices < 1 ? 1 : col_slices), dim3(256), 0, st, descs_dev);
     SVA_HIP(hipGetLastError());
     return 0;
 }
