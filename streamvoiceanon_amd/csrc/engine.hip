@@ -1671,6 +1671,10 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         b->aux[0] = ss.aux0;
         b->aux[1] = b->voc_grouped ? nullptr : ss.aux1;
         if (b->p.pipeline) { b->sa = ss.sa; b->sv = ss.sv; }
+        // split-K scratch per stream, now: a launch inside a stream capture must not allocate (and must not fall back to an
+        // unsplit launch, which sums in a different order than the eager launch of the same shape)
+        for (hipStream_t s_ : {ss.main, ss.aux0, ss.aux1, ss.sa, ss.sv})
+            if (s_) SVA_TRY(conv_gemm_prepare_stream(s_));
     }
     b->out_stream = b->stream;
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));

@@ -464,36 +464,56 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
         }
         if (Z == 1) {
             epilogue(i, t);
-        } else {          // raw partial tile of this K split, register layout (1 KiB per 16x16 tile, coalesced)
+        } else {          // raw partial tile of this K split as self-validating granules {tag = 1, value} (register layout)
+            unsigned long long* gw = reinterpret_cast<unsigned long long*>(g.ks_ws);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                *reinterpret_cast<f32x4*>(g.ks_ws + ((((long)ks * n_tiles + tile) * MT + i) * NT + j) * 256 + lane * 4) = t[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    __hip_atomic_store(gw + ((((long)ks * n_tiles + tile) * MT + i) * NT + j) * 256 + e * 64 + lane,
+                                       (1ull << 32) | (unsigned long long)__float_as_uint(t[j][e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (Z == 1) return;
-    // The last workgroup to arrive for this output tile sums the Z partials in split order (deterministic) and runs the
-    // epilogue.  ks_ws / ks_cnt are uncached memory, so the reader needs no L2 invalidate; the WRITERS do need an agent-scope
-    // release: with a workgroup-scope one (stores merely acknowledged) another XCD occasionally read a stale partial
-    // (tools/pipe_stress.py with SVA_KSPLIT=1 caught it), and the agent-scope release makes the split slower than not
-    // splitting on every shape measured -- which is why the feature stays off.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // The last workgroup to arrive for this output tile sums the Z partials in split order (deterministic) and runs the epilogue.
+    // Hand-off without fences (guide G16, form R2 -- as in ar_decode.hip): every datum is an 8-byte granule {tag, value} written
+    // with one relaxed agent-scope atomic store, the reader polls each granule until its tag is set.  The arrival counter only
+    // ELECTS the reader, it carries no visibility promise: a writer's granules may land after its counter increment, the poll
+    // covers that.  The reader clears the tags it consumed (the next launch on this stream starts behind a kernel boundary).
+    // An agent-scope release per writer -- what a counter-validated hand-off needs across XCDs -- cost more than the split won.
     __syncthreads();
     if (tid == 0) {
-        const unsigned old = atomicAdd(g.ks_cnt + tile, 1u);
-        if (old == (unsigned)(Z - 1)) g.ks_cnt[tile] = 0;          // re-armed for the next launch on this stream
+        const unsigned old = __hip_atomic_fetch_add(g.ks_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(Z - 1)) __hip_atomic_store(g.ks_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
         reinterpret_cast<unsigned*>(red)[0] = old;
     }
     __syncthreads();
     if (reinterpret_cast<const unsigned*>(red)[0] != (unsigned)(Z - 1)) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    unsigned long long* gw = reinterpret_cast<unsigned long long*>(g.ks_ws);
     for (int i = wave; i < MT; i += KW) {
         f32x4 t[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            f32x4 s = *reinterpret_cast<const f32x4*>(g.ks_ws + (((long)tile * MT + i) * NT + j) * 256 + lane * 4);
-            for (int z = 1; z < Z; ++z)
-                s += *reinterpret_cast<const f32x4*>(g.ks_ws + ((((long)z * n_tiles + tile) * MT + i) * NT + j) * 256 + lane * 4);
-            t[j] = s;
+        for (int j = 0; j < NT; ++j) t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < Z; ++z) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                unsigned long long* gp = gw + ((((long)z * n_tiles + tile) * MT + i) * NT + j) * 256 + lane;
+                unsigned long long x[4];
+                unsigned pending = 0xfu;
+                for (int spin = 0; pending && spin < (1 << 20); ++spin) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (pending & (1u << e)) {
+                            x[e] = __hip_atomic_load(gp + e * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)(x[e] >> 32) == 1u) pending &= ~(1u << e);
+                        }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    t[j][e] += __uint_as_float((unsigned)x[e]);
+                    __hip_atomic_store(gp + e * 64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         epilogue(i, t);
     }
@@ -508,7 +528,7 @@ static thread_local int t_ksplit = 1;
 struct KsScratch { float* ws = nullptr; unsigned* cnt = nullptr; };
 static std::mutex g_ks_mu;
 static std::unordered_map<hipStream_t, KsScratch> g_ks;
-constexpr size_t KS_WS_FLOATS = (size_t)8 << 20;      // 32 MiB of partial tiles
+constexpr size_t KS_WS_FLOATS = (size_t)4 << 20;      // granules of partial tiles (8 bytes each: 32 MiB)
 constexpr int KS_CNT = 1 << 16;
 static int ks_scratch(hipStream_t st, KsScratch* out) {
     std::lock_guard<std::mutex> lk(g_ks_mu);
@@ -520,11 +540,20 @@ static int ks_scratch(hipStream_t st, KsScratch* out) {
     // UNCACHED device memory: partial tiles and counters bypass the (per-XCD, mutually incoherent) L2s, so the hand-off
     // needs no agent-scope fence -- an agent-scope release / acquire per workgroup writes back / invalidates the whole
     // L2 and serialises (measured: + 0.37 us per workgroup)
-    SVA_HIP(hipExtMallocWithFlags((void**)&k.ws, KS_WS_FLOATS * sizeof(float), hipDeviceMallocUncached));
+    SVA_HIP(hipExtMallocWithFlags((void**)&k.ws, KS_WS_FLOATS * 8, hipDeviceMallocUncached));
+    SVA_HIP(hipMemset(k.ws, 0, KS_WS_FLOATS * 8));
     SVA_HIP(hipExtMallocWithFlags((void**)&k.cnt, KS_CNT * sizeof(unsigned), hipDeviceMallocUncached));
     SVA_HIP(hipMemset(k.cnt, 0, KS_CNT * sizeof(unsigned)));
     g_ks[st] = k;
     *out = k;
+    return 0;
+}
+
+// split-K scratch of a stream, allocated ahead of time: a launch inside a stream capture cannot allocate and would silently fall
+// back to an unsplit launch -- a different summation order from the eager launch of the same shape
+int conv_gemm_prepare_stream(hipStream_t st) {
+    KsScratch k;
+    SVA_TRY_RC(ks_scratch(st, &k));
     return 0;
 }
 
@@ -673,7 +702,7 @@ static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
 }
 
 static bool ksplit_enabled() {
-    static const bool on = getenv("SVA_KSPLIT") && atoi(getenv("SVA_KSPLIT")) != 0;
+    static const bool on = !getenv("SVA_KSPLIT") || atoi(getenv("SVA_KSPLIT")) != 0;
     return on;
 }
 

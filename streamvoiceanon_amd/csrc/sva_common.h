@@ -110,6 +110,7 @@ __device__ __forceinline__ void xcd_tile(int swz, int nx, int ny, int& bx, int& 
 bool voc_level_supported(int C);
 int launch_voc_level(const float* X, long x_bstride, int xH, int C, int B, int Tl, const float* const W[3][6], const float* const bias[3][6],
                      const int dil[3], float* const y3[3], long y_bstride, const int* frames_done, int rows_per_frame, hipStream_t st);
+int conv_gemm_prepare_stream(hipStream_t st);
 bool pipe_gemm_supported(const ConvGemm& g);
 int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);

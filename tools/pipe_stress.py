@@ -7,7 +7,8 @@ from oracle import sva_oracle as O
 from streamvoiceanon_amd import engine as E, specs
 from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
 
-W = O.load_synth_weights(0, specs.all_specs())
+from streamvoiceanon_amd import synth_weights
+W = synth_weights.generate_all(0, specs.all_specs())
 eng = E.Engine(W)
 n_chunks = int(os.environ.get("NCH", "60"))
 reps = int(os.environ.get("REPS", "6"))
