@@ -331,6 +331,7 @@ struct sva_batch {
     hipGraphExec_t gEm[2] = {nullptr, nullptr}, gEs[2] = {nullptr, nullptr};      // front-end cut behind the backbone: main part / side part, per parity
     hipEvent_t pipe_evFeat[2] = {nullptr, nullptr};
     int enc_cut = 1;
+    int* step_bump = nullptr;              // set around a front-end call whose last kernel should also advance this counter
     int voc_fused_mask = -1;               // -1: default policy; else bit 0: the C = 16 level, bit 1: the C = 32 level
     bool voc_fused = true;                 // narrow vocoder levels (C <= 32) as one fused launch (voc_fused.hip)
     int* d_voc_frames = nullptr;           // code frames the streaming vocoder has consumed since its last reset

@@ -818,8 +818,8 @@ int enc_frontend_merged(sva_batch* b, const int* step_ptr, int n_chunk, int add,
         return 0;
     }
     const long mag_bs = (long)R0 * 1088;
-    SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, M.mag, 1088, mag_bs, 0, Hh, st));
-    SVA_TRY(launch_stft_mag_ring(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, M.mag + (long)(Hh + 6) * 1088, 1088, mag_bs, b->T0 - nm, nm, st));
+    // head frames 0 .. Hh and the nm newest frames of the window in one launch (output rows [0, Hh) and [Hh + 6, R0))
+    SVA_TRY(launch_stft_mag_ring2(b->ring, step_ptr, n_chunk, add, B, b->N, e->twiddle, e->hann, M.mag, 1088, mag_bs, 0, Hh, b->T0 - nm, nm, Hh + 6, st));
     {
         ConvGemm p;
         p.act = ACT_LOGCLAMP; p.skip_lo = Hh; p.skip_hi = Hh + 6;
@@ -829,9 +829,8 @@ int enc_frontend_merged(sva_batch* b, const int* step_ptr, int n_chunk, int add,
     SVA_TRY(gemm_call(b, M.mel.p, M.mel.bstride, 0, c.n_mels, B, R0, 1, 1, 7, c.n_mels, F.stem, M.stem, (long)R0 * C0, 0, C0));
     {   // LayerNorm of the stem output into the first block's input: head rows and new rows (its history rows stay)
         Act& X = M.x[0][0];
-        SVA_TRY(launch_layernorm_rows(M.stem, (long)R0 * C0, 0, C0, B, Hh, C0, F.stem_lnw, F.stem_lnb, 1e-6f, X.p, X.bstride, (long)X.H * C0, C0, st));
-        SVA_TRY(launch_layernorm_rows(M.stem, (long)R0 * C0, (long)(Hh + 6) * C0, C0, B, nm, C0, F.stem_lnw, F.stem_lnb, 1e-6f, X.p, X.bstride,
-                                      (long)(X.H + Hh + 6) * C0, C0, st));
+        SVA_TRY(launch_layernorm_rows(M.stem, (long)R0 * C0, 0, C0, B, R0, C0, F.stem_lnw, F.stem_lnb, 1e-6f, X.p, X.bstride, (long)X.H * C0, C0, st,
+                                      Hh, Hh + 6));
     }
     for (int i = 0; i < 4; ++i) {
         const int C = c.enc_dims[i];
@@ -851,7 +850,7 @@ int enc_frontend_merged(sva_batch* b, const int* step_ptr, int n_chunk, int add,
         }
     }
     SVA_TRY(launch_layernorm_rows(M.xout[3].p, M.xout[3].bstride, 0, D, B, R0, D, F.final_lnw, F.final_lnb, 1e-6f, feat.p, feat.bstride, 0, D, st));
-    if (part == 3) return launch_shift_history(M.d_shift, M.n_shift - n_shift_ds, B, st);
+    if (part == 3) return launch_shift_history(M.d_shift, M.n_shift - n_shift_ds, B, st, 1, b->step_bump, 1);       // (+ the chain's step counter)
     // BSQ downsample x2 (conv k2 s2 + ConvNeXtBlock, bsq_no_upsample.py:48-61); the strided convs run per row group
     SVA_TRY(gemm_call(b, feat.p, feat.bstride, 0, D, B, Hh / 2, 2, 1, 2, D, F.ds_conv[0], M.d1.p, M.d1.bstride, (long)M.d1.H * D, D));
     SVA_TRY(gemm_call(b, feat.p, feat.bstride, (long)(Hh + 6) * D, D, B, nm / 2, 2, 1, 2, D, F.ds_conv[0], M.d1.p, M.d1.bstride,
@@ -2353,8 +2352,10 @@ int steady_pipelined(sva_batch* b) {
                 SVA_TRY(stage_graph(b, &b->gEm[par], se, [&]() -> int {
                     b->stream = se;
                     SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
-                    SVA_TRY(enc_frontend_merged(b, b->d_step, n, 1, 3, par));
-                    return launch_add_i32(b->d_step, 1, se);
+                    b->step_bump = b->d_step;              // the history shift that ends the chain also advances the chunk counter
+                    const int frc = enc_frontend_merged(b, b->d_step, n, 1, 3, par);
+                    b->step_bump = nullptr;
+                    return frc;
                 }));
                 SVA_TRY(mark(1, se));
                 SVA_TRY(mark(2, sx));

@@ -11,6 +11,9 @@ namespace sva {
 //   written, pad columns zeroed
 int launch_stft_mag_ring(const float* ring, const int* step, int n_chunk, int add, int B, int N, const float2* twiddle,
                          const float* hann, float* mag, int ldm, long mag_bstride, int m0, int nfr, hipStream_t st);
+//   two frame ranges in one launch: frames [m0, m0+nfr) -> rows [0, nfr), frames [m0b, m0b+nfrb) -> rows [row_b0, row_b0+nfrb)
+int launch_stft_mag_ring2(const float* ring, const int* step, int n_chunk, int add, int B, int N, const float2* twiddle,
+                          const float* hann, float* mag, int ldm, long mag_bstride, int m0, int nfr, int m0b, int nfrb, int row_b0, hipStream_t st);
 
 // depthwise causal k=7 conv + LayerNorm(eps) over channels (ConvNeXtBlock prologue).
 //   x element (b, r, c): x[b*x_bstride + x_off + r*C + c]; output row t reads rows t..t+6.
@@ -22,7 +25,7 @@ int launch_dwconv7_ln(const float* x, long x_bstride, long x_off, int B, int T, 
 // row LayerNorm / RMSNorm with strided in/out (rows = B*T).
 int launch_layernorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C,
                           const float* w, const float* b, float eps, float* out, long o_bstride, long o_off,
-                          int ldo, hipStream_t st);
+                          int ldo, hipStream_t st, int skip_lo = 0, int skip_hi = 0);      // rows t in [skip_lo, skip_hi) of each item are left alone
 int launch_rmsnorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
                         float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st);
 
@@ -87,7 +90,7 @@ struct ShiftDesc {      // one history buffer: rows [T, T+H) move to [0, H) afte
     int H, T, C;
     int pad;
 };
-int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStream_t st, int col_slices = 1);
+int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStream_t st, int col_slices = 1, int* counter = nullptr, int counter_add = 0);
 
 // small helpers
 int launch_fill_i32(int* p, int n, int v, hipStream_t st);

@@ -55,10 +55,14 @@ int launch_fill_i32(int* p, int n, int v, hipStream_t st) {
 __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ ring, const int* step, int n_chunk,
                                                        int add, int N, const float2* __restrict__ tw,
                                                        const float* __restrict__ hann, float* __restrict__ mag,
-                                                       int ldm, long mag_bstride, int m0) {
+                                                       int ldm, long mag_bstride, int m0, int seg_a, int m0b, int row_b0) {
     __shared__ float re[2048];
     __shared__ float im[2048];
-    const int m = m0 + blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    // frames [0, seg_a) of the grid: window frames m0 .. -> output rows 0 ..; the rest: window frames m0b .. -> output rows row_b0 ..
+    const bool second = (int)blockIdx.x >= seg_a;
+    const int m = second ? m0b + ((int)blockIdx.x - seg_a) : m0 + (int)blockIdx.x;
+    const int out_row = second ? row_b0 + ((int)blockIdx.x - seg_a) : (int)blockIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
     const int start = step ? (int)(((long)(*step + add) * n_chunk) % N) : 0;
     const float* rb = ring + (long)b * N;
     for (int i = tid; i < 2048; i += 256) {
@@ -92,13 +96,22 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
         }
         __syncthreads();
     }
-    float* out = mag + (long)b * mag_bstride + (long)blockIdx.x * ldm;
+    float* out = mag + (long)b * mag_bstride + (long)out_row * ldm;
     for (int k = tid; k < ldm; k += 256) out[k] = k <= 1024 ? sqrtf(re[k] * re[k] + im[k] * im[k] + 1e-6f) : 0.f;
 }
 int launch_stft_mag_ring(const float* ring, const int* step, int n_chunk, int add, int B, int N, const float2* tw,
                          const float* hann, float* mag, int ldm, long mag_bstride, int m0, int nfr, hipStream_t st) {
     SVA_CHECK(N % 512 == 0 && ldm >= 1025 && m0 >= 0 && m0 + nfr <= N / 512, "stft: bad shape");
-    hipLaunchKernelGGL(stft_mag_kernel, dim3(nfr, B), dim3(256), 0, st, ring, step, n_chunk, add, N, tw, hann, mag, ldm, mag_bstride, m0);
+    hipLaunchKernelGGL(stft_mag_kernel, dim3(nfr, B), dim3(256), 0, st, ring, step, n_chunk, add, N, tw, hann, mag, ldm, mag_bstride, m0, nfr, 0, 0);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+// two frame ranges in one launch: frames [m0, m0 + nfr) -> rows [0, nfr), frames [m0b, m0b + nfrb) -> rows [row_b0, row_b0 + nfrb)
+int launch_stft_mag_ring2(const float* ring, const int* step, int n_chunk, int add, int B, int N, const float2* tw,
+                          const float* hann, float* mag, int ldm, long mag_bstride, int m0, int nfr, int m0b, int nfrb, int row_b0, hipStream_t st) {
+    SVA_CHECK(N % 512 == 0 && ldm >= 1025 && m0 >= 0 && m0 + nfr <= N / 512 && m0b >= 0 && m0b + nfrb <= N / 512, "stft: bad shape");
+    hipLaunchKernelGGL(stft_mag_kernel, dim3(nfr + nfrb, B), dim3(256), 0, st, ring, step, n_chunk, add, N, tw, hann, mag, ldm, mag_bstride, m0, nfr,
+                       m0b, row_b0);
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -193,11 +206,12 @@ template <int NPL, bool RMS>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ x, long x_bstride, long x_off, int ldx,
                                                         int T, int C, int rows, const float* __restrict__ w,
                                                         const float* __restrict__ bvec, float eps,
-                                                        float* __restrict__ out, long o_bstride, long o_off, int ldo) {
+                                                        float* __restrict__ out, long o_bstride, long o_off, int ldo, int skip_lo, int skip_hi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const int b = row / T, t = row - b * T;
+    if (t >= skip_lo && t < skip_hi) return;          // rows the caller keeps (streaming history of the merged encoder pass)
     const float* xr = x + (long)b * x_bstride + x_off + (long)t * ldx;
     float* o = out + (long)b * o_bstride + o_off + (long)t * ldo;
     float v[NPL];
@@ -229,11 +243,11 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
 }
 template <bool RMS>
 static int launch_norm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
-                            const float* b, float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st) {
+                            const float* b, float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st, int skip_lo = 0, int skip_hi = 0) {
     SVA_CHECK(C % 64 == 0 && C <= 1024, "norm_rows: C must be a multiple of 64, <= 1024");
     const int rows = B * T;
     dim3 grid((rows + 3) / 4);
-#define SVA_NR(N_) hipLaunchKernelGGL((norm_rows_kernel<N_, RMS>), grid, dim3(256), 0, st, x, x_bstride, x_off, ldx, T, C, rows, w, b, eps, out, o_bstride, o_off, ldo)
+#define SVA_NR(N_) hipLaunchKernelGGL((norm_rows_kernel<N_, RMS>), grid, dim3(256), 0, st, x, x_bstride, x_off, ldx, T, C, rows, w, b, eps, out, o_bstride, o_off, ldo, skip_lo, skip_hi)
     switch (C / 64) {
         case 1: SVA_NR(1); break;
         case 2: SVA_NR(2); break;
@@ -250,8 +264,8 @@ static int launch_norm_rows(const float* x, long x_bstride, long x_off, int ldx,
     return 0;
 }
 int launch_layernorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
-                          const float* b, float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st) {
-    return launch_norm_rows<false>(x, x_bstride, x_off, ldx, B, T, C, w, b, eps, out, o_bstride, o_off, ldo, st);
+                          const float* b, float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st, int skip_lo, int skip_hi) {
+    return launch_norm_rows<false>(x, x_bstride, x_off, ldx, B, T, C, w, b, eps, out, o_bstride, o_off, ldo, st, skip_lo, skip_hi);
 }
 int launch_rmsnorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
                         float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st) {
@@ -1589,7 +1603,9 @@ int launch_conv_post_tanh(const float* x, long x_bstride, long x_off, int B, int
 // ------------------------------------------------------------------------------------------
 // gridDim.z column slices per tensor: element (r, c) moves to (r - T, c), so slices of the channel axis are independent and a long
 // tensor (the encoder's token cache: 88 rows x 512) is not one workgroup's serial loop
-__global__ __launch_bounds__(256) void shift_history_kernel(const ShiftDesc* __restrict__ descs) {
+__global__ __launch_bounds__(256) void shift_history_kernel(const ShiftDesc* __restrict__ descs, int* counter, int counter_add) {
+    // (the step counter of the chain that ends with this launch: every reader of it precedes this kernel in stream order)
+    if (counter && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *counter += counter_add;
     const ShiftDesc d = descs[blockIdx.x];
     float* base = d.ptr + (long)blockIdx.y * d.bstride;
     const int zs = gridDim.z;
@@ -1615,9 +1631,9 @@ __global__ __launch_bounds__(256) void shift_history_kernel(const ShiftDesc* __r
         __syncthreads();
     }
 }
-int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStream_t st, int col_slices) {
-    if (n_desc == 0) return 0;
-    hipLaunchKernelGGL(shift_history_kernel, dim3(n_desc, B, col_slices < 1 ? 1 : col_slices), dim3(256), 0, st, descs_dev);
+int launch_shift_history(const ShiftDesc* descs_dev, int n_desc, int B, hipStream_t st, int col_slices, int* counter, int counter_add) {
+    if (n_desc == 0) return counter ? launch_add_i32(counter, counter_add, st) : 0;
+    hipLaunchKernelGGL(shift_history_kernel, dim3(n_desc, B, col_slices < 1 ? 1 : col_slices), dim3(256), 0, st, descs_dev, counter, counter_add);
     SVA_HIP(hipGetLastError());
     return 0;
 }
