@@ -674,6 +674,11 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
 struct Choice { int kind, a, b, c; int z = 1; };      // z: grid-level K split of the small-M kernel
 
 static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
+    if (ch.kind == 4) {                 // fp32 on the bf16 matrix pipes, six-product split (gemm_split.hip), a = tile variant
+        ConvGemmGroup gg;
+        if (t_group) gg = *t_group; else gg.g[0] = g;
+        return launch_split_gemm(gg, ch.a, st);
+    }
     if (ch.kind == 2) {                 // LDS-DMA ring kernel (gemm_pipe.hip), a = tile variant
         ConvGemmGroup gg;
         if (t_group) gg = *t_group; else gg.g[0] = g;
@@ -706,6 +711,11 @@ static bool ksplit_enabled() {
     return on;
 }
 
+static bool split_enabled() {
+    static const bool on = !(getenv("SVA_GEMM_SPLIT") && atoi(getenv("SVA_GEMM_SPLIT")) == 0);
+    return on;
+}
+
 static bool pipe_enabled() {
     static const bool on = !(getenv("SVA_GEMM_PIPE") && atoi(getenv("SVA_GEMM_PIPE")) == 0);
     return on;
@@ -722,6 +732,13 @@ static int pipe_variant(const ConvGemm& g) {
 }
 
 static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
+    {
+        static const char* force_split = getenv("SVA_SPLIT_VARIANT");        // A/B switch (with SVA_TUNE_TABLE=0): every eligible problem through gemm_split.hip
+        if (force_split && c_vec && split_gemm_supported(g) && g.M >= 64 && g.N >= 64) {
+            const int v = atoi(force_split);
+            if (!(((v == 0 || v == 1) && g.M < 128) || ((v == 0 || v == 2) && g.N < 128))) return Choice{4, v, 0, 0};
+        }
+    }
     {
         const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
         static const bool force_all = getenv("SVA_PIPE_VARIANT") != nullptr;
@@ -936,6 +953,12 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                         if ((v == 2 && g.M < 128) || ((v == 3 || v == 5) && g.N < 128)) continue;
                         cand.push_back(Choice{2, v, 0, 0});
                     }
+                if (c_vec && split_gemm_supported(g) && split_enabled() && g.M >= 64 && g.N >= 64)
+                    for (int v = 0; v <= 3; ++v) {
+                        if ((v == 0 || v == 1) && g.M < 128) continue;
+                        if ((v == 0 || v == 2) && g.N < 128) continue;
+                        cand.push_back(Choice{4, v, 0, 0});
+                    }
                 float base = 0.f;
                 SVA_TRY_RC(time_choice(ch, &base));
                 float best = base * 0.93f;
@@ -966,6 +989,12 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
     if (kind == 2) {
         SVA_CHECK(pipe_gemm_supported(g) && a >= 0 && a <= 6, "conv_gemm_choice: the ring kernel needs Cin % 64 == 0 and 16-byte aligned operands");
         SVA_TRY_RC(launch_choice(g, st, Choice{2, a, 0, 0}));
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
+    if (kind == 4) {
+        SVA_CHECK(split_gemm_supported(g) && a >= 0 && a <= 3 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the split-bf16 kernel needs Cin % 32 == 0 and 16-byte aligned C rows");
+        SVA_TRY_RC(launch_choice(g, st, Choice{4, a, 0, 0}));
         SVA_HIP(hipGetLastError());
         return 0;
     }

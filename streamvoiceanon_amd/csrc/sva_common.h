@@ -111,6 +111,9 @@ bool voc_level_supported(int C);
 int launch_voc_level(const float* X, long x_bstride, int xH, int C, int B, int Tl, const float* const W[3][6], const float* const bias[3][6],
                      const int dil[3], float* const y3[3], long y_bstride, const int* frames_done, int rows_per_frame, hipStream_t st);
 int conv_gemm_prepare_stream(hipStream_t st);
+// gemm_split.hip: fp32 GEMM as six bf16 part products on v_mfma_f32_16x16x32_bf16 (variant 0..3 = 128x128, 128x64, 64x128, 64x64)
+bool split_gemm_supported(const ConvGemm& g);
+int launch_split_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 bool pipe_gemm_supported(const ConvGemm& g);
 int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
