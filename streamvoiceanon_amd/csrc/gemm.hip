@@ -736,7 +736,7 @@ static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
         static const char* force_split = getenv("SVA_SPLIT_VARIANT");        // A/B switch (with SVA_TUNE_TABLE=0): every eligible problem through gemm_split.hip
         if (force_split && c_vec && split_gemm_supported(g) && g.M >= 64 && g.N >= 64) {
             const int v = atoi(force_split);
-            if (!(((v == 0 || v == 1) && g.M < 128) || ((v == 0 || v == 2) && g.N < 128))) return Choice{4, v, 0, 0};
+            if (!(((v == 0 || v == 1 || v == 4) && g.M < 128) || ((v == 0 || v == 2 || v == 4) && g.N < 128))) return Choice{4, v, 0, 0};
         }
     }
     {
@@ -954,9 +954,9 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                         cand.push_back(Choice{2, v, 0, 0});
                     }
                 if (c_vec && split_gemm_supported(g) && split_enabled() && g.M >= 64 && g.N >= 64)
-                    for (int v = 0; v <= 3; ++v) {
-                        if ((v == 0 || v == 1) && g.M < 128) continue;
-                        if ((v == 0 || v == 2) && g.N < 128) continue;
+                    for (int v = 0; v <= 4; ++v) {
+                        if ((v == 0 || v == 1 || v == 4) && g.M < 128) continue;
+                        if ((v == 0 || v == 2 || v == 4) && g.N < 128) continue;
                         cand.push_back(Choice{4, v, 0, 0});
                     }
                 float base = 0.f;
@@ -993,7 +993,7 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
         return 0;
     }
     if (kind == 4) {
-        SVA_CHECK(split_gemm_supported(g) && a >= 0 && a <= 3 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the split-bf16 kernel needs Cin % 32 == 0 and 16-byte aligned C rows");
+        SVA_CHECK(split_gemm_supported(g) && a >= 0 && a <= 4 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the split-bf16 kernel needs Cin % 32 == 0 and 16-byte aligned C rows");
         SVA_TRY_RC(launch_choice(g, st, Choice{4, a, 0, 0}));
         SVA_HIP(hipGetLastError());
         return 0;

@@ -98,7 +98,7 @@ inline int xcd_swizzle_for(unsigned nx, unsigned ny) {
     return on && nx >= 2 && ny >= 16 ? 1 : 0;
 }
 __device__ __forceinline__ void xcd_tile(int swz, int nx, int ny, int& bx, int& by) {
-    if (!swz) return;
+    if (!(swz & 1)) return;
     const int T = nx * ny, L = by * nx + bx;
     const int xcd = L & 7, idx = L >> 3, q = T >> 3, r = T & 7;
     const int V = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;

@@ -649,13 +649,13 @@ def test_every_gemm_dispatch_choice_vs_fp64():
         ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
         tol = 2e-6 * np.sqrt(K) * 4 + 1e-5
         ring = [(3, v, 0, 0) for v in range(7)]            # kind 3: the LDS-DMA ring kernel (gemm_pipe.hip), all tile variants
-        split = [(4, v, 0, 0) for v in range(4)]           # kind 4: fp32 as six bf16 part products (gemm_split.hip), all tile variants
+        split = [(4, v, 0, 0) for v in range(5)]           # kind 4: fp32 as six bf16 part products (gemm_split.hip), all tile variants
         for ch in skinny + tiled + ring + split:
             if ch[0] in (0, 2) and (((ch[3] & 15) == 2 and N % 32) or ((ch[3] & 15) == 4 and N % 64)):
                 continue
             if ch[0] == 1 and ((ch[1] in (1, 4, 6, 7) and M < 128) or (ch[1] in (1, 5, 7) and N < 128)):
                 continue        # the tuner never offers tiles larger than the problem
-            if ch[0] == 4 and ((ch[1] in (0, 1) and M < 128) or (ch[1] in (0, 2) and N < 128)):
+            if ch[0] == 4 and ((ch[1] in (0, 1, 4) and M < 128) or (ch[1] in (0, 2, 4) and N < 128)):
                 continue
             out = E.test_gemm_choice(A, W, ch, bias=bias)
             err = np.abs(out - ref).max()

@@ -14,6 +14,5 @@ if len(sys.argv) > 1:
         fl = 2.0 * s[0] * s[1] * s[2] * s[3] * s[4]
         print(f"{sys.argv[1]:>10} {s}: {us:8.2f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
 else:
-    for tag, env in (("tuned", {}), ("split128", {"SVA_TUNE_TABLE": "0", "SVA_SPLIT_VARIANT": "0"}), ("split64", {"SVA_TUNE_TABLE": "0", "SVA_SPLIT_VARIANT": "3"}),
-                     ("split128x64", {"SVA_TUNE_TABLE": "0", "SVA_SPLIT_VARIANT": "1"})):
+    for tag, env in (("tuned", {}), ("split128", {"SVA_TUNE_TABLE": "0", "SVA_SPLIT_VARIANT": "0"}), ("split_ws", {"SVA_TUNE_TABLE": "0", "SVA_SPLIT_VARIANT": "4"})):
         subprocess.run([sys.executable, __file__, tag], env=dict(os.environ, **env))
