@@ -335,7 +335,11 @@ def main():
                 traffic = round(pj["hbm_bytes_per_launch"], 1)
                 mfma_util = round(pj["gemm_mfma_util"], 4) if pj.get("gemm_mfma_util") is not None else None
             alg_per_launch = alg_bytes / max(nl, 1)
-            roof = {"bound": "mfma", "kernel": "conv-GEMM family: pipe_gemm_kernel / conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32)",
+            roof = {"bound": "mfma", "kernel": "conv-GEMM family: pipe_gemm_kernel / conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32) and split_gemm_kernel / "
+                              "split_ws_kernel (the same fp32 problems as six bf16 part products on v_mfma_f32_16x16x32_bf16, fp32-grade results; the "
+                              "per-shape table picks)",
+                    "peak_note": "157.3 TF/s = dense f32-MFMA peak, the arithmetic the path is specified in; launches that run the split-bf16 kernel are "
+                                 "bounded by the bf16 pipes instead: 2500 / 6 = 416.7 TF/s of algorithmic fp32 work",
                     "achieved": round(ach, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
                     "mode": "one serial step, every conv-GEMM launch bracketed by hipEvents on its launch stream (launches do not overlap)",

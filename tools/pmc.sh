@@ -20,6 +20,6 @@ run WR WRITE_SIZE
 # MFMA pipe occupancy (SURVEY.md 8d reporting): busy cycles of the matrix pipes (summed over SIMDs) against the GPU-active
 # cycles of the same dispatch; separate passes so that a counter this image lacks only loses its own pass
 run MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
-run MOPS SQ_INSTS_VALU_MFMA_MOPS_F32
+run MOPS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16
 python tools/pmc_agg.py ${TAG}
 rm -rf gpurun_out/pmc_${TAG}_RD gpurun_out/pmc_${TAG}_WR gpurun_out/pmc_${TAG}_MFMA gpurun_out/pmc_${TAG}_MOPS   # per-dispatch rows are large; the aggregate JSON is what gets committed

@@ -43,10 +43,12 @@ for k, cs in per.items():
         d["mfma_busy_cycles_avg"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"][1] / max(cs["SQ_VALU_MFMA_BUSY_CYCLES"][0], 1)
         d["gui_active_cycles_avg"] = cs["GRBM_GUI_ACTIVE"][1] / max(cs["GRBM_GUI_ACTIVE"][0], 1)
         d["mfma_util"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (cs["GRBM_GUI_ACTIVE"][1] * 128.0)
+    if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in cs:
+        d["mfma_mops_bf16_avg"] = cs["SQ_INSTS_VALU_MFMA_MOPS_BF16"][1] / max(cs["SQ_INSTS_VALU_MFMA_MOPS_BF16"][0], 1)
     if "SQ_INSTS_VALU_MFMA_MOPS_F32" in cs:
         d["mfma_mops_f32_avg"] = cs["SQ_INSTS_VALU_MFMA_MOPS_F32"][1] / max(cs["SQ_INSTS_VALU_MFMA_MOPS_F32"][0], 1)
     out[k] = d
-gemm = {k: v for k, v in out.items() if "gemm_kernel" in k}
+gemm = {k: v for k, v in out.items() if "gemm_kernel" in k or "split_ws_kernel" in k}
 n = sum(v["calls"] for v in gemm.values()) or 1
 rd = sum(v["read_bytes_avg"] * v["calls"] for v in gemm.values()) / n
 wr = sum(v["write_bytes_avg"] * v["calls"] for v in gemm.values()) / n
