@@ -26,10 +26,9 @@ typedef float vf4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_v(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
-// B fragments of one conv: entry (t, cg, nt) of lane (n16, kk) = W[nt * 16 + n16][t * C + cg * 16 + kk * 4 .. + 3]; from global memory, or
-// from the LDS copy the workgroup made of all six convs of its branch (wl, fragment order: one 1 KB row per (t, cg, nt))
+// B fragments of one conv: entry (t, cg, nt) of lane (n16, kk) = W[nt * 16 + n16][t * C + cg * 16 + kk * 4 .. + 3]
 template <int C, int K>
-__device__ __forceinline__ void load_weights(const float* __restrict__ W, const vf4* __restrict__ wl, int lane, vf4 (&w)[K][C / 16][C / 16]) {
+__device__ __forceinline__ void load_weights(const float* __restrict__ W, int lane, vf4 (&w)[K][C / 16][C / 16]) {
     const int n16 = lane & 15, kk = lane >> 4;
 #pragma unroll
     for (int t = 0; t < K; ++t)
@@ -37,8 +36,7 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ W, const 
         for (int cg = 0; cg < C / 16; ++cg)
 #pragma unroll
             for (int nt = 0; nt < C / 16; ++nt)
-                w[t][cg][nt] = wl ? wl[((t * (C / 16) + cg) * (C / 16) + nt) * 64 + lane]
-                                  : *reinterpret_cast<const vf4*>(W + (long)(nt * 16 + n16) * (K * C) + t * C + cg * 16 + kk * 4);
+                w[t][cg][nt] = *reinterpret_cast<const vf4*>(W + (long)(nt * 16 + n16) * (K * C) + t * C + cg * 16 + kk * 4);
 }
 
 // one conv of the chain over local output rows [lo, lo + n_out): IN/OUT are LDS row buffers with leading dimension C + 4.
@@ -47,12 +45,12 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ W, const 
 // valid0: first local row that lies inside the stream (rows in front of it stay / become zero)
 template <int C, int K, bool FIRST, bool ACT_ON_READ>
 __device__ __forceinline__ void conv_rows(const float* __restrict__ IN, float* __restrict__ OUT, float* __restrict__ OUT_ACT, const float* __restrict__ W,
-                                          const vf4* __restrict__ wl, const float* __restrict__ bias, int dil, int lo, int n_out, int valid0) {
+                                          const float* __restrict__ bias, int dil, int lo, int n_out, int valid0) {
     constexpr int LD = C + 4, NT = C / 16, CG = C / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kk = lane >> 4;
     vf4 w[K][CG][NT];
-    load_weights<C, K>(W, wl, lane, w);
+    load_weights<C, K>(W, lane, w);
     float bv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bv[nt] = bias[nt * 16 + m];
@@ -99,7 +97,6 @@ __device__ __forceinline__ void conv_rows(const float* __restrict__ IN, float* _
 
 struct VocLevelArgs {
     const float* X; long x_bstride; int xH;          // level input: xH history rows, then Tl new rows, C floats per row
-    int wlds;                                        // the branch's six weight tensors are copied to LDS first (C = 16)
     int Tl, TR, rows_alloc, three;                   // three: a third LDS buffer holds silu(y) (conv 1 then reads it without the k-fold activation)
     const float* W[3][6]; const float* bias[3][6];   // per branch: c1, c2 of dilation 0, 1, 2
     int dil[3];
@@ -118,15 +115,6 @@ __device__ __forceinline__ void run_branch(const VocLevelArgs& a, int br, float*
     float* Y = smem;
     float* T = smem + (long)a.rows_alloc * LD;
     float* S = a.three ? T + (long)a.rows_alloc * LD : nullptr;
-    constexpr int WN = K * (C / 16) * (C / 16) * 64;         // vf4 entries of one conv's fragments
-    vf4* WL = a.wlds ? reinterpret_cast<vf4*>(smem + (long)(a.three ? 3 : 2) * a.rows_alloc * LD) : nullptr;
-    if (WL) {
-        for (int i = tid; i < 6 * WN; i += 256) {
-            const int q = i / WN, e = i % WN, lane = e & 63, f = e >> 6;
-            const int nt = f % (C / 16), cg = (f / (C / 16)) % (C / 16), t = f / ((C / 16) * (C / 16));
-            WL[i] = *reinterpret_cast<const vf4*>(a.W[br][q] + (long)(nt * 16 + (lane & 15)) * (K * C) + t * C + cg * 16 + (lane >> 4) * 4);
-        }
-    }
     int fd = *a.frames_done;
     fd = fd > 4 ? 4 : fd;                                    // (only "is the halo inside the stream" matters; no overflow)
     const int valid0 = max(0, -(fd * a.rows_per_frame + t0 - RF));
@@ -144,13 +132,11 @@ __device__ __forceinline__ void run_branch(const VocLevelArgs& a, int br, float*
     for (int j = 0; j < 3; ++j) {
         const int d = a.dil[j];
         consumed += (K - 1) * d;
-        const vf4* w1 = WL ? WL + (2 * j) * WN : nullptr;
-        const vf4* w2 = WL ? WL + (2 * j + 1) * WN : nullptr;
-        if (S) conv_rows<C, K, true, false>(S, T, nullptr, a.W[br][2 * j], w1, a.bias[br][2 * j], d, consumed, n_rows - consumed, valid0);
-        else conv_rows<C, K, true, true>(Y, T, nullptr, a.W[br][2 * j], w1, a.bias[br][2 * j], d, consumed, n_rows - consumed, valid0);
+        if (S) conv_rows<C, K, true, false>(S, T, nullptr, a.W[br][2 * j], a.bias[br][2 * j], d, consumed, n_rows - consumed, valid0);
+        else conv_rows<C, K, true, true>(Y, T, nullptr, a.W[br][2 * j], a.bias[br][2 * j], d, consumed, n_rows - consumed, valid0);
         __syncthreads();
         consumed += (K - 1) * d;
-        conv_rows<C, K, false, false>(T, Y, j < 2 ? S : nullptr, a.W[br][2 * j + 1], w2, a.bias[br][2 * j + 1], d, consumed, n_rows - consumed, valid0);
+        conv_rows<C, K, false, false>(T, Y, j < 2 ? S : nullptr, a.W[br][2 * j + 1], a.bias[br][2 * j + 1], d, consumed, n_rows - consumed, valid0);
         __syncthreads();
     }
     float* yg = a.Y3[br] + (long)bi * a.y_bstride + (long)t0 * C;
@@ -191,16 +177,13 @@ int launch_voc_level(const float* X, long x_bstride, int xH, int C, int B, int T
     VocLevelArgs a;
     a.X = X; a.x_bstride = x_bstride; a.xH = xH; a.Tl = Tl; a.TR = TR; a.rows_alloc = TR + rf_max + 16; a.three = three;
     const size_t act_bytes = sizeof(float) * (three ? 3 : 2) * (size_t)a.rows_alloc * (C + 4);
-    const size_t w_bytes = (size_t)6 * 11 * (C / 16) * (C / 16) * 64 * 16;           // all six convs of the k = 11 branch as fragments
-    static const int wlds_env = getenv("SVA_VOC_WLDS") ? atoi(getenv("SVA_VOC_WLDS")) : 0;      // (measured: no gain -- the weight fetch is not what bounds a conv)
-    a.wlds = wlds_env && act_bytes + w_bytes <= 160 * 1024;
     for (int br = 0; br < 3; ++br) {
         for (int q = 0; q < 6; ++q) { a.W[br][q] = W[br][q]; a.bias[br][q] = bias[br][q]; }
         a.Y3[br] = y3[br];
     }
     for (int j = 0; j < 3; ++j) a.dil[j] = dil[j];
     a.y_bstride = y_bstride; a.frames_done = frames_done; a.rows_per_frame = rows_per_frame;
-    const size_t smem = act_bytes + (a.wlds ? w_bytes : 0);
+    const size_t smem = act_bytes;
     SVA_CHECK(smem <= 160 * 1024, "voc_level: tile does not fit LDS");
     const dim3 grid((Tl + TR - 1) / TR, 3, B);
     static bool attr_done[2] = {false, false};
