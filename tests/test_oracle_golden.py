@@ -22,6 +22,31 @@ def test_mel_filterbank_matches_reference():
     np.testing.assert_array_equal(fb.argmax(0).numpy(), g["argpeak"])
 
 
+def test_mel_filterbank_published_values():
+    """torchaudio is not installable here, so the slaney filterbank is a restatement ("parity unpinned").  What CAN be
+    pinned from published material: (1) the example in librosa's `filters.mel` documentation -- `mel(sr=22050, n_fft=2048)` prints
+    `[[0., 0.016, ..., 0., 0.], ...]` (128 mels, htk=False, norm="slaney"; torchaudio's slaney/slaney bank is its transpose);
+    (2) the two anchors that DEFINE the Slaney scale (Auditory Toolbox): 1 kHz = mel 15, 6.4 kHz = mel 42, linear 200/3 Hz per mel
+    below 1 kHz; (3) Slaney normalisation = unit area of every triangle in Hz."""
+    fb = O.slaney_mel_fb(n_freqs=1025, f_min=0.0, f_max=11025.0, n_mels=128, sample_rate=22050)
+    assert fb.shape == (1025, 128)
+    assert round(float(fb[0, 0]), 3) == 0.0 and round(float(fb[1, 0]), 3) == 0.016 and float(fb[-1, 0]) == 0.0
+    df = 22050 / 2048
+    area = fb.sum(0) * df                              # Riemann sum of each triangle
+    assert float((area[:100] - 1.0).abs().max()) < 0.12     # (sampling error of narrow low filters; exact area is 1)
+    assert float((area[60:] - 1.0).abs().max()) < 0.02
+    peaks = fb.argmax(0).double() * df                 # centre frequencies
+    low = peaks[peaks < 900]
+    steps = low[1:] - low[:-1]
+    assert float((steps - steps.mean()).abs().max()) <= df + 1e-6      # linear region: equal spacing (to one FFT bin)
+    # 160-mel bank of the path (spectrogram.py:93-101): centres cross 1 kHz where mel = 15 of hz_to_mel(22050) * m / 161
+    fb160 = O.slaney_mel_fb()
+    m_max = 15.0 + np.log(22050.0 / 1000.0) / (np.log(6.4) / 27.0)
+    k = int(np.ceil(15.0 * 161 / m_max))               # first filter whose centre is >= 1 kHz
+    c = fb160.argmax(0).double() * (44100 / 2048)
+    assert float(c[k - 2]) < 1000.0 <= float(c[k - 1]) + 44100 / 2048
+
+
 @pytest.mark.parametrize("wseed", [0, 1])
 def test_encoder_indices_bit_exact(wseed, weights0, weights1):
     g = load_golden(f"encoder_s{wseed}")
