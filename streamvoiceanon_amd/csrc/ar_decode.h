@@ -1,4 +1,4 @@
-// Persistent batch-1 decode kernel of the dual AR (ar_decode.hip): one launch = one frame of
+// Persistent small-batch decode kernel of the dual AR (ar_decode.hip): one launch = one frame (of every stream of the batch) of
 // decode_one_token_ar (modules/dual_ar_stream.py:1168-1219) -- 12 slow layers on the two new tokens, the semantic head,
 // 8 x (4 fast layers + codebook head + nucleus sampler) and the frame bookkeeping.
 #pragma once
@@ -50,11 +50,19 @@ struct ArDecodeArgs {
     float inv_temp, top_p;
     int skip_semantic;
     int vocab, codebook_size;
+    // several streams in one launch: gridDim.y = streams, workgroup row y works on slot y = every per-stream pointer above advanced by
+    // y times its stride (elements of the pointer's type).  Each slot has its own granule buffers and epoch: the 96 workgroups of a
+    // slot only ever talk to each other.
+    int slot_base;                // first slot of this launch (workgroup row y works on slot slot_base + y)
+    struct SlotStride {
+        long codes, emb, kv_slot, kv_fast, gran, slow_logits, fast_logits, hidden, tok, step_audio, pred_hist, step_content, noise, forced;
+    } ss;
 };
 
 // wt_half / kv_half: element types of the weights / the slow KV cache (0 = fp32, 1 = fp16)
 // one_per_cu: pad the LDS request so that no two of the 96 workgroups share a CU
-int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st);
+// n_slots: streams decoded by this launch (grid 96 x n_slots; all 96 n_slots workgroups must be co-resident)
+int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st, int n_slots = 1);
 size_t ar_decode_granule_words();     // u64 words the four granule buffers need in total (gx | gbig | gatt | glog | ga, in this order)
 
 }  // namespace sva

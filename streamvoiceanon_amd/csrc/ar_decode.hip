@@ -390,10 +390,39 @@ __device__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float*
 }
 
 // SVA_AR_TIMING=1: workgroup 0 records wall_clock64() (100 MHz) at every phase boundary -- [2k] = input gathered, [2k + 1] = output published
-#define AR_MARK() do { if (a.dbg && wg == 0 && tid == 0) { a.dbg[nmark] = wall_clock64(); } ++nmark; } while (0)
+#define AR_MARK() do { if (s_dbg && wg == 0 && tid == 0) { s_dbg[nmark] = wall_clock64(); } ++nmark; } while (0)
 
 template <typename WT, typename KVT>
 __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a) {
+    // slot of this workgroup row: the per-stream pointers, advanced by y strides (uniform: scalar registers; the argument block itself
+    // stays in the kernarg segment -- a modified private copy of it would be indexed through scratch)
+    const long y = (long)blockIdx.y + a.slot_base;
+    const ArDecodeArgs::SlotStride& t = a.ss;
+    const long long* const s_codes = a.codes + y * t.codes;
+    float* const s_cached_audio_emb = a.cached_audio_emb + y * t.emb;
+    int* const s_last_pos = a.last_pos + y;
+    int* const s_nframes = a.nframes + y;
+    const unsigned long long* const s_seed = a.seed + y;
+    KVT* const s_kv_slow = reinterpret_cast<KVT*>(a.kv_slow) + y * t.kv_slot;
+    float* const s_kv_fast = a.kv_fast + y * t.kv_fast;
+    unsigned long long* const s_gx = a.gx + y * t.gran;
+    unsigned long long* const s_gbig = a.gbig + y * t.gran;
+    unsigned long long* const s_gatt = a.gatt + y * t.gran;
+    unsigned long long* const s_glog = a.glog + y * t.gran;
+    unsigned long long* const s_ga = a.ga + y * t.gran;
+    unsigned* const s_epoch = a.epoch + y;
+    long long* const s_dbg = y ? nullptr : a.dbg;
+    float* const s_slow_logits = a.slow_logits + y * t.slow_logits;
+    float* const s_fast_logits = a.fast_logits + y * t.fast_logits;
+    float* const s_hidden = a.hidden + y * t.hidden;
+    int* const s_sem = a.sem + y;
+    int* const s_tok_raw = a.tok_raw + y * t.tok;
+    int* const s_tok = a.tok + y * t.tok;
+    int* const s_step_audio = a.step_audio + y * t.step_audio;
+    int* const s_pred_hist = a.pred_hist + y * t.pred_hist;
+    int* const s_step_content = a.step_content + y * t.step_content;
+    const float* const s_noise = a.noise ? a.noise + y * t.noise : nullptr;
+    const int* const s_forced = a.forced + y * t.forced;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                          // [2][768] residual stream (fast AR: row 0)
     float* big = xs + GX;                     // [2][2304] qkv / SwiGLU output
@@ -405,14 +434,14 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, gw = wg * 4 + wave;
     // this kernel is a latency chain that shares its CUs with the encoder's / vocoder's throughput kernels: its waves go first
     __builtin_amdgcn_s_setprio(3);
-    unsigned ep = *a.epoch;
+    unsigned ep = *s_epoch;
     int nmark = 0;
-    const int p0 = *a.last_pos + 1;           // positions of the two new tokens (dual_ar_stream.py:821-824)
-    const int frame = *a.nframes;
-    const unsigned long long seed = *a.seed;
-    const int code = (int)a.codes[a.code_off];
+    const int p0 = *s_last_pos + 1;           // positions of the two new tokens (dual_ar_stream.py:821-824)
+    const int frame = *s_nframes;
+    const unsigned long long seed = *s_seed;
+    const int code = (int)s_codes[a.code_off];
     const int use_forced = *a.use_forced;
-    KVT* kv = reinterpret_cast<KVT*>(a.kv_slow);
+    KVT* kv = s_kv_slow;
     const long SH = (long)a.S * 64;           // one head of the cache
 
     // RoPE factors of this wave's three (even, odd) pairs: the two slow positions in registers, the 8 codebook positions in LDS
@@ -431,7 +460,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
     }
     // tokens [cached_new_audio_emb, src_cond] (decode_one, :817-837)
     for (int i = tid; i < D; i += 256) {
-        xs[i] = a.cached_audio_emb[i];
+        xs[i] = s_cached_audio_emb[i];
         xs[D + i] = a.content_emb[(long)code * D + i];
     }
     __syncthreads();
@@ -445,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
 #pragma unroll
             for (int r = 0; r < 6; ++r) w[r].load(L.wqkv, 6L * gw + r, lane);
             asm volatile("" ::: "memory");
-            if (l > 0) gather<6>(a.gx, GX, ep, xs, a.fail, 1);
+            if (l > 0) gather<6>(s_gx, GX, ep, xs, a.fail, 1);
             AR_MARK();
             float o[2][6];
             gemv<WT, D, 6, 2, true>(w, xs, D, L.attn_norm, 1e-5f, lane, o);
@@ -471,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                     if (lane == m * 6 + r) mine = o[m][r];
             if (lane < 12) {
                 const int m = lane / 6, r = lane - m * 6;
-                store_granule(a.gbig + m * I + n0 + r, ep, mine);
+                store_granule(s_gbig + m * I + n0 + r, ep, mine);
                 if (region >= 1) {
                     const int nn = n0 + r - D * region, h = nn >> 6, d = nn & 63;
                     st_kv<KVT>(kl + ((long)(region - 1) * H + h) * SH + (long)(p0 + m) * 64 + d, mine);
@@ -499,7 +528,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                 pvv[i] = ld_kv4<KVT>(vc + (long)t * 64);
             }
             asm volatile("" ::: "memory");
-            gather<18>(a.gbig, GBIG, ep, big, a.fail, 2);
+            gather<18>(s_gbig, GBIG, ep, big, a.fail, 2);
             AR_MARK();
             float4 q = *reinterpret_cast<const float4*>(big + r * I + h * 64 + li * 4);
             q.x *= 0.125f; q.y *= 0.125f; q.z *= 0.125f; q.w *= 0.125f;
@@ -549,13 +578,13 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                     den = fmaf(wgt, lg2, den);
                     if (tid < 64) val = fmaf(wgt, scr[g2 * 68 + tid], val);
                 }
-                store_granule(a.gatt + wg * 66 + tid, ep, tid < 64 ? val : (tid == 64 ? M : den));
+                store_granule(s_gatt + wg * 66 + tid, ep, tid < 64 ? val : (tid == 64 ? M : den));
             }
         }
         {   // ---- B1m: the first workgroup of every (row, head) merges its four key quarters and publishes that head's output ----
             // (two small edges instead of one 6336-granule gather in every workgroup)
             if ((wg & 3) == 0) {
-                gather<2>(a.gatt + wg * 66, 4 * 66, ep, attp, a.fail, 3);
+                gather<2>(s_gatt + wg * 66, 4 * 66, ep, attp, a.fail, 3);
                 AR_MARK();
                 if (tid < 64) {
                     float M = -INFINITY;
@@ -572,7 +601,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                     }
                     const int r = wg / 48, h = (wg % 48) >> 2;
                     AR_MARK();
-                    store_granule(a.ga + r * D + h * 64 + tid, ep + 1, num / den);
+                    store_granule(s_ga + r * D + h * 64 + tid, ep + 1, num / den);
                 } else { AR_MARK(); }
             } else { AR_MARK(); AR_MARK(); }
             ++ep;
@@ -582,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
 #pragma unroll
             for (int r = 0; r < 2; ++r) w[r].load(L.wo, 2L * gw + r, lane);
             asm volatile("" ::: "memory");
-            gather<6>(a.ga, GA, ep, av, a.fail, 13);
+            gather<6>(s_ga, GA, ep, av, a.fail, 13);
             AR_MARK();
             float o[2][2];
             gemv<WT, D, 2, 2, false>(w, av, D, nullptr, 0.f, lane, o);
@@ -596,7 +625,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                     if (lane == m * 2 + r) mine = o[m][r];
             if (lane < 4) {
                 const int m = lane >> 1, n = 2 * gw + (lane & 1);
-                store_granule(a.gx + m * D + n, ep, xs[m * D + n] + mine);
+                store_granule(s_gx + m * D + n, ep, xs[m * D + n] + mine);
             }
         }
         {   // ---- C: RMSNorm + w1|w3 + SwiGLU ----
@@ -604,7 +633,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
 #pragma unroll
             for (int r = 0; r < 12; ++r) w[r].load(L.w13, 12L * gw + r, lane);
             asm volatile("" ::: "memory");
-            gather<6>(a.gx, GX, ep, xs, a.fail, 4);
+            gather<6>(s_gx, GX, ep, xs, a.fail, 4);
             AR_MARK();
             float o[2][12];
             gemv<WT, D, 12, 2, true>(w, xs, D, L.ffn_norm, 1e-5f, lane, o);
@@ -618,7 +647,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                     if (lane == m * 6 + r) mine = silu_f(o[m][r]) * o[m][6 + r];
             if (lane < 12) {
                 const int m = lane / 6, r = lane - m * 6;
-                store_granule(a.gbig + m * I + 6 * gw + r, ep, mine);
+                store_granule(s_gbig + m * I + 6 * gw + r, ep, mine);
             }
         }
         {   // ---- D: w2 + residual ----
@@ -626,7 +655,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
 #pragma unroll
             for (int r = 0; r < 2; ++r) w[r].load(L.w2, 2L * gw + r, lane);
             asm volatile("" ::: "memory");
-            gather<18>(a.gbig, GBIG, ep, big, a.fail, 5);
+            gather<18>(s_gbig, GBIG, ep, big, a.fail, 5);
             AR_MARK();
             float o[2][2];
             gemv<WT, I, 2, 2, false>(w, big, I, nullptr, 0.f, lane, o);
@@ -640,15 +669,15 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                     if (lane == m * 2 + r) mine = o[m][r];
             if (lane < 4) {
                 const int m = lane >> 1, n = 2 * gw + (lane & 1);
-                store_granule(a.gx + m * D + n, ep, xs[m * D + n] + mine);
+                store_granule(s_gx + m * D + n, ep, xs[m * D + n] + mine);
             }
         }
     }
-    gather<6>(a.gx, GX, ep, xs, a.fail, 6);
+    gather<6>(s_gx, GX, ep, xs, a.fail, 6);
     AR_MARK();
     // hidden = pre-norm state of the content token (forward_generate :340-341): tap + input of the fast AR
     if (wg == 0)
-        for (int i = tid; i < D; i += 256) a.hidden[i] = xs[D + i];
+        for (int i = tid; i < D; i += 256) s_hidden[i] = xs[D + i];
     for (int i = tid; i < D; i += 256) xs[i] = xs[D + i];
     __syncthreads();
     if (!a.skip_semantic) {
@@ -669,7 +698,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
             for (int j = 0; j < 11; ++j)
                 if (lane == j) mine = o[0][j];
             const int row = gw + AR_WAVES * (half * 11 + lane);
-            if (lane < 11 && row < a.vocab) __hip_atomic_store(a.slow_logits + row, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < 11 && row < a.vocab) __hip_atomic_store(s_slow_logits + row, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 
@@ -686,7 +715,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
         }
         for (int l = 0; l < AR_FAST_LAYERS; ++l) {
             const ArLayerW& L = a.fast[l];
-            float* kvg = a.kv_fast + (long)l * NCB * 2 * D;             // [8][k 768 | v 768]
+            float* kvg = s_kv_fast + (long)l * NCB * 2 * D;             // [8][k 768 | v 768]
             {   // ---- FA: RMSNorm + wqkv + RoPE (position = codebook index) ----
                 WFrag<WT, D> w[6];
 #pragma unroll
@@ -695,7 +724,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                     else w[r] = wq0[r];
                 }
                 asm volatile("" ::: "memory");
-                if (l > 0) gather<3>(a.gx, D, ep, xs, a.fail, 7);
+                if (l > 0) gather<3>(s_gx, D, ep, xs, a.fail, 7);
                 AR_MARK();
                 float o[1][6];
                 gemv<WT, D, 6, 1, true>(w, xs, D, L.attn_norm, 1e-5f, lane, o);
@@ -717,7 +746,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                 for (int r = 0; r < 6; ++r)
                     if (lane == r) mine = o[0][r];
                 if (lane < 6) {
-                    store_granule(a.gbig + n0 + lane, ep, mine);
+                    store_granule(s_gbig + n0 + lane, ep, mine);
                     if (region >= 1)       // K | V of this codebook position for the later positions of this frame
                         __hip_atomic_store(kvg + (long)cb * 2 * D + (n0 + lane - D), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -749,7 +778,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                         if (t < cb) pv[hh][t] = __hip_atomic_load(kvg + (long)t * 2 * D + D + hb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 asm volatile("" ::: "memory");
-                gather<9>(a.gbig, I, ep, big, a.fail, 8);
+                gather<9>(s_gbig, I, ep, big, a.fail, 8);
                 AR_MARK();
 #pragma unroll
                 for (int hh = 0; hh < 3; ++hh) {
@@ -789,7 +818,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                 ++ep;
                 if (lane < 2) {
                     const int n = 2 * gw + lane;
-                    store_granule(a.gx + n, ep, xs[n] + (lane == 0 ? o[0][0] : o[0][1]));
+                    store_granule(s_gx + n, ep, xs[n] + (lane == 0 ? o[0][0] : o[0][1]));
                 }
             }
             {   // ---- FC ----
@@ -797,7 +826,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
 #pragma unroll
                 for (int r = 0; r < 12; ++r) w[r].load(L.w13, 12L * gw + r, lane);
                 asm volatile("" ::: "memory");
-                gather<3>(a.gx, D, ep, xs, a.fail, 9);
+                gather<3>(s_gx, D, ep, xs, a.fail, 9);
                 AR_MARK();
                 float o[1][12];
                 gemv<WT, D, 12, 1, true>(w, xs, D, L.ffn_norm, 1e-5f, lane, o);
@@ -807,14 +836,14 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
                     if (lane == r) mine = silu_f(o[0][r]) * o[0][6 + r];
-                if (lane < 6) store_granule(a.gbig + 6 * gw + lane, ep, mine);
+                if (lane < 6) store_granule(s_gbig + 6 * gw + lane, ep, mine);
             }
             {   // ---- FD ----
                 WFrag<WT, I> w[2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) w[r].load(L.w2, 2L * gw + r, lane);
                 asm volatile("" ::: "memory");
-                gather<9>(a.gbig, I, ep, big, a.fail, 10);
+                gather<9>(s_gbig, I, ep, big, a.fail, 10);
                 AR_MARK();
                 float o[1][2];
                 gemv<WT, I, 2, 1, false>(w, big, I, nullptr, 0.f, lane, o);
@@ -822,7 +851,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                 ++ep;
                 if (lane < 2) {
                     const int n = 2 * gw + lane;
-                    store_granule(a.gx + n, ep, xs[n] + (lane == 0 ? o[0][0] : o[0][1]));
+                    store_granule(s_gx + n, ep, xs[n] + (lane == 0 ? o[0][0] : o[0][1]));
                 }
             }
         }
@@ -836,7 +865,7 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                 w[j].load(a.fast_out_w, row, lane);
             }
             asm volatile("" ::: "memory");
-            gather<3>(a.gx, D, ep, xs, a.fail, 11);
+            gather<3>(s_gx, D, ep, xs, a.fail, 11);
             AR_MARK();
             float o[1][3];
             gemv<WT, D, 3, 1, true>(w, xs, D, a.fast_norm, 1e-5f, lane, o);
@@ -848,8 +877,8 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                 if (lane == j) mine = o[0][j];
             const int row = gw + AR_WAVES * lane;
             if (lane < 3 && row < V) {
-                store_granule(a.glog + row, ep, mine);
-                a.fast_logits[(long)cb * V + row] = mine;
+                store_granule(s_glog + row, ep, mine);
+                s_fast_logits[(long)cb * V + row] = mine;
             }
         }
         {   // ---- FS: nucleus sample, redundantly in every workgroup (4 waves x 4 logits per lane) ----
@@ -859,18 +888,18 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
                 for (int r = 0; r < 6; ++r) wq0[r].load(a.fast[0].wqkv, 6L * gw + r, lane);
                 asm volatile("" ::: "memory");
             }
-            gather<4>(a.glog, V, ep, lg, a.fail, 12);
+            gather<4>(s_glog, V, ep, lg, a.fail, 12);
             AR_MARK();
             float l[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) l[r] = (tid + 256 * r) < V ? lg[tid + 256 * r] : -INFINITY;
-            const int raw = nucleus_sample<4, 4>(l, V, tid, a.noise ? a.noise + a.vocab + (long)cb * V : nullptr, seed, frame, 1, cb * V, a.inv_temp,
+            const int raw = nucleus_sample<4, 4>(l, V, tid, s_noise ? s_noise + a.vocab + (long)cb * V : nullptr, seed, frame, 1, cb * V, a.inv_temp,
                                                  a.top_p, reinterpret_cast<double*>(scr));
             int t = raw;
-            if (use_forced) t = a.forced[(long)cb * a.chunk + a.ci];
+            if (use_forced) t = s_forced[(long)cb * a.chunk + a.ci];
             tprev = t;
             if (tid == 0) toks[cb] = t;
-            if (wg == 0 && tid == 0) { a.tok_raw[cb] = raw; a.tok[cb] = t; }
+            if (wg == 0 && tid == 0) { s_tok_raw[cb] = raw; s_tok[cb] = t; }
             __syncthreads();          // lg / xs are rewritten by the next codebook step
         }
     }
@@ -882,29 +911,29 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
         float acc = 0.f;
 #pragma unroll
         for (int q = 0; q < NCB; ++q) acc += a.codebook_emb[((long)toks[q] + (long)q * a.codebook_size) * D + i];
-        a.cached_audio_emb[i] = acc;
+        s_cached_audio_emb[i] = acc;
     }
     if (wg != 0) return;
     if (tid < NCB) {
-        a.pred_hist[(long)tid * a.hist_cap + (frame & (a.hist_cap - 1))] = toks[tid];
-        a.step_audio[tid * a.chunk + a.ci] = toks[tid];
+        s_pred_hist[(long)tid * a.hist_cap + (frame & (a.hist_cap - 1))] = toks[tid];
+        s_step_audio[tid * a.chunk + a.ci] = toks[tid];
     }
     if (tid == 0) {
-        a.step_content[a.ci] = code;
-        *a.nframes = frame + 1;
-        *a.last_pos = p0 + 1;
-        *a.epoch = ep;
+        s_step_content[a.ci] = code;
+        *s_nframes = frame + 1;
+        *s_last_pos = p0 + 1;
+        *s_epoch = ep;
     }
     if (!a.skip_semantic) {
         float l[32];
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
             const int e = tid + 256 * r;
-            l[r] = e < a.vocab ? __hip_atomic_load(a.slow_logits + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+            l[r] = e < a.vocab ? __hip_atomic_load(s_slow_logits + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
         }
         __syncthreads();
-        const int s = nucleus_sample<4, 32>(l, a.vocab, tid, a.noise, seed, frame, 0, 0, a.inv_temp, a.top_p, reinterpret_cast<double*>(scr));
-        if (tid == 0) *a.sem = s;
+        const int s = nucleus_sample<4, 32>(l, a.vocab, tid, s_noise, seed, frame, 0, 0, a.inv_temp, a.top_p, reinterpret_cast<double*>(scr));
+        if (tid == 0) *s_sem = s;
     }
 }
 
@@ -914,7 +943,8 @@ constexpr size_t AR_LDS_FLOATS = GX + GBIG + 4 * 68 + GX + GLOG + 16 * 68 + NCB 
 
 size_t ar_decode_granule_words() { return (size_t)GX + GBIG + GATT + GLOG + GA; }
 
-int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st) {
+int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st, int n_slots) {
+    SVA_CHECK(n_slots >= 1 && n_slots <= 8, "ar_decode: 1..8 streams per launch");
     SVA_CHECK(a.vocab <= 22 * AR_WAVES && a.codebook_size <= 3 * AR_WAVES && a.codebook_size <= 1024 && (a.hist_cap & (a.hist_cap - 1)) == 0,
               "ar_decode: unsupported head sizes");
     // one_per_cu: ask for more than half of a CU's LDS so that the 96 workgroups land on 96 different CUs (the AR stream's own
@@ -930,10 +960,10 @@ int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_p
         SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<float, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         attr = true;
     }
-    if (wt_half && kv_half) hipLaunchKernelGGL((ar_decode_kernel<__half, __half>), dim3(AR_WGS), dim3(256), smem, st, a);
-    else if (wt_half) hipLaunchKernelGGL((ar_decode_kernel<__half, float>), dim3(AR_WGS), dim3(256), smem, st, a);
-    else if (kv_half) hipLaunchKernelGGL((ar_decode_kernel<float, __half>), dim3(AR_WGS), dim3(256), smem, st, a);
-    else hipLaunchKernelGGL((ar_decode_kernel<float, float>), dim3(AR_WGS), dim3(256), smem, st, a);
+    if (wt_half && kv_half) hipLaunchKernelGGL((ar_decode_kernel<__half, __half>), dim3(AR_WGS, n_slots), dim3(256), smem, st, a);
+    else if (wt_half) hipLaunchKernelGGL((ar_decode_kernel<__half, float>), dim3(AR_WGS, n_slots), dim3(256), smem, st, a);
+    else if (kv_half) hipLaunchKernelGGL((ar_decode_kernel<float, __half>), dim3(AR_WGS, n_slots), dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((ar_decode_kernel<float, float>), dim3(AR_WGS, n_slots), dim3(256), smem, st, a);
     SVA_HIP(hipGetLastError());
     return 0;
 }

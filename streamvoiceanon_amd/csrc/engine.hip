@@ -1256,9 +1256,24 @@ int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_
     a.vocab = c.ar_vocab; a.codebook_size = c.codebook_size;
     // on its own CU partition the kernel pads its LDS request so that the 96 workgroups land on 96 different CUs; on shared CUs it
     // keeps its small footprint so that the other stages' GEMM workgroups fit beside it
+    {   // strides between the per-stream blocks (elements of each pointer's type)
+        const int ncb = c.num_codebooks, D = c.ar_dim;
+        a.ss.codes = b->T2; a.ss.emb = D; a.ss.kv_slot = b->kv_slow_slot; a.ss.kv_fast = (long)AR_FAST_LAYERS * 8 * 2 * D;
+        a.ss.gran = (long)ar_decode_granule_words(); a.ss.slow_logits = c.ar_vocab; a.ss.fast_logits = (long)ncb * c.codebook_size; a.ss.hidden = D;
+        a.ss.tok = ncb; a.ss.step_audio = (long)ncb * b->p.chunk_frames; a.ss.pred_hist = (long)ncb * b->hist_cap;
+        a.ss.step_content = b->p.chunk_frames; a.ss.noise = (long)b->p.chunk_frames * nstride; a.ss.forced = (long)ncb * b->p.chunk_frames;
+    }
     static const char* share_env = getenv("SVA_AR_SHARE_CU");
     const bool share = share_env ? atoi(share_env) != 0 : !b->ar_partitioned;
-    return launch_ar_decode(a, c.ar_dtype == 1, b->kv_half, !share, b->stream);
+    // at most two streams per launch: 192 workgroups find a CU each and leave half of every register file to the other stages'
+    // kernels; four streams in one launch (two 256-register workgroups on half of the CUs) measured 1.75 ms for the frame AND
+    // locked the encoder / vocoder kernels out of those CUs (2.69 ms per pipelined step against 1.9 with two launches of two)
+    static const int per_launch = getenv("SVA_AR_MEGA_GROUP") ? atoi(getenv("SVA_AR_MEGA_GROUP")) : 2;
+    for (int s0 = 0; s0 < b->B; s0 += per_launch) {
+        a.slot_base = s0;
+        SVA_TRY(launch_ar_decode(a, c.ar_dtype == 1, b->kv_half, !share, b->stream, std::min(per_launch, b->B - s0)));
+    }
+    return 0;
 }
 
 // semantic head + 8-step fast AR + bookkeeping of one frame; the slow hidden state of slot s is row
@@ -1661,7 +1676,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // one stream with the persistent AR decode kernel: no CU partition -- that kernel is a single launch of 96 workgroups that
         // mostly wait on hand-offs, so the AR chain no longer queues behind the other stages' workgroups, and the encoder /
         // vocoder GEMMs want the whole chip (measured 1.41 ms per step with the 96 | 128 | 32 split, 1.13 without)
-        const bool will_mega = B == 1 && e->mega_ok && !(getenv("SVA_FUSED_DECODE") && atoi(getenv("SVA_FUSED_DECODE")) == 0) &&
+        const bool will_mega = B <= (getenv("SVA_AR_MEGA_MAXB") ? atoi(getenv("SVA_AR_MEGA_MAXB")) : 4) && B <= 8 && e->mega_ok && !(getenv("SVA_FUSED_DECODE") && atoi(getenv("SVA_FUSED_DECODE")) == 0) &&
                                !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
         const int part_streams = b->p.pipeline ? (will_mega && !getenv("SVA_CU_PART") ? 0 : B) : 0;
         SVA_TRY(get_streams(e->device, !b->voc_grouped, part_streams, &ss));
@@ -1854,12 +1869,15 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         b->kv_fast = p2;
     }
     // persistent batch-1 decode kernel (ar_decode.hip): granule buffers, tag epoch, timeout word, fast K/V scratch
-    b->use_mega = B == 1 && e->mega_ok && b->fused_decode && !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
+    // up to mega_max_b streams decode in ONE launch of it (96 workgroups per stream, each stream's group talks only to itself); the
+    // multi-launch chain of the batched path (~200 dependent launches, 2.4-3.3 ms per frame at 2-8 streams) takes over above that
+    static const int mega_max_b = getenv("SVA_AR_MEGA_MAXB") ? atoi(getenv("SVA_AR_MEGA_MAXB")) : 4;
+    b->use_mega = B <= mega_max_b && B <= 8 && e->mega_ok && b->fused_decode && !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
     if (b->use_mega) {
-        SVA_TRY(dev_alloc(A, &b->d_gran, ar_decode_granule_words()));
-        SVA_TRY(dev_alloc(A, &b->d_epoch, 1));
+        SVA_TRY(dev_alloc(A, &b->d_gran, ar_decode_granule_words() * B));
+        SVA_TRY(dev_alloc(A, &b->d_epoch, B));
         SVA_TRY(dev_alloc(A, &b->d_ar_fail, 1));
-        SVA_TRY(dev_alloc(A, &b->kv_fast_mega, (size_t)AR_FAST_LAYERS * 8 * 2 * D));
+        SVA_TRY(dev_alloc(A, &b->kv_fast_mega, (size_t)B * AR_FAST_LAYERS * 8 * 2 * D));
         if (getenv("SVA_AR_TIMING")) SVA_TRY(dev_alloc(A, &b->d_ar_dbg, 1024));
     }
     SVA_TRY(dev_alloc(A, &b->cached_audio_emb, (size_t)B * D));
