@@ -739,6 +739,13 @@ static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
             if (!(((v == 0 || v == 1 || v == 4) && g.M < 128) || ((v == 0 || v == 2 || v == 4) && g.N < 128))) return Choice{4, v, 0, 0};
         }
     }
+    // MFMA-bound problems outside the tuned table (batch sizes the tuning runs did not visit): the split-bf16 kernel, tile shape by
+    // the rule the table shows -- wave-specialised 128x128 for narrow outputs with a long K, plain 128x128 otherwise, 64x64 for N < 128
+    if (split_enabled() && c_vec && split_gemm_supported(g) && g.M >= 2048 && g.N >= 64) {
+        if (g.N < 128) return Choice{4, 3, 0, 0};
+        const long K = (long)g.taps * g.Cin;
+        return Choice{4, (g.N <= 512 && K >= 1024) ? 4 : 0, 0, 0};
+    }
     {
         const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
         static const bool force_all = getenv("SVA_PIPE_VARIANT") != nullptr;
