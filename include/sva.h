@@ -112,7 +112,8 @@ int sva_streams_begin(sva_batch* b);
  *   forced_codes host int32[B][8][chunk] teacher-forces the AR (parity tests), or NULL */
 int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const float* noise, const int32_t* forced_codes);
 /* same with device pointers (no host copies); asynchronous: d_pcm_in must stay valid and d_pcm_out must not be read until
- * sva_sync() (or a later synchronous call on the handle) returns.  With sva_stream_params.pipeline the stages of consecutive
+ * sva_sync() (or a later synchronous call on the handle) returns.  The engine runs on streams of its own and does NOT synchronise
+ * with the caller's: whatever produced d_pcm_in (a kernel or copy on another stream) must have COMPLETED before this call.  With sva_stream_params.pipeline the stages of consecutive
  * calls overlap on three streams. */
 int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm_out);
 int sva_sync(sva_batch* b);

@@ -376,6 +376,8 @@ class Batch:
         return out[:max(n, 0)]
 
     def step_device(self, d_in_ptr, d_out_ptr):
+        """sva_step_device: asynchronous chunk-step on device buffers.  The engine runs on streams of its own: the producer of d_in (a
+        torch op on torch's stream, say) must have completed before the call, and d_out is valid after sync()."""
         _check(self.lib.sva_step_device(self.h, C.c_void_p(d_in_ptr), C.c_void_p(d_out_ptr)), "sva_step_device")
 
     def stream_chunks(self, pcm_in):

@@ -17,21 +17,23 @@ def main():
     W = synth_weights.generate_all(0, specs.all_specs())
     eng = E.Engine(W)
     h_pcm, h_codes = hashlib.sha256(), hashlib.sha256()
-    for B in (1, 2):
+    for B in [int(x) for x in os.environ.get("DET_B", "1,2").split(",")]:
         b = E.Batch(eng, n_streams=B, pipeline=True)
         for s in range(B):
             ac, cc, style, timbre = synth_prompt(2000 + s, 107)
             b.prefill_prompt(s, cc, ac, style, timbre, noise_seed=1000 + s)
         b.begin()
         n_chunks = 10
+        n_sync = int(os.environ.get("DET_SYNC", "5"))
         src = np.stack([synth_utterance(1000 + s, 2048 * 24)[:2048 * n_chunks] for s in range(B)])
-        for i in range(5):                                   # caller-synchronised steps
+        for i in range(n_sync):                              # caller-synchronised steps
             out = b.step(src[:, i * 2048:(i + 1) * 2048])
             h_pcm.update(np.ascontiguousarray(out).tobytes())
         d_in = torch.from_numpy(src).cuda()
         d_out = torch.empty(B, 2048, device="cuda")
-        for i in range(5, n_chunks):                         # overlapped (stage-pipelined) steps
+        for i in range(n_sync, n_chunks):                    # overlapped (stage-pipelined) steps
             chunk = d_in[:, i * 2048:(i + 1) * 2048].contiguous()
+            torch.cuda.synchronize()             # the engine runs on its own streams: the caller's buffer must be complete before the call
             b.step_device(chunk.data_ptr(), d_out.data_ptr())
             b.sync()
             h_pcm.update(d_out.cpu().numpy().tobytes())

@@ -1024,6 +1024,7 @@ def test_stage_pipelining_equals_serial(eng):
             b.prefill_prompt(i, cc, ac, style, timbre, noise_seed=500 + i)
         b.begin()
         out = torch.zeros(n_chunks, B, 2048, device="cuda")
+        torch.cuda.synchronize()                # the engine's streams do not wait for torch's: buffers complete before they are handed over
         pos = []
         for k in range(n_chunks):
             x = chunks[k]
