@@ -1676,7 +1676,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // one stream with the persistent AR decode kernel: no CU partition -- that kernel is a single launch of 96 workgroups that
         // mostly wait on hand-offs, so the AR chain no longer queues behind the other stages' workgroups, and the encoder /
         // vocoder GEMMs want the whole chip (measured 1.41 ms per step with the 96 | 128 | 32 split, 1.13 without)
-        const bool will_mega = B <= (getenv("SVA_AR_MEGA_MAXB") ? atoi(getenv("SVA_AR_MEGA_MAXB")) : 4) && B <= 8 && e->mega_ok && !(getenv("SVA_FUSED_DECODE") && atoi(getenv("SVA_FUSED_DECODE")) == 0) &&
+        const bool will_mega = B <= (getenv("SVA_AR_MEGA_MAXB") ? atoi(getenv("SVA_AR_MEGA_MAXB")) : 6) && B <= 8 && e->mega_ok && !(getenv("SVA_FUSED_DECODE") && atoi(getenv("SVA_FUSED_DECODE")) == 0) &&
                                !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
         const int part_streams = b->p.pipeline ? (will_mega && !getenv("SVA_CU_PART") ? 0 : B) : 0;
         SVA_TRY(get_streams(e->device, !b->voc_grouped, part_streams, &ss));
@@ -1871,7 +1871,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     // persistent batch-1 decode kernel (ar_decode.hip): granule buffers, tag epoch, timeout word, fast K/V scratch
     // up to mega_max_b streams decode in ONE launch of it (96 workgroups per stream, each stream's group talks only to itself); the
     // multi-launch chain of the batched path (~200 dependent launches, 2.4-3.3 ms per frame at 2-8 streams) takes over above that
-    static const int mega_max_b = getenv("SVA_AR_MEGA_MAXB") ? atoi(getenv("SVA_AR_MEGA_MAXB")) : 4;
+    static const int mega_max_b = getenv("SVA_AR_MEGA_MAXB") ? atoi(getenv("SVA_AR_MEGA_MAXB")) : 6;
     b->use_mega = B <= mega_max_b && B <= 8 && e->mega_ok && b->fused_decode && !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
     if (b->use_mega) {
         SVA_TRY(dev_alloc(A, &b->d_gran, ar_decode_granule_words() * B));
