@@ -123,3 +123,19 @@ def test_sampling_kwargs_are_validated_not_dropped():
     for bad in ({"repetition_penalty": 1.5}, {"previous_tokens": [1]}, {"top_k": 5}):
         with pytest.raises(NotImplementedError):
             check_sampling_kwargs(bad)
+
+
+def test_xcd_tile_remap_is_a_bijection():
+    """The workgroup-id remap of the tiled GEMM kernels (csrc/sva_common.h: xcd_tile) must visit every tile exactly once for ANY tile
+    count -- the simple `(id % 8) * ceil(T / 8) + id / 8` is not a bijection when T % 8 != 0 -- and must hand XCD k (ids = k mod 8) a
+    contiguous range of the tile sequence."""
+    def remap(L, T):
+        xcd, idx, q, r = L & 7, L >> 3, T >> 3, T & 7
+        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
+
+    for T in list(range(1, 300)) + [765, 1020, 1536, 4097]:
+        V = [remap(L, T) for L in range(T)]
+        assert sorted(V) == list(range(T)), T
+        for k in range(min(8, T)):
+            mine = sorted(V[L] for L in range(k, T, 8))
+            assert mine == list(range(mine[0], mine[0] + len(mine))), (T, k)
