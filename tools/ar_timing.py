@@ -20,15 +20,20 @@ b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=1000)
 b.begin()
 src = synth_utterance(1000, 2048 * 40)
 labels = []
+v2 = os.environ.get("SVA_AR_MEGA2", "0") != "0"      # second-generation kernel (ar_decode2.hip): the sampler is fused into the next FA
 for l in range(12):
     for ph in ("A", "B1", "B1m", "B2", "C", "D"):
         labels += [f"s{l}.{ph}.in", f"s{l}.{ph}.out"]
-labels.append("hidden.in")
+if not v2:
+    labels.append("hidden.in")
 for cb in range(8):
     for l in range(4):
         for ph in ("FA", "FB", "FC", "FD"):
-            labels += [f"f{cb}.{l}.{ph}.in", f"f{cb}.{l}.{ph}.out"]
-    labels += [f"f{cb}.FH.in", f"f{cb}.FH.out", f"f{cb}.FS.in"]
+            ph2 = "FSA" if (v2 and ph == "FA" and l == 0 and cb > 0) else ph
+            labels += [f"f{cb}.{l}.{ph2}.in", f"f{cb}.{l}.{ph2}.out"]
+    labels += [f"f{cb}.FH.in", f"f{cb}.FH.out"] + ([] if v2 else [f"f{cb}.FS.in"])
+if v2:
+    labels += ["f8.FS.in", "f8.FS.out"]
 acc = None
 n = 0
 for i in range(30):
