@@ -9,10 +9,6 @@ namespace sva {
 constexpr int AR_WGS = 96;            // workgroups of the persistent kernel (= CUs of the AR stream's partition)
 constexpr int AR_WAVES = AR_WGS * 4;
 constexpr int AR_SLOW_LAYERS = 12, AR_FAST_LAYERS = 4;
-// second-generation single-stream kernel (ar_decode2.hip): 192 workgroups x 4 waves, plus 32 workgroups that run the semantic
-// head off the critical path
-constexpr int AR2_WGS = 192, AR2_SEM_WGS = 32, AR2_THREADS = 256;
-
 // weights of one layer in the decode kernel's layout: row-major [N][K] (fp32 or fp16 by the kernel's template argument);
 // w13: wave w of the kernel owns rows [12w, 12w + 12) = w1 rows 6w..6w+5 followed by w3 rows 6w..6w+5
 struct ArLayerW {
@@ -66,14 +62,6 @@ struct ArDecodeArgs {
 // one_per_cu: pad the LDS request so that no two of the 96 workgroups share a CU
 // n_slots: streams decoded by this launch (grid 96 x n_slots; all 96 n_slots workgroups must be co-resident)
 int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st, int n_slots = 1);
-// ar_decode2.hip: one stream (slot a.slot_base) per launch; a.gx = base of the stream's granule block (ar_decode2_granule_words()
-// words, the kernel lays its buffers out itself; gbig / gatt / glog / ga are ignored), a.kv_fast = base of the per-workgroup fast
-// K / V scratch (ar_decode2_kvfast_floats() floats per stream, stride a.ss.kv_fast)
-int launch_ar_decode2(const ArDecodeArgs& a, int wt_half, int kv_half, hipStream_t st);
-size_t ar_decode2_granule_words();
-size_t ar_decode2_kvfast_floats();
-size_t ar_decode2_lds_bytes();
-const void* ar_decode2_func(int wt_half, int kv_half);
 size_t ar_decode_granule_words();     // u64 words the four granule buffers need in total (gx | gbig | gatt | glog | ga, in this order)
 
 }  // namespace sva

@@ -564,7 +564,8 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) l[r] = (tid + 256 * r) < V ? lg[tid + 256 * r] : -INFINITY;
             const int raw = nucleus_sample<4, 4>(l, V, tid, s_noise ? s_noise + a.vocab + (long)cb * V : nullptr, seed, frame, 1, cb * V, a.inv_temp,
-                                                 a.top_p, reinterpret_cast<double*>(scr));
+                                                 a.top_p, reinterpret_cast<double*>(scr), (s_dbg && wg == 0 && cb == 1) ? s_dbg + 900 : nullptr);
+            if (s_dbg && wg == 0 && cb == 1 && tid == 0) s_dbg[906] = wall_clock64();
             int t = raw;
             if (use_forced) t = s_forced[(long)cb * a.chunk + a.ci];
             tprev = t;

@@ -1,5 +1,5 @@
-// Device helpers shared by the persistent AR decode kernels (ar_decode.hip: 96 workgroups per stream, several streams per
-// launch;  ar_decode2.hip: the single-stream kernel with a communication wave and a layer-deep weight prefetch).
+// Device helpers of the persistent AR decode kernel (ar_decode.hip): granule stores, per-wave weight fragments, the GEMV with a
+// folded RMSNorm and the sort-free nucleus sampler.
 #pragma once
 #include "device_util.h"
 
@@ -157,7 +157,9 @@ __device__ __forceinline__ unsigned umax_wave(unsigned v) {
 // token in every participating thread.  red: LDS scratch of >= 64 doubles (NW > 1 only).
 template <int NW, int PER>
 __device__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float* noise, unsigned long long seed, int frame, int kind,
-                              int noise_elem_off, float inv_temp, float top_p, double* red) {
+                              int noise_elem_off, float inv_temp, float top_p, double* red, long long* dbg = nullptr) {
+#define NS_MARK(k) do { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); } while (0)
+    NS_MARK(0);
     constexpr int ES = NW * 64;
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % NW;
     int slot = 0;
@@ -214,6 +216,7 @@ __device__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float*
         p[r] = p[r] / denom;
         key[r] = __builtin_bit_cast(unsigned, p[r]);
     }
+    NS_MARK(1);
     bool keep[PER];
     double all = 0.0;
 #pragma unroll
@@ -266,6 +269,8 @@ __device__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float*
             if ((float)fm > top_p) { lo = ~kgi; f_lo = fm; }
             else { hi = kl + 1u; f_hi = fm; }
         }
+        NS_MARK(2);
+        if (dbg && threadIdx.x == 0) dbg[7] = it;
         const unsigned kb = lo;
         const float pb = __builtin_bit_cast(float, kb);
         double above = 0.0;
@@ -304,6 +309,7 @@ __device__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float*
             keep[r] = e < V && (key[r] > kb || (key[r] == kb && e <= id_cut));
         }
     }
+    NS_MARK(3);
     const float m2 = mx * inv_temp;
     float e2[PER];
     float s2 = 0.f;
@@ -324,6 +330,7 @@ __device__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float*
         const float rr = pr / q;
         if (rr > best || (rr == best && e < best_id)) { best = rr; best_id = e; }
     }
+    NS_MARK(4);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o, 64);
@@ -339,6 +346,7 @@ __device__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float*
             if (fred[slot * NW + w] > best || (fred[slot * NW + w] == best && ired[w] < best_id)) { best = fred[slot * NW + w]; best_id = ired[w]; }
         __syncthreads();
     }
+    NS_MARK(5);
     return best_id;
 }
 

@@ -197,7 +197,6 @@ struct sva_batch {
     bool concurrency = true;
     bool fused_decode = true;              // B <= 2: GEMV path with fused norm / RoPE / KV-write / SwiGLU
     bool use_mega = false;                 // B == 1: one persistent kernel per decoded frame (ar_decode.hip)
-    bool use_mega2 = false;                // one stream, whole chip: the second-generation kernel (ar_decode2.hip: 192 + 32 workgroups, communication waves)
     bool ar_partitioned = false;           // the AR stream has a CU partition of its own
     unsigned long long* d_gran = nullptr;  // its granule buffers (gx | gbig | gatt | glog)
     unsigned* d_epoch = nullptr;           // [1] running phase counter of the granule tags

@@ -1254,10 +1254,6 @@ int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_
     const float tclamp = b->p.temperature > 1e-5f ? b->p.temperature : 1e-5f;
     a.inv_temp = 1.0f / tclamp; a.top_p = b->p.top_p; a.skip_semantic = b->p.skip_semantic;
     a.vocab = c.ar_vocab; a.codebook_size = c.codebook_size;
-    if (b->use_mega2) {       // one stream: slot 0, every pointer is already this stream's
-        a.slot_base = 0;
-        return launch_ar_decode2(a, c.ar_dtype == 1, b->kv_half, b->stream);
-    }
     // on its own CU partition the kernel pads its LDS request so that the 96 workgroups land on 96 different CUs; on shared CUs it
     // keeps its small footprint so that the other stages' GEMM workgroups fit beside it
     {   // strides between the per-stream blocks (elements of each pointer's type)
@@ -1877,20 +1873,11 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     // multi-launch chain of the batched path (~200 dependent launches, 2.4-3.3 ms per frame at 2-8 streams) takes over above that
     static const int mega_max_b = getenv("SVA_AR_MEGA_MAXB") ? atoi(getenv("SVA_AR_MEGA_MAXB")) : 6;
     b->use_mega = B <= mega_max_b && B <= 8 && e->mega_ok && b->fused_decode && !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
-    // one stream on an unpartitioned chip: the second-generation kernel, if the device can hold its whole grid at once (every
-    // workgroup of a persistent kernel must be resident: checked here against the occupancy query, never assumed)
-    b->use_mega2 = false;
-    if (b->use_mega && B == 1 && !b->ar_partitioned && (getenv("SVA_AR_MEGA2") && atoi(getenv("SVA_AR_MEGA2")) != 0)) {
-        int per_cu = 0, cus = 0;
-        SVA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ar_decode2_func(c.ar_dtype == 1, b->kv_half), AR2_THREADS, ar_decode2_lds_bytes()));
-        SVA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-        b->use_mega2 = per_cu >= 1 && cus >= AR2_WGS + AR2_SEM_WGS;       // one workgroup per CU: no reliance on a second slot being free
-    }
     if (b->use_mega) {
-        SVA_TRY(dev_alloc(A, &b->d_gran, std::max(ar_decode_granule_words() * B, b->use_mega2 ? ar_decode2_granule_words() : (size_t)0)));
+        SVA_TRY(dev_alloc(A, &b->d_gran, ar_decode_granule_words() * B));
         SVA_TRY(dev_alloc(A, &b->d_epoch, B));
         SVA_TRY(dev_alloc(A, &b->d_ar_fail, 1));
-        SVA_TRY(dev_alloc(A, &b->kv_fast_mega, std::max((size_t)B * AR_FAST_LAYERS * 8 * 2 * D, b->use_mega2 ? ar_decode2_kvfast_floats() : (size_t)0)));
+        SVA_TRY(dev_alloc(A, &b->kv_fast_mega, (size_t)B * AR_FAST_LAYERS * 8 * 2 * D));
         if (getenv("SVA_AR_TIMING")) SVA_TRY(dev_alloc(A, &b->d_ar_dbg, 1024));
     }
     SVA_TRY(dev_alloc(A, &b->cached_audio_emb, (size_t)B * D));

@@ -20,7 +20,7 @@ b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=1000)
 b.begin()
 src = synth_utterance(1000, 2048 * 40)
 labels = []
-v2 = os.environ.get("SVA_AR_MEGA2", "0") != "0"      # second-generation kernel (ar_decode2.hip): the sampler is fused into the next FA
+v2 = False      # label set of the 192-workgroup experiment (commit c4feb26, profiles/r03_ar2_*): sampler fused into the next FA
 for l in range(12):
     for ph in ("A", "B1", "B1m", "B2", "C", "D"):
         labels += [f"s{l}.{ph}.in", f"s{l}.{ph}.out"]
@@ -53,4 +53,8 @@ for k in range(len(acc)):
 print(f"ar_dtype={ar_dtype}  frame span (first mark -> last mark): {acc.sum():.1f} us   fail={b.tap('ar_fail', (1,), np.int32)[0]}")
 for key, v in kinds.items():
     print(f"  {key:24s} n={len(v):3d} mean {np.mean(v):6.2f} us  min {np.min(v):6.2f}  max {np.max(v):6.2f}  sum {np.sum(v):7.1f}")
+if not v2:
+    ns = b.tap("ar_timing", (1024,), np.int64)[900:908].astype(np.float64)
+    print("sampler raw marks (us from entry: softmax done, [search done], ties done, final softmax done, argmax done, back in kernel):",
+          [round((x - ns[0]) * 0.01, 2) for x in ns[1:7]], "probes", int(ns[7]))
 print("timings:", b.timings())
