@@ -66,8 +66,16 @@ def parse():
                     help="replay the captured single-stream hipGraph of the whole steady step (3.8 ms at B=1 against 3.6 ms for eager "
                          "serial stepping and 1.6 ms for the pipelined default, see DESIGN.md)")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
-    ap.add_argument("--torch-gpu-baseline", action="store_true",
-                    help="also time the reference's formulation under eager PyTorch-ROCm on this GPU (second baseline, N=1 only)")
+    ap.add_argument("--no-torch-gpu-baseline", dest="torch_gpu_baseline", action="store_false",
+                    help="skip the second baseline: the reference's formulation under PyTorch-ROCm on this GPU, eager and "
+                         "torch.compile(mode='reduce-overhead') (N=1 only; the compiled leg runs in a time-boxed subprocess)")
+    ap.add_argument("--torch-gpu-baseline", dest="torch_gpu_baseline", action="store_true", help="(default)")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false",
+                    help="skip the two rocprofv3 --pmc passes (subprocesses of this script) that measure roofline.traffic")
+    ap.add_argument("--no-offline", dest="offline", action="store_false", help="skip the offline infer() block (BASELINE.json configs[0] on the GPU)")
+    ap.add_argument("--compiled-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--compile-timeout", type=float, default=240.0, help="wall-clock cap (s) of the torch.compile baseline subprocess")
+    ap.set_defaults(torch_gpu_baseline=True)
     return ap.parse_args()
 
 
@@ -152,8 +160,284 @@ def torch_gpu_baseline(args, W, steps=20):
             "rtf": round(dt / steps / (args.chunk * FRAME_S), 4)}
 
 
+def pmc_traffic(B, chunk):
+    """HBM bytes per conv-GEMM launch, measured NOW: two rocprofv3 --pmc passes (kernel trace + counters only, as
+    MI355X_MICROARCH.md 'HBM' prescribes: separate passes; reads = 32 B x RDREQ_32B + 2 x 64 B x (RDREQ - RDREQ_32B), the x2 being the
+    guide's gfx950 correction for wide coalesced requests; writes = WRITE_SIZE KiB) over a short single-stream-engine run of this
+    script, reduced over the steady-state steps.  Returns (bytes per launch | None, info dict)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None, {"error": "rocprofv3 not on PATH"}
+    tmp = tempfile.mkdtemp(prefix="sva_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", SVA_CONCURRENCY="0")
+    acc = {}
+    t0 = time.perf_counter()
+    try:
+        for name, counters in (("RD", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"]), ("WR", ["WRITE_SIZE"])):
+            d = os.path.join(tmp, name)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "24", "--warmup", "3", "--streams", str(B), "--chunk", str(chunk),
+                   "--no-cpu-baseline", "--no-roofline", "--no-pipeline", "--no-batched", "--no-pmc", "--no-torch-gpu-baseline", "--no-offline", "--no-pin"]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=200)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, {"error": f"pass {name}: rc {r.returncode}, {len(files)} counter files", "stderr_tail": r.stderr.decode(errors="replace")[-300:]}
+            rows = list(csv.DictReader(open(files[0])))
+            # steady state: every non-pipelined step starts with one ring_write_kernel; skip prefill / delay fill / warm-up and the tail
+            marks = sorted({int(x["Dispatch_Id"]) for x in rows if "ring_write" in x["Kernel_Name"]})
+            lo, hi = (marks[8], marks[min(8 + 24, len(marks) - 1)]) if len(marks) > 12 else (0, 1 << 62)
+            for x in rows:
+                kn = x["Kernel_Name"]
+                if not ("gemm_kernel" in kn or "split_ws_kernel" in kn) or not (lo <= int(x["Dispatch_Id"]) < hi):
+                    continue
+                a_ = acc.setdefault(x["Counter_Name"], [0, 0.0])
+                a_[0] += 1
+                a_[1] += float(x["Counter_Value"])
+    except Exception as ex:
+        return None, {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if not all(k in acc and acc[k][0] for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "WRITE_SIZE")):
+        return None, {"error": "counters missing from the rocprofv3 output", "have": sorted(acc)}
+    rd = acc["TCC_EA0_RDREQ_sum"][1] / acc["TCC_EA0_RDREQ_sum"][0]
+    rd32 = acc["TCC_EA0_RDREQ_32B_sum"][1] / acc["TCC_EA0_RDREQ_32B_sum"][0]
+    wr = acc["WRITE_SIZE"][1] / acc["WRITE_SIZE"][0] * 1024.0
+    reads = rd32 * 32.0 + (rd - rd32) * 64.0 * 2.0
+    return reads + wr, {"read_bytes_per_launch": round(reads, 1), "write_bytes_per_launch": round(wr, 1), "launches_counted": acc["WRITE_SIZE"][0],
+                        "source": "rocprofv3 --kernel-trace --pmc, two passes run by this bench.py invocation (steady-state steps of a 24-step single-queue run)",
+                        "seconds": round(time.perf_counter() - t0, 1)}
+
+
+class CompiledReference:
+    """The reference's fast mode (modules/arvc_wrapper.py:36-41, evaluations/infer_arvc.py:128-142): torch.compile(fullgraph,
+    mode='reduce-overhead') around decode_one_token_ar, firefly.head and speech_tokenizer.encode.  The reference cannot travel to the
+    GPU box, so these are torch restatements in the reference's own compile-friendly form: a STATIC slow KV cache [layers, H, S, 64]
+    written with index_copy_ and read in full under the causal mask of the query positions (dual_ar_stream.py:312-356, 895-936), the
+    8-step fast AR with its 8-slot cache, window recompute of encoder (128 frames) and vocoder (64 frames).  Sampling = argmax(p / q)
+    with Exp(1) noise drawn on the device, as multinomial_sample_one_no_sync does."""
+
+    def __init__(self, W, dev, S=2048, fullgraph=True):
+        import torch
+        import torch.nn.functional as F
+        from oracle import sva_oracle as O
+
+        self.torch, self.F, self.O, self.W, self.dev = torch, F, O, W, dev
+        cfg = O.ARConfig()
+        self.cfg, self.hd, self.S = cfg, cfg.dim // cfg.n_head, S
+        self.k = torch.zeros(cfg.n_layer, cfg.n_head, S, self.hd, device=dev)
+        self.v = torch.zeros_like(self.k)
+        self.tab = O.rope_table(S, self.hd).to(dev)
+        self.fast_tab = O.rope_table(cfg.num_codebooks, self.hd).to(dev)
+        self.fullgraph = fullgraph
+        O._FB_CACHE.clear()                      # the mel filterbank as a resident device tensor (the oracle caches it per process)
+        fb_key = (1025, 0.0, 22050.0, O.N_MELS, O.SR)
+        fb = O.slaney_mel_fb()
+        O._FB_CACHE[fb_key] = fb.to(dev)
+        self.ar_step = torch.compile(self._ar_step, fullgraph=fullgraph, mode="reduce-overhead")
+        self.encode = torch.compile(lambda win: O.encode_window(win, W), fullgraph=fullgraph, mode="reduce-overhead")
+        self.vocode = torch.compile(lambda codes: O.vocode_window(codes, W), fullgraph=fullgraph, mode="reduce-overhead")
+
+    def _block(self, x, p, tab, kc, vc, pos, L):
+        torch, F, W, H, hd = self.torch, self.F, self.W, self.cfg.n_head, self.hd
+        M = x.shape[0]
+        h = self.O.rms_norm(x, W[p + "attention_norm.weight"])
+        q, k, v = F.linear(h, W[p + "attention.wqkv.weight"]).split([H * hd] * 3, dim=-1)
+        q = self.O.apply_rope(q.view(M, H, hd), tab[pos]).transpose(0, 1)
+        k = self.O.apply_rope(k.view(M, H, hd), tab[pos]).transpose(0, 1)
+        v = v.view(M, H, hd).transpose(0, 1)
+        kc.index_copy_(1, pos, k)
+        vc.index_copy_(1, pos, v)
+        mask = torch.arange(L, device=x.device)[None, :] <= pos[:, None]
+        y = F.scaled_dot_product_attention(q[None], kc[None], vc[None], attn_mask=mask[None, None])[0]
+        x = x + F.linear(y.transpose(0, 1).reshape(M, H * hd), W[p + "attention.wo.weight"])
+        h = self.O.rms_norm(x, W[p + "ffn_norm.weight"])
+        return x + F.linear(F.silu(F.linear(h, W[p + "feed_forward.w1.weight"])) * F.linear(h, W[p + "feed_forward.w3.weight"]), W[p + "feed_forward.w2.weight"])
+
+    def _sample(self, logits):
+        torch = self.torch
+        s, idx = torch.sort(logits, descending=True)
+        rm = torch.cumsum(torch.softmax(s, dim=-1), dim=-1) > 0.7
+        rm[0] = False
+        logits = logits.masked_fill(torch.zeros_like(rm).scatter(0, idx, rm), -float("inf")) / 0.7
+        return torch.argmax(torch.softmax(logits, dim=-1) / torch.empty_like(logits).exponential_(1))
+
+    def _ar_step(self, x, pos):
+        """decode_one_token_ar (dual_ar_stream.py:1168-1219): x [2, 768] at positions pos [2] -> codes [8]"""
+        torch, W, cfg = self.torch, self.W, self.cfg
+        for l in range(cfg.n_layer):
+            x = self._block(x, f"arvc.decoder.model.layers.{l}.", self.tab, self.k[l], self.v[l], pos, self.S)
+        hidden = x[-1]
+        sem = self._sample(self.F.linear(self.O.rms_norm(hidden, W["arvc.decoder.model.norm.weight"]), W["arvc.decoder.model.output.weight"]))
+        kc = torch.zeros(cfg.n_fast_layer, cfg.n_head, cfg.num_codebooks, self.hd, device=x.device)
+        vc = torch.zeros_like(kc)
+        xx, codes = hidden, []
+        for cb in range(cfg.num_codebooks):
+            p1 = torch.full((1,), cb, device=x.device, dtype=torch.long)
+            h = xx[None]
+            for l in range(cfg.n_fast_layer):
+                h = self._block(h, f"arvc.decoder.model.fast_layers.{l}.", self.fast_tab, kc[l], vc[l], p1, cfg.num_codebooks)
+            tok = self._sample(self.F.linear(self.O.rms_norm(h[0], W["arvc.decoder.model.fast_norm.weight"]), W["arvc.decoder.model.fast_output.weight"]))
+            codes.append(tok)
+            xx = W["arvc.decoder.model.fast_embeddings.weight"][tok]
+        return torch.stack(codes), sem
+
+
+def compiled_baseline_worker(args):
+    """child process of bench.py: time the compiled formulation, print one JSON line"""
+    import torch
+
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import specs, synth_weights
+    from streamvoiceanon_amd.synth_audio import synth_utterance
+
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda")
+    W = {k: torch.from_numpy(v).to(dev) for k, v in synth_weights.generate_all(0, specs.all_specs()).items()}
+    t_c0 = time.perf_counter()
+    with dev:
+        ref = CompiledReference(W, dev, fullgraph=True)
+        n, steps, warm = 2048, 20, 4
+        src = torch.from_numpy(synth_utterance(1000, n * (warm + steps))).to(dev)[None]
+        window = torch.zeros(1, 128 * 2048, device=dev)
+        pred = torch.zeros(8, 64, dtype=torch.long, device=dev)
+        emb_c, emb_a = W["arvc.embedding.weight"], W["arvc.decoder.model.codebook_embeddings.weight"]
+        cached = torch.zeros(1, 768, device=dev)
+        pos0 = 33 + 2 * args.prompt_frames + 3
+        offs = torch.arange(8, device=dev) * 1000
+
+        def step(i, window, pred, cached):
+            window = torch.cat([window[:, n:], src[:, i * n:(i + 1) * n]], dim=-1)
+            code = ref.encode(window)[0, 0, -1]
+            x = torch.cat([cached, emb_c[code][None]], dim=0)
+            pos = torch.arange(2, device=dev) + (pos0 + 2 * i)
+            codes, _ = ref.ar_step(x, pos)
+            codes = codes.clone()
+            cached = emb_a[codes + offs].sum(0, keepdim=True)
+            pred = torch.cat([pred[:, 1:], codes[:, None]], dim=1)
+            wav = ref.vocode(pred[None])
+            return window, pred, cached, wav
+
+        graph_note = "fullgraph=True"
+        try:
+            st_ = step(0, window, pred, cached)
+        except Exception as ex:          # a graph break under fullgraph=True: the reference's flag, relaxed (reported)
+            graph_note = f"fullgraph=False (fullgraph=True failed: {type(ex).__name__})"
+            torch._dynamo.reset()
+            ref = CompiledReference(W, dev, fullgraph=False)
+            st_ = step(0, window, pred, cached)
+        window, pred, cached, wav = st_
+        for i in range(1, warm):
+            window, pred, cached, wav = step(i, window, pred, cached)
+        torch.cuda.synchronize()
+        t_compile = time.perf_counter() - t_c0
+        t0 = time.perf_counter()
+        for i in range(warm, warm + steps):
+            window, pred, cached, wav = step(i, window, pred, cached)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(json.dumps({"value": round(steps / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "kind": "port",
+                      "rtf": round(dt / steps / FRAME_S, 4), "compile_and_warmup_s": round(t_compile, 1),
+                      "sample": f"{steps} steady chunk-steps, B=1, chunk=1: torch.compile({graph_note}, mode='reduce-overhead') around the three callables "
+                                f"the reference compiles (decode_one_token_ar with a static 2048-slot KV cache, speech_tokenizer.encode on the 128-frame window, "
+                                f"firefly.head(quantizer.decode) on the 64-frame window), torch {torch.__version__} on cuda:0, fp32"}))
+
+
+def compiled_baseline(args):
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--compiled-baseline-worker", "--prompt-frames", str(args.prompt_frames)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.compile_timeout, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"torch.compile baseline did not finish within {args.compile_timeout:.0f} s (Inductor / Triton compilation on ROCm)"}
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        err = [ln for ln in r.stderr.decode(errors="replace").strip().splitlines() if ln.strip() and "TORCHDYNAMO_VERBOSE" not in ln and "TORCH_LOGS" not in ln
+               and "MIOpen" not in ln]
+        return {"error": f"rc {r.returncode}: " + " | ".join(err[-4:])[-500:]}
+    return json.loads(lines[-1])
+
+
+def _wrapper_with_prompt_path():
+    """the host mirror with every optional tensor loaded (firefly encoder of the prompt path, CAM++, SparkTTS speaker encoder)"""
+    from streamvoiceanon_amd import specs, synth_weights
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+
+    W2 = synth_weights.generate_all(0, specs.all_specs(prompt_path=True))
+    W2.update(synth_weights.generate_all(0, specs.prompt_encoder_specs()))
+    return InferenceWrapper(weights=W2)
+
+
+def offline_block(w, args):
+    """BASELINE.json configs[0] on the GPU: offline InferenceWrapper.infer (evaluations/infer_arvc.py:261-380) of one utterance, the
+    published example's shape (prompt R = 168 frames, source S = 153 frames): whole-utterance content encode -> DualARWrapper.generate
+    (prompt prefill + S decode steps) -> whole-utterance vocode.  Each seam is a host-synchronous call; wall-clock per seam."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    R, S = 168, 153
+    ac, cc, style, timbre = synth_prompt(2100, R)
+    src = synth_utterance(1100, 2048 * S)
+    res = {}
+    for rep in range(2):            # first pass warms allocations; the second is reported
+        t0 = time.perf_counter()
+        src_codes = w.encode_content(src)
+        t1 = time.perf_counter()
+        b = E.Batch(w.engine, n_streams=1, delay=2, voc_max_frames=S)
+        t1b = time.perf_counter()
+        out = b.generate(cc, ac, np.asarray(src_codes).reshape(-1), style, timbre, noise_seed=7)
+        t2 = time.perf_counter()
+        pcm = b.vocode_window(out[None])
+        t3 = time.perf_counter()
+        b.close()
+        res = {"encode_ms": round((t1 - t0) * 1e3, 2), "batch_create_ms": round((t1b - t1) * 1e3, 2), "generate_ms": round((t2 - t1b) * 1e3, 2),
+               "vocode_ms": round((t3 - t2) * 1e3, 2), "total_ms": round((t3 - t0) * 1e3, 2)}
+    res.update({"workload": f"BASELINE.json configs[0] on the GPU: offline infer, delay=2, synthetic prompt R={R} frames, source S={S} frames "
+                            f"({S * FRAME_S:.2f} s of audio), fp32",
+                "frames_per_s": round(S / (res["total_ms"] * 1e-3), 1), "rtf": round(res["total_ms"] * 1e-3 / (S * FRAME_S), 5),
+                "generate_ms_per_frame": round(res["generate_ms"] / S, 3), "pcm_samples": int(np.asarray(pcm).size)})
+    return res
+
+
+def prompt_latency_block(w):
+    """Once-per-utterance latencies (evaluations/infer_arvc.py:382-441, 463-489): calculate_prompt of a reference wav (device: firefly
+    encode + content encode + CAM++ style vector + SparkTTS timbre latents, incl. the 16 kHz resample on the host) and the KV prefill,
+    R = 107 and 256 frames."""
+    import torch
+
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    res = {}
+    for R in (107, 256):
+        ac, cc, style, timbre = synth_prompt(2200 + R, R)
+        b = E.Batch(w.engine, n_streams=1, chunk_frames=1, delay=2)
+        v = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=1)
+            v.append((time.perf_counter() - t0) * 1e3)
+        b.close()
+        res[f"prefill_prompt_R{R}_ms"] = round(min(v), 3)
+        wav = torch.from_numpy(synth_utterance(7300 + R, 2048 * R + 100))[None]
+        v = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            w.calculate_prompt(wav, alpha=1.0)
+            v.append((time.perf_counter() - t0) * 1e3)
+        res[f"calculate_prompt_R{R}_ms"] = round(min(v), 3)
+    return res
+
+
 def main():
     args = parse()
+    if args.compiled_baseline_worker:
+        return compiled_baseline_worker(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -312,41 +596,64 @@ def main():
             alg_bytes = batch.gemm_bytes()
             tot_ms, nl = batch.gemm_profile()
             tm_prof = batch.timings()          # stage times of this serial, event-bracketed step
+            tab = batch.gemm_profile_table()
+            pipes = {"f32_mfma": [0.0, 0.0, 0], "bf16_split": [0.0, 0.0, 0]}       # flops, us, launches
+            for M_, N_, K_, taps_, mode_, us in tab:
+                kind = (int(mode_) >> 8) - 1            # 0 small-M, 1 tiled, 2 pipelined: v_mfma_f32_16x16x4_f32;  4: six bf16 part products
+                pp = pipes["bf16_split" if kind == 4 else "f32_mfma"]
+                pp[0] += 2.0 * M_ * N_ * K_; pp[1] += us; pp[2] += 1
             if os.environ.get("SVA_GEMM_TABLE"):
-                tab = batch.gemm_profile_table()
                 agg = {}
                 for M_, N_, K_, taps_, mode_, us in tab:
-                    key = (int(M_), int(N_), int(K_), int(taps_), int(mode_))
+                    key = (int(M_), int(N_), int(K_), int(taps_), int(mode_) & 255, (int(mode_) >> 8) - 1)
                     a_ = agg.setdefault(key, [0, 0.0])
                     a_[0] += 1; a_[1] += us
                 with open(os.environ["SVA_GEMM_TABLE"] + (f".b{B}" if B != args.streams else ""), "w") as f:
-                    f.write("M,N,K,taps,mode,calls,total_us,avg_us,TFLOPs\n")
+                    f.write("M,N,K,taps,mode,kernel_kind,calls,total_us,avg_us,TFLOPs\n")
                     for key, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                         fl = 2.0 * key[0] * key[1] * key[2] * cnt
                         f.write(",".join(map(str, key)) + f",{cnt},{us:.1f},{us / cnt:.2f},{fl / us / 1e6:.2f}\n")
             batch.profile_gemm(False)
             ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-            # HBM bytes per conv-GEMM launch from the committed PMC passes of the same command (tools/pmc.sh ->
-            # profiles/rNN_pmc_b<B>.json; rocprofv3 cannot run inside bench.py): reads per the guide's gfx950 correction
+            # HBM bytes per conv-GEMM launch: measured by this invocation (two rocprofv3 --pmc child runs) when B is the headline
+            # workload; the committed profile's number is reported under its own name, never as `traffic`
             import glob
-            traffic, mfma_util, cands = None, None, sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_b{B}.json")))
+            traffic, pmc_info = None, None
+            if args.pmc and world == 1 and B == args.streams:
+                batch.sync()
+                traffic, pmc_info = pmc_traffic(B, c)
+            prof_traffic, mfma_util, cands = None, None, sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_b{B}.json")))
             if cands and c == 1:
                 pj = json.load(open(cands[-1]))
-                traffic = round(pj["hbm_bytes_per_launch"], 1)
+                prof_traffic = round(pj["hbm_bytes_per_launch"], 1)
                 mfma_util = round(pj["gemm_mfma_util"], 4) if pj.get("gemm_mfma_util") is not None else None
             alg_per_launch = alg_bytes / max(nl, 1)
+            PEAK_SPLIT = 2500.0 / 6.0
+            by_pipe = {}
+            for name, (fl, us, cnt) in pipes.items():
+                if cnt:
+                    pk = PEAK_F32_MFMA_TFLOPS if name == "f32_mfma" else PEAK_SPLIT
+                    by_pipe[name] = {"launches": cnt, "ms": round(us * 1e-3, 4), "gflop": round(fl / 1e9, 3), "achieved": round(fl / us / 1e6, 3),
+                                     "peak": round(pk, 1), "frac": round(fl / us / 1e6 / pk, 5)}
+            # the fraction of what the launches COULD have done in their own time on the pipes they ran on
+            cap = sum(v["ms"] * v["peak"] for v in by_pipe.values())
+            frac_own = (flops / 1e9) / cap if cap > 0 else 0.0
             roof = {"bound": "mfma", "kernel": "conv-GEMM family: pipe_gemm_kernel / conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32) and split_gemm_kernel / "
                               "split_ws_kernel (the same fp32 problems as six bf16 part products on v_mfma_f32_16x16x32_bf16, fp32-grade results; the "
                               "per-shape table picks)",
-                    "peak_note": "157.3 TF/s = dense f32-MFMA peak, the arithmetic the path is specified in; launches that run the split-bf16 kernel are "
-                                 "bounded by the bf16 pipes instead: 2500 / 6 = 416.7 TF/s of algorithmic fp32 work",
+                    "peak_note": "peak = 157.3 TF/s, the dense f32-MFMA peak (the arithmetic the path is specified in) -- `frac` = achieved / 157.3 as the contract "
+                                 "defines it; launches of the split-bf16 kernel run on the bf16 pipes, whose ceiling for this work is 2500 / 6 = 416.7 TF/s: `by_pipe` "
+                                 "prices each kernel family against its own pipe and `frac_of_own_pipes` is the time-weighted combination (the honest figure when "
+                                 "split launches are present)",
                     "achieved": round(ach, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
+                    "frac_of_own_pipes": round(frac_own, 5), "by_pipe": by_pipe,
                     "mode": "one serial step, every conv-GEMM launch bracketed by hipEvents on its launch stream (launches do not overlap)",
-                    "traffic": traffic, "traffic_source": os.path.basename(cands[-1]) if traffic is not None else None,
+                    "traffic": round(traffic, 1) if traffic is not None else None, "traffic_measurement": pmc_info,
+                    "traffic_from_committed_profile": prof_traffic, "committed_profile": os.path.basename(cands[-1]) if prof_traffic is not None else None,
                     "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
                     "traffic_over_algorithmic": round(traffic / alg_per_launch, 3) if traffic else None,
-                    "mfma_util_pmc": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024) over the same kernels (tools/pmc.sh)
+                    "mfma_util_pmc_committed_profile": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024) over the same kernels (tools/pmc.sh)
                     "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
                     "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4),
                     "stage_ms_profiled_step": {k_: round(v, 4) for k_, v in tm_prof.items()}}
@@ -388,7 +695,7 @@ def main():
         weight_bytes = ENC_PARAMS * 4 + VOC_PARAMS * 4 + AR_PARAMS * wb * c
         enc_gflop = 13.9 * B_                                                # merged incremental pass: head 160 + 6 + 4c rows, 128-token transformer
         voc_gflop = 2.646 * c * B_
-        r = {"timed": {"ms_per_step": round(ms_step, 4), "algorithmic_gflop_per_step": round(gflop_step, 3),
+        r = {"timed": {"note": "the K timed steps as run (stages of consecutive steps overlapped): algorithmic conv-GEMM FLOPs of a step / ms_per_step", "ms_per_step": round(ms_step, 4), "algorithmic_gflop_per_step": round(gflop_step, 3),
                        "tflops": round(gflop_step / ms_step, 3), "frac_f32_mfma": round(gflop_step / ms_step / PEAK_F32_MFMA_TFLOPS, 5),
                        "unique_weight_bytes_per_step": int(weight_bytes), "weight_stream_GBs": round(weight_bytes / ms_step / 1e6, 1),
                        "frac_hbm": round(weight_bytes / ms_step / 1e6 / PEAK_HBM_GBS, 5)},
@@ -415,6 +722,21 @@ def main():
                                      "x_realtime": round(64 * c * 10 / dt2 * FRAME_S, 2),
                                      "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm2.items()},
                                      "roofline": ({**roof2, **stage_rates(64, ms2, tm2, roof2["algorithmic_gflop_per_step"])} if roof2 else None), **extra2}
+    if world == 1 and args.offline:
+        import traceback
+        wrap = None
+        try:
+            wrap = _wrapper_with_prompt_path()
+            out["offline"] = offline_block(wrap, args)
+        except Exception as ex:
+            out["offline"] = {"error": f"{type(ex).__name__}: {ex}"[:300], "where": traceback.format_exc().strip().splitlines()[-3][:200]}
+        try:
+            if wrap is not None:
+                out["prompt_latency"] = prompt_latency_block(wrap)
+        except Exception as ex:
+            out["prompt_latency"] = {"error": f"{type(ex).__name__}: {ex}"[:300], "where": traceback.format_exc().strip().splitlines()[-3][:200]}
+        if wrap is not None:
+            wrap.engine.close()
     if world == 1 and not args.no_cpu_baseline:
         os.sched_setaffinity(0, cpus_at_start)      # the CPU leg uses all host cores again
         import torch as _t
@@ -422,6 +744,7 @@ def main():
     if world == 1 and args.torch_gpu_baseline:
         import torch as _t
         eng.close()
+        os.sched_setaffinity(0, cpus_at_start)
         try:
             from oracle import sva_oracle as _O
             _O._FB_CACHE.clear()             # (the oracle caches its mel filterbank on the device it was first built on)
@@ -429,6 +752,8 @@ def main():
             _O._FB_CACHE.clear()
         except Exception as ex:          # a reported extra, never a reason to lose the bench line
             out["torch_gpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        _t.cuda.empty_cache()
+        out["torch_compile_gpu_baseline"] = compiled_baseline(args)
     print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()

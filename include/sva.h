@@ -116,6 +116,15 @@ int sva_step(sva_batch* b, const float* pcm_in, float* pcm_out, const float* noi
  * with the caller's: whatever produced d_pcm_in (a kernel or copy on another stream) must have COMPLETED before this call.  With sva_stream_params.pipeline the stages of consecutive
  * calls overlap on three streams. */
 int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm_out);
+/* Stream-ordered form -- what a torch caller wants: process_one_chunk in the reference runs on the caller's current stream
+ * (evaluations/infer_arvc.py:495-508), so the producer of the input is ordered before it and the consumer of the output after it.
+ * caller_stream is a hipStream_t (NULL = the legacy default stream; pass torch.cuda.current_stream().cuda_stream).  The engine's first
+ * access to d_pcm_in waits (event, on the device) for everything enqueued on caller_stream so far; with join_output != 0 the
+ * caller's stream then waits for the step's output, i.e. full same-stream semantics (and no overlap between consecutive steps);
+ * with join_output == 0 consecutive steps keep overlapping, d_pcm_in must not be rewritten and d_pcm_out not read before a later
+ * sva_join_stream(b, stream) (device-side wait for all engine work enqueued so far) or sva_sync(). */
+int sva_step_device_on(sva_batch* b, const float* d_pcm_in, float* d_pcm_out, void* caller_stream, int join_output);
+int sva_join_stream(sva_batch* b, void* caller_stream);
 int sva_sync(sva_batch* b);
 /* stream_infer's chunk loop (evaluations/infer_arvc.py:650-675) in one call: n_chunks consecutive sva_step_device steps over
  * host arrays pcm_in / pcm_out float[B][n_chunks * 2048 * chunk] (staged through device memory, stages pipelined when
@@ -214,6 +223,14 @@ int sva_op_stft_mag(sva_engine* e, const float* wave, long n, int n_fft, int win
 int sva_op_attention(sva_engine* e, const float* q, const float* kv, int Lq, int Lk, int n_valid, int H, float* out, float* scratch /* [Lq][H][Lk] */);
 int sva_op_geglu(sva_engine* e, const float* h, long ldh, int T, int Dh, float* out, long ldo);
 int sva_op_l2norm(sva_engine* e, const float* x, int T, int C, const float* gamma, float scale, float* y);
+
+/* 1 if the batch decodes with the persistent kernel (ar_decode.hip): <= 6 streams, reference layer sizes, and the residency check at
+ * sva_batch_create passed (all its workgroups fit the AR stream's CUs at once); 0 = the multi-launch decode.  A persistent launch whose
+ * workgroups are NOT all resident (GPU shared with another process) times out after ~50 ms: the next sva_sync / sva_step returns an
+ * error, every later step fails, and sva_prefill_prompt + sva_streams_begin restart the streams on the multi-launch decode. */
+int sva_batch_uses_persistent_decode(sva_batch* b);
+/* test hook: set the persistent kernel's device-side timeout word, as a launch with non-resident workgroups would */
+int sva_test_force_ar_timeout(sva_batch* b);
 
 /* kernel unit-test hook: C = A[M,K] * W[N,K]^T (+bias) through the conv-GEMM kernel (host arrays) */
 int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C);

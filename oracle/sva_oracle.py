@@ -31,12 +31,12 @@ SR = 44100
 # =========================================================================================
 # shared pieces
 # =========================================================================================
-def rope_table(seq_len: int, n_elem: int, base: float = 10000.0) -> torch.Tensor:
+def rope_table(seq_len: int, n_elem: int, base: float = 10000.0, device=None) -> torch.Tensor:
     """cos/sin table rounded to bf16, as float32 [seq_len, n_elem/2, 2].
     modules/dual_ar_stream.py:993-1001 and modules/vqgan/windowed_transformer.py:356-365:
     both return ``cache.to(bfloat16)``; the rounded values are then used in fp32 math."""
-    freqs = 1.0 / (base ** (torch.arange(0, n_elem, 2)[: n_elem // 2].float() / n_elem))
-    ang = torch.outer(torch.arange(seq_len).float(), freqs)
+    freqs = 1.0 / (base ** (torch.arange(0, n_elem, 2, device=device)[: n_elem // 2].float() / n_elem))
+    ang = torch.outer(torch.arange(seq_len, device=device).float(), freqs)
     tab = torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1)
     return tab.to(torch.bfloat16).float()
 
@@ -134,7 +134,7 @@ def stft_magnitude(audio: torch.Tensor) -> torch.Tensor:
     audio [B, N] -> [B, 1025, N/512]."""
     y = F.pad(audio.float(), (N_FFT - HOP, 0))
     frames = y.unfold(-1, N_FFT, HOP)                         # [B, T, 2048]
-    spec = torch.fft.rfft(frames * torch.hann_window(N_FFT), dim=-1)
+    spec = torch.fft.rfft(frames * torch.hann_window(N_FFT, device=frames.device), dim=-1)
     mag = torch.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-6)
     return mag.transpose(1, 2)
 
@@ -142,7 +142,7 @@ def stft_magnitude(audio: torch.Tensor) -> torch.Tensor:
 def log_mel(audio: torch.Tensor) -> torch.Tensor:
     """LogMelSpectrogram.forward, modules/vqgan/spectrogram.py:117-130 -> [B, 160, T]."""
     mag = stft_magnitude(audio)
-    mel = torch.matmul(mag.transpose(1, 2), slaney_mel_fb()).transpose(1, 2)
+    mel = torch.matmul(mag.transpose(1, 2), slaney_mel_fb().to(mag.device)).transpose(1, 2)
     return torch.log(torch.clamp(mel, min=1e-5))
 
 
@@ -168,10 +168,10 @@ def window_transformer(x: torch.Tensor, W: dict, p: str, n_layer=8, n_head=8) ->
     x = x.transpose(1, 2)
     B, T, C = x.shape
     hd = C // n_head
-    tab = rope_table(2048, hd)[:T]
+    tab = rope_table(2048, hd, device=x.device)[:T]
     win_mask = None
     if T > 512:
-        r = torch.arange(T)
+        r = torch.arange(T, device=x.device)
         win_mask = (r[None, :] <= r[:, None]) & (r[None, :] >= (r[:, None] - 511).clamp(min=0))
     for l in range(n_layer):
         q = f"{p}layers.{l}."
@@ -210,7 +210,7 @@ def bsq_encode(feat: torch.Tensor, W: dict, p: str = "tok.quantizer.", return_u:
                  W[p + "residual_bsq.rvqs.0.project_in.bias"])
     u = F.normalize(u.float(), dim=-1)
     nbits = u.shape[-1]
-    weights = 2 ** torch.arange(nbits - 1, -1, -1)
+    weights = 2 ** torch.arange(nbits - 1, -1, -1, device=u.device)
     idx = ((u > 0).long() * weights).sum(-1)
     return (idx, u) if return_u else idx
 
@@ -221,9 +221,9 @@ def encode_window(audio: torch.Tensor, W: dict, lengths: torch.Tensor | None = N
     mel = log_mel(audio)
     T = mel.shape[-1]
     if lengths is None:
-        mask = torch.ones(audio.shape[0], 1, T)
+        mask = torch.ones(audio.shape[0], 1, T, device=audio.device)
     else:
-        mask = (torch.arange(T)[None] < (lengths // HOP)[:, None])[:, None, :].float()
+        mask = (torch.arange(T, device=audio.device)[None] < (lengths // HOP)[:, None])[:, None, :].float()
     mel = mel * mask
     feat = convnext_encoder(mel, W, "tok.backbone.") * mask
     idx, u = bsq_encode(feat, W, return_u=True)
@@ -453,8 +453,8 @@ def fsq_decode(codes: torch.Tensor, W: dict) -> torch.Tensor:
     code_d = (digit_d - half_d) / half_d with half = level // 2 = [4, 2, 2, 2]; one quantizer
     per group so the residual scale is 1; per-group Linear 4 -> 64; groups concatenated.
     codes int [B, 8, T] -> [B, 512, T]."""
-    levels = torch.tensor(FSQ_LEVELS)
-    basis = torch.cumprod(torch.tensor((1,) + FSQ_LEVELS[:-1]), 0)
+    levels = torch.tensor(FSQ_LEVELS, device=codes.device)
+    basis = torch.cumprod(torch.tensor((1,) + FSQ_LEVELS[:-1], device=codes.device), 0)
     half = levels // 2
     outs = []
     for g in range(codes.shape[1]):

@@ -612,6 +612,13 @@ constexpr size_t AR_LDS_FLOATS = GX + GBIG + 4 * 68 + GX + GLOG + 16 * 68 + NCB 
 
 }  // namespace
 
+int ar_decode_occupancy(int wt_half, int kv_half, int* blocks_per_cu) {
+    const void* f = wt_half ? (kv_half ? (const void*)ar_decode_kernel<__half, __half> : (const void*)ar_decode_kernel<__half, float>)
+                            : (kv_half ? (const void*)ar_decode_kernel<float, __half> : (const void*)ar_decode_kernel<float, float>);
+    SVA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, 256, AR_LDS_FLOATS * sizeof(float)));
+    return 0;
+}
+
 size_t ar_decode_granule_words() { return (size_t)GX + GBIG + GATT + GLOG + GA; }
 
 int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st, int n_slots) {
@@ -623,13 +630,13 @@ int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_p
     const size_t smem_max = (size_t)88 * 1024;
     const size_t smem = one_per_cu ? smem_max : AR_LDS_FLOATS * sizeof(float);
     static_assert(AR_LDS_FLOATS * sizeof(float) <= (size_t)88 * 1024, "LDS layout");
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    if (attr.needed()) {
         SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<__half, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<__half, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<float, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
-        attr = true;
+        attr.done();
     }
     if (wt_half && kv_half) hipLaunchKernelGGL((ar_decode_kernel<__half, __half>), dim3(AR_WGS, n_slots), dim3(256), smem, st, a);
     else if (wt_half) hipLaunchKernelGGL((ar_decode_kernel<__half, float>), dim3(AR_WGS, n_slots), dim3(256), smem, st, a);

@@ -126,6 +126,11 @@ struct ResConv {
 struct sva_engine {
     sva_config cfg;
     int device = 0;
+    // persistent AR decode launches of DIFFERENT batches of this engine are chained (event): two half-resident persistent grids
+    // waiting for each other's CUs would only end at their spin timeouts
+    hipEvent_t mega_ev = nullptr;
+    bool mega_ev_valid = false;
+    const void* mega_last = nullptr;
     bool finalized = false;
     std::unordered_map<std::string, sva::HostTensor> host;
     sva::DevPool allocs;
@@ -196,7 +201,9 @@ struct sva_batch {
     int evi = 0;
     bool concurrency = true;
     bool fused_decode = true;              // B <= 2: GEMV path with fused norm / RoPE / KV-write / SwiGLU
+    bool ar_failed = false;                // a persistent launch timed out: every step fails until sva_streams_begin, which falls back to the multi-launch decode
     bool use_mega = false;                 // B == 1: one persistent kernel per decoded frame (ar_decode.hip)
+    int mega_per_launch = 1;               // streams per persistent launch (2 when 192 workgroups find a CU each)
     bool ar_partitioned = false;           // the AR stream has a CU partition of its own
     unsigned long long* d_gran = nullptr;  // its granule buffers (gx | gbig | gatt | glog)
     unsigned* d_epoch = nullptr;           // [1] running phase counter of the granule tags

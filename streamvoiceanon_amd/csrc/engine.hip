@@ -67,6 +67,22 @@ using namespace sva;
 // joins the AR / vocoder streams of the pipelined mode back into the main stream (no-op when nothing is in flight there)
 namespace { int quiesce(sva_batch* b); }
 
+// Recovery from a persistent-kernel timeout (called by sva_prefill_prompt / sva_streams_begin): clear the device flag, leave the
+// persistent kernel for the multi-launch decode (whatever kept its workgroups from being co-resident may still be there), drop the
+// graphs that captured its launches, and require fresh prompts: the KV caches and positions of the failed frames are garbage.
+static int recover_ar_failure(sva_batch* b) {
+    if (!b->ar_failed) return 0;
+    SVA_HIP(hipDeviceSynchronize());
+    SVA_HIP(hipMemset(b->d_ar_fail, 0, sizeof(int)));
+    b->use_mega = false;
+    for (auto& ge : b->pipe_graph_a) if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
+    if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
+    std::fill(b->prefilled.begin(), b->prefilled.end(), 0);
+    b->begun = false;
+    b->ar_failed = false;
+    return 0;
+}
+
 // ============================================================================================
 // config defaults
 // ============================================================================================
@@ -542,6 +558,7 @@ int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda,
         SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n], b->stream));
         int rc = launch_conv_gemm(g, b->stream);
         SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n + 1], b->stream));
+        b->prof_shapes.back()[4] += 256 * (conv_gemm_last_kind() + 1);        // kernel family of the launch, for the per-pipe roofline
         b->prof_n += 2;
         return rc;
     }
@@ -603,6 +620,7 @@ int gemm_group_call(sva_batch* b, const ConvGemm* gs, int n) {
         SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n], b->stream));
         int rc = launch_conv_gemm_group(gs, n, b->stream);
         SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n + 1], b->stream));
+        b->prof_shapes.back()[4] += 256 * (conv_gemm_last_kind() + 1);
         b->prof_n += 2;
         return rc;
     }
@@ -1216,7 +1234,18 @@ int ar_decode_frame(sva_batch* b, int ci) {
     const int B = b->B, D = c.ar_dim, chunk = b->p.chunk_frames;
     hipStream_t st = b->stream;
     const int code_off = b->T2 - chunk + ci;
-    if (b->use_mega) return ar_decode_frame_mega(b, ci, b->d_codes, code_off);
+    if (b->use_mega) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool eager = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;     // (events of other batches cannot enter a capture)
+        if (eager && e->mega_ev_valid && e->mega_last != b) SVA_HIP(hipStreamWaitEvent(st, e->mega_ev, 0));
+        SVA_TRY(ar_decode_frame_mega(b, ci, b->d_codes, code_off));
+        if (eager) {
+            if (!e->mega_ev) SVA_HIP(hipEventCreateWithFlags(&e->mega_ev, hipEventDisableTiming));
+            SVA_HIP(hipEventRecord(e->mega_ev, st));
+            e->mega_ev_valid = true; e->mega_last = b;
+        }
+        return 0;
+    }
     hipLaunchKernelGGL(ar_prepare_step_kernel, dim3(B), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, b->d_codes, b->T2,
                        code_off, b->d_last_pos, D, b->ax, b->d_slot, b->d_pos, b->d_step_content, chunk, ci);
     SVA_TRY(ar_layers_pass(b, e->ar_layers, 2 * B, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
@@ -1268,7 +1297,7 @@ int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_
     // at most two streams per launch: 192 workgroups find a CU each and leave half of every register file to the other stages'
     // kernels; four streams in one launch (two 256-register workgroups on half of the CUs) measured 1.75 ms for the frame AND
     // locked the encoder / vocoder kernels out of those CUs (2.69 ms per pipelined step against 1.9 with two launches of two)
-    static const int per_launch = getenv("SVA_AR_MEGA_GROUP") ? atoi(getenv("SVA_AR_MEGA_GROUP")) : 2;
+    const int per_launch = b->mega_per_launch;
     for (int s0 = 0; s0 < b->B; s0 += per_launch) {
         a.slot_base = s0;
         SVA_TRY(launch_ar_decode(a, c.ar_dtype == 1, b->kv_half, !share, b->stream, std::min(per_launch, b->B - s0)));
@@ -1874,6 +1903,17 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     static const int mega_max_b = getenv("SVA_AR_MEGA_MAXB") ? atoi(getenv("SVA_AR_MEGA_MAXB")) : 6;
     b->use_mega = B <= mega_max_b && B <= 8 && e->mega_ok && b->fused_decode && !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
     if (b->use_mega) {
+        // every workgroup of a persistent launch must be resident at once: check the launch geometry against the occupancy query and
+        // the CUs the AR stream may use, never assume it.  One workgroup per CU is what the kernel is sized for (256 registers, 4 waves);
+        // the query's answer beyond 1 is not relied on (it over-reports by one on SGPR-heavy kernels, MI355X_MICROARCH.md).
+        int per_cu = 0, cus = 0;
+        SVA_TRY(ar_decode_occupancy(c.ar_dtype == 1, b->kv_half, &per_cu));
+        SVA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+        const int avail = b->ar_partitioned ? std::min(cus, 96) : cus;       // the AR stream's CU mask (get_streams) is CUs 0..95
+        b->mega_per_launch = (avail >= 2 * AR_WGS && !b->ar_partitioned) ? 2 : 1;
+        if (per_cu < 1 || avail < AR_WGS) b->use_mega = false;                // fall back to the multi-launch decode
+    }
+    if (b->use_mega) {
         SVA_TRY(dev_alloc(A, &b->d_gran, ar_decode_granule_words() * B));
         SVA_TRY(dev_alloc(A, &b->d_epoch, B));
         SVA_TRY(dev_alloc(A, &b->d_ar_fail, 1));
@@ -2023,6 +2063,7 @@ extern "C" int sva_prefill_prompt(sva_batch* b, int slot, const int64_t* ref_con
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
     SVA_TRY(quiesce(b));
+    SVA_TRY(recover_ar_failure(b));
     const sva_config& c = b->e->cfg;
     const int ncb = c.num_codebooks;
     std::vector<int64_t> cc(ref_content_codes, ref_content_codes + R);
@@ -2137,6 +2178,7 @@ extern "C" int sva_streams_begin(sva_batch* b) {
     SVA_HIP(hipSetDevice(b->e->device));
     (void)hipGetLastError();
     SVA_TRY(quiesce(b));
+    SVA_TRY(recover_ar_failure(b));
     const int B = b->B, ncb = b->e->cfg.num_codebooks, c = b->p.chunk_frames;
     for (int i = 0; i < B; ++i) SVA_CHECK(b->prefilled[i], "every slot needs sva_prefill_prompt before sva_streams_begin");
     // setup_stream_caches (infer_arvc.py:443-460)
@@ -2566,6 +2608,7 @@ int quiesce(sva_batch* b) {
 int step_body(sva_batch* b) {
     sva_engine* e = b->e;
     (void)e;
+    SVA_CHECK(!b->ar_failed, "this batch's persistent AR decode kernel timed out earlier: call sva_streams_begin to restart its streams");
     const int B = b->B, chunk = b->p.chunk_frames, d = b->p.delay, n = 2048 * chunk;
     hipStream_t st = b->stream;
     const bool steady = b->delay_filled && (b->h_ncontent + chunk >= d);
@@ -2710,6 +2753,44 @@ extern "C" int sva_step_device(sva_batch* b, const float* d_pcm_in, float* d_pcm
     return 0;
 }
 
+// Stream-ordered variants: the reference's process_one_chunk runs on the caller's current stream, so whatever filled the input
+// buffer is ordered before it and whatever reads the output after it (evaluations/infer_arvc.py:495-508 on torch's stream).  The
+// engine keeps streams of its own; these entry points tie them to the caller's stream with events instead of host synchronisation.
+extern "C" int sva_step_device_on(sva_batch* b, const float* d_pcm_in, float* d_pcm_out, void* caller_stream, int join_output) {
+    SVA_CHECK(b && b->begun, "sva_step_device_on: bad argument");
+    SVA_HIP(hipSetDevice(b->e->device));
+    hipStream_t cs = (hipStream_t)caller_stream;
+    {   // everything already enqueued on the caller's stream happens before the engine's first access to d_pcm_in
+        hipEvent_t ev = next_event(b);
+        SVA_HIP(hipEventRecord(ev, cs));
+        SVA_HIP(hipStreamWaitEvent(b->main_stream, ev, 0));
+    }
+    SVA_TRY(sva_step_device(b, d_pcm_in, d_pcm_out));
+    if (join_output) return sva_join_stream(b, caller_stream);
+    return 0;
+}
+
+extern "C" int sva_join_stream(sva_batch* b, void* caller_stream) {
+    SVA_CHECK(b, "null batch");
+    SVA_HIP(hipSetDevice(b->e->device));
+    hipStream_t cs = (hipStream_t)caller_stream;
+    // the caller's stream waits (on the device, not the host) for every chain of the engine: the stage streams of a pipelined batch,
+    // the encoder's side stream and the main stream; the pipelined regime itself is left untouched
+    hipStream_t all[4] = {b->main_stream, b->p.pipeline ? b->sa : nullptr, b->p.pipeline ? b->sv : nullptr, b->aux[0]};
+    for (hipStream_t st_ : all) {
+        if (!st_) continue;
+        hipEvent_t ev = next_event(b);
+        SVA_HIP(hipEventRecord(ev, st_));
+        SVA_HIP(hipStreamWaitEvent(cs, ev, 0));
+    }
+    if (b->out_stream && b->out_stream != b->main_stream) {
+        hipEvent_t ev = next_event(b);
+        SVA_HIP(hipEventRecord(ev, b->out_stream));
+        SVA_HIP(hipStreamWaitEvent(cs, ev, 0));
+    }
+    return 0;
+}
+
 extern "C" int sva_stream_chunks(sva_batch* b, const float* pcm_in, float* pcm_out, int n_chunks) {
     SVA_CHECK(b && pcm_in && pcm_out && b->begun && n_chunks >= 1, "sva_stream_chunks: bad argument");
     SVA_HIP(hipSetDevice(b->e->device));
@@ -2743,10 +2824,24 @@ static int check_ar_fail(sva_batch* b) {
     if (!b->use_mega || !b->d_ar_fail) return 0;
     int f = 0;
     SVA_HIP(hipMemcpy(&f, b->d_ar_fail, sizeof(int), hipMemcpyDeviceToHost));
+    if (f != 0) b->ar_failed = true;
     SVA_CHECK(f == 0, "persistent AR decode kernel timed out waiting for a workgroup hand-off (code " + std::to_string(f) +
-                      "): are all 96 workgroups resident? (SVA_AR_MEGA=0 selects the multi-launch decode)");
+                      "): its workgroups were not all resident (GPU shared with another process / a long kernel?).  The frames since the last "
+                      "synchronisation are invalid; sva_streams_begin restarts the streams on the multi-launch decode");
     return 0;
 }
+
+// test hook: make the batch look as if its persistent decode kernel had timed out (sets the device-side fail word)
+extern "C" int sva_test_force_ar_timeout(sva_batch* b) {
+    SVA_CHECK(b && b->use_mega && b->d_ar_fail, "sva_test_force_ar_timeout: the batch does not use the persistent decode kernel");
+    SVA_HIP(hipSetDevice(b->e->device));
+    SVA_TRY(quiesce(b));
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    const int code = 99;
+    SVA_HIP(hipMemcpy(b->d_ar_fail, &code, sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int sva_batch_uses_persistent_decode(sva_batch* b) { return b && b->use_mega ? 1 : 0; }
 
 extern "C" int sva_sync(sva_batch* b) {
     SVA_CHECK(b, "null batch");
@@ -2755,6 +2850,7 @@ extern "C" int sva_sync(sva_batch* b) {
     SVA_TRY(quiesce(b));
     SVA_HIP(hipStreamSynchronize(b->stream));
     SVA_TRY(check_ar_fail(b));
+    SVA_TRY(conv_gemm_check_errors());
     float t;
     if (!b->graph_step)
         for (int i = 0; i < 3; ++i)

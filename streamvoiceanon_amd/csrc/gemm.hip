@@ -21,6 +21,8 @@
 
 namespace sva {
 
+constexpr int KS_ERR_WORD = (1 << 16) - 1;      // last word of a stream's split-K arrival counters: set when a partial never arrived
+
 #define SVA_TRY_RC(expr)     \
     do {                     \
         int _rc = (expr);    \
@@ -508,8 +510,12 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
                             if ((unsigned)(x[e] >> 32) == 1u) pending &= ~(1u << e);
                         }
                 }
+                // (every writer finished its stores before it took its arrival ticket, so the poll only bridges their flight time;
+                // a partial that never shows up is a hardware / protocol fault: flag it -- sva_sync reports it -- and leave its tag alone)
+                if (pending) __hip_atomic_store(g.ks_cnt + KS_ERR_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    if (pending & (1u << e)) continue;
                     t[j][e] += __uint_as_float((unsigned)x[e]);
                     __hip_atomic_store(gp + e * 64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -530,6 +536,18 @@ static std::mutex g_ks_mu;
 static std::unordered_map<hipStream_t, KsScratch> g_ks;
 constexpr size_t KS_WS_FLOATS = (size_t)4 << 20;      // granules of partial tiles (8 bytes each: 32 MiB)
 constexpr int KS_CNT = 1 << 16;
+static_assert(KS_ERR_WORD == KS_CNT - 1, "error word = last counter");
+// sva_sync: has any split-K reader on any stream of this process flagged a missing partial?
+int conv_gemm_check_errors() {
+    std::lock_guard<std::mutex> lk(g_ks_mu);
+    for (auto& kv : g_ks) {
+        if (!kv.second.cnt) continue;
+        unsigned v = 0;
+        SVA_HIP(hipMemcpy(&v, kv.second.cnt + KS_ERR_WORD, sizeof(unsigned), hipMemcpyDeviceToHost));
+        SVA_CHECK(v == 0, "split-K GEMM: a partial tile never arrived (hand-off fault)");
+    }
+    return 0;
+}
 static int ks_scratch(hipStream_t st, KsScratch* out) {
     std::lock_guard<std::mutex> lk(g_ks_mu);
     auto it = g_ks.find(st);
@@ -569,15 +587,15 @@ static int launch_skinny_op(const ConvGemm& g, hipStream_t st) {
         if (Z > nkb) Z = (int)nkb;
         const size_t tiles = (size_t)grid.x * grid.y;
         KsScratch k;
-        if (Z > 1 && (tiles > (size_t)KS_CNT || (size_t)Z * tiles * MT * NT * 256 > KS_WS_FLOATS)) Z = 1;
+        if (Z > 1 && (tiles >= (size_t)KS_ERR_WORD || (size_t)Z * tiles * MT * NT * 256 > KS_WS_FLOATS)) Z = 1;
         if (Z > 1) { SVA_TRY_RC(ks_scratch(st, &k)); if (!k.ws) Z = 1; }
         gg.g[0].ksplit = Z; gg.g[0].ks_ws = k.ws; gg.g[0].ks_cnt = k.cnt;
         grid.z = Z;
     }
-    static bool attr = false;
-    if (!attr && smem > 48 * 1024) {
+    static DeviceOnce attr;
+    if (attr.needed() && smem > 48 * 1024) {
         SVA_HIP(hipFuncSetAttribute((const void*)skinny_gemm_kernel<MT, NT, KW, D, AOP>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL((skinny_gemm_kernel<MT, NT, KW, D, AOP>), grid, dim3(64 * KW), smem, st, gg);
     return 0;
@@ -655,10 +673,10 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
     constexpr size_t smem_ab = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     constexpr size_t smem_c = (size_t)BM * (BN + 4) * sizeof(float);          // epilogue staging tile reuses the buffers
     constexpr size_t smem = smem_ab > smem_c ? smem_ab : smem_c;
-    static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
+    static DeviceOnce attr_set;
+    if (attr_set.needed() && smem > 48 * 1024) {
         SVA_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.done();
     }
     ConvGemmGroup gg;
     if (t_group) gg = *t_group; else gg.g[0] = g;
@@ -672,6 +690,7 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
 // tiles per wave); kind 1 = LDS-tiled kernel (a: 0 = 64x64, 1 = 128x128, 2 = 128x32, 3 = 256x16, 4 = 128x64, 5 = 64x128,
 // 6 = 256x64, 7 = 256x128 on 8 waves; 4..7 are reached through the autotuner only).
 struct Choice { int kind, a, b, c; int z = 1; };      // z: grid-level K split of the small-M kernel
+static thread_local int t_last_kind = -1;                // kernel family of this thread's latest dispatch (bench.py: per-pipe roofline)
 
 static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
     if (ch.kind == 4) {                 // fp32 on the bf16 matrix pipes, six-product split (gemm_split.hip), a = tile variant
@@ -863,7 +882,13 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
     {
         const auto& tab = static_table();
         auto it = tab.find({g.M, g.N, g.taps * g.Cin, g.taps, (int)key_flags, g.stride});
-        if (it != tab.end()) ch = it->second;
+        if (it != tab.end()) {
+            // the table is keyed by shape only; the pipelined / split kernels also need aligned operands (a seam such as sva_op_conv can
+            // present a tuned shape with other strides): keep the tuned choice only if its kernel accepts THIS problem
+            const Choice& tc = it->second;
+            const bool ok = (tc.kind == 2) ? (c_vec && pipe_gemm_supported(g)) : (tc.kind == 4) ? (c_vec && split_gemm_supported(g)) : (tc.kind == 1 ? c_vec || tc.a == 0 : true);
+            if (ok) ch = tc;
+        }
     }
     // Deterministic by default: the kernel / configuration of a problem shape comes from the compiled-in table (tune_table.inc,
     // generated offline from a logged tuning run) or the heuristic -- never from wall-clock measurements of this process, so two
@@ -985,10 +1010,13 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
             }
         }
     }
+    t_last_kind = ch.kind;
     SVA_TRY_RC(launch_choice(g, st, ch));
     SVA_HIP(hipGetLastError());
     return 0;
 }
+
+int conv_gemm_last_kind() { return t_last_kind; }
 
 // test hook: run one specific dispatch choice (kind 0: a = rows/16, b = K split, c = column tiles; kind 1: a = tile variant)
 int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, int b, int c) {

@@ -261,10 +261,10 @@ int launch_pipe_p(const ConvGemmGroup& gg_in, hipStream_t st) {
     constexpr size_t epi = ((size_t)BM * (BN + 4) + BM) * sizeof(float);
     constexpr size_t smem = ring > epi ? ring : epi;
     static_assert(smem <= 160 * 1024, "LDS");
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    if (attr.needed()) {
         SVA_HIP(hipFuncSetAttribute((const void*)pipe_gemm_kernel<BM, BN, RS, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
+        attr.done();
     }
     const ConvGemm& g = gg.g[0];
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, gg.n);

@@ -462,10 +462,10 @@ int launch_split_ws(const ConvGemmGroup& gg_in, hipStream_t st) {
     constexpr size_t smem_ab = (size_t)2 * 3 * (BM + BN) * 48 * sizeof(unsigned short);
     constexpr size_t smem_c = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t smem = smem_ab > smem_c ? smem_ab : smem_c;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.needed()) {
         SVA_HIP(hipFuncSetAttribute((const void*)split_ws_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
+        attr_set.done();
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, gg.n);
     static const int dbg = getenv("SVA_SPLIT_DBG") ? atoi(getenv("SVA_SPLIT_DBG")) : 0;      // 1: idle producers, 2: idle consumers (timing only)
@@ -481,10 +481,10 @@ int launch_split_t(const ConvGemmGroup& gg_in, hipStream_t st) {
     constexpr size_t smem_ab = (size_t)3 * (BM + BN) * 48 * sizeof(unsigned short);
     constexpr size_t smem_c = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t smem = smem_ab > smem_c ? smem_ab : smem_c;
-    static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
+    static DeviceOnce attr_set;
+    if (attr_set.needed() && smem > 48 * 1024) {
         SVA_HIP(hipFuncSetAttribute((const void*)split_gemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
+        attr_set.done();
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, gg.n);
     gg.xcd_swz = xcd_swizzle_for(grid.x, grid.y);

@@ -540,10 +540,10 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
     static const bool valu_only = getenv("SVA_ENC_ATTN_VALU") != nullptr;          // A/B switch
     if (T % 16 == 0 && T <= 128 && !valu_only) {
         const size_t sm = ((size_t)T * 68 + 64 * (size_t)(T + 4) + 4 * 16 * (size_t)(T + 4)) * sizeof(float);
-        static bool attr_m = false;
-        if (!attr_m) {
+        static DeviceOnce attr_m;
+        if (attr_m.needed()) {
             SVA_HIP(hipFuncSetAttribute((const void*)enc_attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_m = true;
+            attr_m.done();
         }
         const int tiles = T / 16 - row0 / 16;
         int qsplit = 1;                                    // more workgroups per (head, stream) while the chip is under-filled
@@ -558,10 +558,10 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
         SVA_HIP(hipGetLastError());
         return 0;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.needed()) {
         SVA_HIP(hipFuncSetAttribute((const void*)enc_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.done();
     }
     // rows row0..T-1 are produced; the loop trip count must be uniform over the workgroup's 4 waves (barriers inside),
     // so a partial row range is walked with one row per workgroup-wave slot (rows >= T fall out of the loop together
@@ -1402,10 +1402,10 @@ int launch_sampler(const float* logits, int rows, int V, int ldl, const float* n
     while (P < V) P <<= 1;
     SVA_CHECK(P <= 16384, "sampler: vocabulary too large");
     const size_t smem = (size_t)P * 6 + 16 * 8 + 16 * 4 + 16 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.needed()) {
         SVA_HIP(hipFuncSetAttribute((const void*)sampler_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
+        attr_set.done();
     }
     const float tclamp = temperature > 1e-5f ? temperature : 1e-5f;
     static const bool legacy = getenv("SVA_SAMPLER_LDS") != nullptr;       // A/B switch: the all-LDS bitonic sort

@@ -4,11 +4,28 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 namespace sva {
 
 void set_error(const std::string& msg);
+
+// hipFuncSetAttribute applies to the CURRENT device only, and one process may hold engines on several GPUs: a per-call-site,
+// per-device "done" mask (bit = device ordinal), safe against concurrent first launches (setting the attribute twice is harmless)
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool needed() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return true;
+        const unsigned long long bit = 1ull << (dev & 63);
+        return !(mask.load(std::memory_order_relaxed) & bit);
+    }
+    void done() {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) mask.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+    }
+};
 
 #define SVA_HIP(expr)                                                                        \
     do {                                                                                     \
@@ -111,12 +128,14 @@ bool voc_level_supported(int C);
 int launch_voc_level(const float* X, long x_bstride, int xH, int C, int B, int Tl, const float* const W[3][6], const float* const bias[3][6],
                      const int dil[3], float* const y3[3], long y_bstride, const int* frames_done, int rows_per_frame, hipStream_t st);
 int conv_gemm_prepare_stream(hipStream_t st);
+int conv_gemm_check_errors();          // split-K hand-off fault word of every stream (checked at sva_sync)
 // gemm_split.hip: fp32 GEMM as six bf16 part products on v_mfma_f32_16x16x32_bf16 (variant 0..3 = 128x128, 128x64, 64x128, 64x64)
 bool split_gemm_supported(const ConvGemm& g);
 int launch_split_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 bool pipe_gemm_supported(const ConvGemm& g);
 int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
+int conv_gemm_last_kind();          // kernel family the calling thread's latest launch_conv_gemm[_group] picked: 0 small-M, 1 tiled, 2 pipelined (f32 MFMA), 4 split-bf16
 int launch_conv_gemm_group(const ConvGemm* gs, int n, hipStream_t st);
 // true when launch_conv_gemm would route this (M, N) problem to the K-split small-M kernel, which can normalise its A rows
 bool conv_gemm_can_fuse_rms(int M, int N);

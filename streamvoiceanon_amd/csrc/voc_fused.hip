@@ -186,12 +186,12 @@ int launch_voc_level(const float* X, long x_bstride, int xH, int C, int B, int T
     const size_t smem = act_bytes;
     SVA_CHECK(smem <= 160 * 1024, "voc_level: tile does not fit LDS");
     const dim3 grid((Tl + TR - 1) / TR, 3, B);
-    static bool attr_done[2] = {false, false};
+    static DeviceOnce attr_done[2];
     if (C == 16) {
-        if (!attr_done[0]) { SVA_HIP(hipFuncSetAttribute((const void*)voc_level_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done[0] = true; }
+        if (attr_done[0].needed()) { SVA_HIP(hipFuncSetAttribute((const void*)voc_level_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done[0].done(); }
         hipLaunchKernelGGL(voc_level_kernel<16>, grid, dim3(256), smem, st, a);
     } else {
-        if (!attr_done[1]) { SVA_HIP(hipFuncSetAttribute((const void*)voc_level_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done[1] = true; }
+        if (attr_done[1].needed()) { SVA_HIP(hipFuncSetAttribute((const void*)voc_level_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done[1].done(); }
         hipLaunchKernelGGL(voc_level_kernel<32>, grid, dim3(256), smem, st, a);
     }
     SVA_HIP(hipGetLastError());

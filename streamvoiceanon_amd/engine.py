@@ -72,6 +72,10 @@ def load_library():
     lib.sva_streams_begin.argtypes = [vp]
     lib.sva_step.argtypes = [vp, vp, vp, vp, vp]
     lib.sva_step_device.argtypes = [vp, vp, vp]
+    lib.sva_step_device_on.argtypes = [vp, vp, vp, vp, C.c_int]
+    lib.sva_join_stream.argtypes = [vp, vp]
+    lib.sva_batch_uses_persistent_decode.argtypes = [vp]
+    lib.sva_test_force_ar_timeout.argtypes = [vp]
     lib.sva_sync.argtypes = [vp]
     lib.sva_encode_window.argtypes = [vp, vp, vp, vp]
     lib.sva_vocode_window.argtypes = [vp, vp, i32, vp]
@@ -106,7 +110,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "sva_last_error", "sva_config_default", "sva_stream_params_default", "sva_engine_create",
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
-    "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_sync", "sva_stream_chunks", "sva_encode_window", "sva_firefly_encode",
+    "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_step_device_on", "sva_join_stream", "sva_batch_uses_persistent_decode", "sva_test_force_ar_timeout", "sva_sync", "sva_stream_chunks", "sva_encode_window", "sva_firefly_encode",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_quantizer_decode", "sva_vocoder_head", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
     "sva_dev_alloc", "sva_dev_free", "sva_dev_upload", "sva_dev_download", "sva_op_conv", "sva_op_affine", "sva_op_unary", "sva_op_colstats",
     "sva_op_cam_context", "sva_op_mul", "sva_op_add", "sva_op_conv2d", "sva_op_cf_to_rows", "sva_op_fbank_power", "sva_op_stft_mag", "sva_op_attention",
@@ -379,6 +383,25 @@ class Batch:
         """sva_step_device: asynchronous chunk-step on device buffers.  The engine runs on streams of its own: the producer of d_in (a
         torch op on torch's stream, say) must have completed before the call, and d_out is valid after sync()."""
         _check(self.lib.sva_step_device(self.h, C.c_void_p(d_in_ptr), C.c_void_p(d_out_ptr)), "sva_step_device")
+
+    def step_device_on(self, d_in_ptr, d_out_ptr, stream=None, join_output=True):
+        """sva_step_device_on: the stream-ordered chunk-step.  `stream` = a hipStream_t handle as int (default: torch's current
+        stream); no host synchronisation anywhere: the engine waits on the device for the stream's earlier work, and (join_output) the
+        stream waits for the step's output."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        _check(self.lib.sva_step_device_on(self.h, C.c_void_p(d_in_ptr), C.c_void_p(d_out_ptr), C.c_void_p(stream), int(bool(join_output))),
+               "sva_step_device_on")
+
+    def uses_persistent_decode(self):
+        return bool(self.lib.sva_batch_uses_persistent_decode(self.h))
+
+    def join_stream(self, stream=None):
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        _check(self.lib.sva_join_stream(self.h, C.c_void_p(stream)), "sva_join_stream")
 
     def stream_chunks(self, pcm_in):
         """n consecutive chunk-steps over a host array [B, n_chunks * 2048 * chunk] in one call (device RNG; stages pipelined

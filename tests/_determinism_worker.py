@@ -32,10 +32,8 @@ def main():
         d_in = torch.from_numpy(src).cuda()
         d_out = torch.empty(B, 2048, device="cuda")
         for i in range(n_sync, n_chunks):                    # overlapped (stage-pipelined) steps
-            chunk = d_in[:, i * 2048:(i + 1) * 2048].contiguous()
-            torch.cuda.synchronize()             # the engine runs on its own streams: the caller's buffer must be complete before the call
-            b.step_device(chunk.data_ptr(), d_out.data_ptr())
-            b.sync()
+            chunk = d_in[:, i * 2048:(i + 1) * 2048].contiguous()        # a torch kernel on torch's stream ...
+            b.step_device_on(chunk.data_ptr(), d_out.data_ptr())        # ... ordered before the engine's read, the output before torch's copy
             h_pcm.update(d_out.cpu().numpy().tobytes())
         for s in range(B):
             h_codes.update(b.pred_codes(s).tobytes())

@@ -1015,7 +1015,6 @@ def test_stage_pipelining_equals_serial(eng):
     n_chunks, B = 70, 2
     audio = torch.from_numpy(np.stack([synth_utterance(7600 + i, 2048 * n_chunks) for i in range(B)])).cuda()
     chunks = audio.reshape(B, n_chunks, 2048).transpose(0, 1).contiguous()      # persistent: the engine reads its input asynchronously
-    torch.cuda.synchronize()
 
     def run(pipeline):
         b = E.Batch(eng, n_streams=B, max_seq_frames=160, buffer_frames=16, pipeline=pipeline)
@@ -1024,17 +1023,16 @@ def test_stage_pipelining_equals_serial(eng):
             b.prefill_prompt(i, cc, ac, style, timbre, noise_seed=500 + i)
         b.begin()
         out = torch.zeros(n_chunks, B, 2048, device="cuda")
-        torch.cuda.synchronize()                # the engine's streams do not wait for torch's: buffers complete before they are handed over
-        pos = []
+        pos = []        # no host synchronisation: sva_step_device_on orders the engine's streams behind torch's current stream
         for k in range(n_chunks):
             x = chunks[k]
             if k == 33:                                                # a synchronous host-buffer step in the middle
                 out[k] = torch.from_numpy(b.step(x.cpu().numpy())).cuda()
             else:
-                b.step_device(x.data_ptr(), out[k].data_ptr())
+                b.step_device_on(x.data_ptr(), out[k].data_ptr(), join_output=False)       # consecutive steps keep overlapping
             if k in (20, 50):
                 pos.append(b.tap("last_pos", (B,), np.int32).copy())   # taps drain the pipeline first
-        b.sync()
+        b.join_stream()                         # torch's stream waits (on the device) for the engine: the copy below is ordered
         res = out.cpu().numpy()
         b.close()
         return res, np.stack(pos)
@@ -1328,3 +1326,80 @@ def test_fp16_ar_persistent_kernel_equals_batched_path(eng_fp16):
     n_diff = int((res[0] != res[1]).sum())
     print("fp16 AR, persistent vs batched path: differing codes", n_diff, "of", res[0].size)
     assert n_diff <= res[0].size // 20          # same rounded weights, different reduction trees: a near-tie may flip and then diverge
+
+
+def test_persistent_decode_timeout_recovers_on_the_multi_launch_decode(eng):
+    """A persistent AR launch whose workgroups are not all resident times out (bounded spins) and sets a device-side word.  Simulated
+    with the test hook: the next synchronisation reports it, every later step refuses, and sva_prefill_prompt + sva_streams_begin
+    restart the SAME batch on the multi-launch decode -- which reproduces the codes of an undisturbed run."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    ac, cc, style, timbre = synth_prompt(2000, 60)
+    src = synth_utterance(4100, 2048 * 10)
+
+    def run(b):
+        b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=77)
+        b.begin()
+        pcm = [b.step(src[i * 2048:(i + 1) * 2048][None])[0].copy() for i in range(10)]
+        return np.stack(pcm), b.pred_codes(0).copy()
+
+    ref = E.Batch(eng, n_streams=1)
+    assert ref.uses_persistent_decode()            # one stream on an otherwise idle MI355X: the residency check passes
+    pcm0, codes0 = run(ref)
+    ref.close()
+    b = E.Batch(eng, n_streams=1)
+    b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=77)
+    b.begin()
+    b.step(src[:2048][None])
+    _check = b.lib.sva_test_force_ar_timeout(b.h)
+    assert _check == 0
+    with pytest.raises(RuntimeError, match="timed out"):
+        b.sync()
+    with pytest.raises(RuntimeError, match="timed out earlier"):
+        b.step(src[:2048][None])
+    with pytest.raises(RuntimeError):              # the prompts are gone with the failed frames
+        b.begin()
+    pcm1, codes1 = run(b)
+    assert not b.uses_persistent_decode()
+    np.testing.assert_array_equal(codes1, codes0)
+    np.testing.assert_allclose(pcm1, pcm0, atol=5e-5)       # persistent (GEMV) vs multi-launch (MFMA) kernels: same codes, fp32 summation order
+    b.close()
+
+
+def test_two_pipelined_batches_interleaved(eng):
+    """Two single-stream batches of one engine, both decoding with the persistent kernel and both stage-pipelined, stepped alternately:
+    their persistent launches are chained by an event (never two half-resident grids), and each stream's output equals its solo run."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    n = 24
+    srcs = [torch.from_numpy(synth_utterance(4200 + i, 2048 * n)).cuda().reshape(n, 1, 2048).contiguous() for i in range(2)]
+
+    def make(i):
+        b = E.Batch(eng, n_streams=1, pipeline=True)
+        ac, cc, style, timbre = synth_prompt(2300 + i, 50 + 20 * i)
+        b.prefill_prompt(0, cc, ac, style, timbre, noise_seed=900 + i)
+        b.begin()
+        return b
+
+    solo = []
+    for i in range(2):
+        b = make(i)
+        out = torch.zeros(n, 1, 2048, device="cuda")
+        for k in range(n):
+            b.step_device_on(srcs[i][k].data_ptr(), out[k].data_ptr(), join_output=False)
+        b.join_stream()
+        solo.append((out.cpu().numpy(), b.pred_codes(0).copy()))
+        b.close()
+    bs = [make(0), make(1)]
+    outs = [torch.zeros(n, 1, 2048, device="cuda") for _ in range(2)]
+    for k in range(n):
+        for i in range(2):
+            bs[i].step_device_on(srcs[i][k].data_ptr(), outs[i][k].data_ptr(), join_output=False)
+    for i in range(2):
+        bs[i].join_stream()
+    for i in range(2):
+        np.testing.assert_array_equal(bs[i].pred_codes(0), solo[i][1])
+        np.testing.assert_array_equal(outs[i].cpu().numpy(), solo[i][0])
+        bs[i].close()

@@ -139,3 +139,32 @@ def test_xcd_tile_remap_is_a_bijection():
         for k in range(min(8, T)):
             mine = sorted(V[L] for L in range(k, T, 8))
             assert mine == list(range(mine[0], mine[0] + len(mine))), (T, k)
+
+
+def test_compiled_reference_restatement_matches_oracle():
+    """bench.py's torch.compile baseline (SURVEY.md 8f N4) times a static-KV-cache restatement of decode_one_token_ar (the reference's
+    compile-friendly form, dual_ar_stream.py:312-356): run eagerly on the CPU it must reproduce the oracle's slow-AR hidden state."""
+    import torch
+
+    import bench
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import specs, synth_weights
+    from streamvoiceanon_amd.synth_audio import synth_prompt
+
+    torch.set_grad_enabled(False)
+    W = {k: torch.from_numpy(v) for k, v in synth_weights.generate_all(0, specs.all_specs()).items() if k.startswith("arvc.")}
+    ac, cc, style, timbre = synth_prompt(2000, 6)
+    ar = O.DualAR(W)
+    ar.prefill_prompt(torch.from_numpy(cc), torch.from_numpy(ac), torch.from_numpy(style), torch.from_numpy(timbre), 2)
+    ref = bench.CompiledReference(W, torch.device("cpu"), S=ar.k[0].shape[1] if hasattr(ar, "k") else 2048)
+    for l in range(ar.cfg.n_layer):
+        ref.k[l].copy_(ar.k[l]); ref.v[l].copy_(ar.v[l])
+    x = torch.randn(2, 768, generator=torch.Generator().manual_seed(3)) * 0.1
+    pos = torch.arange(2) + ar.last_pos + 1
+    hidden_o, logits_o = ar.slow_forward(x.clone(), pos)
+    h = x.clone()
+    for l in range(ar.cfg.n_layer):
+        h = ref._block(h, f"arvc.decoder.model.layers.{l}.", ref.tab, ref.k[l], ref.v[l], pos, ref.S)
+    assert (h[-1] - hidden_o).abs().max() <= 2e-4 * max(1.0, float(hidden_o.abs().max()))
+    for l in range(ar.cfg.n_layer):          # the static cache received the same K / V rows
+        assert torch.allclose(ref.k[l][:, pos], ar.k[l][:, pos], atol=1e-5)
