@@ -8,6 +8,7 @@ namespace sva {
 
 constexpr int AR_WGS = 96;            // workgroups of the persistent kernel (= CUs of the AR stream's partition)
 constexpr int AR_WAVES = AR_WGS * 4;
+constexpr int AR_SEM_WGS = 4;         // extra workgroups per stream that run the semantic head + its sampler off the critical path
 constexpr int AR_SLOW_LAYERS = 12, AR_FAST_LAYERS = 4;
 // weights of one layer in the decode kernel's layout: row-major [N][K] (fp32 or fp16 by the kernel's template argument);
 // w13: wave w of the kernel owns rows [12w, 12w + 12) = w1 rows 6w..6w+5 followed by w3 rows 6w..6w+5
@@ -64,6 +65,6 @@ struct ArDecodeArgs {
 int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st, int n_slots = 1);
 // blocks of the kernel the runtime says fit one CU at the launch's LDS size (hipOccupancyMaxActiveBlocksPerMultiprocessor)
 int ar_decode_occupancy(int wt_half, int kv_half, int* blocks_per_cu);
-size_t ar_decode_granule_words();     // u64 words the four granule buffers need in total (gx | gbig | gatt | glog | ga, in this order)
+size_t ar_decode_granule_words();     // u64 words of a stream's granule block (gx | gbig | gatt | glog | ga | semantic logits | acks, in this order)
 
 }  // namespace sva

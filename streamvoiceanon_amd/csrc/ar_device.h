@@ -331,11 +331,11 @@ __device__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float*
         if (rr > best || (rr == best && e < best_id)) { best = rr; best_id = e; }
     }
     NS_MARK(4);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(best_id, o, 64);
-        if (ob > best || (ob == best && oi < best_id)) { best = ob; best_id = oi; }
+    {   // wave argmax (ties: the smaller index) with DPP reductions only: the maximum, then the least index among its holders
+        const float bm = wave_max(best);
+        const unsigned cand = best == bm ? (unsigned)best_id : 0x7fffffffu;
+        best_id = (int)~umax_wave(~cand);
+        best = bm;
     }
     if constexpr (NW > 1) {
         if (lane == 0) { fred[slot * NW + wave] = best; ired[wave] = best_id; }

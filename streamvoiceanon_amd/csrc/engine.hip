@@ -442,7 +442,7 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
         e->ar_layers.resize(c.ar_layers);
         // the persistent batch-1 decode kernel (ar_decode.hip) is built for the reference's sizes
         e->mega_ok = c.ar_layers == AR_SLOW_LAYERS && c.ar_fast_layers == AR_FAST_LAYERS && D == 768 && c.ar_inter == 2304 && c.ar_heads == 12 &&
-                     c.num_codebooks == 8 && c.ar_vocab <= 22 * AR_WAVES && c.codebook_size <= 1024;
+                     c.num_codebooks == 8 && c.ar_vocab <= 8192 && c.ar_vocab % 2 == 0 && c.codebook_size <= 1024 && c.codebook_size % 2 == 0;
         const bool mg = e->mega_ok;
         for (int l = 0; l < c.ar_layers; ++l) SVA_TRY(P.llama(m + "layers." + std::to_string(l) + ".", e->ar_layers[l], D, c.ar_inter, false, mg));
         e->ar_fast_layers.resize(c.ar_fast_layers);
@@ -1910,8 +1910,9 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         SVA_TRY(ar_decode_occupancy(c.ar_dtype == 1, b->kv_half, &per_cu));
         SVA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
         const int avail = b->ar_partitioned ? std::min(cus, 96) : cus;       // the AR stream's CU mask (get_streams) is CUs 0..95
-        b->mega_per_launch = (avail >= 2 * AR_WGS && !b->ar_partitioned) ? 2 : 1;
-        if (per_cu < 1 || avail < AR_WGS) b->use_mega = false;                // fall back to the multi-launch decode
+        const int wgs = AR_WGS + AR_SEM_WGS;                             // decode + semantic-head workgroups of one stream
+        b->mega_per_launch = (avail >= 2 * wgs && !b->ar_partitioned) ? 2 : 1;
+        if (per_cu < 1 || avail < wgs) b->use_mega = false;                // fall back to the multi-launch decode
     }
     if (b->use_mega) {
         SVA_TRY(dev_alloc(A, &b->d_gran, ar_decode_granule_words() * B));
@@ -3000,6 +3001,11 @@ extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* 
             const int rc0 = ar_frame_tail(b, 0, 0, (long)(M - 1) * D, d_remq, S, 0, 0);
             b->p.temperature = t_user; b->p.top_p = p_user;
             SVA_TRY(rc0);
+        } else if (b->use_mega) {
+            // decode steps of the offline loop (dual_ar_stream.py:735-760) through the persistent kernel: the same two tokens
+            // [embed(previous codes), cond_i] at the next two positions, one launch per frame instead of ~200
+            SVA_TRY(ar_decode_frame_mega(b, 0, d_remq, i));
+            b->h_last_pos[0] += 2;
         } else {
             hipLaunchKernelGGL(prepare_offline_step_kernel, dim3(1), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, d_remq, i, b->d_last_pos, D,
                                b->ax, b->d_slot, b->d_pos);
