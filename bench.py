@@ -174,7 +174,7 @@ def pmc_traffic(B, chunk):
     if shutil.which("rocprofv3") is None:
         return None, {"error": "rocprofv3 not on PATH"}
     tmp = tempfile.mkdtemp(prefix="sva_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", SVA_CONCURRENCY="0")
+    env = dict(os.environ, TMPDIR="/tmp", SVA_DEBUG="concurrency=0")
     acc = {}
     t0 = time.perf_counter()
     try:

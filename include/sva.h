@@ -229,6 +229,10 @@ int sva_op_l2norm(sva_engine* e, const float* x, int T, int C, const float* gamm
  * workgroups are NOT all resident (GPU shared with another process) times out after ~50 ms: the next sva_sync / sva_step returns an
  * error, every later step fails, and sva_prefill_prompt + sva_streams_begin restart the streams on the multi-launch decode. */
 int sva_batch_uses_persistent_decode(sva_batch* b);
+/* debug options of the process ("key=value,key=value"; the same keys as the SVA_DEBUG environment variable, the engine's only
+ * environment input -- listed in csrc/sva_common.h: ar_timing, pipe_trace, concurrency, ar_persistent, voc_fused_mask, autotune,
+ * tune_log, tune_table, tune_dump).  Profiling and test switches; batches created afterwards see the change. */
+int sva_debug_configure(const char* kv);
 /* test hook: set the persistent kernel's device-side timeout word, as a launch with non-resident workgroups would */
 int sva_test_force_ar_timeout(sva_batch* b);
 

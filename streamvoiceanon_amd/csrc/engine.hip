@@ -31,8 +31,7 @@ static int dev_alloc(DevPool& pool, T** out, size_t n, bool zero = true) {
     if (n == 0) n = 1;
     const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
     if (bytes > pool.left) {
-        static const char* env = getenv("SVA_ARENA_MB");       // 0: one hipMalloc per tensor (A/B switch)
-        const size_t want = env ? (size_t)atol(env) << 20 : pool.chunk_bytes;
+        const size_t want = pool.chunk_bytes;
         const size_t sz = bytes > want ? bytes : want;
         void* c = nullptr;
         SVA_HIP(hipMalloc(&c, sz));
@@ -65,6 +64,38 @@ static int alloc_act(DevPool& pool, Act& a, int B, int H, long Tmax, int C) {
 using namespace sva;
 
 // joins the AR / vocoder streams of the pipelined mode back into the main stream (no-op when nothing is in flight there)
+namespace sva {
+static void parse_debug(DebugOptions& o, const char* env) {
+    if (!env) return;
+    std::string all(env);
+    size_t pos = 0;
+    while (pos <= all.size()) {
+        const size_t end = std::min(all.find(',', pos), all.size());
+        const std::string kv = all.substr(pos, end - pos);
+        const size_t eq = kv.find('=');
+        if (eq != std::string::npos) {
+            const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
+            if (k == "ar_timing") o.ar_timing = atoi(v.c_str());
+            else if (k == "pipe_trace") o.pipe_trace = atoi(v.c_str());
+            else if (k == "concurrency") o.concurrency = atoi(v.c_str());
+            else if (k == "ar_persistent") o.ar_persistent = atoi(v.c_str());
+            else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
+            else if (k == "autotune") o.autotune = atoi(v.c_str());
+            else if (k == "tune_log") o.tune_log = atoi(v.c_str());
+            else if (k == "tune_table") o.tune_table = atoi(v.c_str());
+            else if (k == "tune_dump") o.tune_dump = v;
+            else fprintf(stderr, "[sva] debug option '%s' unknown, ignored\n", k.c_str());
+        }
+        pos = end + 1;
+    }
+}
+static DebugOptions& debug_options_mut() {
+    static DebugOptions opt = [] { DebugOptions o; parse_debug(o, getenv("SVA_DEBUG")); return o; }();
+    return opt;
+}
+const DebugOptions& debug_options() { return debug_options_mut(); }
+}  // namespace sva
+
 namespace { int quiesce(sva_batch* b); }
 
 // Recovery from a persistent-kernel timeout (called by sva_prefill_prompt / sva_streams_begin): clear the device flag, leave the
@@ -652,8 +683,7 @@ int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs
     SVA_CHECK(o.C == C, "cnx_block: bad output activation");
     ConvGemm p1;
     p1.act = ACT_GELU;
-    static const bool fuse_off = getenv("SVA_CNX_FUSE") && atoi(getenv("SVA_CNX_FUSE")) == 0;          // A/B switch
-    if (b->B * T <= 16 && C <= 512 && !fuse_off) {
+    if (b->B * T <= 16 && C <= 512) {
         // a handful of rows (streaming pass, upsampler at small B): depthwise conv + LayerNorm happen in the prologue of the
         // pointwise GEMM (every column block recomputes them -- a few thousand FMAs -- instead of a launch of their own)
         p1.dw_wT = c.dwT; p1.dw_b = c.dwb; p1.ln_w = c.lnw; p1.ln_b = c.lnb; p1.ln_eps = 1e-6f;
@@ -1292,8 +1322,7 @@ int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_
         a.ss.tok = ncb; a.ss.step_audio = (long)ncb * b->p.chunk_frames; a.ss.pred_hist = (long)ncb * b->hist_cap;
         a.ss.step_content = b->p.chunk_frames; a.ss.noise = (long)b->p.chunk_frames * nstride; a.ss.forced = (long)ncb * b->p.chunk_frames;
     }
-    static const char* share_env = getenv("SVA_AR_SHARE_CU");
-    const bool share = share_env ? atoi(share_env) != 0 : !b->ar_partitioned;
+    const bool share = !b->ar_partitioned;
     // at most two streams per launch: 192 workgroups find a CU each and leave half of every register file to the other stages'
     // kernels; four streams in one launch (two 256-register workgroups on half of the CUs) measured 1.75 ms for the frame AND
     // locked the encoder / vocoder kernels out of those CUs (2.69 ms per pipelined step against 1.9 with two launches of two)
@@ -1631,10 +1660,6 @@ int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSe
     int variant = !partitioned ? 0 : n_streams_if_pipelined == 1 ? 1 : 2;
     int part[6] = {0, 96, 96, 160, 96, 160};
     if (variant == 1) { part[3] = 128; part[4] = 224; part[5] = 32; }
-    if (const char* e = getenv("SVA_CU_PART")) {
-        if (!strcmp(e, "off")) partitioned = false;
-        else if (partitioned) { sscanf(e, "%d,%d,%d,%d,%d,%d", part, part + 1, part + 2, part + 3, part + 4, part + 5); variant = 3; }
-    }
     if (partitioned) {
         hipDeviceProp_t prop;
         SVA_HIP(hipGetDeviceProperties(&prop, device));
@@ -1698,18 +1723,16 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     // its queue mates), and streams created after others were destroyed land on unlucky queues -- measured: the pipelined
     // mode gains 16 % at 64 streams in a fresh process and nothing after one create / destroy cycle.  Batches that are
     // alive at the same time therefore share the streams (in-order, so still correct).
-    if (const char* ev = getenv("SVA_VOC_GROUPED")) b->voc_grouped = atoi(ev) != 0;
     if (b->p.pipeline) SVA_CHECK(b->voc_grouped, "stage pipelining needs the grouped vocoder launches");
     {
         StreamSet ss;
         // one stream with the persistent AR decode kernel: no CU partition -- that kernel is a single launch of 96 workgroups that
         // mostly wait on hand-offs, so the AR chain no longer queues behind the other stages' workgroups, and the encoder /
         // vocoder GEMMs want the whole chip (measured 1.41 ms per step with the 96 | 128 | 32 split, 1.13 without)
-        const bool will_mega = B <= (getenv("SVA_AR_MEGA_MAXB") ? atoi(getenv("SVA_AR_MEGA_MAXB")) : 6) && B <= 8 && e->mega_ok && !(getenv("SVA_FUSED_DECODE") && atoi(getenv("SVA_FUSED_DECODE")) == 0) &&
-                               !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
-        const int part_streams = b->p.pipeline ? (will_mega && !getenv("SVA_CU_PART") ? 0 : B) : 0;
+        const bool will_mega = B <= AR_PERSISTENT_MAX_STREAMS && e->mega_ok && debug_options().ar_persistent != 0;
+        const int part_streams = b->p.pipeline ? (will_mega ? 0 : B) : 0;
         SVA_TRY(get_streams(e->device, !b->voc_grouped, part_streams, &ss));
-        b->ar_partitioned = part_streams >= 1 && part_streams <= 8 && !(getenv("SVA_CU_PART") && !strcmp(getenv("SVA_CU_PART"), "off"));
+        b->ar_partitioned = part_streams >= 1 && part_streams <= 8;
         b->stream = b->main_stream = ss.main;
         b->aux[0] = ss.aux0;
         b->aux[1] = b->voc_grouped ? nullptr : ss.aux1;
@@ -1721,22 +1744,15 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     }
     b->out_stream = b->stream;
     for (int i = 0; i < 64; ++i) SVA_HIP(hipEventCreateWithFlags(&b->evpool[i], hipEventDisableTiming));
-    if (const char* ev = getenv("SVA_PIPE_GRAPH")) b->pipe_graph_mode = atoi(ev);
-    if (const char* ev = getenv("SVA_STAGE_GRAPHS")) b->stage_graphs = atoi(ev) != 0;
-    if (const char* ev = getenv("SVA_ENC_CUT")) b->enc_cut = atoi(ev);
-    if (const char* ev = getenv("SVA_PIPE_SPLIT_E")) b->pipe_split_e = atoi(ev);
-    if (const char* ev = getenv("SVA_STREAM_CUT")) b->stream_cut = atoi(ev);
-    if (const char* ev = getenv("SVA_PIPE_TRACE")) {
-        b->trace_n = atoi(ev);
+    if (debug_options().pipe_trace > 0) {
+        b->trace_n = debug_options().pipe_trace;
         b->trace_ev.resize((size_t)b->trace_n * 9);
         for (auto& t : b->trace_ev) SVA_HIP(hipEventCreate(&t));
     }
     // a whole-step graph is captured from ONE stream: a capture that forks to the side stream replays at 14 ms per step on this
     // runtime, the single-stream one at 3.8 (eager multi-stream: 3.6)
     if (b->p.use_graph) b->concurrency = false;
-    if (const char* ev = getenv("SVA_CONCURRENCY")) b->concurrency = atoi(ev) != 0;
-    if (const char* ev = getenv("SVA_FUSED_DECODE")) b->fused_decode = atoi(ev) != 0;
-    // SVA_CONCURRENCY=0: single stream (PMC profiling)
+    if (!debug_options().concurrency) b->concurrency = false;      // single stream (PMC profiling)
     auto& A = b->allocs;
     const int chunk = p->chunk_frames;
     // control block
@@ -1815,7 +1831,6 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         SVA_TRY(dev_alloc(A, &b->d_shift_d2c, 1));
         SVA_HIP(hipMemcpy(b->d_shift_d2c, &dc, sizeof(ShiftDesc), hipMemcpyHostToDevice));
     }
-    if (const char* ev = getenv("SVA_ENC_MERGED")) b->enc_merged = atoi(ev) != 0;
     if (b->enc_incremental && b->enc_merged) {
         EncMerged& M = b->em;
         M.Hh = 4 * b->Ht; M.nm = 4 * chunk;
@@ -1900,8 +1915,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     // persistent batch-1 decode kernel (ar_decode.hip): granule buffers, tag epoch, timeout word, fast K/V scratch
     // up to mega_max_b streams decode in ONE launch of it (96 workgroups per stream, each stream's group talks only to itself); the
     // multi-launch chain of the batched path (~200 dependent launches, 2.4-3.3 ms per frame at 2-8 streams) takes over above that
-    static const int mega_max_b = getenv("SVA_AR_MEGA_MAXB") ? atoi(getenv("SVA_AR_MEGA_MAXB")) : 6;
-    b->use_mega = B <= mega_max_b && B <= 8 && e->mega_ok && b->fused_decode && !(getenv("SVA_AR_MEGA") && atoi(getenv("SVA_AR_MEGA")) == 0);
+    b->use_mega = B <= AR_PERSISTENT_MAX_STREAMS && e->mega_ok && b->fused_decode && debug_options().ar_persistent != 0;
     if (b->use_mega) {
         // every workgroup of a persistent launch must be resident at once: check the launch geometry against the occupancy query and
         // the CUs the AR stream may use, never assume it.  One workgroup per CU is what the kernel is sized for (256 registers, 4 waves);
@@ -1919,7 +1933,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         SVA_TRY(dev_alloc(A, &b->d_epoch, B));
         SVA_TRY(dev_alloc(A, &b->d_ar_fail, 1));
         SVA_TRY(dev_alloc(A, &b->kv_fast_mega, (size_t)B * AR_FAST_LAYERS * 8 * 2 * D));
-        if (getenv("SVA_AR_TIMING")) SVA_TRY(dev_alloc(A, &b->d_ar_dbg, 1024));
+        if (debug_options().ar_timing) SVA_TRY(dev_alloc(A, &b->d_ar_dbg, 1024));
     }
     SVA_TRY(dev_alloc(A, &b->cached_audio_emb, (size_t)B * D));
     SVA_TRY(dev_alloc(A, &b->cached_ref_emb, (size_t)B * c.max_delay * D));
@@ -1948,8 +1962,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     // vocoder
     const int Tv = b->Tv = b->p.voc_max_frames;
     const int V = c.voc_dim;
-    if (const char* ev = getenv("SVA_VOC_FUSED")) b->voc_fused = atoi(ev) != 0;
-    if (const char* ev = getenv("SVA_VOC_FUSED_MASK")) b->voc_fused_mask = atoi(ev);
+    if (debug_options().voc_fused_mask >= 0) b->voc_fused_mask = debug_options().voc_fused_mask;
     SVA_TRY(dev_alloc(A, &b->d_voc_frames, 1));
     SVA_HIP(hipMemset(b->d_voc_frames, 0, sizeof(int)));
     SVA_TRY(alloc_act(A, b->zq, B, 0, Tv, V));
@@ -2829,6 +2842,14 @@ static int check_ar_fail(sva_batch* b) {
     SVA_CHECK(f == 0, "persistent AR decode kernel timed out waiting for a workgroup hand-off (code " + std::to_string(f) +
                       "): its workgroups were not all resident (GPU shared with another process / a long kernel?).  The frames since the last "
                       "synchronisation are invalid; sva_streams_begin restarts the streams on the multi-launch decode");
+    return 0;
+}
+
+// test / tool hook: change debug options of this process after start-up ("key=value,..." as in SVA_DEBUG; batches created afterwards
+// see them -- the GEMM dispatch table and the autotune switch are read once, before the first launch)
+extern "C" int sva_debug_configure(const char* kv) {
+    SVA_CHECK(kv, "null argument");
+    parse_debug(sva::debug_options_mut(), kv);
     return 0;
 }
 

@@ -661,10 +661,6 @@ static void skinny_heuristic(const ConvGemm& g, int NT, int* mt_out, int* kw_out
     int kw = 4;
     while (kw < 8 && blocks(mt) * kw < 2048 && nk / (2 * kw) >= 2) kw *= 2;
     if (kw == 8 && blocks(mt) * 8 < 512 && nk / 32 >= 2 && mt == 1) kw = 16;     // a handful of column blocks: split K deeper
-    static const char* env_mt = getenv("SVA_SKINNY_MT");
-    static const char* env_kw = getenv("SVA_SKINNY_KW");
-    if (env_mt) mt = atoi(env_mt) < mt_total ? atoi(env_mt) : (mt_total < 4 ? mt_total : 4);
-    if (env_kw) { kw = atoi(env_kw); if (mt >= 2 && kw == 16) kw = 8; }
     *mt_out = mt; *kw_out = kw;
 }
 
@@ -725,24 +721,8 @@ static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
     }
 }
 
-static bool ksplit_enabled() {
-    static const bool on = !getenv("SVA_KSPLIT") || atoi(getenv("SVA_KSPLIT")) != 0;
-    return on;
-}
-
-static bool split_enabled() {
-    static const bool on = !(getenv("SVA_GEMM_SPLIT") && atoi(getenv("SVA_GEMM_SPLIT")) == 0);
-    return on;
-}
-
-static bool pipe_enabled() {
-    static const bool on = !(getenv("SVA_GEMM_PIPE") && atoi(getenv("SVA_GEMM_PIPE")) == 0);
-    return on;
-}
 // tile variant of the ring kernel for an under-filled grid: the largest tile that still gives every CU of a partition work
 static int pipe_variant(const ConvGemm& g) {
-    static const char* force = getenv("SVA_PIPE_VARIANT");        // A/B switch
-    if (force) return atoi(force);
     auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
     if (tiles(128, 64) >= 192) return 2;
     if (tiles(64, 64) >= 160) return 1;
@@ -751,24 +731,16 @@ static int pipe_variant(const ConvGemm& g) {
 }
 
 static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
-    {
-        static const char* force_split = getenv("SVA_SPLIT_VARIANT");        // A/B switch (with SVA_TUNE_TABLE=0): every eligible problem through gemm_split.hip
-        if (force_split && c_vec && split_gemm_supported(g) && g.M >= 64 && g.N >= 64) {
-            const int v = atoi(force_split);
-            if (!(((v == 0 || v == 1 || v == 4) && g.M < 128) || ((v == 0 || v == 2 || v == 4) && g.N < 128))) return Choice{4, v, 0, 0};
-        }
-    }
     // MFMA-bound problems outside the tuned table (batch sizes the tuning runs did not visit): the split-bf16 kernel, tile shape by
     // the rule the table shows -- wave-specialised 128x128 for narrow outputs with a long K, plain 128x128 otherwise, 64x64 for N < 128
-    if (split_enabled() && c_vec && split_gemm_supported(g) && g.M >= 2048 && g.N >= 64) {
+    if (c_vec && split_gemm_supported(g) && g.M >= 2048 && g.N >= 64) {
         if (g.N < 128) return Choice{4, 3, 0, 0};
         const long K = (long)g.taps * g.Cin;
         return Choice{4, (g.N <= 512 && K >= 1024) ? 4 : 0, 0, 0};
     }
     {
         const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-        static const bool force_all = getenv("SVA_PIPE_VARIANT") != nullptr;
-        if (pipe_enabled() && c_vec && pipe_gemm_supported(g) && g.M >= 32 && g.N >= 32 && (t64 < 1024 || force_all)) return Choice{2, pipe_variant(g), 0, 0};
+        if (c_vec && pipe_gemm_supported(g) && g.M >= 32 && g.N >= 32 && t64 < 1024) return Choice{2, pipe_variant(g), 0, 0};
     }
     // the K tile is as deep as Cin allows (bytes in flight per workgroup hide the L2/HBM latency of the register-staged
     // pipeline); 128x128 tiles only when they still fill the 256 CUs
@@ -785,12 +757,7 @@ static Choice heuristic_choice(const ConvGemm& g, bool c_vec) {
         // time grows with K alone), so when the tiles do not cover the 256 CUs the K axis is split over more workgroups
         const long wgs = (long)((g.N + 16 * ch.c - 1) / (16 * ch.c)) * (((g.M + 15) / 16 + ch.a - 1) / ch.a);
         const long nkb = (long)g.taps * g.Cin / 16;
-        // OFF unless SVA_KSPLIT=1: with the release the hand-off needs for correctness (see the kernel) a split launch is
-        // slower than an unsplit one on every shape of this model.
-        if (ksplit_enabled())
-            while (ch.z < 8 && wgs * ch.z * 2 <= 256 && nkb / (2L * ch.z * ch.b) >= 2) ch.z *= 2;
-        static const char* env_z = getenv("SVA_SKINNY_Z");
-        if (env_z) ch.z = atoi(env_z);
+        while (ch.z < 8 && wgs * ch.z * 2 <= 256 && nkb / (2L * ch.z * ch.b) >= 2) ch.z *= 2;
         return ch;
     }
     if (g.N <= 16 && !g.w13) return Choice{1, 3, 0, 0};
@@ -812,7 +779,7 @@ static const TuneRow kTuneTable[] = {
 static const std::map<std::array<int, 6>, Choice>& static_table() {
     static const std::map<std::array<int, 6>, Choice> m = [] {
         std::map<std::array<int, 6>, Choice> t;
-        if (getenv("SVA_TUNE_TABLE") && atoi(getenv("SVA_TUNE_TABLE")) == 0) return t;
+        if (!debug_options().tune_table) return t;
         for (const TuneRow& r : kTuneTable) {
             if (r.kind < 0) continue;
             Choice c{r.kind, r.a, r.b, r.c};
@@ -823,11 +790,10 @@ static const std::map<std::array<int, 6>, Choice>& static_table() {
     }();
     return m;
 }
-// SVA_TUNE_DUMP=<file>: the shapes tuned by this process (SVA_AUTOTUNE=1) are appended as table rows when the library unloads
+// SVA_DEBUG=tune_dump=<file>: the shapes tuned by this process (autotune=1) are appended as table rows when the library unloads
 static void dump_tune_table() {
-    const char* path = getenv("SVA_TUNE_DUMP");
-    if (!path) return;
-    FILE* f = fopen(path, "a");
+    if (debug_options().tune_dump.empty()) return;
+    FILE* f = fopen(debug_options().tune_dump.c_str(), "a");
     if (!f) return;
     for (const auto& kv : g_tune)
         fprintf(f, "{{%d, %d, %d, %d, %d, %d}, %d, %d, %d, %d, %d},\n", kv.first[0], kv.first[1], kv.first[2], kv.first[3], kv.first[4], kv.first[5],
@@ -892,8 +858,8 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
     }
     // Deterministic by default: the kernel / configuration of a problem shape comes from the compiled-in table (tune_table.inc,
     // generated offline from a logged tuning run) or the heuristic -- never from wall-clock measurements of this process, so two
-    // processes, ranks or runs sum in the same order.  SVA_AUTOTUNE=1 re-enables the timed search (tools/make_tune_table.py uses it).
-    static const bool tune = !(getenv("SVA_SKINNY_MT") || getenv("SVA_SKINNY_KW")) && (getenv("SVA_AUTOTUNE") && atoi(getenv("SVA_AUTOTUNE")) != 0);
+    // processes, ranks or runs sum in the same order.  SVA_DEBUG=autotune=1 re-enables the timed search (tools/make_tune_table.py uses it).
+    static const bool tune = debug_options().autotune != 0;
     if (tune) {
         // Shape-keyed autotune: the first eager launch of a problem shape times the candidate kernels / configurations on
         // the real operands with the output redirected to scratch, and keeps a candidate only if it beats the heuristic
@@ -962,7 +928,7 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                                 if (mts[a] > mt_total || (mts[a] >= 2 && kws[b2] == 16) || nk / kws[b2] < 1) continue;
                                 if (nt == 4 && kws[b2] == 16) continue;
                                 cand.push_back(Choice{0, mts[a], kws[b2], nt});
-                                if (g.rms_w || group_n > 1 || !ksplit_enabled()) continue;
+                                if (g.rms_w || group_n > 1) continue;
                                 const long wgs = (long)((g.N + 16 * nt - 1) / (16 * nt)) * ((mt_total + mts[a] - 1) / mts[a]);
                                 for (int z = 2; z <= 8; z *= 2)
                                     if (wgs * z <= 512 && nk / ((long)z * kws[b2]) >= 1) cand.push_back(Choice{0, mts[a], kws[b2], nt, z});
@@ -979,13 +945,13 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                     if (g.N <= 64) cand.push_back(Choice{1, 2, 0, 0});
                     if (g.N <= 16 && !g.w13) cand.push_back(Choice{1, 3, 0, 0});
                 }
-                if (c_vec && pipe_gemm_supported(g) && g.M >= 32 && g.N >= 32 && pipe_enabled())
+                if (c_vec && pipe_gemm_supported(g) && g.M >= 32 && g.N >= 32)
                     for (int v = 0; v <= 6; ++v) {
                         if (v == 4 && (g.M < 128 || g.N < 128)) continue;
                         if ((v == 2 && g.M < 128) || ((v == 3 || v == 5) && g.N < 128)) continue;
                         cand.push_back(Choice{2, v, 0, 0});
                     }
-                if (c_vec && split_gemm_supported(g) && split_enabled() && g.M >= 64 && g.N >= 64)
+                if (c_vec && split_gemm_supported(g) && g.M >= 64 && g.N >= 64)
                     for (int v = 0; v <= 4; ++v) {
                         if ((v == 0 || v == 1 || v == 4) && g.M < 128) continue;
                         if ((v == 0 || v == 2 || v == 4) && g.N < 128) continue;
@@ -1002,7 +968,7 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                 }
                 (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
                 t_group = real_group;
-                static const bool tlog = getenv("SVA_TUNE_LOG") != nullptr;
+                static const bool tlog = debug_options().tune_log != 0;
                 if (tlog)
                     fprintf(stderr, "[sva tune] M=%d N=%d K=%d taps=%d flags=%llu: heuristic %.1f us -> kind %d (%d,%d,%d) z%d %.1f us\n", g.M, g.N,
                             g.taps * g.Cin, g.taps, flags, base * 200.f, ch.kind, ch.a, ch.b, ch.c, ch.z, (best < base * 0.93f ? best : base) * 200.f);

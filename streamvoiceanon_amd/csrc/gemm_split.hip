@@ -329,15 +329,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (nk > 2) gload(2, ra[0], rb[0]);
         __syncthreads();
         // iteration kt stores tile kt + 1 (set (kt + 1) & 1) and requests tile kt + 3 into the set it just freed
-        const bool idle_p = (gg.xcd_swz >> 4) & 1;          // (measurement knob: producers only keep the barriers)
         for (int kt = 0; kt < nk; kt += 2) {
-            if (kt + 1 < nk && !idle_p) {
+            if (kt + 1 < nk) {
                 lstore(1, ra[1], rb[1]);
                 if (kt + 3 < nk) gload(kt + 3, ra[1], rb[1]);
             }
             __syncthreads();
             if (kt + 1 < nk) {
-                if (kt + 2 < nk && !idle_p) {
+                if (kt + 2 < nk) {
                     lstore(0, ra[0], rb[0]);
                     if (kt + 4 < nk) gload(kt + 4, ra[0], rb[0]);
                 }
@@ -346,10 +345,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     } else {
         const int fr = lane & 15, fk = lane >> 4;
-        const bool idle_c = (gg.xcd_swz >> 5) & 1;          // (measurement knob: consumers only keep the barriers)
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
-            if (idle_c) { __syncthreads(); continue; }
             const unsigned short* Ap = lds + (kt & 1) * BUF;
             const unsigned short* Bp = Ap + 3 * PLANE_A;
             const unsigned short* Ab = Ap + (wm * TM + fr) * RS + fk * 8;
@@ -468,8 +465,7 @@ int launch_split_ws(const ConvGemmGroup& gg_in, hipStream_t st) {
         attr_set.done();
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, gg.n);
-    static const int dbg = getenv("SVA_SPLIT_DBG") ? atoi(getenv("SVA_SPLIT_DBG")) : 0;      // 1: idle producers, 2: idle consumers (timing only)
-    gg.xcd_swz = xcd_swizzle_for(grid.x, grid.y) | (dbg << 4);
+    gg.xcd_swz = xcd_swizzle_for(grid.x, grid.y);
     hipLaunchKernelGGL((split_ws_kernel<BM, BN>), grid, dim3(512), smem, st, gg);
     return 0;
 }

@@ -537,8 +537,7 @@ __global__ __launch_bounds__(256) void enc_attention_flash_kernel(const float* _
 
 int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out, int row0, hipStream_t st) {
     SVA_CHECK(hd == 64 && T % 4 == 0, "enc_attention: head_dim must be 64 and T a multiple of 4");
-    static const bool valu_only = getenv("SVA_ENC_ATTN_VALU") != nullptr;          // A/B switch
-    if (T % 16 == 0 && T <= 128 && !valu_only) {
+    if (T % 16 == 0 && T <= 128) {
         const size_t sm = ((size_t)T * 68 + 64 * (size_t)(T + 4) + 4 * 16 * (size_t)(T + 4)) * sizeof(float);
         static DeviceOnce attr_m;
         if (attr_m.needed()) {
@@ -1390,10 +1389,9 @@ __global__ __launch_bounds__(THREADS) void sampler_bisect_kernel(const float* __
         for (int c = tid; c < D; c += THREADS) emb_out[(long)row * ldo + c] = emb_table[(long)t * D + c];
     }
 }
-static int sampler_mode() {      // A/B switch: SVA_SAMPLER_SORT=1 restores the sorting kernels
-    static const int m = getenv("SVA_SAMPLER_SORT") ? atoi(getenv("SVA_SAMPLER_SORT")) : 0;
-    return m;
-}
+// The production sampler is the sort-free threshold search with interpolated, key-snapped probes; the sorting kernels and the other
+// search shapes below stay reachable through the unit-test hook only (sva_test_sampler variants 1..7, tests compare them all).
+static constexpr int sampler_mode() { return 0; }
 
 int launch_sampler(const float* logits, int rows, int V, int ldl, const float* noise, int ldn,
                    const unsigned long long* seed, const int* frame, int kind, int noise_elem_off, float temperature,
@@ -1408,10 +1406,9 @@ int launch_sampler(const float* logits, int rows, int V, int ldl, const float* n
         attr_set.done();
     }
     const float tclamp = temperature > 1e-5f ? temperature : 1e-5f;
-    static const bool legacy = getenv("SVA_SAMPLER_LDS") != nullptr;       // A/B switch: the all-LDS bitonic sort
+    constexpr bool legacy = false;
     if (P == 8192 && !legacy && !sampler_mode()) {
-        static const int bv = getenv("SVA_SAMPLER_BISECT") ? atoi(getenv("SVA_SAMPLER_BISECT")) : 1;      // 512 x 16 (24.8 us) beats 1024 x 8 (28.2 us)
-        static const int srch = getenv("SVA_SAMPLER_SEARCH") ? atoi(getenv("SVA_SAMPLER_SEARCH")) : 2;   // 0: plain bisection
+        constexpr int bv = 1, srch = 2;      // 512 x 16 (24.8 us) beats 1024 x 8 (28.2 us); interpolated probes
         if (bv == 1 && srch)
             hipLaunchKernelGGL((sampler_bisect_kernel<512, 16, 2>), dim3(rows), dim3(512), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind,
                                noise_elem_off, 1.0f / tclamp, top_p, tok_out, tok_stride, (int*)nullptr, (const int*)nullptr, 0,
@@ -1996,14 +1993,13 @@ int launch_sampler_small(const float* logits, int rows, int V, int ldl, const fl
                          const int* use_forced, const float* emb_table, int D, float* emb_out, int ldo, hipStream_t st) {
     SVA_CHECK(V <= 1024, "sampler_small: V <= 1024");
     const float tclamp = temperature > 1e-5f ? temperature : 1e-5f;
-    static const int variant = getenv("SVA_SAMPLER_SMALL") ? atoi(getenv("SVA_SAMPLER_SMALL")) : 0;     // A/B switch
-    static const int sbv = getenv("SVA_SAMPLER_SMALL_BISECT") ? atoi(getenv("SVA_SAMPLER_SMALL_BISECT")) : 1;
+    constexpr int variant = 0, sbv = 1;
     if (variant == 0 && !sampler_mode() && sbv) {
 #define SVA_BIS(T_, P_)                                                                                                          \
     hipLaunchKernelGGL((sampler_bisect_kernel<T_, P_>), dim3(rows), dim3(T_), 0, st, logits, V, ldl, noise, ldn, seed, frame, kind, \
                        noise_elem_off, 1.0f / tclamp, top_p, tok_raw, tok_stride, tok, forced, forced_stride, use_forced, emb_table, D, \
                        emb_out, ldo)
-        static const int srch = getenv("SVA_SAMPLER_SEARCH") ? atoi(getenv("SVA_SAMPLER_SEARCH")) : 2;   // 0: plain bisection
+        constexpr int srch = 2;
         if (sbv == 2) SVA_BIS(128, 8);
         else if (sbv == 3) SVA_BIS(64, 16);
         else if (sbv == 4) SVA_BIS(512, 2);

@@ -11,6 +11,21 @@ namespace sva {
 
 void set_error(const std::string& msg);
 
+// The engine's only environment input: SVA_DEBUG="key=value,key=value" (read once per process).  Profiling, table generation and the
+// parity tests' kernel selection -- nothing a deployment sets; every kernel choice of the product path is compiled in.
+//   ar_timing=1      persistent AR kernel stamps its phases (tap "ar_timing"; tools/ar_timing.py)
+//   pipe_trace=N     per-chain start / end events of the last N pipelined steps, printed when the batch is destroyed
+//   concurrency=0    one stream for everything (rocprofv3 --pmc serialises dispatches: tools/pmc.sh, bench.py's traffic passes)
+//   ar_persistent=0  multi-launch AR decode instead of the persistent kernel (A/B, parity of the fallback)
+//   voc_fused_mask=M which narrow HiFiGAN levels run as the fused kernel (bit 0: C = 16, bit 1: C = 32; parity tests)
+//   autotune=1, tune_log=1, tune_table=0, tune_dump=PATH   timed search / its log / ignore the compiled-in table / dump the choices
+//                    (tools/make_tune_table.py)
+struct DebugOptions {
+    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1;
+    std::string tune_dump;
+};
+const DebugOptions& debug_options();
+
 // hipFuncSetAttribute applies to the CURRENT device only, and one process may hold engines on several GPUs: a per-call-site,
 // per-device "done" mask (bit = device ordinal), safe against concurrent first launches (setting the attribute twice is harmless)
 struct DeviceOnce {
@@ -109,10 +124,9 @@ struct ConvGemmGroup {
 // workgroups that share an A row panel sit on eight XCDs and each of the eight private L2s fetches the panel from the fabric;
 // this bijective remap gives XCD k the k-th contiguous eighth of the tile sequence, i.e. a band of M tiles with all its N
 // tiles -- the panel is fetched once and re-read from that XCD's L2 (cdna_hip_programming.md, "XCD swizzle must be bijective").
-// host side: remap only grids that give every XCD several M bands' worth of tiles (SVA_XCD_SWIZZLE=0 disables)
+// host side: remap only grids that give every XCD several M bands' worth of tiles
 inline int xcd_swizzle_for(unsigned nx, unsigned ny) {
-    static const int on = getenv("SVA_XCD_SWIZZLE") ? atoi(getenv("SVA_XCD_SWIZZLE")) : 1;
-    return on && nx >= 2 && ny >= 16 ? 1 : 0;
+    return nx >= 2 && ny >= 16 ? 1 : 0;
 }
 __device__ __forceinline__ void xcd_tile(int swz, int nx, int ny, int& bx, int& by) {
     if (!(swz & 1)) return;

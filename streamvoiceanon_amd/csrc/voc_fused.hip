@@ -167,13 +167,10 @@ int launch_voc_level(const float* X, long x_bstride, int xH, int C, int B, int T
     SVA_CHECK(xH >= rf_max, "voc_level: the level input keeps too little history");
     SVA_CHECK(rows_per_frame >= rf_max, "voc_level: a frame is shorter than the receptive field");
     // tile rows: as large as LDS allows once the launch fills the chip, smaller (more workgroups) for few streams
-    static const int three_env = getenv("SVA_VOC_THREE") ? atoi(getenv("SVA_VOC_THREE")) : 1;
-    static const int tr_env = getenv("SVA_VOC_TR") ? atoi(getenv("SVA_VOC_TR")) : 0;
-    const int three = three_env;
+    const int three = 1;
     const int tr_max = three ? (C == 16 ? 256 : 128) : (C == 16 ? 512 : 256);
     int TR = 64;
     while (TR < tr_max && (long)((Tl + 2 * TR - 1) / (2 * TR)) * 3 * B >= 256) TR *= 2;
-    if (tr_env) TR = tr_env;
     VocLevelArgs a;
     a.X = X; a.x_bstride = x_bstride; a.xH = xH; a.Tl = Tl; a.TR = TR; a.rows_alloc = TR + rf_max + 16; a.three = three;
     const size_t act_bytes = sizeof(float) * (three ? 3 : 2) * (size_t)a.rows_alloc * (C + 4);

@@ -76,6 +76,7 @@ def load_library():
     lib.sva_join_stream.argtypes = [vp, vp]
     lib.sva_batch_uses_persistent_decode.argtypes = [vp]
     lib.sva_test_force_ar_timeout.argtypes = [vp]
+    lib.sva_debug_configure.argtypes = [C.c_char_p]
     lib.sva_sync.argtypes = [vp]
     lib.sva_encode_window.argtypes = [vp, vp, vp, vp]
     lib.sva_vocode_window.argtypes = [vp, vp, i32, vp]
@@ -110,7 +111,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "sva_last_error", "sva_config_default", "sva_stream_params_default", "sva_engine_create",
     "sva_engine_load_weight", "sva_engine_finalize", "sva_engine_destroy", "sva_batch_create", "sva_batch_destroy",
-    "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_step_device_on", "sva_join_stream", "sva_batch_uses_persistent_decode", "sva_test_force_ar_timeout", "sva_sync", "sva_stream_chunks", "sva_encode_window", "sva_firefly_encode",
+    "sva_prefill_prompt", "sva_streams_begin", "sva_step", "sva_step_device", "sva_step_device_on", "sva_join_stream", "sva_batch_uses_persistent_decode", "sva_test_force_ar_timeout", "sva_debug_configure", "sva_sync", "sva_stream_chunks", "sva_encode_window", "sva_firefly_encode",
     "sva_vocode_window", "sva_vocode_stream", "sva_vocode_reset", "sva_quantizer_decode", "sva_vocoder_head", "sva_ar_delay_fill", "sva_ar_decode_one", "sva_generate", "sva_get_tap", "sva_get_timings",
     "sva_dev_alloc", "sva_dev_free", "sva_dev_upload", "sva_dev_download", "sva_op_conv", "sva_op_affine", "sva_op_unary", "sva_op_colstats",
     "sva_op_cam_context", "sva_op_mul", "sva_op_add", "sva_op_conv2d", "sva_op_cf_to_rows", "sva_op_fbank_power", "sva_op_stft_mag", "sva_op_attention",

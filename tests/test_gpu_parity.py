@@ -89,17 +89,17 @@ def test_encoder_window_64(eng, weights0):
 
 
 @pytest.mark.parametrize("fused_mask", [None, 0, 3])
-def test_vocoder_window_and_stream(eng, weights0, fused_mask, monkeypatch):
+def test_vocoder_window_and_stream(eng, weights0, fused_mask):
     """fused_mask: None = the default policy (C = 16 level fused at this batch size), 0 = every level as tap-split GEMMs,
     3 = both narrow levels (C = 16 and C = 32) through the fused LDS-resident kernel (voc_fused.hip)."""
     from oracle import sva_oracle as O
     from streamvoiceanon_amd import engine as E
 
-    if fused_mask is not None:
-        monkeypatch.setenv("SVA_VOC_FUSED_MASK", str(fused_mask))
+    E.load_library().sva_debug_configure(f"voc_fused_mask={-1 if fused_mask is None else fused_mask}".encode())      # read at batch creation
     g = load_golden("vocoder_s0")
     codes = g["codes"].astype(np.int32)
     b = E.Batch(eng, n_streams=1, voc_max_frames=64)
+    E.load_library().sva_debug_configure(b"voc_fused_mask=-1")           # (the option is read when a batch is created: back to the default policy)
     pcm = b.vocode_window(codes)
     ref = O.vocode_window(torch.from_numpy(g["codes"]), weights0)[:, 0].numpy()
     assert np.abs(pcm - ref).max() <= PCM_TOL
@@ -1261,7 +1261,7 @@ def test_two_fresh_processes_bit_identical():
 
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_determinism_worker.py")
     env = dict(os.environ)
-    env.pop("SVA_AUTOTUNE", None)
+    env.pop("SVA_DEBUG", None)
     digests = []
     for _ in range(2):
         r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600, env=env)

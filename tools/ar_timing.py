@@ -1,9 +1,9 @@
-"""Phase timeline of the persistent AR decode kernel (SVA_AR_TIMING=1): workgroup 0 stamps wall_clock64() (100 MHz) when a
+"""Phase timeline of the persistent AR decode kernel (SVA_DEBUG=ar_timing=1): workgroup 0 stamps wall_clock64() (100 MHz) when a
 phase's input has been gathered ("in") and when its outputs are computed ("out").  Prints the mean over a few frames."""
 import os
 import sys
 
-os.environ["SVA_AR_TIMING"] = "1"
+os.environ["SVA_DEBUG"] = "ar_timing=1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 

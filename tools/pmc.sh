@@ -3,14 +3,14 @@
 # /opt/skills/guides/MI355X_MICROARCH.md "HBM").  rocprofv3's derived FETCH_SIZE crashes the tool on this image, so
 # the read side is taken from its definition: FETCH_SIZE = 64 B x TCC_EA0_RDREQ (32 B for the _32B requests), and the
 # guide's gfx950 correction (a wide coalesced stream is tallied at half its bytes) doubles the non-32B part.
-# Single-stream engine (SVA_CONCURRENCY=0): counter collection serialises dispatches.
+# Single-stream engine (SVA_DEBUG=concurrency=0): counter collection serialises dispatches.
 #   tools/pmc.sh TAG [bench args...]
 TAG=$1; shift
 export TMPDIR=/tmp
 run() {  # name, counters...
   local NAME=$1; shift
   rm -rf gpurun_out/pmc_${TAG}_${NAME}
-  SVA_CONCURRENCY=0 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${TAG}_${NAME} -o p -- \
+  SVA_DEBUG=concurrency=0 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${TAG}_${NAME} -o p -- \
       python bench.py --no-cpu-baseline --no-roofline --no-pipeline "${BENCH_ARGS[@]}" > gpurun_out/pmc_${TAG}_${NAME}.log 2>&1
   echo "pass ${NAME} rc=$?"
 }

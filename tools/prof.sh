@@ -3,7 +3,7 @@
 TAG=$1; shift
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_${TAG}
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG} -o p -- python bench.py --no-cpu-baseline "$@" > gpurun_out/prof_${TAG}.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG} -o p -- python bench.py --no-cpu-baseline --no-pmc --no-torch-gpu-baseline --no-offline "$@" > gpurun_out/prof_${TAG}.log 2>&1
 tail -1 gpurun_out/prof_${TAG}.log | cut -c1-400
 python - <<PY
 import csv

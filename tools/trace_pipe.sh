@@ -3,7 +3,7 @@
 # kernels (sharing CUs) or by gaps between its kernels (dispatch / dependencies)?
 export TMPDIR=/tmp
 rm -rf gpurun_out/trace_pipe
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_pipe -o t -- python bench.py --no-cpu-baseline --no-batched --no-roofline --steps 40 --warmup 6 "$@" > gpurun_out/trace_pipe.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_pipe -o t -- python bench.py --no-cpu-baseline --no-pmc --no-torch-gpu-baseline --no-offline --no-batched --no-roofline --steps 40 --warmup 6 "$@" > gpurun_out/trace_pipe.log 2>&1
 python - <<'PY'
 import csv, collections, re
 rows = list(csv.DictReader(open("gpurun_out/trace_pipe/t_kernel_trace.csv")))

@@ -3,7 +3,7 @@
 # kernel on the same queue, aggregated per kernel name.  tools/trace_step.sh [bench args]
 export TMPDIR=/tmp
 rm -rf gpurun_out/trace_step
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_step -o t -- python bench.py --no-cpu-baseline --no-batched --no-roofline --steps 12 --warmup 3 "$@" > gpurun_out/trace_step.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_step -o t -- python bench.py --no-cpu-baseline --no-pmc --no-torch-gpu-baseline --no-offline --no-batched --no-roofline --steps 12 --warmup 3 "$@" > gpurun_out/trace_step.log 2>&1
 python - <<'PY'
 import csv, collections, re
 rows = list(csv.DictReader(open("gpurun_out/trace_step/t_kernel_trace.csv")))
