@@ -239,15 +239,17 @@ int sva_test_force_ar_timeout(sva_batch* b);
 /* kernel unit-test hook: C = A[M,K] * W[N,K]^T (+bias) through the conv-GEMM kernel (host arrays) */
 int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C);
 
-/* same through one specific dispatch choice of the autotuned GEMM (kind 0: small-M K-split kernel, a = 16-row tiles per
- * workgroup, b = K-split waves, c = 16-column tiles per wave; kind 1: LDS-tiled kernel, a = tile variant 0..6; kind 2: the
- * small-M kernel with its K axis also split over c >> 4 workgroups, c & 15 = column tiles; launched twice; kind 3: the LDS-DMA
- * ring kernel, a = tile variant 0..6, needs K % 64 == 0) */
+/* same through one specific dispatch choice of the GEMM dispatcher (kind 0: small-M K-split kernel, a = 16-row tiles per
+ * workgroup, b = K-split waves, c = 16-column tiles per wave; kind 1: LDS-tiled f32-MFMA kernel, a = tile variant 0..7; kind 2: the
+ * small-M kernel with its K axis also split over c >> 4 workgroups (fence-free tagged hand-off), c & 15 = column tiles, launched
+ * twice; kind 3: the register-staged pipelined f32-MFMA kernel (gemm_pipe.hip), a = tile variant 0..6, needs K % 64 == 0; kind 4: the
+ * six-product split-bf16 kernel (gemm_split.hip), a = tile variant 0..4, needs 16-byte aligned operands) */
 int sva_test_gemm_choice(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int kind,
                          int a, int b, int c);
 
 /* host cost (microseconds) of enqueueing one kernel from the calling thread, measured over `iters` launches of a one-element
- * kernel into an idle stream.  A single-stream step is ~430 launches, so the enqueueing thread's launch rate bounds the step
+ * kernel into an idle stream.  A synchronous single-stream step is ~170 launches (a pipelined one: four graph launches + the persistent
+ * AR kernel), so the enqueueing thread's launch rate still matters for the synchronous mode
  * rate; on a multi-socket host it depends on the core the thread runs on -- see engine.py pin_enqueue_thread() */
 int sva_host_launch_cost(int device, int iters, float* us_per_launch);
 

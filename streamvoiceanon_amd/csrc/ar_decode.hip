@@ -50,6 +50,9 @@ __device__ __forceinline__ void gather(const u64* g, int n, unsigned ep, float* 
     int spins = 0;
     if (*reinterpret_cast<volatile int*>(fail)) pending = 0;       // an earlier gather timed out (e.g. not all 96 workgroups resident): run through
     while (pending) {
+        // the buffer-load builtin is an ordinary memory read to the optimiser (unlike the agent-scope atomic loads of the 8-byte form):
+        // without a compiler barrier in the loop it is hoisted out and the loop polls a register
+        asm volatile("" ::: "memory");
         v4i x[PP];
 #pragma unroll
         for (int k = 0; k < PP; ++k)

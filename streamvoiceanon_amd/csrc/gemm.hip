@@ -988,7 +988,7 @@ int conv_gemm_last_kind() { return t_last_kind; }
 int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, int b, int c) {
     SVA_CHECK(g.Cin % 16 == 0 && g.lda % 4 == 0, "conv_gemm_choice: alignment");
     if (kind == 2) {
-        SVA_CHECK(pipe_gemm_supported(g) && a >= 0 && a <= 6, "conv_gemm_choice: the ring kernel needs Cin % 64 == 0 and 16-byte aligned operands");
+        SVA_CHECK(pipe_gemm_supported(g) && a >= 0 && a <= 6, "conv_gemm_choice: the pipelined kernel needs Cin % 64 == 0 and 16-byte aligned operands");
         SVA_TRY_RC(launch_choice(g, st, Choice{2, a, 0, 0}));
         SVA_HIP(hipGetLastError());
         return 0;

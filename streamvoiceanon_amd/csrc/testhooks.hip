@@ -35,7 +35,7 @@ static int test_gemm_impl(int device, int M, int N, int K, const float* A, const
     g.W = dW; g.N = N; g.bias = dB; g.C = dC; g.c_bstride = (long)M * N; g.ldc = N;
     // kind 2: small-M kernel with a grid-level K split, c = column tiles + 16 * splits
     int rc = !choice ? launch_conv_gemm(g, 0)
-             : choice[0] == 3 ? launch_conv_gemm_choice(g, 0, 2, choice[1], 0, 0)       // the LDS-DMA ring kernel, tile variant choice[1]
+             : choice[0] == 3 ? launch_conv_gemm_choice(g, 0, 2, choice[1], 0, 0)       // the register-staged pipelined kernel (gemm_pipe.hip), tile variant choice[1]
              : choice[0] == 4 ? launch_conv_gemm_choice(g, 0, 4, choice[1], 0, 0)       // the split-bf16 kernel, tile variant choice[1]
              : choice[0] == 2 ? launch_conv_gemm_choice_z(g, 0, choice[1], choice[2], choice[3] & 15, choice[3] >> 4)
                               : launch_conv_gemm_choice(g, 0, choice[0], choice[1], choice[2], choice[3]);

@@ -231,9 +231,10 @@ class InferenceWrapper:
     def calculate_prompt(self, ref_wav_tensors, alpha=1.0, spk_emb_collate_type="concat_mel", style_vectors=None,
                          timbre_latents=None):
         """:382-441.  The two code streams of the prompt (firefly.encode audio codes, speech-tokenizer content codes) are
-        computed on the device.  The CAM++ style vector and the SparkTTS timbre latents (N1 iii/iv, not built) come from
-        `self.style_encoder(wav)` / `self.timbre_encoder(wav)` callables if the caller installed them, or from the
-        `style_vectors` / `timbre_latents` arguments; alpha noise mixing (:426-427) is applied to them here."""
+        computed on the device, and so are the CAM++ style vector and the SparkTTS timbre latents (prompt_encoders.py, SURVEY 8f N1
+        iii / iv) when the engine holds the `style.*` / `timbre.*` weights: `self.style_encoder(wav)` / `self.timbre_encoder(wav)`.
+        The `style_vectors` / `timbre_latents` arguments (or caller-installed encoder callables) override them; without weights and
+        without overrides the call raises.  Alpha noise mixing (:426-427) is applied to the embeddings here."""
         import torch
 
         ref_list = ref_wav_tensors if isinstance(ref_wav_tensors, (list, tuple)) else [ref_wav_tensors]

@@ -568,8 +568,8 @@ def test_firefly_encode_batched_vs_oracle(eng, weights0, record_property):
 
 def test_calculate_prompt_mirror_feeds_stream(weights0):
     """InferenceWrapper.calculate_prompt mirror: ragged prompt wav -> (audio codes, content codes) on the device with
-    caller-supplied style / timbre, then straight into prefill_prompt + stream_infer; the CAM++ / SparkTTS encoders
-    (N1 iii/iv) are not built and must be refused loudly, as must firefly.encode on an engine without its weights."""
+    caller-supplied style / timbre, then straight into prefill_prompt + stream_infer.  An engine WITHOUT the CAM++ / SparkTTS
+    weights (`style.*` / `timbre.*`, loaded in test_stream_infer_from_wav_files) must refuse loudly to invent the embeddings."""
     from oracle import sva_oracle as O
     from streamvoiceanon_amd import engine as E, specs
     from streamvoiceanon_amd.infer_arvc import InferenceWrapper
@@ -809,7 +809,8 @@ def test_reference_main_call_sequence_and_module_seams(weights0, tmp_path):
     -- same flags, `InferenceWrapper(config_path, checkpoint_path, compile_*=...)`, `stream_infer(src_path, ref_path, out_dir,
     ...)` / `infer(...)` with save_result defaulting to True -- and the four module seams the hot loop crosses
     (`speech_tokenizer.encode`, `model.decode_one`, `firefly.quantizer.decode`, `firefly.head`, :506-508, 535-537, 175) as
-    attributes with the reference's argument / return conventions.  Style / timbre vectors are injected (N1 iii/iv)."""
+    attributes with the reference's argument / return conventions.  Style / timbre vectors are injected here (the device encoders have
+    their own tests: test_prompt_speaker_encoders_vs_reference_golden, test_stream_infer_from_wav_files)."""
     import os
 
     from oracle import sva_oracle as O

@@ -49,6 +49,7 @@ __device__ __forceinline__ void gather16(const u64* g, int n, unsigned epoch, fl
     for (int k = 0; k < MAXPER; ++k) if (2 * (tid0 + k * nthr) < n) pending |= 1u << k;
     v4i x[DEPTH][MAXPER];
     auto issue = [&](int d) {
+        asm volatile("" ::: "memory");      // (the buffer-load builtin is a plain read to the optimiser: keep it inside the poll loop)
 #pragma unroll
         for (int k = 0; k < MAXPER; ++k)
             if (pending >> k & 1) x[d][k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, (tid0 + k * nthr) * 16, 0, 16));
