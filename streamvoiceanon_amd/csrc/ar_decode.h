@@ -8,7 +8,6 @@ namespace sva {
 
 constexpr int AR_WGS = 96;            // workgroups of the persistent kernel (= CUs of the AR stream's partition)
 constexpr int AR_WAVES = AR_WGS * 4;
-constexpr int AR_SEM_WGS = 4;         // extra workgroups per stream that run the semantic head + its sampler off the critical path
 constexpr int AR_SLOW_LAYERS = 12, AR_FAST_LAYERS = 4;
 constexpr int AR_PERSISTENT_MAX_STREAMS = 6;      // batches up to this size decode with the persistent kernel (two streams per launch); above it
                                                   // the batched MFMA chain is faster (profiles/r02_streams_curve.txt)
@@ -67,6 +66,6 @@ struct ArDecodeArgs {
 int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st, int n_slots = 1);
 // blocks of the kernel the runtime says fit one CU at the launch's LDS size (hipOccupancyMaxActiveBlocksPerMultiprocessor)
 int ar_decode_occupancy(int wt_half, int kv_half, int* blocks_per_cu);
-size_t ar_decode_granule_words();     // u64 words of a stream's granule block (gx | gbig | gatt | glog | ga | semantic logits | acks, in this order)
+size_t ar_decode_granule_words();     // u64 words of a stream's granule block (gx | gbig | gatt | glog | ga, in this order)
 
 }  // namespace sva

@@ -29,8 +29,7 @@ namespace sva {
 namespace {
 
 using namespace ardev;
-constexpr int GX = 2 * D, GBIG = 2 * I, GATT = AR_WGS * 66, GLOG = 1024, GA = 2 * D, GSEM = 8192, GACK = 32;
-constexpr unsigned EP_HIDDEN = 6 * AR_SLOW_LAYERS;      // phases before the hidden state of the content token is published
+constexpr int GX = 2 * D, GBIG = 2 * I, GATT = AR_WGS * 66, GLOG = 1024, GA = 2 * D;
 constexpr int SPIN_LIMIT = 1 << 16;                // polls before a gather gives up (~50 ms); a healthy edge takes a handful
 
 // all 256 threads: wait for the n granules (n even, g 16-byte aligned) of a published vector (tags == ep) and unpack them into LDS.
@@ -94,8 +93,6 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
     unsigned long long* const s_gatt = a.gatt + y * t.gran;
     unsigned long long* const s_glog = a.glog + y * t.gran;
     unsigned long long* const s_ga = a.ga + y * t.gran;
-    unsigned long long* const s_gsem = s_ga + GA;               // semantic logits, published among the semantic workgroups
-    unsigned long long* const s_gack = s_gsem + GSEM;           // "frame header read" of every semantic workgroup
     unsigned* const s_epoch = a.epoch + y;
     long long* const s_dbg = y ? nullptr : a.dbg;
     float* const s_slow_logits = a.slow_logits + y * t.slow_logits;
@@ -129,53 +126,6 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
     const int use_forced = *a.use_forced;
     KVT* kv = s_kv_slow;
     const long SH = (long)a.S * 64;           // one head of the cache
-    const unsigned ep0 = ep;
-
-    // ======================================= semantic head: workgroups AR_WGS .. AR_WGS + AR_SEM_WGS - 1 =======================================
-    // dual_ar_stream.py:1181-1186: 8192 x 768 logits of the content token and a nucleus sample that every caller of decode_one
-    // discards (:833).  Off the frame's critical path: these workgroups take the hidden state when the slow layers publish it,
-    // exchange the logits among themselves and one of them samples, while the 96 decode workgroups go on with the fast AR.
-    if (wg >= AR_WGS) {
-        const int sw = wg - AR_WGS;
-        if (tid == 0) store_granule(s_gack + sw, ep0 + 1, 0.f);     // workgroup 0 rewrites the frame header only after every one of these
-        gather<3>(s_gx + D, D, ep0 + EP_HIDDEN, xs, a.fail, 20);
-        const int sgw = sw * 4 + wave;                               // rows sgw + 64 j
-        constexpr int SW = AR_SEM_WGS * 4;
-        for (int c8 = 0; c8 * 8 * SW < a.vocab; ++c8) {
-            WFrag<WT, D> w[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int row = sgw + SW * (c8 * 8 + j);
-                if (row > a.vocab - 1) row = a.vocab - 1;
-                w[j].load(a.out_w, row, lane);
-            }
-            float o[1][8];
-            gemv<WT, D, 8, 1, true>(w, xs, D, a.out_norm, 1e-5f, lane, o);
-            float mine = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (lane == j) mine = o[0][j];
-            const int row = sgw + SW * (c8 * 8 + lane);
-            if (lane < 8 && row < a.vocab) {
-                s_slow_logits[row] = mine;
-                store_granule(s_gsem + row, ep0 + EP_HIDDEN, mine);
-            }
-        }
-        if (sw != 0) return;
-        __syncthreads();
-        float* const sl = lds;                                        // [8192] (the whole LDS block: the decode buffers are unused here)
-        gather<32>(s_gsem, a.vocab, ep0 + EP_HIDDEN, sl, a.fail, 21);
-        float l[32];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const int e = tid + 256 * r;
-            l[r] = e < a.vocab ? sl[e] : -INFINITY;
-        }
-        __syncthreads();
-        const int s = nucleus_sample<4, 32>(l, a.vocab, tid, s_noise, seed, frame, 0, 0, a.inv_temp, a.top_p, reinterpret_cast<double*>(lds + 8192));
-        if (tid == 0) *s_sem = s;
-        return;
-    }
 
     // RoPE factors of this wave's three (even, odd) pairs: the two slow positions in registers, the 8 codebook positions in LDS
     float rc[2][3], rsn[2][3];
@@ -413,6 +363,27 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
         for (int i = tid; i < D; i += 256) s_hidden[i] = xs[D + i];
     for (int i = tid; i < D; i += 256) xs[i] = xs[D + i];
     __syncthreads();
+    if (!a.skip_semantic) {
+        // semantic-token logits (dual_ar_stream.py:1181-1186; the sample is discarded by every caller, :833): rows gw + 384 j,
+        // written through (agent scope) for the sampler that workgroup 0 runs at the end of the frame
+        for (int half = 0; half < 2; ++half) {
+            WFrag<WT, D> w[11];
+#pragma unroll
+            for (int j = 0; j < 11; ++j) {
+                int row = gw + AR_WAVES * (half * 11 + j);
+                if (row > a.vocab - 1) row = a.vocab - 1;
+                w[j].load(a.out_w, row, lane);
+            }
+            float o[1][11];
+            gemv<WT, D, 11, 1, true>(w, xs, D, a.out_norm, 1e-5f, lane, o);
+            float mine = 0.f;
+#pragma unroll
+            for (int j = 0; j < 11; ++j)
+                if (lane == j) mine = o[0][j];
+            const int row = gw + AR_WAVES * (half * 11 + lane);
+            if (lane < 11 && row < a.vocab) __hip_atomic_store(s_slow_logits + row, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     // ======================================= fast AR: 8 codebooks x 4 layers on M = 1 row =======================================
     __shared__ int toks[NCB];                  // the frame's codes (every workgroup samples the same token)
@@ -627,8 +598,6 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
         s_cached_audio_emb[i] = acc;
     }
     if (wg != 0) return;
-    // the frame header (epoch, positions, frame counter) is rewritten only after every semantic workgroup has read it
-    if (!a.skip_semantic) gather<1>(s_gack, AR_SEM_WGS, ep0 + 1, lg, a.fail, 22);
     if (tid < NCB) {
         s_pred_hist[(long)tid * a.hist_cap + (frame & (a.hist_cap - 1))] = toks[tid];
         s_step_audio[tid * a.chunk + a.ci] = toks[tid];
@@ -639,10 +608,20 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
         *s_last_pos = p0 + 1;
         *s_epoch = ep;
     }
+    if (!a.skip_semantic) {
+        float l[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int e = tid + 256 * r;
+            l[r] = e < a.vocab ? __hip_atomic_load(s_slow_logits + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+        }
+        __syncthreads();
+        const int s = nucleus_sample<4, 32>(l, a.vocab, tid, s_noise, seed, frame, 0, 0, a.inv_temp, a.top_p, reinterpret_cast<double*>(scr));
+        if (tid == 0) *s_sem = s;
+    }
 }
 
 constexpr size_t AR_LDS_FLOATS = GX + GBIG + 4 * 68 + GX + GLOG + 16 * 68 + NCB * 64;
-static_assert(AR_LDS_FLOATS >= 8192 + 256, "the semantic sampler stages 8192 logits + its scratch in the same LDS block");
 
 }  // namespace
 
@@ -653,11 +632,11 @@ int ar_decode_occupancy(int wt_half, int kv_half, int* blocks_per_cu) {
     return 0;
 }
 
-size_t ar_decode_granule_words() { return (size_t)GX + GBIG + GATT + GLOG + GA + GSEM + GACK; }
+size_t ar_decode_granule_words() { return (size_t)GX + GBIG + GATT + GLOG + GA; }
 
 int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st, int n_slots) {
     SVA_CHECK(n_slots >= 1 && n_slots <= 8, "ar_decode: 1..8 streams per launch");
-    SVA_CHECK(a.vocab <= 8192 && a.vocab % 2 == 0 && a.codebook_size <= 3 * AR_WAVES && a.codebook_size <= 1024 && a.codebook_size % 2 == 0 && (a.hist_cap & (a.hist_cap - 1)) == 0,
+    SVA_CHECK(a.vocab <= 22 * AR_WAVES && a.codebook_size <= 3 * AR_WAVES && a.codebook_size <= 1024 && a.codebook_size % 2 == 0 && (a.hist_cap & (a.hist_cap - 1)) == 0,
               "ar_decode: unsupported head sizes");
     // one_per_cu: ask for more than half of a CU's LDS so that the 96 workgroups land on 96 different CUs (the AR stream's own
     // partition: every CU's load bandwidth counts); otherwise the small footprint lets other kernels share the CUs
@@ -672,10 +651,10 @@ int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_p
         SVA_HIP(hipFuncSetAttribute((const void*)ar_decode_kernel<float, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         attr.done();
     }
-    if (wt_half && kv_half) hipLaunchKernelGGL((ar_decode_kernel<__half, __half>), dim3(AR_WGS + (a.skip_semantic ? 0 : AR_SEM_WGS), n_slots), dim3(256), smem, st, a);
-    else if (wt_half) hipLaunchKernelGGL((ar_decode_kernel<__half, float>), dim3(AR_WGS + (a.skip_semantic ? 0 : AR_SEM_WGS), n_slots), dim3(256), smem, st, a);
-    else if (kv_half) hipLaunchKernelGGL((ar_decode_kernel<float, __half>), dim3(AR_WGS + (a.skip_semantic ? 0 : AR_SEM_WGS), n_slots), dim3(256), smem, st, a);
-    else hipLaunchKernelGGL((ar_decode_kernel<float, float>), dim3(AR_WGS + (a.skip_semantic ? 0 : AR_SEM_WGS), n_slots), dim3(256), smem, st, a);
+    if (wt_half && kv_half) hipLaunchKernelGGL((ar_decode_kernel<__half, __half>), dim3(AR_WGS, n_slots), dim3(256), smem, st, a);
+    else if (wt_half) hipLaunchKernelGGL((ar_decode_kernel<__half, float>), dim3(AR_WGS, n_slots), dim3(256), smem, st, a);
+    else if (kv_half) hipLaunchKernelGGL((ar_decode_kernel<float, __half>), dim3(AR_WGS, n_slots), dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((ar_decode_kernel<float, float>), dim3(AR_WGS, n_slots), dim3(256), smem, st, a);
     SVA_HIP(hipGetLastError());
     return 0;
 }

@@ -473,7 +473,7 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
         e->ar_layers.resize(c.ar_layers);
         // the persistent batch-1 decode kernel (ar_decode.hip) is built for the reference's sizes
         e->mega_ok = c.ar_layers == AR_SLOW_LAYERS && c.ar_fast_layers == AR_FAST_LAYERS && D == 768 && c.ar_inter == 2304 && c.ar_heads == 12 &&
-                     c.num_codebooks == 8 && c.ar_vocab <= 8192 && c.ar_vocab % 2 == 0 && c.codebook_size <= 1024 && c.codebook_size % 2 == 0;
+                     c.num_codebooks == 8 && c.ar_vocab <= 22 * AR_WAVES && c.codebook_size <= 1024 && c.codebook_size % 2 == 0;
         const bool mg = e->mega_ok;
         for (int l = 0; l < c.ar_layers; ++l) SVA_TRY(P.llama(m + "layers." + std::to_string(l) + ".", e->ar_layers[l], D, c.ar_inter, false, mg));
         e->ar_fast_layers.resize(c.ar_fast_layers);
@@ -1924,7 +1924,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         SVA_TRY(ar_decode_occupancy(c.ar_dtype == 1, b->kv_half, &per_cu));
         SVA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
         const int avail = b->ar_partitioned ? std::min(cus, 96) : cus;       // the AR stream's CU mask (get_streams) is CUs 0..95
-        const int wgs = AR_WGS + AR_SEM_WGS;                             // decode + semantic-head workgroups of one stream
+        const int wgs = AR_WGS;
         b->mega_per_launch = (avail >= 2 * wgs && !b->ar_partitioned) ? 2 : 1;
         if (per_cu < 1 || avail < wgs) b->use_mega = false;                // fall back to the multi-launch decode
     }

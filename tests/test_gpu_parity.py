@@ -1404,3 +1404,52 @@ def test_two_pipelined_batches_interleaved(eng):
         np.testing.assert_array_equal(bs[i].pred_codes(0), solo[i][1])
         np.testing.assert_array_equal(outs[i].cpu().numpy(), solo[i][0])
         bs[i].close()
+
+
+@pytest.mark.gpu
+def test_stream_server_equals_custom_infer(weights0):
+    """The streaming server (streamvoiceanon_amd/stream_server.py: the GUI's audio loop, real-time-gui.py:1204-1358, behind a socket)
+    returns, block for block, what RealtimeSession.custom_infer returns in process -- across a reference change and a block-size change
+    -- and reports protocol errors without dropping the connection."""
+    import threading
+
+    from streamvoiceanon_amd import stream_server as S
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.realtime import RealtimeSession
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    _, _, style, timbre = synth_prompt(2500, 8)
+    refs = {"a.wav": synth_utterance(7300, 2048 * 70 + 100), "b.wav": synth_utterance(7301, 2048 * 66)}
+    src = synth_utterance(7302, 2048 * 12)
+
+    def make():
+        w = InferenceWrapper(weights=weights0)
+        w.style_encoder = lambda wav: style
+        w.timbre_encoder = lambda wav: timbre
+        return w
+
+    w_srv, w_ref, sess = make(), make(), RealtimeSession()
+    ready = threading.Event()
+    th = threading.Thread(target=S.serve, args=(w_srv, "127.0.0.1", 0, 1, ready), daemon=True)
+    th.start()
+    assert ready.wait(30)
+    c = S.Client(port=ready.port)
+    with pytest.raises(RuntimeError, match="reference"):
+        c.convert(src[:2048])                                  # no reference yet: an error frame, the connection survives
+    c.configure(alpha=1.0, block_frame=1, n_frame_delay=2)
+    c.set_reference("a.wav", refs["a.wav"])
+    for i in range(5):
+        got = c.convert(src[i * 2048:(i + 1) * 2048])
+        want = sess.custom_infer(w_ref, refs["a.wav"], "a.wav", src[i * 2048:(i + 1) * 2048], n_frame_delay=2, alpha=1.0)
+        np.testing.assert_array_equal(got, want)
+    c.set_reference("b.wav", refs["b.wav"])
+    c.configure(alpha=1.0, block_frame=2, n_frame_delay=2)
+    with pytest.raises(RuntimeError, match="block_frame"):
+        c.convert(src[:2048])                                  # wrong block length for the configured block_frame
+    for i in range(3):
+        blk = src[(5 + 2 * i) * 2048:(7 + 2 * i) * 2048]
+        np.testing.assert_array_equal(c.convert(blk), sess.custom_infer(w_ref, refs["b.wav"], "b.wav", blk, n_frame_delay=2, alpha=1.0))
+    assert sess.prefills == 2
+    c.close()
+    th.join(30)
+    w_srv.engine.close(); w_ref.engine.close()

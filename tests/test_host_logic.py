@@ -168,3 +168,50 @@ def test_compiled_reference_restatement_matches_oracle():
     assert (h[-1] - hidden_o).abs().max() <= 2e-4 * max(1.0, float(hidden_o.abs().max()))
     for l in range(ar.cfg.n_layer):          # the static cache received the same K / V rows
         assert torch.allclose(ref.k[l][:, pos], ar.k[l][:, pos], atol=1e-5)
+
+
+def test_stream_server_protocol_with_a_stub_model():
+    """stream_server.py's wire protocol and its lazy re-prefill bookkeeping (real-time-gui.py:32-49) against a stub model set: no GPU."""
+    import threading
+
+    import numpy as np
+
+    from streamvoiceanon_amd import stream_server as S
+
+    class Stub:
+        def __init__(self):
+            self.prefills, self.setups = [], []
+
+        def prefill_prompt(self, ref, max_prompt_frames=64, delay=2, alpha=1.0):
+            self.prefills.append((float(np.asarray(ref).sum()), delay, alpha))
+
+        def setup_stream_caches(self, **kw):
+            self.setups.append(kw["decode_chunk_frames"])
+
+        def process_one_chunk(self, block):
+            return np.asarray(block) * 0.5
+
+    stub, ready = Stub(), threading.Event()
+    th = threading.Thread(target=S.serve, args=(stub, "127.0.0.1", 0, 1, ready), daemon=True)
+    th.start()
+    assert ready.wait(10)
+    c = S.Client(port=ready.port)
+    x = np.arange(4096, dtype=np.float32)
+    try:
+        c.convert(x[:2048])
+        raise AssertionError("a block before any reference must be refused")
+    except RuntimeError as ex:
+        assert "reference" in str(ex)
+    c.set_reference("r1", np.ones(2048 * 4, np.float32))
+    c.configure(alpha=0.5, block_frame=1, n_frame_delay=3)
+    np.testing.assert_array_equal(c.convert(x[:2048]), x[:2048] * 0.5)
+    np.testing.assert_array_equal(c.convert(x[2048:]), x[2048:] * 0.5)
+    assert len(stub.prefills) == 1 and stub.prefills[0][1:] == (3, 0.5) and stub.setups == [1]
+    c.configure(alpha=0.5, block_frame=2, n_frame_delay=3)
+    np.testing.assert_array_equal(c.convert(x), x * 0.5)                 # new block size: caches rebuilt
+    c.set_reference("r2", np.full(2048 * 4, 2.0, np.float32))
+    c.convert(x)
+    assert len(stub.prefills) == 3 and stub.setups == [1, 2, 2]
+    c.close()
+    th.join(10)
+    assert not th.is_alive()
