@@ -597,10 +597,10 @@ def main():
             tot_ms, nl = batch.gemm_profile()
             tm_prof = batch.timings()          # stage times of this serial, event-bracketed step
             tab = batch.gemm_profile_table()
-            pipes = {"f32_mfma": [0.0, 0.0, 0], "bf16_split": [0.0, 0.0, 0]}       # flops, us, launches
+            pipes = {"f32_mfma": [0.0, 0.0, 0], "bf16_split": [0.0, 0.0, 0], "f16_weights": [0.0, 0.0, 0]}       # flops, us, launches
             for M_, N_, K_, taps_, mode_, us in tab:
-                kind = (int(mode_) >> 8) - 1            # 0 small-M, 1 tiled, 2 pipelined: v_mfma_f32_16x16x4_f32;  4: six bf16 part products
-                pp = pipes["bf16_split" if kind == 4 else "f32_mfma"]
+                kind = (int(mode_) >> 8) - 1            # 0 small-M, 1 tiled, 2 pipelined: v_mfma_f32_16x16x4_f32;  4: six bf16 part products;
+                pp = pipes["bf16_split" if kind == 4 else "f16_weights" if kind == 5 else "f32_mfma"]      # 5: fp16 weights x (hi + lo) fp16 activations
                 pp[0] += 2.0 * M_ * N_ * K_; pp[1] += us; pp[2] += 1
             if os.environ.get("SVA_GEMM_TABLE"):
                 agg = {}
@@ -629,10 +629,11 @@ def main():
                 mfma_util = round(pj["gemm_mfma_util"], 4) if pj.get("gemm_mfma_util") is not None else None
             alg_per_launch = alg_bytes / max(nl, 1)
             PEAK_SPLIT = 2500.0 / 6.0
+            PEAK_F16W = 2500.0 / 2.0          # v_mfma_f32_16x16x32_f16, two part products (activation hi, lo) per weight block
             by_pipe = {}
             for name, (fl, us, cnt) in pipes.items():
                 if cnt:
-                    pk = PEAK_F32_MFMA_TFLOPS if name == "f32_mfma" else PEAK_SPLIT
+                    pk = PEAK_F32_MFMA_TFLOPS if name == "f32_mfma" else PEAK_SPLIT if name == "bf16_split" else PEAK_F16W
                     by_pipe[name] = {"launches": cnt, "ms": round(us * 1e-3, 4), "gflop": round(fl / 1e9, 3), "achieved": round(fl / us / 1e6, 3),
                                      "peak": round(pk, 1), "frac": round(fl / us / 1e6 / pk, 5)}
             # the fraction of what the launches COULD have done in their own time on the pipes they ran on
@@ -644,7 +645,8 @@ def main():
                     "peak_note": "peak = 157.3 TF/s, the dense f32-MFMA peak (the arithmetic the path is specified in) -- `frac` = achieved / 157.3 as the contract "
                                  "defines it; launches of the split-bf16 kernel run on the bf16 pipes, whose ceiling for this work is 2500 / 6 = 416.7 TF/s: `by_pipe` "
                                  "prices each kernel family against its own pipe and `frac_of_own_pipes` is the time-weighted combination (the honest figure when "
-                                 "split launches are present)",
+                                 "split launches are present); an ar_dtype = 1 batch adds `f16_weights` (gemm_f16w.hip: fp16 weights, activations as hi + lo fp16 "
+                                 "parts, ceiling 2500 / 2 TF/s -- those launches are decode-sized and bound by their weight stream, not by the pipe)",
                     "achieved": round(ach, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
                     "frac_of_own_pipes": round(frac_own, 5), "by_pipe": by_pipe,

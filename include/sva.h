@@ -246,6 +246,11 @@ int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* 
  * six-product split-bf16 kernel (gemm_split.hip), a = tile variant 0..4, needs 16-byte aligned operands) */
 int sva_test_gemm_choice(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int kind,
                          int a, int b, int c);
+/* fp16-weight GEMM of the batched fp16 AR decode (csrc/gemm_f16w.hip; the reference's autocast(fp16) linear layers,
+ * modules/dual_ar_stream.py:1168-1219): C = epi(A x fp16(W)^T), mode bits 1 = RMSNorm prologue, 2 = residual, 4 = SwiGLU pairs;
+ * iters > 0 also returns the average microseconds per launch. */
+int sva_test_gemm_f16w(int device, int M, int N, int K, const float* A, const float* W, const float* bias, const float* rms_w,
+                       const float* res, int mode, float* C, int iters, float* out_us);
 
 /* host cost (microseconds) of enqueueing one kernel from the calling thread, measured over `iters` launches of a one-element
  * kernel into an idle stream.  A synchronous single-stream step is ~170 launches (a pipelined one: four graph launches + the persistent

@@ -35,6 +35,7 @@ struct DevPool {
 // [N][K] row-major weight (K = taps * Cin, tap-major) + optional bias [N]
 struct Lin {
     float* W = nullptr;
+    void* Wh = nullptr;          // fp16 copy in the same [N][K] layout (AR layers of an ar_dtype = 1 engine)
     float* b = nullptr;
     int N = 0, K = 0;
 };

@@ -83,6 +83,7 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());
             else if (k == "tune_table") o.tune_table = atoi(v.c_str());
+            else if (k == "f16_weights") o.f16_weights = atoi(v.c_str());
             else if (k == "tune_dump") o.tune_dump = v;
             else fprintf(stderr, "[sva] debug option '%s' unknown, ignored\n", k.c_str());
         }
@@ -328,6 +329,7 @@ struct Packer {
             if (e->cfg.ar_dtype == 1) SVA_TRY(upload_half(mega_w13, mp));
             else { float* f = nullptr; SVA_TRY(upload(e->allocs, &f, mp)); *mega_w13 = f; }
         }
+        if (e->cfg.ar_dtype == 1 && mega_w13) SVA_TRY(upload_half(&l.Wh, out));      // the batched chain's interleaved layout in fp16
         return upload(e->allocs, &l.W, out);
     }
     // fp16 copy of an already uploaded [N][K] matrix's host values (ar_dtype = 1) or the fp32 device pointer itself
@@ -348,6 +350,7 @@ struct Packer {
             SVA_TRY(mega_copy(p + "attention.wqkv", L.wqkv, &L.m_wqkv));
             SVA_TRY(mega_copy(p + "attention.wo", L.wo, &L.m_wo));
             SVA_TRY(mega_copy(p + "feed_forward.w2", L.w2, &L.m_w2));
+            if (e->cfg.ar_dtype == 1) { L.wqkv.Wh = L.m_wqkv; L.wo.Wh = L.m_wo; L.w2.Wh = L.m_w2; }      // the same fp16 matrices feed the batched chain
         }
         if (layerscale) {
             SVA_TRY(vec(p + "attention_layer_scale.gamma", &L.ls_attn, D));
@@ -486,6 +489,7 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
         if (mg) {
             SVA_TRY(P.mega_copy(m + "output", e->ar_output, &e->m_output));
             SVA_TRY(P.mega_copy(m + "fast_output", e->ar_fast_output, &e->m_fast_output));
+            if (c.ar_dtype == 1) { e->ar_output.Wh = e->m_output; e->ar_fast_output.Wh = e->m_fast_output; }
         }
         SVA_TRY(P.linear("arvc.context_in", e->context_in, D, c.timbre_dim));
         SVA_TRY(P.linear("arvc.style_in", e->style_in, D, c.style_dim));
@@ -571,7 +575,7 @@ int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda,
     ConvGemm g = proto;
     g.A = A; g.a_bstride = a_bstride; g.a_off = a_off; g.lda = lda;
     g.T = T; g.M = nb * T; g.stride = stride; g.dil = dil; g.taps = taps; g.Cin = Cin;
-    g.W = w.W; g.N = w.N; g.bias = w.b;
+    g.W = w.W; g.Wh = w.Wh; g.N = w.N; g.bias = w.b;
     g.C = C; g.c_bstride = c_bstride; g.c_off = c_off; g.ldc = ldc;
     SVA_CHECK(w.K == taps * Cin, "gemm_call: weight K mismatch");
     b->gemm_flops += 2.0 * g.M * (double)g.N * w.K;

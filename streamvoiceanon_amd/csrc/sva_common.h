@@ -20,8 +20,9 @@ void set_error(const std::string& msg);
 //   voc_fused_mask=M which narrow HiFiGAN levels run as the fused kernel (bit 0: C = 16, bit 1: C = 32; parity tests)
 //   autotune=1, tune_log=1, tune_table=0, tune_dump=PATH   timed search / its log / ignore the compiled-in table / dump the choices
 //                    (tools/make_tune_table.py)
+//   f16_weights=0     ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B)
 struct DebugOptions {
-    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1;
+    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1;
     std::string tune_dump;
 };
 const DebugOptions& debug_options();
@@ -80,6 +81,7 @@ struct ConvGemm {
     int M = 0;                  // B * T
     int stride = 1, dil = 1, taps = 1, Cin = 0;
     const float* W = nullptr;   // [N][taps*Cin], K contiguous
+    const void* Wh = nullptr;   // optional fp16 copy of W (ar_dtype = 1 AR layers): decode-sized problems stream it instead (gemm_f16w.hip)
     int N = 0;
     const float* bias = nullptr;    // [N]
     const float* gamma = nullptr;   // [N]  (ConvNeXt gamma / LayerScale)
@@ -148,8 +150,11 @@ bool split_gemm_supported(const ConvGemm& g);
 int launch_split_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 bool pipe_gemm_supported(const ConvGemm& g);
 int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
+// gemm_f16w.hip: fp16 weights on the f16 matrix pipes (fp32 activations split hi + lo), plain linear layers of the AR chain
+bool f16w_gemm_supported(const ConvGemm& g);
+int launch_f16w_gemm(const ConvGemm& g, hipStream_t st);
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
-int conv_gemm_last_kind();          // kernel family the calling thread's latest launch_conv_gemm[_group] picked: 0 small-M, 1 tiled, 2 pipelined (f32 MFMA), 4 split-bf16
+int conv_gemm_last_kind();          // kernel family the calling thread's latest launch_conv_gemm[_group] picked: 0 small-M, 1 tiled, 2 pipelined (f32 MFMA), 4 split-bf16, 5 fp16 weights (f16 MFMA)
 int launch_conv_gemm_group(const ConvGemm* gs, int n, hipStream_t st);
 // true when launch_conv_gemm would route this (M, N) problem to the K-split small-M kernel, which can normalise its A rows
 bool conv_gemm_can_fuse_rms(int M, int N);

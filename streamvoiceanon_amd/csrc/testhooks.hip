@@ -3,6 +3,7 @@
 #include "kernels.h"
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -44,6 +45,49 @@ static int test_gemm_impl(int device, int M, int N, int K, const float* A, const
     SVA_HIP(hipDeviceSynchronize());
     SVA_HIP(hipMemcpy(C, dC, sizeof(float) * (size_t)M * N, hipMemcpyDeviceToHost));
     (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); if (dB) (void)hipFree(dB);
+    return 0;
+}
+
+// fp16-weight GEMM of the batched fp16 AR (gemm_f16w.hip): W is rounded to fp16 here; mode bits: 1 = RMSNorm prologue (rms_w [K]),
+// 2 = residual add (res [M][N]), 4 = SwiGLU over 16-row interleaved (gate, up) weights (C is [M][N/2]).  iters > 0 also times it.
+extern "C" int sva_test_gemm_f16w(int device, int M, int N, int K, const float* A, const float* W, const float* bias, const float* rms_w,
+                                  const float* res, int mode, float* C, int iters, float* out_us) {
+    SVA_HIP(hipSetDevice(device));
+    const int NC = (mode & 4) ? N / 2 : N;
+    float *dA, *dC, *dB = nullptr, *dN = nullptr, *dR = nullptr;
+    uint16_t* dW;
+    std::vector<uint16_t> hb((size_t)N * K);
+    for (size_t i = 0; i < hb.size(); ++i) { const _Float16 h = (_Float16)W[i]; memcpy(&hb[i], &h, 2); }
+    SVA_HIP(hipMalloc(&dA, sizeof(float) * (size_t)M * K));
+    SVA_HIP(hipMalloc(&dW, 2 * (size_t)N * K));
+    SVA_HIP(hipMalloc(&dC, sizeof(float) * (size_t)M * NC));
+    SVA_HIP(hipMemcpy(dA, A, sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(dW, hb.data(), 2 * (size_t)N * K, hipMemcpyHostToDevice));
+    if (bias) { SVA_HIP(hipMalloc(&dB, sizeof(float) * N)); SVA_HIP(hipMemcpy(dB, bias, sizeof(float) * N, hipMemcpyHostToDevice)); }
+    if (mode & 1) { SVA_HIP(hipMalloc(&dN, sizeof(float) * K)); SVA_HIP(hipMemcpy(dN, rms_w, sizeof(float) * K, hipMemcpyHostToDevice)); }
+    if (mode & 2) { SVA_HIP(hipMalloc(&dR, sizeof(float) * (size_t)M * N)); SVA_HIP(hipMemcpy(dR, res, sizeof(float) * (size_t)M * N, hipMemcpyHostToDevice)); }
+    ConvGemm g;
+    g.A = dA; g.a_bstride = (long)M * K; g.lda = K; g.T = M; g.M = M; g.Cin = K; g.taps = 1;
+    g.Wh = dW; g.N = N; g.bias = dB; g.C = dC; g.c_bstride = (long)M * NC; g.ldc = NC;
+    g.rms_w = dN; g.res = dR; g.r_bstride = (long)M * N; g.ldr = N; g.w13 = (mode & 4) ? 1 : 0;
+    SVA_CHECK(f16w_gemm_supported(g), "sva_test_gemm_f16w: unsupported shape");
+    { const int rc = launch_f16w_gemm(g, 0); if (rc) return rc; }
+    SVA_HIP(hipDeviceSynchronize());
+    SVA_HIP(hipMemcpy(C, dC, sizeof(float) * (size_t)M * NC, hipMemcpyDeviceToHost));
+    if (iters > 0 && out_us) {
+        hipEvent_t e0, e1;
+        SVA_HIP(hipEventCreate(&e0)); SVA_HIP(hipEventCreate(&e1));
+        SVA_HIP(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) if (launch_f16w_gemm(g, 0)) return -1;
+        SVA_HIP(hipEventRecord(e1, 0));
+        SVA_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SVA_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *out_us = ms * 1000.f / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC);
+    if (dB) (void)hipFree(dB); if (dN) (void)hipFree(dN); if (dR) (void)hipFree(dR);
     return 0;
 }
 

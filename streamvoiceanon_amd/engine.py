@@ -102,6 +102,7 @@ def load_library():
     lib.sva_bench_gemm.argtypes = [i32] * 9 + [f32p]
     lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
     lib.sva_test_gemm_choice.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32]
+    lib.sva_test_gemm_f16w.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp]
     lib.sva_host_launch_cost.argtypes = [i32, i32, f32p]
     lib.sva_test_sampler.argtypes = [i32, i32, i32, i32, vp, vp, C.c_float, C.c_float, vp, i32, f32p]
     _lib = lib
@@ -116,7 +117,7 @@ EXPORTED_SYMBOLS = [
     "sva_dev_alloc", "sva_dev_free", "sva_dev_upload", "sva_dev_download", "sva_op_conv", "sva_op_affine", "sva_op_unary", "sva_op_colstats",
     "sva_op_cam_context", "sva_op_mul", "sva_op_add", "sva_op_conv2d", "sva_op_cf_to_rows", "sva_op_fbank_power", "sva_op_stft_mag", "sva_op_attention",
     "sva_op_geglu", "sva_op_l2norm",
-    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
+    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
 ]
 
 
@@ -452,6 +453,22 @@ def test_gemm(A, W, bias=None, device=0):
     b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
     _check(lib.sva_test_gemm(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out)), "sva_test_gemm")
     return out
+
+
+def test_gemm_f16w(A, W, bias=None, rms_w=None, res=None, swiglu=False, iters=0, device=0):
+    """The fp16-weight GEMM of the batched fp16 AR decode (csrc/gemm_f16w.hip): epi(norm(A) @ fp16(W).T).  Returns (C, us_per_launch)."""
+    lib = load_library()
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    M, K = A.shape
+    N = W.shape[0]
+    out = np.empty((M, N // 2 if swiglu else N), dtype=np.float32)
+    cv = lambda x: None if x is None else np.ascontiguousarray(x, dtype=np.float32)
+    b, nw, r = cv(bias), cv(rms_w), cv(res)
+    us = np.zeros(1, dtype=np.float32)
+    mode = (1 if nw is not None else 0) | (2 if r is not None else 0) | (4 if swiglu else 0)
+    _check(lib.sva_test_gemm_f16w(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(nw), _ptr(r), mode, _ptr(out), int(iters), _ptr(us)), "sva_test_gemm_f16w")
+    return out, float(us[0])
 
 
 def test_gemm_choice(A, W, choice, bias=None, device=0):

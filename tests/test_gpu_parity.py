@@ -1306,9 +1306,44 @@ def test_fp16_ar_teacher_forced_logits_and_codes(eng_fp16, weights0, record_prop
     assert np.isfinite(np.concatenate(outs2)).all() and np.abs(np.concatenate(outs2)).max() > 0.01
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(2, 2304, 768, "rms"), (16, 768, 768, "res"), (24, 4608, 768, "rms+swiglu"), (128, 768, 2304, "res"),
+                                        (128, 4608, 768, "rms+swiglu"), (256, 8200, 768, "rms"), (33, 1032, 1024, "bias"), (200, 2304, 768, "rms")])
+def test_f16w_gemm_matches_fp64_on_rounded_weights(M, N, K, mode):
+    """gemm_f16w.hip (batched fp16 AR linear layers): fp32 activations x fp16 weights on the f16 pipes with the activations split
+    hi + lo.  Against float64 on the SAME fp16-rounded weights the error is fp32-accumulation sized (tolerance 2e-6 relative to the
+    row scale -- three orders below what a plain fp16 rounding of the activations would give), for every epilogue of the chain.  The
+    M = 200 / 128 cases caught a contraction hazard: one element per ~2^13 was a whole fp16 ulp off (see split8)."""
+    from streamvoiceanon_amd import engine as E
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)).astype(np.float32) * 3.0
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    Wr = W.astype(np.float16).astype(np.float64)
+    x = A.astype(np.float64)
+    kw = {}
+    if "rms" in mode:
+        kw["rms_w"] = (1.0 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+        x = x * kw["rms_w"].astype(np.float64) / np.sqrt((x * x).mean(-1, keepdims=True) + 1e-5)
+    ref = x @ Wr.T
+    if "bias" in mode:
+        kw["bias"] = rng.standard_normal(N).astype(np.float32)
+        ref = ref + kw["bias"]
+    if "res" in mode:
+        kw["res"] = rng.standard_normal((M, N)).astype(np.float32)
+        ref = ref + kw["res"]
+    if "swiglu" in mode:
+        r3 = ref.reshape(M, N // 32, 2, 16)
+        gate, up = r3[:, :, 0], r3[:, :, 1]
+        ref = (gate / (1.0 + np.exp(-gate)) * up).reshape(M, N // 2)
+        kw["swiglu"] = True
+    out, _ = E.test_gemm_f16w(A, W, **kw)
+    err = np.abs(out - ref).max() / max(np.abs(ref).max(), 1.0)
+    print("f16w gemm", (M, N, K, mode), "max err / scale", err)
+    assert err < 2e-6
+
+
 def test_fp16_ar_persistent_kernel_equals_batched_path(eng_fp16):
     """The two fp16 decode paths hold the same fp16-rounded weights: one stream (persistent kernel, fp16 weight fragments) and the
-    same utterance in a batch of two (MFMA GEMMs on the fp32 copy of the rounded values, fp16 KV) produce the same codes."""
+    same utterance in a batch of two (fp16-weight MFMA GEMMs with hi + lo split activations, gemm_f16w.hip, fp16 KV) produce the same codes."""
     from streamvoiceanon_amd import engine as E
     from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
 
