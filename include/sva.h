@@ -236,6 +236,16 @@ int sva_debug_configure(const char* kv);
 /* test hook: set the persistent kernel's device-side timeout word, as a launch with non-resident workgroups would */
 int sva_test_force_ar_timeout(sva_batch* b);
 
+/* The optional sampler edits of decode_one_token_ar (modules/dual_ar_stream.py:1175-1213 -> logits_to_probs :1099-1117):
+ *   previous_tokens [1 + num_codebooks][W] int32 (row 0 edits the token head, row cb + 1 codebook cb; negative entries are
+ *   skipped): repetition penalty  s < 0 ? s * p : s / p  on the listed tokens, each once;
+ *   suppress_tokens [n_suppress]: token-head logits set to -inf (:1189 passes the list to the first sample() only).
+ * They apply to every stream of the batch from the next decoded frame on (sva_generate: from frame 1 -- the prefill's decode
+ * takes no sampling_kwargs, :722); W = 0 and n_suppress = 0 remove them.  While edits are set the batch decodes with the
+ * multi-launch path (the persistent kernel has no edit stage); at most 4096 entries per list. */
+int sva_set_sampler_edits(sva_batch* b, const int32_t* previous_tokens, int W, float repetition_penalty, const int32_t* suppress_tokens,
+                          int n_suppress);
+
 /* kernel unit-test hook: C = A[M,K] * W[N,K]^T (+bias) through the conv-GEMM kernel (host arrays) */
 int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C);
 

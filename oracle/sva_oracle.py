@@ -235,17 +235,36 @@ def encode_window(audio: torch.Tensor, W: dict, lengths: torch.Tensor | None = N
 # =========================================================================================
 # A: dual-AR conversion transformer (modules/dual_ar_stream.py, modules/arvc_wrapper.py)
 # =========================================================================================
-def sample_token(logits: torch.Tensor, noise: torch.Tensor, temperature: float = 0.7, top_p: float = 0.7) -> int:
-    """logits_to_probs + multinomial_sample_one_no_sync, modules/dual_ar_stream.py:1092-1132
-    with previous_tokens=None: nucleus cut on the *sorted inclusive* cumulative softmax (no
-    right shift, rank 0 always kept), then temperature, softmax, argmax(p / Exp(1) noise)."""
+def token_probs(logits: torch.Tensor, temperature: float = 0.7, top_p: float = 0.7,
+                previous_tokens: torch.Tensor | None = None, repetition_penalty: float = 1.5, suppress_tokens=None) -> torch.Tensor:
+    """logits_to_probs, modules/dual_ar_stream.py:1099-1132: optional
+    repetition penalty over `previous_tokens` (scores gathered, s < 0 ? s * p : s / p, scattered back -- every
+    listed token once, :1107-1114) and `suppress_tokens` -> -inf (:1115-1117), then the nucleus cut on the
+    *sorted inclusive* cumulative softmax (no right shift, rank 0 always kept), temperature, softmax.
+    Pinned against the reference's own function on tests/golden/sampler_edits.npz."""
+    if previous_tokens is not None or suppress_tokens is not None:
+        logits = logits.clone()          # (the reference edits its argument in place; callers here keep their logits)
+    if previous_tokens is not None:
+        pt = torch.as_tensor(previous_tokens).long()
+        score = torch.gather(logits, 0, pt)
+        score = torch.where(score < 0, score * repetition_penalty, score / repetition_penalty)
+        logits.scatter_(0, pt, score)
+    if suppress_tokens is not None:
+        for t in suppress_tokens:
+            logits[int(t)] = -float("inf")
     s, order = torch.sort(logits, descending=True)
     cum = torch.cumsum(torch.softmax(s, dim=-1), dim=-1)
     rm_sorted = cum > top_p
     rm_sorted[0] = False
     rm = torch.zeros_like(rm_sorted).scatter(0, order, rm_sorted)
     lg = logits.masked_fill(rm, -float("inf")) / max(temperature, 1e-5)
-    p = torch.softmax(lg, dim=-1)
+    return torch.softmax(lg, dim=-1)
+
+
+def sample_token(logits: torch.Tensor, noise: torch.Tensor, temperature: float = 0.7, top_p: float = 0.7,
+                 previous_tokens: torch.Tensor | None = None, repetition_penalty: float = 1.5, suppress_tokens=None) -> int:
+    """sample = logits_to_probs + multinomial_sample_one_no_sync (modules/dual_ar_stream.py:1081-1096): argmax(p / Exp(1) noise)."""
+    p = token_probs(logits, temperature, top_p, previous_tokens, repetition_penalty, suppress_tokens)
     return int(torch.argmax(p / noise))
 
 
@@ -270,6 +289,9 @@ class DualAR:
     def __init__(self, W: dict, cfg: ARConfig = ARConfig(), temperature: float = 0.7, top_p: float = 0.7):
         self.W, self.cfg = W, cfg
         self.temperature, self.top_p = temperature, top_p
+        # decode_one_token_ar's optional edits (dual_ar_stream.py:1175-1213): previous_tokens [1 + num_codebooks, W] (row 0 -> the
+        # token head, row cb + 1 -> codebook cb), suppress_tokens (token head only), repetition_penalty (logits_to_probs default 1.5)
+        self.previous_tokens, self.suppress_tokens, self.repetition_penalty = None, None, 1.5
         hd = cfg.dim // cfg.n_head
         self.hd = hd
         self.tab = rope_table(cfg.max_seq_len, hd)
@@ -350,7 +372,9 @@ class DualAR:
                 h = self._block(h, f"arvc.decoder.model.fast_layers.{l}.", self.fast_tab, kc[l], vc[l], pos)
             lg = F.linear(rms_norm(h[0], self.W["arvc.decoder.model.fast_norm.weight"]),
                           self.W["arvc.decoder.model.fast_output.weight"])
-            tok = sample_token(lg, noise[cb], self.temperature, self.top_p)
+            tok = sample_token(lg, noise[cb], self.temperature, self.top_p,
+                               previous_tokens=None if self.previous_tokens is None else self.previous_tokens[cb + 1],
+                               repetition_penalty=self.repetition_penalty)
             all_logits.append(lg)
             codes.append(tok)
             nxt = tok if forced is None else int(forced[cb])
@@ -361,7 +385,9 @@ class DualAR:
         """decode_one_token_ar, modules/dual_ar_stream.py:1168-1219 (the semantic-token sample is
         drawn and discarded by every caller, :833, but consumes noise)."""
         hidden, logits = self.slow_forward(x, pos)
-        sem = sample_token(logits, noise_slow, self.temperature, self.top_p)
+        sem = sample_token(logits, noise_slow, self.temperature, self.top_p,
+                           previous_tokens=None if self.previous_tokens is None else self.previous_tokens[0],
+                           repetition_penalty=self.repetition_penalty, suppress_tokens=self.suppress_tokens)
         codes, fast_logits = self.fast_decode(hidden, noise_fast, forced)
         return dict(semantic=sem, codes=codes, hidden=hidden, logits=logits, fast_logits=fast_logits)
 
@@ -420,13 +446,13 @@ class DualAR:
         remaining = torch.cat([src_cond[d:], W["arvc.decoder.wait4end_embedding.weight"][:d]], dim=0)
         seq = torch.cat([seq, remaining[:1]], dim=0)
         pos = torch.arange(seq.shape[0])
-        # the prefill's decode_one_token_ar call passes no sampling_kwargs (dual_ar_stream.py:722): defaults 0.7 / 0.7
-        user = (self.temperature, self.top_p)
-        self.temperature, self.top_p = 0.7, 0.7
+        # the prefill's decode_one_token_ar call passes no sampling_kwargs (dual_ar_stream.py:722): defaults 0.7 / 0.7, no edits
+        user = (self.temperature, self.top_p, self.previous_tokens, self.suppress_tokens)
+        self.temperature, self.top_p, self.previous_tokens, self.suppress_tokens = 0.7, 0.7, None, None
         try:
             out = self.decode_tokens(seq, pos, *noise_fn(0))
         finally:
-            self.temperature, self.top_p = user
+            self.temperature, self.top_p, self.previous_tokens, self.suppress_tokens = user
         codes = [out["codes"]]
         last = int(pos[-1])
         for i in range(remaining.shape[0] - 1):

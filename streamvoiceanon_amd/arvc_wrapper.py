@@ -53,8 +53,11 @@ class ARVCWrapper:
         from .infer_arvc import check_sampling_kwargs
 
         kw.update(check_sampling_kwargs(sampling_kwargs))
+        edits = kw.pop("edits", None)
         batch = E.Batch(self.engine, n_streams=1, delay=self.delay, **kw)
         try:
+            if edits:
+                batch.set_sampler_edits(**edits)       # applied from the second frame on, like the reference's loop (dual_ar_stream.py:722 vs :749-754)
             codes = batch.generate(_np(ref_content_codes, np.int64), _np(ref_audio_codes, np.int32), _np(src_content_codes, np.int64),
                                    _np(style_vectors, np.float32), _np(timbre_latents, np.float32).reshape(32, -1),
                                    noise_seed=self.noise_seed, noise=noise)

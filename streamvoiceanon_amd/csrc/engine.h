@@ -33,6 +33,8 @@ struct DevPool {
 };
 
 // [N][K] row-major weight (K = taps * Cin, tap-major) + optional bias [N]
+constexpr int EDIT_CAP = 4096;           // previous tokens per head / suppressed tokens (sva_set_sampler_edits)
+
 struct Lin {
     float* W = nullptr;
     void* Wh = nullptr;          // fp16 copy in the same [N][K] layout (AR layers of an ar_dtype = 1 engine)
@@ -221,6 +223,11 @@ struct sva_batch {
     int* d_ncontent = nullptr;             // [B] content codes seen
     unsigned long long* d_seed = nullptr;  // [B]
     int* d_use_forced = nullptr;           // [1]
+    // sampler edits (sva_set_sampler_edits): previous_tokens [1 + num_codebooks][EDIT_CAP], suppress list, {W, n_suppress, penalty}
+    int* d_edit_prev = nullptr;
+    int* d_edit_suppress = nullptr;
+    int* d_edit_params = nullptr;          // [1 + num_codebooks][4]
+    bool edits_on = false, edits_skip = false;
 
     // ---- encoder workspace ----
     int We = 0, N = 0, T0 = 0, T2 = 0;

@@ -1268,7 +1268,7 @@ int ar_decode_frame(sva_batch* b, int ci) {
     const int B = b->B, D = c.ar_dim, chunk = b->p.chunk_frames;
     hipStream_t st = b->stream;
     const int code_off = b->T2 - chunk + ci;
-    if (b->use_mega) {
+    if (b->use_mega && !b->edits_on) {          // (sampler edits run on the multi-launch decode: same KV, positions and counters)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool eager = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;     // (events of other batches cannot enter a capture)
         if (eager && e->mega_ev_valid && e->mega_last != b) SVA_HIP(hipStreamWaitEvent(st, e->mega_ev, 0));
@@ -1361,6 +1361,8 @@ int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const lon
             SVA_TRY(launch_rmsnorm_rows(b->hidden, (long)B * D, 0, D, 1, B, D, e->ar_norm, 1e-5f, b->ahn, (long)B * D, 0, D, st));
             SVA_TRY(gemm_call(b, b->ahn, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_output, b->slow_logits, (long)B * c.ar_vocab, 0, c.ar_vocab));
         }
+        if (b->edits_on && !b->edits_skip)
+            SVA_TRY(launch_logit_edits(b->slow_logits, B, c.ar_vocab, c.ar_vocab, b->d_edit_prev, EDIT_CAP, b->d_edit_suppress, b->d_edit_params, st));
         SVA_TRY(launch_sampler(b->slow_logits, B, c.ar_vocab, c.ar_vocab, noise, ldn, b->d_seed, b->d_nframes, 0, 0, b->p.temperature,
                                b->p.top_p, b->d_sem, 1, st));
     }
@@ -1377,6 +1379,9 @@ int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const lon
             SVA_TRY(launch_rmsnorm_rows(b->xf, (long)B * D, 0, D, 1, B, D, e->ar_fast_norm, 1e-5f, b->ahn, (long)B * D, 0, D, st));
             SVA_TRY(gemm_call(b, b->ahn, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_fast_output, lg, (long)B * ncb * cbs, 0, ncb * cbs));
         }
+        if (b->edits_on && !b->edits_skip)          // codebook cb reads previous_tokens[cb + 1]; no suppress list (dual_ar_stream.py:1205-1213)
+            SVA_TRY(launch_logit_edits(lg, B, cbs, ncb * cbs, b->d_edit_prev + (long)(cb + 1) * EDIT_CAP, EDIT_CAP, b->d_edit_suppress,
+                                       b->d_edit_params + (cb + 1) * 4, st));
         // sample (+ teacher forcing) and gather the next fast-AR input embedding in the same launch
         const float* nz = noise ? noise + c.ar_vocab + (long)cb * cbs : nullptr;
         if (cbs <= 1024) {
@@ -2867,7 +2872,43 @@ extern "C" int sva_test_force_ar_timeout(sva_batch* b) {
     SVA_HIP(hipMemcpy(b->d_ar_fail, &code, sizeof(int), hipMemcpyHostToDevice));
     return 0;
 }
-extern "C" int sva_batch_uses_persistent_decode(sva_batch* b) { return b && b->use_mega ? 1 : 0; }
+extern "C" int sva_batch_uses_persistent_decode(sva_batch* b) { return b && b->use_mega && !b->edits_on ? 1 : 0; }
+
+// previous_tokens / repetition_penalty / suppress_tokens of decode_one_token_ar (modules/dual_ar_stream.py:1099-1117, 1175-1213)
+extern "C" int sva_set_sampler_edits(sva_batch* b, const int32_t* previous_tokens, int W, float repetition_penalty, const int32_t* suppress_tokens,
+                                     int n_suppress) {
+    SVA_CHECK(b, "sva_set_sampler_edits: null batch");
+    SVA_CHECK(W >= 0 && W <= EDIT_CAP && n_suppress >= 0 && n_suppress <= EDIT_CAP, "sva_set_sampler_edits: at most 4096 previous tokens per head / suppressed tokens");
+    SVA_CHECK((W == 0 || previous_tokens) && (n_suppress == 0 || suppress_tokens), "sva_set_sampler_edits: null list");
+    SVA_CHECK(repetition_penalty > 0.f, "sva_set_sampler_edits: repetition_penalty must be positive");
+    SVA_HIP(hipSetDevice(b->e->device));
+    SVA_TRY(quiesce(b));
+    SVA_HIP(hipStreamSynchronize(b->stream));
+    const int heads = 1 + b->e->cfg.num_codebooks;
+    const bool on = W > 0 || n_suppress > 0;
+    if (on && !b->d_edit_prev) {
+        SVA_TRY(dev_alloc(b->allocs, &b->d_edit_prev, (size_t)heads * EDIT_CAP));
+        SVA_TRY(dev_alloc(b->allocs, &b->d_edit_suppress, (size_t)EDIT_CAP));
+        SVA_TRY(dev_alloc(b->allocs, &b->d_edit_params, (size_t)heads * 4));
+    }
+    if (on) {
+        for (int h = 0; h < heads && W > 0; ++h)
+            SVA_HIP(hipMemcpy(b->d_edit_prev + (size_t)h * EDIT_CAP, previous_tokens + (size_t)h * W, sizeof(int) * (size_t)W, hipMemcpyHostToDevice));
+        if (n_suppress) SVA_HIP(hipMemcpy(b->d_edit_suppress, suppress_tokens, sizeof(int) * (size_t)n_suppress, hipMemcpyHostToDevice));
+        std::vector<int> prm((size_t)heads * 4, 0);
+        int pbits;
+        memcpy(&pbits, &repetition_penalty, 4);
+        for (int h = 0; h < heads; ++h) { prm[h * 4] = W; prm[h * 4 + 1] = h == 0 ? n_suppress : 0; prm[h * 4 + 2] = pbits; }     // the list goes to the token head only (:1189)
+        SVA_HIP(hipMemcpy(b->d_edit_params, prm.data(), sizeof(int) * prm.size(), hipMemcpyHostToDevice));
+    }
+    if (on != b->edits_on) {
+        // the AR stage's captured launches change (edit kernels in / out, persistent kernel out / in): drop its graphs
+        for (auto& ge : b->pipe_graph_a) if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
+        if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
+        b->edits_on = on;
+    }
+    return 0;
+}
 
 extern "C" int sva_sync(sva_batch* b) {
     SVA_CHECK(b, "null batch");
@@ -3023,10 +3064,12 @@ extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* 
             // (dual_ar_stream.py:722), i.e. with temperature = top_p = 0.7
             const float t_user = b->p.temperature, p_user = b->p.top_p;
             b->p.temperature = 0.7f; b->p.top_p = 0.7f;
+            b->edits_skip = true;                     // ... and without previous_tokens / suppress_tokens
             const int rc0 = ar_frame_tail(b, 0, 0, (long)(M - 1) * D, d_remq, S, 0, 0);
+            b->edits_skip = false;
             b->p.temperature = t_user; b->p.top_p = p_user;
             SVA_TRY(rc0);
-        } else if (b->use_mega) {
+        } else if (b->use_mega && !b->edits_on) {
             // decode steps of the offline loop (dual_ar_stream.py:735-760) through the persistent kernel: the same two tokens
             // [embed(previous codes), cond_i] at the next two positions, one launch per frame instead of ~200
             SVA_TRY(ar_decode_frame_mega(b, 0, d_remq, i));

@@ -24,14 +24,15 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x))
 
 // eight fp32 -> (hi, lo) fp16 fragments with hi + lo == x to 2^-22 relative (RNE conversions, exact fp32 residuals)
 __device__ __forceinline__ void split8(const float4& a, const float4& b, f16x8& hi, f16x8& lo) {
-    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        // The value is made opaque first: with the RMSNorm product feeding it, hipcc otherwise contracts the two uses differently --
-        // hi from the fp32-rounded product (v_cvt_pk_f16_f32) and lo against v_fma_mixlo_f16 of the EXACT product -- and the two
-        // roundings of hi disagree by one fp16 ulp about once per 2^13 elements (measured: single elements 2^-12 off).
-        asm("" : "+v"(v[i]));
-        const _Float16 h = (_Float16)v[i];
+        // hi is made opaque before lo is derived from it: with the RMSNorm product feeding v, hipcc otherwise contracts the two uses
+        // differently -- the hi operand of the MFMA from the fp32-rounded product (v_cvt_pk_f16_f32), lo against v_fma_mixlo_f16 of
+        // the EXACT product -- and the two roundings of hi disagree by one fp16 ulp about once per 2^13 elements (measured: single
+        // elements 2^-12 off).  With one hi, lo = v - hi is consistent whichever way v is evaluated.
+        _Float16 h = (_Float16)v[i];
+        asm("" : "+v"(h));
         hi[i] = h;
         lo[i] = (_Float16)(v[i] - (float)h);
     }
@@ -40,6 +41,7 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, f16x8& 
 template <int MT, int NT, int KW, bool RMS>
 __global__ __launch_bounds__(64 * KW) void f16w_gemm_kernel(const ConvGemm g, const _Float16* __restrict__ Wh) {
     constexpr int D = 2;                                   // K blocks in flight per wave
+    constexpr int LPS = NT + 2 * MT + (RMS ? 2 : 0);      // 16-byte loads per slot (issue())
     extern __shared__ __attribute__((aligned(16))) float red[];      // [KW][MT*NT][64][4] (+ [KW][MT][16] row sums of squares)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * (16 * NT);
@@ -96,6 +98,12 @@ __global__ __launch_bounds__(64 * KW) void f16w_gemm_kernel(const ConvGemm g, co
     for (int it = 0; it < my_n; it += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
+            // Explicit, counted wait for slot d's loads (the other slot's LPS loads, issued later, may stay in flight; vector memory
+            // returns in order).  hipcc's own waitcnt placement was WRONG for the <2, 2, 4, RMS> instantiation: the row sums of
+            // squares read A registers whose loads had not landed (1-4 % low, different from launch to launch; correct under
+            // -amdgpu-waitcnt-forcezero) -- found by the M = 24 / 32 SwiGLU unit tests.  The memory clobber pins the loads on
+            // their side of the wait.
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * (D - 1)) : "memory");
             const int kb = wave + (it + d) * KW;
             const float keep = kb < nk ? 1.f : 0.f;
             f16x8 w[NT], ah[MT], al[MT];
@@ -160,6 +168,7 @@ __global__ __launch_bounds__(64 * KW) void f16w_gemm_kernel(const ConvGemm g, co
                 const float inv = 1.f / sqrtf(tot / (float)K + g.rms_eps);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) t[j][r] *= inv;
+
             }
         }
 #pragma unroll

@@ -62,6 +62,12 @@ int launch_sampler(const float* logits, int rows, int V, int ldl, const float* n
                    const unsigned long long* seed, const int* frame, int kind, int noise_elem_off,
                    float temperature, float top_p, int* tok_out, int tok_stride, hipStream_t st);
 
+// logits_to_probs' edits ahead of the nucleus cut (modules/dual_ar_stream.py:1107-1117), in place on rows [rows][ldl]:
+//   repetition penalty on the tokens of prev[0 .. W) (negative entries skipped): l < 0 ? l * penalty : l / penalty, every listed token
+//   once (the reference gathers the ORIGINAL scores and scatters them back, so duplicates do not compound);
+//   then logits[suppress[i]] = -inf.  params = {W, n_suppress, penalty bits} in device memory (stable kernel arguments under graphs).
+int launch_logit_edits(float* logits, int rows, int V, int ldl, const int* prev, int prev_cap, const int* suppress, const int* params, hipStream_t st);
+
 // out[r, :] = table[idx[r*idx_stride] + idx_offset, :]
 int launch_gather_rows(const float* table, const int* idx, int idx_stride, int idx_offset, int rows, int D,
                        float* out, int ldo, hipStream_t st);

@@ -1161,6 +1161,44 @@ __global__ __launch_bounds__(THREADS) void sampler_reg_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Sampler edits (previous_tokens / repetition_penalty / suppress_tokens of logits_to_probs, modules/dual_ar_stream.py:1099-1117)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logit_edit_kernel(float* __restrict__ logits, int V, int ldl, const int* __restrict__ prev, int prev_cap,
+                                                         const int* __restrict__ suppress, const int* __restrict__ params) {
+    constexpr int PER = 16;                                  // 256 x 16 = 4096 listed tokens at most
+    float* row = logits + (long)blockIdx.x * ldl;
+    const int W = min(params[0], prev_cap), ns = params[1];
+    const float penalty = __int_as_float(params[2]);
+    // phase 1: every listed token's ORIGINAL score (torch.gather before scatter_: duplicates all read the unedited value)
+    float sc[PER];
+    int id[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = threadIdx.x + k * 256;
+        id[k] = i < W ? prev[i] : -1;
+        if (id[k] >= V) id[k] = -1;
+        sc[k] = id[k] >= 0 ? row[id[k]] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (id[k] >= 0) row[id[k]] = sc[k] < 0.f ? sc[k] * penalty : sc[k] / penalty;
+    __syncthreads();
+    for (int i = threadIdx.x; i < ns; i += 256) {
+        const int t = suppress[i];
+        if (t >= 0 && t < V) row[t] = -INFINITY;
+    }
+}
+
+int launch_logit_edits(float* logits, int rows, int V, int ldl, const int* prev, int prev_cap, const int* suppress, const int* params, hipStream_t st) {
+    SVA_CHECK(prev_cap <= 4096, "logit edits: at most 4096 previous tokens per head");
+    hipLaunchKernelGGL(logit_edit_kernel, dim3(rows), dim3(256), 0, st, logits, V, ldl, prev, prev_cap, suppress, params);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+
 // Sort-free variant.  The nucleus rule only needs to know, for each entry, whether the probability mass of the entries
 // that precede it in descending order (itself included) exceeds top_p; without ties that mass is F(p_i) = sum of all
 // p_j >= p_i, a non-increasing step function of the threshold.  So instead of sorting, bisect the threshold over the

@@ -102,6 +102,7 @@ def load_library():
     lib.sva_bench_gemm.argtypes = [i32] * 9 + [f32p]
     lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
     lib.sva_test_gemm_choice.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32]
+    lib.sva_set_sampler_edits.argtypes = [vp, vp, i32, C.c_float, vp, i32]
     lib.sva_test_gemm_f16w.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp]
     lib.sva_host_launch_cost.argtypes = [i32, i32, f32p]
     lib.sva_test_sampler.argtypes = [i32, i32, i32, i32, vp, vp, C.c_float, C.c_float, vp, i32, f32p]
@@ -117,7 +118,7 @@ EXPORTED_SYMBOLS = [
     "sva_dev_alloc", "sva_dev_free", "sva_dev_upload", "sva_dev_download", "sva_op_conv", "sva_op_affine", "sva_op_unary", "sva_op_colstats",
     "sva_op_cam_context", "sva_op_mul", "sva_op_add", "sva_op_conv2d", "sva_op_cf_to_rows", "sva_op_fbank_power", "sva_op_stft_mag", "sva_op_attention",
     "sva_op_geglu", "sva_op_l2norm",
-    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
+    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_set_sampler_edits", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
 ]
 
 
@@ -330,6 +331,18 @@ class Batch:
         c = np.ascontiguousarray(codes, dtype=np.int64).reshape(self.B, self.p.delay)
         _check(self.lib.sva_ar_delay_fill(self.h, _ptr(c)), "sva_ar_delay_fill")
 
+    def set_sampler_edits(self, previous_tokens=None, repetition_penalty=1.5, suppress_tokens=None):
+        """decode_one_token_ar's previous_tokens [1 + num_codebooks, W] / repetition_penalty / suppress_tokens
+        (modules/dual_ar_stream.py:1099-1117, 1175-1213); no arguments = no edits."""
+        pt = None if previous_tokens is None else np.ascontiguousarray(_as_np(previous_tokens), dtype=np.int32)
+        if pt is not None:
+            assert pt.ndim == 2 and pt.shape[0] == 1 + self.engine.cfg.num_codebooks, "previous_tokens must be [1 + num_codebooks, W]"
+        sp = None if suppress_tokens is None else np.ascontiguousarray(np.asarray(list(suppress_tokens)), dtype=np.int32).reshape(-1)
+        W = 0 if pt is None else int(pt.shape[1])
+        ns = 0 if sp is None else int(sp.size)
+        _check(self.lib.sva_set_sampler_edits(self.h, _ptr(pt) if W else None, W, float(repetition_penalty), _ptr(sp) if ns else None, ns),
+               "sva_set_sampler_edits")
+
     def ar_decode_one(self, code, noise=None, forced=None):
         c = np.ascontiguousarray(code, dtype=np.int64).reshape(self.B)
         nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float32).reshape(self.B, self.noise_stride)
@@ -453,6 +466,10 @@ def test_gemm(A, W, bias=None, device=0):
     b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
     _check(lib.sva_test_gemm(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out)), "sva_test_gemm")
     return out
+
+
+def _as_np(x):
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
 def test_gemm_f16w(A, W, bias=None, rms_w=None, res=None, swiglu=False, iters=0, device=0):

@@ -36,19 +36,24 @@ def _like(ref, arr):
 
 
 def check_sampling_kwargs(sampling_kwargs: dict) -> dict:
-    """`sample(logits, previous_tokens=None, temperature=0.7, top_p=0.7, repetition_penalty=1.0)` (modules/dual_ar_stream.py:1081-1132):
-    temperature / top_p go to the engine; a repetition penalty needs previous_tokens, which no caller on the path passes (:1088) --
-    anything the engine would silently ignore is refused instead."""
-    out = {}
+    """`decode_one_token_ar(..., previous_tokens=None, suppress_tokens=None, **sampling_kwargs)` -> `sample` -> `logits_to_probs(
+    logits, previous_tokens, suppress_tokens, temperature=0.7, top_p=0.7, repetition_penalty=1.5)` (modules/dual_ar_stream.py:
+    1081-1132, 1175-1213).  temperature / top_p become batch parameters; previous_tokens / suppress_tokens / repetition_penalty
+    are returned under "edits" (-> `Batch.set_sampler_edits`; the penalty only acts through previous_tokens, as in the reference).
+    Unknown names raise TypeError like the reference's signature would."""
+    out, edits = {}, {}
     for k, v in sampling_kwargs.items():
         if k in ("temperature", "top_p"):
             out[k] = float(v)
-        elif k == "repetition_penalty" and float(v) == 1.0:
-            continue
-        elif k == "previous_tokens" and v is None:
-            continue
+        elif k == "repetition_penalty":
+            edits[k] = float(v)
+        elif k in ("previous_tokens", "suppress_tokens"):
+            if v is not None:
+                edits[k] = v
         else:
-            raise NotImplementedError(f"sampling argument {k}={v!r} is not supported by the engine's sampler (temperature, top_p only)")
+            raise TypeError(f"logits_to_probs() got an unexpected keyword argument '{k}'")
+    if "previous_tokens" in edits or "suppress_tokens" in edits:
+        out["edits"] = edits
     return out
 
 
@@ -374,8 +379,11 @@ class InferenceWrapper:
         S = src_codes.shape[0]
         d = 2 if delay is None else int(delay)
         kw = check_sampling_kwargs(sampling_kwargs)
+        edits = kw.pop("edits", None)
         b = E.Batch(self.engine, n_streams=1, delay=d, voc_max_frames=S, **kw)
         try:
+            if edits:
+                b.set_sampler_edits(**edits)
             codes = b.generate(ref_content_codes.reshape(-1), ref_audio_codes.reshape(8, -1), src_codes, style_vectors.reshape(-1),
                                timbre_latents.reshape(32, -1), noise_seed=noise_seed)
             wav = b.vocode_window(codes[None])[0]

@@ -467,8 +467,53 @@ def test_offline_generate_sampling_kwargs_frame0_defaults(eng, weights0):
     dflt = m.generate(*args, noise=noise)
     np.testing.assert_array_equal(dflt.numpy()[..., 0], codes.numpy()[..., 0])       # frame 0 does not see the kwargs
     assert (dflt.numpy() != codes.numpy()).any()                                     # later frames do
-    with pytest.raises(NotImplementedError):
-        m.generate(*args, noise=noise, repetition_penalty=1.2)
+    # a penalty without previous_tokens changes nothing (logits_to_probs only reads it under `if previous_tokens is not None`)
+    np.testing.assert_array_equal(m.generate(*args, noise=noise, repetition_penalty=1.2).numpy(), dflt.numpy())
+    with pytest.raises(TypeError):
+        m.generate(*args, noise=noise, top_k=5)
+
+
+def test_offline_generate_sampler_edits_vs_oracle(eng, weights0):
+    """previous_tokens / repetition_penalty / suppress_tokens (decode_one_token_ar, modules/dual_ar_stream.py:1175-1213 ->
+    logits_to_probs :1099-1117) through ARVCWrapper.generate: the same codes as the oracle, frame 0 untouched (the prefill's decode
+    takes no sampling_kwargs), later frames changed; removing the edits restores the default codes and the persistent kernel."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.arvc_wrapper import ARVCWrapper
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt
+
+    useed, S = 883, 12
+    ac, cc, style, timbre = synth_prompt(2302, 24)
+    src_codes = (np.arange(S, dtype=np.int64) * 2654435761 % 8192).astype(np.int64)
+    noise = np.stack([np.concatenate([frame_noise(useed, s)[0], frame_noise(useed, s)[1].reshape(-1)]) for s in range(S)])
+    m = ARVCWrapper(eng, delay=2)
+    args = (torch.from_numpy(cc)[None], torch.from_numpy(ac)[None], torch.from_numpy(src_codes)[None],
+            torch.from_numpy(style)[None], torch.from_numpy(timbre)[None])
+    dflt = m.generate(*args, noise=noise)
+    # penalise what the default run produced (the strongest candidates), with duplicates and a huge penalty; suppress its token-head picks
+    rng = np.random.default_rng(5)
+    prev = np.concatenate([rng.integers(0, 8192, (1, 48)),
+                           np.concatenate([dflt.numpy()[0], dflt.numpy()[0, :, :4], rng.integers(0, 1000, (8, 32))], 1)], 0).astype(np.int32)
+    assert prev.shape == (9, 48)
+    suppress = [int(x) for x in rng.integers(0, 8192, 300)]
+    kw = dict(previous_tokens=torch.from_numpy(prev), repetition_penalty=50.0, suppress_tokens=suppress, temperature=1.1, top_p=0.9)
+    codes = m.generate(*args, noise=noise, **kw)
+    ar = O.DualAR(weights0, temperature=1.1, top_p=0.9)
+    ar.previous_tokens, ar.repetition_penalty, ar.suppress_tokens = torch.from_numpy(prev).long(), 50.0, suppress
+    ref = ar.generate(torch.from_numpy(cc), torch.from_numpy(ac), torch.from_numpy(src_codes), torch.from_numpy(style),
+                      torch.from_numpy(timbre), 2, noise_fn=lambda s_: tuple(torch.from_numpy(a) for a in frame_noise(useed, s_)))
+    np.testing.assert_array_equal(codes.numpy(), ref.numpy())
+    np.testing.assert_array_equal(codes.numpy()[..., 0], dflt.numpy()[..., 0])
+    plain = m.generate(*args, noise=noise, temperature=1.1, top_p=0.9)
+    assert (plain.numpy() != codes.numpy()).any()                                    # the edits did something
+    # the streaming batch: edits on -> multi-launch decode, off -> the persistent kernel again, same codes as an undisturbed batch
+    b = E.Batch(eng, n_streams=1)
+    if b.uses_persistent_decode():
+        b.set_sampler_edits(previous_tokens=prev, repetition_penalty=2.0)
+        assert not b.uses_persistent_decode()
+        b.set_sampler_edits()
+        assert b.uses_persistent_decode()
+    b.close()
 
 
 def test_inference_wrapper_offline_infer(weights0):
@@ -1307,7 +1352,8 @@ def test_fp16_ar_teacher_forced_logits_and_codes(eng_fp16, weights0, record_prop
 
 
 @pytest.mark.parametrize("M,N,K,mode", [(2, 2304, 768, "rms"), (16, 768, 768, "res"), (24, 4608, 768, "rms+swiglu"), (128, 768, 2304, "res"),
-                                        (128, 4608, 768, "rms+swiglu"), (256, 8200, 768, "rms"), (33, 1032, 1024, "bias"), (200, 2304, 768, "rms")])
+                                        (128, 4608, 768, "rms+swiglu"), (256, 8200, 768, "rms"), (33, 1032, 1024, "bias"), (200, 2304, 768, "rms"), (32, 4608, 768, "rms+swiglu"),
+                                        (17, 2304, 768, "rms"), (30, 768, 2304, "res"), (48, 4608, 768, "rms+swiglu"), (8, 8200, 768, "rms")])
 def test_f16w_gemm_matches_fp64_on_rounded_weights(M, N, K, mode):
     """gemm_f16w.hip (batched fp16 AR linear layers): fp32 activations x fp16 weights on the f16 pipes with the activations split
     hi + lo.  Against float64 on the SAME fp16-rounded weights the error is fp32-accumulation sized (tolerance 2e-6 relative to the
@@ -1339,6 +1385,8 @@ def test_f16w_gemm_matches_fp64_on_rounded_weights(M, N, K, mode):
     err = np.abs(out - ref).max() / max(np.abs(ref).max(), 1.0)
     print("f16w gemm", (M, N, K, mode), "max err / scale", err)
     assert err < 2e-6
+    for _ in range(3):          # a fixed reduction order: bit-identical from launch to launch
+        np.testing.assert_array_equal(E.test_gemm_f16w(A, W, **kw)[0], out)
 
 
 def test_fp16_ar_persistent_kernel_equals_batched_path(eng_fp16):

@@ -114,15 +114,17 @@ def test_load_checkpoints_unwraps_like_the_reference(tmp_path):
 
 
 def test_sampling_kwargs_are_validated_not_dropped():
-    """sample()'s arguments (modules/dual_ar_stream.py:1081-1132): temperature/top_p pass through, the no-op values of the
-    others are accepted, anything the engine cannot honour raises."""
+    """sample()'s arguments (modules/dual_ar_stream.py:1081-1132, 1175-1213): temperature / top_p become batch parameters, the
+    edit arguments travel under "edits" (a penalty without previous_tokens does nothing, as in the reference), unknown names raise."""
     from streamvoiceanon_amd.infer_arvc import check_sampling_kwargs
 
     assert check_sampling_kwargs({}) == {}
-    assert check_sampling_kwargs({"temperature": 1, "top_p": 0.9, "repetition_penalty": 1.0, "previous_tokens": None}) == {"temperature": 1.0, "top_p": 0.9}
-    for bad in ({"repetition_penalty": 1.5}, {"previous_tokens": [1]}, {"top_k": 5}):
-        with pytest.raises(NotImplementedError):
-            check_sampling_kwargs(bad)
+    assert check_sampling_kwargs({"temperature": 1, "top_p": 0.9, "repetition_penalty": 1.2, "previous_tokens": None}) == {"temperature": 1.0, "top_p": 0.9}
+    got = check_sampling_kwargs({"previous_tokens": [[1]] * 9, "repetition_penalty": 1.3, "suppress_tokens": [5]})
+    assert got == {"edits": {"previous_tokens": [[1]] * 9, "repetition_penalty": 1.3, "suppress_tokens": [5]}}
+    assert check_sampling_kwargs({"suppress_tokens": [7]}) == {"edits": {"suppress_tokens": [7]}}
+    with pytest.raises(TypeError):
+        check_sampling_kwargs({"top_k": 5})
 
 
 def test_xcd_tile_remap_is_a_bijection():

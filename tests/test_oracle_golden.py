@@ -156,6 +156,25 @@ def test_sampler_rules():
     assert O.sample_token(logits, noise, 1.0, 0.85) == 1         # cum=.5,.8 kept
 
 
+def test_sampler_edits_match_reference():
+    """previous_tokens / repetition_penalty / suppress_tokens: the oracle's logits_to_probs against the reference's own function
+    (fixture: tools/make_golden.py sampler_edits) -- the same support, probabilities to 1e-6, and the same sampled token."""
+    g = load_golden("sampler_edits")
+    for k in range(int(g["n_cases"])):
+        pen, temp, top_p = [float(x) for x in g[f"params{k}"]]
+        prev, sup = g[f"prev{k}"], g[f"suppress{k}"]
+        logits = torch.from_numpy(g[f"logits{k}"])
+        kw = dict(previous_tokens=torch.from_numpy(prev) if prev.size else None, repetition_penalty=pen,
+                  suppress_tokens=[int(t) for t in sup] if sup.size else None)
+        p = O.token_probs(logits, temp, top_p, **kw)
+        ref = torch.from_numpy(g[f"probs{k}"])
+        assert torch.equal(p > 0, ref > 0)
+        assert float((p - ref).abs().max()) < 1e-6
+        noise = torch.from_numpy(g[f"noise{k}"])
+        assert O.sample_token(logits, noise, temp, top_p, **kw) == int(torch.argmax(ref / noise))
+        assert torch.equal(logits, torch.from_numpy(g[f"logits{k}"]))          # the oracle leaves its argument alone
+
+
 def test_prompt_encoders_match_reference():
     """Style (CAM++) and timbre (SparkTTS) encoders of the prompt path (SURVEY.md 8f N1 iii / iv): the oracle's restatement against
     outputs of the reference's own modules (tools/make_golden.py prompt_encoders; torchaudio's two front-ends are restatements on

@@ -14,6 +14,7 @@ Fixture contents (SURVEY.md §8c "Golden vectors to capture"):
   stream_chunk4.npz    chunk = 4 stream (config-5 shape), delay 2
   offline_s0.npz       offline ARVCWrapper.generate codes for a short source
   melfb.npz            mel filterbank checksums
+  sampler_edits.npz    logits_to_probs with previous_tokens / repetition_penalty / suppress_tokens: probabilities per case
 """
 from __future__ import annotations
 
@@ -298,6 +299,29 @@ def prompt_encoder_fixture(wseed=0):
     print("prompt encoder fixture", {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def sampler_edits_fixture(das):
+    """logits_to_probs (modules/dual_ar_stream.py:1099-1132) with its optional edits, on seeded logits: the reference's output
+    probabilities per case (inputs are stored too: they are data, 1000-8192 floats)."""
+    rng = np.random.default_rng(77)
+    out = {}
+    cases = [(1000, 48, 0, 1.5, 0.7, 0.7), (8192, 64, 300, 50.0, 1.1, 0.9), (1000, 0, 0, 1.5, 0.7, 0.7), (8192, 0, 17, 1.5, 0.7, 0.7),
+             (1000, 200, 0, 0.5, 1.3, 0.95)]
+    for k, (V, W, ns, pen, temp, top_p) in enumerate(cases):
+        logits = (rng.standard_normal(V) * 3.0).astype(np.float32)
+        top = np.argsort(-logits)[:max(W // 2, 1)]
+        prev = np.concatenate([top, top[: W // 4], rng.integers(0, V, W)])[:W].astype(np.int64)     # strong candidates, duplicates, random ones
+        sup = rng.integers(0, V, ns).astype(np.int64)
+        probs = das.logits_to_probs(torch.from_numpy(logits.copy()), previous_tokens=torch.from_numpy(prev) if W else None,
+                                    suppress_tokens=[int(t) for t in sup] if ns else None, temperature=temp, top_p=top_p,
+                                    repetition_penalty=pen)
+        out[f"logits{k}"] = logits; out[f"prev{k}"] = prev; out[f"suppress{k}"] = sup
+        out[f"params{k}"] = np.array([pen, temp, top_p], np.float64); out[f"probs{k}"] = probs.numpy()
+        out[f"noise{k}"] = rng.exponential(1.0, V).astype(np.float32)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "sampler_edits.npz"), **out)
+    print("sampler_edits.npz written")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rh.install_stubs()
@@ -309,6 +333,10 @@ def main():
     np.savez_compressed(os.path.join(OUT, "melfb.npz"), col_sum=fb.sum(0).numpy(), row_sum=fb.sum(1).numpy(),
                         peak=fb.max(0).values.numpy(), argpeak=fb.argmax(0).numpy())
     only = sys.argv[1] if len(sys.argv) > 1 else None     # e.g. `make_golden.py prompt` adds one fixture without rewriting the rest
+    if only in (None, "sampler_edits"):
+        sampler_edits_fixture(das)
+        if only:
+            return
     if only == "encoder_long":
         encoder_long_fixture(rh.build_wrapper(seed=0))
         return
