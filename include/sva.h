@@ -261,6 +261,11 @@ int sva_test_gemm_choice(int device, int M, int N, int K, const float* A, const 
  * iters > 0 also returns the average microseconds per launch. */
 int sva_test_gemm_f16w(int device, int M, int N, int K, const float* A, const float* W, const float* bias, const float* rms_w,
                        const float* res, int mode, float* C, int iters, float* out_us);
+/* Prefill attention of the slow AR (modules/dual_ar_stream.py:338-356 with causal_mask[kv_pos]): M query rows [M][H*64] at positions
+ * pos0 .. pos0 + M - 1 against keys / values [pos0 + M][H*64] placed in a cache of S positions (fp32, or fp16 when half_kv).
+ * out_ref: the per-row kernel, out_mfma: the flash-style MFMA kernel; us[2] their launch times when iters > 0. */
+int sva_test_prefill_attention(int device, int M, int H, int pos0, int S, const float* q, const float* keys, const float* vals,
+                               int half_kv, float* out_ref, float* out_mfma, int iters, float* us);
 
 /* host cost (microseconds) of enqueueing one kernel from the calling thread, measured over `iters` launches of a one-element
  * kernel into an idle stream.  A synchronous single-stream step is ~170 launches (a pipelined one: four graph launches + the persistent

@@ -1016,8 +1016,10 @@ int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add, 
 
 // ---- A: slow / fast transformer passes ------------------------------------------------------------
 // rows [M, dim] in b->ax, slot/pos arrays on device; KV written at pos, attention over 0..pos
+// run_slot >= 0: the rows sit at CONSECUTIVE positions run_pos0 .. run_pos0 + M - 1 of that one slot (prompt prefill, re-prefill,
+// offline generate) -- their attention runs as the flash-style MFMA kernel instead of one workgroup per (head, row)
 int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int* d_slot, const int* d_pos, const float* rope,
-                   float* kv, long kv_layer, long kv_slot, int S, float* x) {
+                   float* kv, long kv_layer, long kv_slot, int S, float* x, int run_slot = -1, int run_pos0 = 0) {
     const sva_config& c = b->e->cfg;
     const int D = c.ar_dim, I = c.ar_inter, H = c.ar_heads;
     hipStream_t st = b->stream;
@@ -1074,10 +1076,12 @@ int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int*
         } else if (half_kv) {
             __half* ch = reinterpret_cast<__half*>(kv) + (long)l * kv_layer;
             SVA_TRY(launch_rope_kvwrite<__half>(b->aqkv, M, H, 64, d_slot, d_pos, rope, ch, kv_slot, S, st));
-            SVA_TRY(launch_ar_attention<__half>(b->aqkv, M, H, 64, d_slot, d_pos, ch, kv_slot, S, b->aatt, st));
+            if (run_slot >= 0 && M >= 96) SVA_TRY(launch_ar_prefill_attention<__half>(b->aqkv, M, H, 64, run_slot, run_pos0, ch, kv_slot, S, b->aatt, st));
+            else SVA_TRY(launch_ar_attention<__half>(b->aqkv, M, H, 64, d_slot, d_pos, ch, kv_slot, S, b->aatt, st));
         } else {
             SVA_TRY(launch_rope_kvwrite<float>(b->aqkv, M, H, 64, d_slot, d_pos, rope, cache, kv_slot, S, st));
-            SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
+            if (run_slot >= 0 && M >= 96) SVA_TRY(launch_ar_prefill_attention<float>(b->aqkv, M, H, 64, run_slot, run_pos0, cache, kv_slot, S, b->aatt, st));
+            else SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
         }
         ConvGemm po;
         po.res = x; po.r_bstride = (long)M * D; po.r_off = 0; po.ldr = D;
@@ -1428,7 +1432,7 @@ int ar_prefill_slot(sva_batch* b, int slot, int R, bool tap_logits = false) {
     SVA_HIP(hipMemcpyAsync(b->d_pos, hp.data(), sizeof(int) * M, hipMemcpyHostToDevice, st));
     SVA_HIP(hipStreamSynchronize(st));       // hs/hp are stack-lifetime host buffers
     SVA_TRY(ar_layers_pass(b, e->ar_layers, M, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer, b->kv_slow_slot,
-                           c.max_seq_len, b->ax));
+                           c.max_seq_len, b->ax, slot, 0));
     // cached_ref_emb = embed(ref_audio_codes)[-d:]  (:775)
     SVA_TRY(launch_audio_embed(e->codebook_emb, b->d_prompt_ac + (R - d), 1, b->Pmax, d, c.num_codebooks, c.codebook_size, D,
                                b->cached_ref_emb + (long)slot * c.max_delay * D, D, st));
@@ -3048,7 +3052,7 @@ extern "C" int sva_generate(sva_batch* b, const int64_t* ref_cc, const int32_t* 
     SVA_HIP(hipMemcpyAsync(b->d_pos, hp.data(), sizeof(int) * M, hipMemcpyHostToDevice, st));
     SVA_HIP(hipStreamSynchronize(st));
     SVA_TRY(ar_layers_pass(b, e->ar_layers, M, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer, b->kv_slow_slot,
-                           c.max_seq_len, b->ax));
+                           c.max_seq_len, b->ax, 0, 0));
     const int lp = M - 1;
     SVA_TRY(h2d(b, b->d_last_pos, &lp, sizeof(int)));
     b->h_last_pos[0] = lp;

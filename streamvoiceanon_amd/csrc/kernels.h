@@ -52,6 +52,11 @@ int launch_ar_fast_attention(const float* qkv, int M, int H, const int* slot, co
 template <typename KV>
 int launch_ar_attention(const float* qkv, int M, int H, int hd, const int* slot, const int* pos, const KV* cache,
                         long slot_stride, int S, float* out, hipStream_t st, float* partial = nullptr, int splits = 1);
+// The same attention for M rows at CONSECUTIVE positions pos0 .. pos0 + M - 1 of ONE slot (prefill / re-prefill / offline generate):
+// flash-style MFMA kernel, one 16-row query tile per workgroup, its four waves splitting the key blocks.
+template <typename KV>
+int launch_ar_prefill_attention(const float* qkv, int M, int H, int hd, int slot0, int pos0, const KV* cache, long slot_stride, int S, float* out,
+                                hipStream_t st);
 // partial != null: split-key decode -- `splits` workgroups per (head, row) write unnormalised partials
 // partial[((m*H + h)*splits + s)*68 + {0..63: P.V, 64: max score, 65: exp-sum}] that gemv mode 4 merges
 

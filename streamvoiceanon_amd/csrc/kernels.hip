@@ -799,6 +799,173 @@ template int launch_ar_attention<float>(const float*, int, int, int, const int*,
 template int launch_ar_attention<__half>(const float*, int, int, int, const int*, const int*, const __half*, long, int, float*, hipStream_t, float*, int);
 
 // ------------------------------------------------------------------------------------------
+// Prefill attention (prompt prefill / re-prefill / offline generate: hundreds of query rows at CONSECUTIVE positions of ONE slot,
+// modules/dual_ar_stream.py:764-796 -> forward_generate :338-356 with causal_mask[kv_pos]): flash-style on the matrix pipes.
+// One workgroup = ONE 16-row query tile of one head (12 heads x M / 16 tiles: 240 workgroups at M = 314); its four waves split
+// the tile's KEY blocks of 64 round-robin (flash-decoding style), each with its own online softmax, and merge their (max, sum,
+// P.V) triples through LDS at the end.  Scores Q.K^T and P.V are v_mfma_f32_16x16x4_f32 (fp32 operands and accumulation, the
+// arithmetic class of the per-row kernel above); K and V fragments come straight from the slot's cache in global memory (the
+// cache rows are the B operands: no staging, no workgroup barrier in the key loop), row statistics are reduced over the 16
+// lanes of an accumulator row with DPP, P goes through a wave-private LDS slab into the A operand of the second product.
+// (A first version with 64 query rows per workgroup and LDS-staged K / V^T was no faster than the per-row kernel below M = 400:
+// 60 workgroups, every block a load -> barrier -> compute round trip.)
+// ------------------------------------------------------------------------------------------
+template <typename KV> __device__ __forceinline__ float4 ld_kv_f4(const KV* p);
+template <> __device__ __forceinline__ float4 ld_kv_f4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld_kv_f4<__half>(const __half* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
+    return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
+}
+
+template <typename KV>
+__global__ __launch_bounds__(256) void ar_prefill_attention_kernel(const float* __restrict__ qkv, int M, int H, int pos0,
+                                                                   const KV* __restrict__ cache_slot, int S, float* __restrict__ out) {
+    constexpr int HD = 64, KB = 64, LV = KB + 4;
+    __shared__ __attribute__((aligned(16))) float Ps[4 * 16 * LV];        // per wave [row][key]
+    __shared__ float Ms[4 * 16], Ls[4 * 16];                              // per wave row max / exp-sum
+    __shared__ __attribute__((aligned(16))) float Os[4 * 16 * (HD + 4)];  // per wave unnormalised P.V
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    const int D = H * HD;
+    const KV* kc = cache_slot + (long)h * S * HD;
+    const KV* vc = kc + (long)H * S * HD;
+    const int q0 = blockIdx.y * 16;
+    const int L = pos0 + M;                                               // keys of this pass: 0 .. L-1
+    const int last_key = min(q0 + 15, M - 1) + pos0;                      // last key any row of the tile may see
+    // Q fragments: lane (fr, fk) holds dims 16 blk + 4 fk .. +3 of row q0 + fr (RoPE already applied in place)
+    float4 qa[4];
+    {
+        const int m = min(q0 + fr, M - 1);
+        const float* qrow = qkv + (long)m * 3 * D + h * HD + 4 * fk;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) qa[blk] = *reinterpret_cast<const float4*>(qrow + 16 * blk);
+    }
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sum[4] = {0.f, 0.f, 0.f, 0.f};
+    attn_f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (attn_f32x4){0.f, 0.f, 0.f, 0.f};
+    float* Pw = Ps + wave * 16 * LV;
+    for (int j0 = wave * KB; j0 <= last_key; j0 += 4 * KB) {
+        // K fragments of the block's four key tiles, then V: everything in flight before the first MFMA
+        float4 kf[4][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const long j = min(j0 + kt * 16 + fr, L - 1);
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) kf[kt][blk] = ld_kv_f4<KV>(kc + j * HD + 16 * blk + 4 * fk);
+        }
+        float vf[4][4][4];                                                // [key tile][dim tile][key 4 fk + c]
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long j = min(j0 + kt * 16 + 4 * fk + c, L - 1);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) vf[kt][dt][c] = from_kv(vc[j * HD + dt * 16 + fr]);
+            }
+        attn_f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = (attn_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[blk].x, kf[kt][blk].x, s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[blk].y, kf[kt][blk].y, s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[blk].z, kf[kt][blk].z, s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[blk].w, kf[kt][blk].w, s[kt], 0, 0, 0);
+            }
+        }
+        // accumulator element r of a lane: query row q0 + 4 fk + r (position pos0 + that), key j0 + 16 kt + fr
+        float bm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = s[kt][r] * 0.125f;
+                if (j0 + kt * 16 + fr > pos0 + q0 + 4 * fk + r) v = -INFINITY;
+                s[kt][r] = v;
+                bm[r] = fmaxf(bm[r], v);
+            }
+        float corr[4], bs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mn = fmaxf(mx[r], row16_max(bm[r]));
+            // a row may see none of this wave's keys so far (its diagonal lies below the block): keep exp() away from inf - inf
+            corr[r] = mn == -INFINITY ? 1.f : expf(mx[r] - mn);
+            mx[r] = mn;
+            bs[r] = 0.f;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = mx[r] == -INFINITY ? 0.f : expf(s[kt][r] - mx[r]);
+                bs[r] += e;
+                Pw[(4 * fk + r) * LV + kt * 16 + fr] = e;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = sum[r] * corr[r] + row16_sum(bs[r]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= corr[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const float4 pa = *reinterpret_cast<const float4*>(Pw + fr * LV + kt * 16 + 4 * fk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.x, vf[kt][dt][0], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.y, vf[kt][dt][1], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.z, vf[kt][dt][2], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.w, vf[kt][dt][3], o[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                  // Pw is rewritten by this wave's next block
+    }
+    // merge the four waves' partial softmaxes (wave 0 always holds block 0, whose key 0 every row sees: the merged max is finite)
+    if (fr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Ms[wave * 16 + 4 * fk + r] = mx[r]; Ls[wave * 16 + 4 * fk + r] = sum[r]; }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Os[(wave * 16 + 4 * fk + r) * (HD + 4) + dt * 16 + fr] = o[dt][r];
+    __syncthreads();
+    for (int idx = tid; idx < 16 * (HD / 4); idx += 256) {
+        const int row = idx >> 4, c4 = (idx & 15) * 4;
+        const int m = q0 + row;
+        if (m >= M) continue;
+        const float m0 = Ms[row], m1 = Ms[16 + row], m2 = Ms[32 + row], m3 = Ms[48 + row];
+        const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        const float w0 = expf(m0 - mm), w1 = m1 == -INFINITY ? 0.f : expf(m1 - mm), w2 = m2 == -INFINITY ? 0.f : expf(m2 - mm),
+                    w3 = m3 == -INFINITY ? 0.f : expf(m3 - mm);
+        const float inv = 1.f / (Ls[row] * w0 + Ls[16 + row] * w1 + Ls[32 + row] * w2 + Ls[48 + row] * w3);
+        const float4 a = *reinterpret_cast<const float4*>(Os + row * (HD + 4) + c4);
+        const float4 b = *reinterpret_cast<const float4*>(Os + (16 + row) * (HD + 4) + c4);
+        const float4 c = *reinterpret_cast<const float4*>(Os + (32 + row) * (HD + 4) + c4);
+        const float4 e = *reinterpret_cast<const float4*>(Os + (48 + row) * (HD + 4) + c4);
+        float4 r4;
+        r4.x = (a.x * w0 + b.x * w1 + c.x * w2 + e.x * w3) * inv;
+        r4.y = (a.y * w0 + b.y * w1 + c.y * w2 + e.y * w3) * inv;
+        r4.z = (a.z * w0 + b.z * w1 + c.z * w2 + e.z * w3) * inv;
+        r4.w = (a.w * w0 + b.w * w1 + c.w * w2 + e.w * w3) * inv;
+        *reinterpret_cast<float4*>(out + (long)m * D + h * HD + c4) = r4;
+    }
+}
+template <typename KV>
+int launch_ar_prefill_attention(const float* qkv, int M, int H, int hd, int slot0, int pos0, const KV* cache, long slot_stride, int S, float* out,
+                                hipStream_t st) {
+    SVA_CHECK(hd == 64 && M >= 1 && pos0 >= 0 && pos0 + M <= S, "ar_prefill_attention: head_dim 64, rows inside the cache");
+    hipLaunchKernelGGL((ar_prefill_attention_kernel<KV>), dim3(H, (M + 15) / 16), dim3(256), 0, st, qkv, M, H, pos0, cache + (long)slot0 * slot_stride, S, out);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+template int launch_ar_prefill_attention<float>(const float*, int, int, int, int, int, const float*, long, int, float*, hipStream_t);
+template int launch_ar_prefill_attention<__half>(const float*, int, int, int, int, int, const __half*, long, int, float*, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
 // Fast-AR attention for batched decode (cache of <= 8 codebook positions): RoPE on q / k, the KV-cache write and the
 // attention itself in one launch, one WAVE per (row, head), lane = head dimension.  Replaces rope_kvwrite + ar_attention
 // (two launches of 256-thread workgroups with LDS and barriers for at most 8 keys).

@@ -103,6 +103,7 @@ def load_library():
     lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
     lib.sva_test_gemm_choice.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32]
     lib.sva_set_sampler_edits.argtypes = [vp, vp, i32, C.c_float, vp, i32]
+    lib.sva_test_prefill_attention.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]
     lib.sva_test_gemm_f16w.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp]
     lib.sva_host_launch_cost.argtypes = [i32, i32, f32p]
     lib.sva_test_sampler.argtypes = [i32, i32, i32, i32, vp, vp, C.c_float, C.c_float, vp, i32, f32p]
@@ -118,7 +119,7 @@ EXPORTED_SYMBOLS = [
     "sva_dev_alloc", "sva_dev_free", "sva_dev_upload", "sva_dev_download", "sva_op_conv", "sva_op_affine", "sva_op_unary", "sva_op_colstats",
     "sva_op_cam_context", "sva_op_mul", "sva_op_add", "sva_op_conv2d", "sva_op_cf_to_rows", "sva_op_fbank_power", "sva_op_stft_mag", "sva_op_attention",
     "sva_op_geglu", "sva_op_l2norm",
-    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_set_sampler_edits", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
+    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_test_prefill_attention", "sva_set_sampler_edits", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
 ]
 
 
@@ -486,6 +487,21 @@ def test_gemm_f16w(A, W, bias=None, rms_w=None, res=None, swiglu=False, iters=0,
     mode = (1 if nw is not None else 0) | (2 if r is not None else 0) | (4 if swiglu else 0)
     _check(lib.sva_test_gemm_f16w(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(nw), _ptr(r), mode, _ptr(out), int(iters), _ptr(us)), "sva_test_gemm_f16w")
     return out, float(us[0])
+
+
+def test_prefill_attention(q, keys, vals, pos0=0, S=2048, half_kv=False, iters=0, device=0):
+    """q [M, H*64], keys / vals [pos0 + M, H*64] -> (per-row kernel output, MFMA flash kernel output, (us_ref, us_mfma))."""
+    lib = load_library()
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    keys = np.ascontiguousarray(keys, dtype=np.float32)
+    vals = np.ascontiguousarray(vals, dtype=np.float32)
+    M, D = q.shape
+    assert keys.shape == (pos0 + M, D) and vals.shape == keys.shape and D % 64 == 0
+    o1, o2 = np.empty((M, D), np.float32), np.empty((M, D), np.float32)
+    us = np.zeros(2, np.float32)
+    _check(lib.sva_test_prefill_attention(device, M, D // 64, int(pos0), int(S), _ptr(q), _ptr(keys), _ptr(vals), int(bool(half_kv)), _ptr(o1), _ptr(o2),
+                                          int(iters), _ptr(us)), "sva_test_prefill_attention")
+    return o1, o2, (float(us[0]), float(us[1]))
 
 
 def test_gemm_choice(A, W, choice, bias=None, device=0):

@@ -1354,6 +1354,31 @@ def test_fp16_ar_teacher_forced_logits_and_codes(eng_fp16, weights0, record_prop
     assert np.isfinite(np.concatenate(outs2)).all() and np.abs(np.concatenate(outs2)).max() > 0.01
 
 
+@pytest.mark.parametrize("M,pos0,half_kv", [(314, 0, False), (64, 0, False), (33, 7, False), (612, 0, False), (100, 300, False), (247, 0, True)])
+def test_prefill_attention_mfma_vs_fp64(M, pos0, half_kv):
+    """ar_prefill_attention_kernel (flash-style MFMA causal attention of prompt prefill / re-prefill / offline generate) against a
+    float64 softmax(QK^T / 8) V with the causal mask of consecutive positions, and against the per-row kernel it replaces."""
+    from streamvoiceanon_amd import engine as E
+    H = 12
+    rng = np.random.default_rng(M + pos0)
+    L = pos0 + M
+    q = rng.standard_normal((M, H * 64)).astype(np.float32) * 1.5
+    k = rng.standard_normal((L, H * 64)).astype(np.float32)
+    v = rng.standard_normal((L, H * 64)).astype(np.float32)
+    o_ref, o_mfma, us = E.test_prefill_attention(q, k, v, pos0=pos0, half_kv=half_kv, iters=20)
+    kk, vv = (k.astype(np.float16), v.astype(np.float16)) if half_kv else (k, v)
+    q3 = q.astype(np.float64).reshape(M, H, 64).transpose(1, 0, 2)
+    k3 = kk.astype(np.float64).reshape(L, H, 64).transpose(1, 0, 2)
+    v3 = vv.astype(np.float64).reshape(L, H, 64).transpose(1, 0, 2)
+    s = q3 @ k3.transpose(0, 2, 1) / 8.0
+    mask = np.arange(L)[None, :] > (pos0 + np.arange(M))[:, None]
+    s[:, mask] = -np.inf
+    p = np.exp(s - s.max(-1, keepdims=True))
+    want = ((p / p.sum(-1, keepdims=True)) @ v3).transpose(1, 0, 2).reshape(M, H * 64)
+    print("prefill attention", (M, pos0, half_kv), "max err mfma", np.abs(o_mfma - want).max(), "per-row", np.abs(o_ref - want).max(), "us (per-row, mfma)", us)
+    assert np.abs(o_mfma - want).max() < 2e-5 and np.abs(o_ref - want).max() < 2e-5
+
+
 @pytest.mark.parametrize("B", [8, 64])
 def test_fp16_batched_decode_teacher_forced_logits(eng_fp16, weights0, B, record_property):
     """The batched fp16 decode (more than 6 streams: gemm_f16w.hip, fp16 weights on the f16 pipes, fp16 KV) against the fp32 fixture:
