@@ -1478,8 +1478,8 @@ int ar_delay_fill(sva_batch* b) {
 // Which HiFiGAN levels run as the fused LDS-resident kernel (voc_fused.hip).  Measured on MI355X (profiles/r02_voc_fused.txt): the
 // C = 16 level takes 27-33 us fused against 7 launches / ~70 us at one stream and breaks even around 4-8 streams; from there on,
 // and for C = 32 at any batch, the tap-split GEMM formulation is faster (the fused kernel recomputes an 18 (k - 1)-row halo per
-// tile and runs one workgroup per CU), so the default fuses C = 16 for <= 4 streams.  SVA_VOC_FUSED_MASK (bit 0: C = 16,
-// bit 1: C = 32) / SVA_VOC_FUSED=0 override.
+// tile and runs one workgroup per CU), so the default fuses C = 16 for <= 4 streams.  SVA_DEBUG=voc_fused_mask=M (bit 0: C = 16,
+// bit 1: C = 32) / sva_debug_configure override it for the parity tests.
 bool voc_level_is_fused(const sva_batch* b, int C) {
     if (!b->voc_fused || !voc_level_supported(C)) return false;
     if (b->voc_fused_mask >= 0) return (b->voc_fused_mask & (C == 16 ? 1 : 2)) != 0;
