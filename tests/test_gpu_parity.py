@@ -424,6 +424,56 @@ def test_stream_configs_vs_oracle(eng, weights0, cfg):
     b.close()
 
 
+def test_stream_sampler_edits_switch_mid_stream_vs_oracle(eng, weights0):
+    """Sampler edits on a LIVE two-stream batch: installed after a few frames (persistent kernel -> multi-launch decode with the
+    edit kernels), changed, then removed again (back on the persistent kernel) -- content and audio codes of both slots follow an
+    oracle session whose DualAR gets the same previous_tokens / penalty / suppress list at the same frames."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    useed, R, n_chunks = 4100, 70, 16
+    ac, cc, style, timbre = synth_prompt(2290, R)
+    sess = O.StreamSession(weights0, torch.from_numpy(cc), torch.from_numpy(ac), torch.from_numpy(style), torch.from_numpy(timbre),
+                           noise_fn=lambda f: tuple(torch.from_numpy(a) for a in frame_noise(useed, f)), delay=2,
+                           encode_window_frames=128, decode_chunk_frames=1)
+    b = E.Batch(eng, n_streams=2, pipeline=False)
+    for s_ in range(2):
+        b.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=useed)
+    b.begin()
+    rng = np.random.default_rng(9)
+    src = synth_utterance(useed, 2048 * n_chunks)
+    frame, persistent = 0, []
+    for i in range(n_chunks):
+        if i == 5:       # strong penalty on recent picks + random tokens, suppress list on the token head
+            prev = np.concatenate([rng.integers(0, 8192, (1, 24)), np.concatenate([sess.pred_codes[:, -3:].numpy(), rng.integers(0, 1000, (8, 21))], 1)], 0)
+            sup = [int(x) for x in rng.integers(0, 8192, 100)]
+            b.set_sampler_edits(previous_tokens=prev, repetition_penalty=30.0, suppress_tokens=sup)
+            sess.ar.previous_tokens, sess.ar.repetition_penalty, sess.ar.suppress_tokens = torch.from_numpy(prev).long(), 30.0, sup
+        if i == 9:       # a different window, default penalty, no suppress list
+            prev = np.concatenate([rng.integers(0, 8192, (1, 6)), sess.pred_codes[:, -6:].numpy()], 0)
+            b.set_sampler_edits(previous_tokens=prev)
+            sess.ar.previous_tokens, sess.ar.repetition_penalty, sess.ar.suppress_tokens = torch.from_numpy(prev).long(), 1.5, None
+        if i == 12:
+            b.set_sampler_edits()
+            sess.ar.previous_tokens, sess.ar.suppress_tokens = None, None
+        persistent.append(b.uses_persistent_decode())
+        ch = src[i * 2048:(i + 1) * 2048]
+        ref = sess.process_one_chunk(torch.from_numpy(ch)[None])[0].numpy()
+        ns, nf = frame_noise(useed, frame)
+        nz = np.concatenate([ns, nf.reshape(-1)])[None, None].repeat(2, 0)
+        out = b.step(np.stack([ch, ch]), noise=nz)
+        if np.abs(ref).max() > 0:
+            got = b.tap("audio_codes", (2, 8, 1), np.int32)
+            np.testing.assert_array_equal(got[0], sess.pred_codes[:, -1:].numpy(), err_msg=f"chunk {i}")
+            np.testing.assert_array_equal(got[1], got[0])
+            frame += 1
+        assert np.abs(out[0] - ref).max() <= PCM_TOL, i
+    assert persistent[0] == persistent[-1] and (not persistent[0] or (not persistent[6] and not persistent[10]))
+    np.testing.assert_array_equal(b.pred_codes(1), sess.pred_codes.numpy())
+    b.close()
+
+
 def test_offline_generate_vs_reference_golden(eng, weights0):
     """Offline path: ARVCWrapper.generate + code2wav on the fixture captured from the reference's
     own generate(): identical codes under the shared noise (incl. the wait4end-driven last `delay` frames), PCM within tol."""
