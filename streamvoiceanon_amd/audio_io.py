@@ -13,12 +13,14 @@ with ``torchaudio.save`` (:378, 687).  Neither library is vendored in the refere
 
 Plain numpy; nothing here touches the GPU.
 """
+import functools
 import math
 import struct
 
 import numpy as np
 
 
+@functools.lru_cache(maxsize=16)
 def _sinc_resample_kernel(orig: int, new: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
     """torchaudio.functional.functional._get_sinc_resample_kernel (v2.4.0), sinc_interp_hann; orig/new already reduced
     by their gcd.  Returns (kernels [new, 2*width + orig] float64, width)."""
@@ -43,7 +45,7 @@ def resample(x, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, ro
         return x.copy()
     g = math.gcd(int(orig_freq), int(new_freq))
     orig, new = int(orig_freq) // g, int(new_freq) // g
-    kern, width = _sinc_resample_kernel(orig, new, lowpass_filter_width, rolloff)
+    kern, width = _sinc_resample_kernel(orig, new, lowpass_filter_width, rolloff)        # (cached per rate pair)
     kern = kern.astype(np.float32)
     lead = x.shape[:-1]
     w = x.reshape(-1, x.shape[-1])
@@ -54,7 +56,16 @@ def resample(x, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, ro
     # frames [rows, n_out, klen] as a strided view, then one matmul against the phase kernels
     s0, s1 = padded.strides
     frames = np.lib.stride_tricks.as_strided(padded, shape=(w.shape[0], n_out, klen), strides=(s0, s1 * orig, s1), writeable=False)
-    out = frames @ kern.T                                  # [rows, n_out, new]
+    # materialised once (a few hundred KB) and multiplied on ONE BLAS thread: the product is 75 MFLOP for a 5 s prompt -- 0.8 ms on one
+    # core, 15-100 ms when OpenBLAS fans it out over a many-core host (that was 40 % of calculate_prompt's latency)
+    fc, kt = np.ascontiguousarray(frames), np.ascontiguousarray(kern.T)
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                                    # plain numpy: same result, the library's own threading
+        out = fc @ kt
+    else:
+        with threadpool_limits(limits=1, user_api="blas"):
+            out = fc @ kt                                  # [rows, n_out, new]
     out = out.reshape(w.shape[0], n_out * new)
     target = int(math.ceil(new * length / orig))
     return out[:, :target].reshape(*lead, target).astype(np.float32)

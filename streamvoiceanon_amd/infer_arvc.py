@@ -145,6 +145,7 @@ class InferenceWrapper:
         self.engine = E.Engine(weights, device=device, ar_dtype=1 if fp16 else 0)
         self.use_graph = bool(compile_ar or compile_decoder or compile_encoder)   # the reference's --compile
         self.batch = None
+        self._win_batch = None            # (Wp, Batch) of the last whole-utterance encode: see _window_batch
         self._prompt = None
         # the module seams the reference's hot loop crosses (:506-508, 535-537, 175)
         from .arvc_wrapper import ARVCWrapper
@@ -219,6 +220,28 @@ class InferenceWrapper:
         return {k: v for k, v in out.items() if hasattr(v, "dtype") and v.dtype.is_floating_point}
 
     # ---- prompt ------------------------------------------------------------------------------------------
+    def _window_batch(self, Wp):
+        """The batch behind the whole-utterance seams (`firefly.encode`, `speech_tokenizer.encode`): creating one costs 3-4 ms of
+        allocations, which was half of either call, and calculate_prompt makes both on the same window length -- the last one is
+        kept (closed when another length is asked for, or by close())."""
+        if self._win_batch is not None and self._win_batch[0] == Wp:
+            return self._win_batch[1]
+        if self._win_batch is not None:
+            self._win_batch[1].close()
+            self._win_batch = None
+        b = E.Batch(self.engine, n_streams=1, encode_window_frames=Wp)
+        self._win_batch = (Wp, b)
+        return b
+
+    def close(self):
+        """Release the batches this wrapper holds (the engine and its weights stay with `self.engine`)."""
+        if self._win_batch is not None:
+            self._win_batch[1].close()
+            self._win_batch = None
+        if self.batch is not None:
+            self.batch.close()
+            self.batch = None
+
     def wav2target_fn(self, waves):
         """:168-171 firefly.encode of a whole prompt -> acoustic codes int32 [1, 8, R], R = len // 2048 (right-padded with
         zeros to a multiple of 4 frames for the stride-4 front-end; causal, so the first R columns are unaffected)."""
@@ -227,11 +250,7 @@ class InferenceWrapper:
         Wp = ((R + 3) // 4) * 4
         buf = np.zeros(Wp * self.SAMPLES_PER_FRAME, np.float32)
         buf[:R * self.SAMPLES_PER_FRAME] = wav[:R * self.SAMPLES_PER_FRAME]
-        b = E.Batch(self.engine, n_streams=1, encode_window_frames=Wp)
-        try:
-            return b.firefly_encode(buf[None])[:, :, :R]
-        finally:
-            b.close()
+        return self._window_batch(Wp).firefly_encode(buf[None])[:, :, :R]
 
     def calculate_prompt(self, ref_wav_tensors, alpha=1.0, spk_emb_collate_type="concat_mel", style_vectors=None,
                          timbre_latents=None):
@@ -355,12 +374,7 @@ class InferenceWrapper:
             raise ValueError(f"utterance of {S} frames: the tokenizer's transformer has rotary tables for 2048 positions (95 s)")
         buf = np.zeros(Wp * self.SAMPLES_PER_FRAME, np.float32)
         buf[:S * self.SAMPLES_PER_FRAME] = wav[:S * self.SAMPLES_PER_FRAME]
-        b = E.Batch(self.engine, n_streams=1, encode_window_frames=Wp)
-        try:
-            codes = b.encode_window(buf[None])[0, :S]
-        finally:
-            b.close()
-        return codes
+        return self._window_batch(Wp).encode_window(buf[None])[0, :S]
 
     def infer(self, src, ref_path=None, out_dir=None, output_path=None, delay=None, ref_crop_lengths=None, alpha=1.0,
               spk_emb_collate_type="concat_mel", save_result=True, prompt=None, noise_seed=0, **sampling_kwargs):
