@@ -99,10 +99,11 @@ __global__ __launch_bounds__(64 * KW) void f16w_gemm_kernel(const ConvGemm g, co
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             // Explicit, counted wait for slot d's loads (the other slot's LPS loads, issued later, may stay in flight; vector memory
-            // returns in order).  hipcc's own waitcnt placement was WRONG for the <2, 2, 4, RMS> instantiation: the row sums of
-            // squares read A registers whose loads had not landed (1-4 % low, different from launch to launch; correct under
-            // -amdgpu-waitcnt-forcezero) -- found by the M = 24 / 32 SwiGLU unit tests.  The memory clobber pins the loads on
-            // their side of the wait.
+            // returns in order); the memory clobber pins the loads on their side of the wait.  History: the <2, 2, 4, RMS> instantiation
+            // computed row sums of squares 1-4 % low, differently per launch (found by the M = 24 / 32 SwiGLU unit tests); with these
+            // waits that build was clean, but an -amdgpu-waitcnt-forcezero build then failed the same way in <4, 2, 4, RMS>.  What
+            // both have in common is hipcc re-loading parts of an A fragment for one of its two uses; the opaque copy below gives
+            // both uses one set of registers.  tools/f16w_stress.py must pass under both builds (tools/waitcnt_audit.sh).
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * (D - 1)) : "memory");
             const int kb = wave + (it + d) * KW;
             const float keep = kb < nk ? 1.f : 0.f;
@@ -112,6 +113,9 @@ __global__ __launch_bounds__(64 * KW) void f16w_gemm_kernel(const ConvGemm g, co
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 float4 a0 = av[d][i][0], a1 = av[d][i][1];
+                // one physical copy of the landed values feeds both the row norms and the split (hipcc otherwise re-loads parts of
+                // the fragment for one of the two uses)
+                asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w));
                 a0.x *= keep; a0.y *= keep; a0.z *= keep; a0.w *= keep;
                 a1.x *= keep; a1.y *= keep; a1.z *= keep; a1.w *= keep;
                 if constexpr (RMS) {
