@@ -102,8 +102,9 @@ __global__ __launch_bounds__(64 * KW) void f16w_gemm_kernel(const ConvGemm g, co
             // returns in order); the memory clobber pins the loads on their side of the wait.  History: the <2, 2, 4, RMS> instantiation
             // computed row sums of squares 1-4 % low, differently per launch (found by the M = 24 / 32 SwiGLU unit tests); with these
             // waits that build was clean, but an -amdgpu-waitcnt-forcezero build then failed the same way in <4, 2, 4, RMS>.  What
-            // both have in common is hipcc re-loading parts of an A fragment for one of its two uses; the opaque copy below gives
-            // both uses one set of registers.  tools/f16w_stress.py must pass under both builds (tools/waitcnt_audit.sh).
+            // The defect follows the packed-fp32 code hipcc makes of the sum-of-squares tree (see below), not the waits; the
+            // opaque copy below additionally gives both uses of a fragment one set of registers.  tools/f16w_stress.py must pass
+            // under both builds (tools/waitcnt_audit.sh).
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * (D - 1)) : "memory");
             const int kb = wave + (it + d) * KW;
             const float keep = kb < nk ? 1.f : 0.f;
@@ -119,7 +120,12 @@ __global__ __launch_bounds__(64 * KW) void f16w_gemm_kernel(const ConvGemm g, co
                 a0.x *= keep; a0.y *= keep; a0.z *= keep; a0.w *= keep;
                 a1.x *= keep; a1.y *= keep; a1.z *= keep; a1.w *= keep;
                 if constexpr (RMS) {
-                    ssq[i] += (a0.x * a0.x + a0.y * a0.y) + (a0.z * a0.z + a0.w * a0.w) + (a1.x * a1.x + a1.y * a1.y) + (a1.z * a1.z + a1.w * a1.w);
+                    // a plain FMA chain: the pairwise tree this replaced is what hipcc turned into the v_pk_mul / v_pk_fma / op_sel
+                    // sequence that mis-summed (same source, forcezero build: tree 8 of 12 cases wrong, chain 0 of 12)
+                    float t_ = ssq[i];
+                    t_ = __builtin_fmaf(a0.x, a0.x, t_); t_ = __builtin_fmaf(a0.y, a0.y, t_); t_ = __builtin_fmaf(a0.z, a0.z, t_); t_ = __builtin_fmaf(a0.w, a0.w, t_);
+                    t_ = __builtin_fmaf(a1.x, a1.x, t_); t_ = __builtin_fmaf(a1.y, a1.y, t_); t_ = __builtin_fmaf(a1.z, a1.z, t_); t_ = __builtin_fmaf(a1.w, a1.w, t_);
+                    ssq[i] = t_;
                     a0.x *= nv[d][0].x; a0.y *= nv[d][0].y; a0.z *= nv[d][0].z; a0.w *= nv[d][0].w;
                     a1.x *= nv[d][1].x; a1.y *= nv[d][1].y; a1.z *= nv[d][1].z; a1.w *= nv[d][1].w;
                 }
