@@ -84,6 +84,8 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());
             else if (k == "tune_table") o.tune_table = atoi(v.c_str());
             else if (k == "f16_weights") o.f16_weights = atoi(v.c_str());
+            else if (k == "cu_partition") o.cu_partition = atoi(v.c_str());
+            else if (k == "cu_ar") o.cu_ar = atoi(v.c_str());
             else if (k == "tune_dump") o.tune_dump = v;
             else fprintf(stderr, "[sva] debug option '%s' unknown, ignored\n", k.c_str());
         }
@@ -1661,25 +1663,30 @@ std::map<int, StreamSet> g_streams;          // per device, process lifetime
 // `partitioned`: the AR stream and the encoder / vocoder streams get disjoint compute-unit masks (hipExtStreamCreateWithCUMask;
 // mask bit i -> XCD i % 8, so every range is spread over all XCDs).  With few streams the three stage chains are strings of
 // short dependent kernels that each leave most of the chip idle, yet when they share CUs the AR chain's kernels queue behind
-// the encoder's and vocoder's workgroups.  The gain shrinks with the batch and turns into a loss from 16 streams on, where
-// the GEMMs want the whole chip.  SVA_CU_PART="alo,an,elo,en,vlo,vn" overrides the ranges, SVA_CU_PART=off disables.
-int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSet* out) {
+// the encoder's and vocoder's workgroups.  The gain shrinks with the batch (and wants a smaller AR share as it grows) and turns
+// into a loss beyond 32 streams, where the GEMMs want the whole chip.  SVA_DEBUG=cu_partition=0|1[,cu_ar=N] overrides for A/B runs.
+int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSet* out, int ar_cus = 96) {
     std::lock_guard<std::mutex> lk(g_streams_mu);
     // variant 1 (one stream): AR 96 CUs | encoder 128 | vocoder 32 (12 / 16 / 4 per XCD) -- 2.11 -> 1.75 ms per step, 1.60 with the
     // encoder split; 96/136/24 measures the same but leaves the vocoder no slack (96/138/22 and 92/140/24 lose the whole gain:
-    // the AR GEMV grids are multiples of 96 workgroups, the vocoder is throughput-bound on its share).  variant 2 (2..8 streams): AR 96 | encoder
-    // and vocoder share the other 160 (+23 % at 2 and 4 streams, +11 % at 8; the three-way split is worse there).
-    bool partitioned = n_streams_if_pipelined >= 1 && n_streams_if_pipelined <= 8;
-    int variant = !partitioned ? 0 : n_streams_if_pipelined == 1 ? 1 : 2;
+    // the AR GEMV grids are multiples of 96 workgroups, the vocoder is throughput-bound on its share).  Two streams and more: AR
+    // `ar_cus` CUs | encoder and vocoder share the rest (the three-way split is worse there); the caller picks ar_cus by batch size.
+    bool partitioned = n_streams_if_pipelined >= 1;
+    int variant = !partitioned ? 0 : n_streams_if_pipelined == 1 ? 1 : ar_cus;      // (a stream set per split, created on first use)
     int part[6] = {0, 96, 96, 160, 96, 160};
     if (variant == 1) { part[3] = 128; part[4] = 224; part[5] = 32; }
+    if (variant > 1) {
+        const int n = std::min(std::max(ar_cus & ~7, 32), 224);
+        part[1] = n; part[2] = part[4] = n; part[3] = part[5] = 256 - n;
+        variant = n;
+    }
     if (partitioned) {
         hipDeviceProp_t prop;
         SVA_HIP(hipGetDeviceProperties(&prop, device));
         if (prop.multiProcessorCount != 256) partitioned = false;         // the ranges are sized for the 256 CUs of an MI355X
     }
     if (!partitioned) variant = 0;
-    StreamSet& s = g_streams[device * 4 + variant];
+    StreamSet& s = g_streams[device * 256 + variant];
     if (!s.main) {
         auto make = [&](hipStream_t* st, int lo, int n) -> int {
             if (!partitioned || n <= 0 || n >= 256) { SVA_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking)); return 0; }
@@ -1743,9 +1750,22 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // mostly wait on hand-offs, so the AR chain no longer queues behind the other stages' workgroups, and the encoder /
         // vocoder GEMMs want the whole chip (measured 1.41 ms per step with the 96 | 128 | 32 split, 1.13 without)
         const bool will_mega = B <= AR_PERSISTENT_MAX_STREAMS && e->mega_ok && debug_options().ar_persistent != 0;
-        const int part_streams = b->p.pipeline ? (will_mega ? 0 : B) : 0;
-        SVA_TRY(get_streams(e->device, !b->voc_grouped, part_streams, &ss));
-        b->ar_partitioned = part_streams >= 1 && part_streams <= 8;
+        // multi-launch decode (more than 6 streams): its ~265 small launches per frame are a latency chain that the encoder's and
+        // vocoder's chip-filling GEMMs would otherwise queue in front of -- disjoint CU masks (AR n | encoder + vocoder 256 - n)
+        // win up to 32 streams, with a smaller AR share as the batch grows (tools/part_ab.sh, part_ab2.sh;
+        // profiles/r03_partition_ab.txt -- fp32 AR: 8 streams 1873 unpartitioned / 2206 with 96 CUs / 2497 with 128; 12: 2683 / 3422
+        // with 96; 24: 3960 / 4312 with 64; 32: 5008 / 5322 with 64; 48: 5725 / 5628.  fp16 AR: 12: 3053 / 3989 with 64; 16: 3682 /
+        // 4234; 24: 4415 / 4884; 32: 5337 / 5421).  Round 2 partitioned 7-8 streams only, always 96 | 160.
+        int ar_cus = 96, part_streams = 0;
+        if (b->p.pipeline && !will_mega && B <= 32) {
+            part_streams = B;
+            if (B >= 2) ar_cus = c.ar_dtype == 1 ? (B <= 8 ? 96 : 64) : (B <= 8 ? 128 : B <= 20 ? 96 : 64);
+        }
+        if (debug_options().cu_partition == 0) part_streams = 0;
+        else if (debug_options().cu_partition == 1 && b->p.pipeline) { part_streams = B; if (debug_options().cu_ar > 0) ar_cus = debug_options().cu_ar; }
+        SVA_TRY(get_streams(e->device, !b->voc_grouped, part_streams, &ss, ar_cus));
+        b->ar_cus = part_streams >= 1 ? ar_cus : 0;
+        b->ar_partitioned = part_streams >= 1;
         b->stream = b->main_stream = ss.main;
         b->aux[0] = ss.aux0;
         b->aux[1] = b->voc_grouped ? nullptr : ss.aux1;
@@ -1936,7 +1956,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         int per_cu = 0, cus = 0;
         SVA_TRY(ar_decode_occupancy(c.ar_dtype == 1, b->kv_half, &per_cu));
         SVA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-        const int avail = b->ar_partitioned ? std::min(cus, 96) : cus;       // the AR stream's CU mask (get_streams) is CUs 0..95
+        const int avail = b->ar_partitioned ? std::min(cus, b->ar_cus > 0 ? b->ar_cus : 96) : cus;       // the AR stream's CU mask (get_streams) is CUs 0 .. ar_cus - 1
         const int wgs = AR_WGS;
         b->mega_per_launch = (avail >= 2 * wgs && !b->ar_partitioned) ? 2 : 1;
         if (per_cu < 1 || avail < wgs) b->use_mega = false;                // fall back to the multi-launch decode
