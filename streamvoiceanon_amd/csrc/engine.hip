@@ -93,7 +93,8 @@ static void parse_debug(DebugOptions& o, const char* env) {
     }
 }
 static DebugOptions& debug_options_mut() {
-    static DebugOptions opt = [] { DebugOptions o; parse_debug(o, getenv("SVA_DEBUG")); return o; }();
+    // never destroyed: the tuning dump (an atexit handler registered before this object exists) reads it during process teardown
+    static DebugOptions& opt = *new DebugOptions([] { DebugOptions o; parse_debug(o, getenv("SVA_DEBUG")); return o; }());
     return opt;
 }
 const DebugOptions& debug_options() { return debug_options_mut(); }
