@@ -228,6 +228,7 @@ struct sva_batch {
     int* d_edit_suppress = nullptr;
     int* d_edit_params = nullptr;          // [1 + num_codebooks][4]
     bool edits_on = false, edits_skip = false;
+    int mega_max = 6;                      // most streams the persistent decode kernel serves for this engine's AR dtype
     int ar_cus = 0;                        // CUs of the AR stream's mask when the pipelined mode is partitioned (0: whole chip)
 
     // ---- encoder workspace ----

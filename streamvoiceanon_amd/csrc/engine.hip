@@ -1750,7 +1750,11 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // one stream with the persistent AR decode kernel: no CU partition -- that kernel is a single launch of 96 workgroups that
         // mostly wait on hand-offs, so the AR chain no longer queues behind the other stages' workgroups, and the encoder /
         // vocoder GEMMs want the whole chip (measured 1.41 ms per step with the 96 | 128 | 32 split, 1.13 without)
-        const bool will_mega = B <= AR_PERSISTENT_MAX_STREAMS && e->mega_ok && debug_options().ar_persistent != 0;
+        // (fp16 AR: the batched decode on the f16 pipes overtakes the persistent kernel at 5 streams -- 2191 vs 1645 frames/s, 6: 2562 vs
+        // 2064, 4: 1420 vs 1919; fp32: the persistent kernel wins up to 6 -- tools/part_ab3.sh)
+        const int mega_max = c.ar_dtype == 1 ? std::min(4, AR_PERSISTENT_MAX_STREAMS) : AR_PERSISTENT_MAX_STREAMS;
+        const bool will_mega = B <= mega_max && e->mega_ok && debug_options().ar_persistent != 0;
+        b->mega_max = mega_max;
         // multi-launch decode (more than 6 streams): its ~265 small launches per frame are a latency chain that the encoder's and
         // vocoder's chip-filling GEMMs would otherwise queue in front of -- disjoint CU masks (AR n | encoder + vocoder 256 - n)
         // win up to 32 streams, with a smaller AR share as the batch grows (tools/part_ab.sh, part_ab2.sh;
@@ -1949,7 +1953,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     // persistent batch-1 decode kernel (ar_decode.hip): granule buffers, tag epoch, timeout word, fast K/V scratch
     // up to mega_max_b streams decode in ONE launch of it (96 workgroups per stream, each stream's group talks only to itself); the
     // multi-launch chain of the batched path (~200 dependent launches, 2.4-3.3 ms per frame at 2-8 streams) takes over above that
-    b->use_mega = B <= AR_PERSISTENT_MAX_STREAMS && e->mega_ok && b->fused_decode && debug_options().ar_persistent != 0;
+    b->use_mega = B <= b->mega_max && e->mega_ok && b->fused_decode && debug_options().ar_persistent != 0;
     if (b->use_mega) {
         // every workgroup of a persistent launch must be resident at once: check the launch geometry against the occupancy query and
         // the CUs the AR stream may use, never assume it.  One workgroup per CU is what the kernel is sized for (256 registers, 4 waves);
