@@ -1762,7 +1762,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // with 96; 24: 3960 / 4312 with 64; 32: 5008 / 5322 with 64; 48: 5725 / 5628.  fp16 AR: 12: 3053 / 3989 with 64; 16: 3682 /
         // 4234; 24: 4415 / 4884; 32: 5337 / 5421).  Round 2 partitioned 7-8 streams only, always 96 | 160.
         int ar_cus = 96, part_streams = 0;
-        if (b->p.pipeline && !will_mega && B <= 32) {
+        if (b->p.pipeline && !will_mega && B <= (p->chunk_frames > 1 ? 16 : 32)) {      // (chunk 4: 16 streams +11 %, 32 streams -15 %: tools/part_ab4.sh)
             part_streams = B;
             if (B >= 2) ar_cus = c.ar_dtype == 1 ? (B <= 8 ? 96 : 64) : (B <= 8 ? 128 : B <= 20 ? 96 : 64);
         }
