@@ -1143,6 +1143,39 @@ def test_stage_pipelining_equals_serial(eng):
     np.testing.assert_array_equal(serial, piped)
 
 
+@pytest.mark.parametrize("B,fp16", [(8, False), (12, False), (24, False), (5, True), (12, True)])
+def test_partitioned_pipelining_equals_serial(eng, eng_fp16, B, fp16):
+    """The multi-launch decode's pipelined mode runs on disjoint CU masks sized by the batch (AR stream 128 / 96 / 64 CUs, fp16: 96 / 64;
+    engine.hip batch_create_impl): same samples and codes as serial stepping of the same batch, bit for bit, for every split in use."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    e, n_chunks = (eng_fp16 if fp16 else eng), 10
+    audio = torch.from_numpy(np.stack([synth_utterance(7700 + i % 4, 2048 * n_chunks) for i in range(B)])).cuda()
+    chunks = audio.reshape(B, n_chunks, 2048).transpose(0, 1).contiguous()
+
+    def run(pipeline):
+        b = E.Batch(e, n_streams=B, pipeline=pipeline)
+        assert not b.uses_persistent_decode()
+        for i in range(B):
+            ac, cc, style, timbre = synth_prompt(2950 + i % 3, 40 + 10 * (i % 3))
+            b.prefill_prompt(i, cc, ac, style, timbre, noise_seed=600 + i)
+        b.begin()
+        out = torch.zeros(n_chunks, B, 2048, device="cuda")
+        for k in range(n_chunks):
+            b.step_device_on(chunks[k].data_ptr(), out[k].data_ptr(), join_output=False)
+        b.join_stream()
+        res, codes = out.cpu().numpy(), np.stack([b.pred_codes(i) for i in range(B)])
+        b.close()
+        return res, codes
+
+    serial, codes_s = run(False)
+    piped, codes_p = run(True)
+    assert np.abs(serial[3:]).max() > 1e-3
+    np.testing.assert_array_equal(codes_s, codes_p)
+    np.testing.assert_array_equal(serial, piped)
+
+
 def test_stream_infer_one_call_equals_chunk_by_chunk(weights0):
     """InferenceWrapper.stream_infer runs its chunk loop as one pipelined engine call (sva_stream_chunks); feeding the same
     padded source chunk by chunk through process_one_chunk (synchronous host buffers) gives the same samples."""
