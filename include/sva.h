@@ -224,7 +224,7 @@ int sva_op_attention(sva_engine* e, const float* q, const float* kv, int Lq, int
 int sva_op_geglu(sva_engine* e, const float* h, long ldh, int T, int Dh, float* out, long ldo);
 int sva_op_l2norm(sva_engine* e, const float* x, int T, int C, const float* gamma, float scale, float* y);
 
-/* 1 if the batch decodes with the persistent kernel (ar_decode.hip): <= 6 streams, reference layer sizes, and the residency check at
+/* 1 if the batch decodes with the persistent kernel (ar_decode.hip): <= 6 streams (<= 4 with ar_dtype = 1, whose batched decode on the f16 pipes is faster from 5), reference layer sizes, and the residency check at
  * sva_batch_create passed (all its workgroups fit the AR stream's CUs at once); 0 = the multi-launch decode.  A persistent launch whose
  * workgroups are NOT all resident (GPU shared with another process) times out after ~50 ms: the next sva_sync / sva_step returns an
  * error, every later step fails, and sva_prefill_prompt + sva_streams_begin restart the streams on the multi-launch decode. */

@@ -9,7 +9,7 @@ namespace sva {
 constexpr int AR_WGS = 96;            // workgroups of the persistent kernel (= CUs of the AR stream's partition)
 constexpr int AR_WAVES = AR_WGS * 4;
 constexpr int AR_SLOW_LAYERS = 12, AR_FAST_LAYERS = 4;
-constexpr int AR_PERSISTENT_MAX_STREAMS = 6;      // batches up to this size decode with the persistent kernel (two streams per launch); above it
+constexpr int AR_PERSISTENT_MAX_STREAMS = 6;      // batches up to this size (fp16 AR: up to 4, engine.hip) decode with the persistent kernel (two streams per launch); above it
                                                   // the batched MFMA chain is faster (profiles/r02_streams_curve.txt)
 // weights of one layer in the decode kernel's layout: row-major [N][K] (fp32 or fp16 by the kernel's template argument);
 // w13: wave w of the kernel owns rows [12w, 12w + 12) = w1 rows 6w..6w+5 followed by w3 rows 6w..6w+5
