@@ -86,6 +86,7 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "f16_weights") o.f16_weights = atoi(v.c_str());
             else if (k == "cu_partition") o.cu_partition = atoi(v.c_str());
             else if (k == "cu_ar") o.cu_ar = atoi(v.c_str());
+            else if (k == "pipe_skip") o.pipe_skip = atoi(v.c_str());
             else if (k == "tune_dump") o.tune_dump = v;
             else fprintf(stderr, "[sva] debug option '%s' unknown, ignored\n", k.c_str());
         }
@@ -2385,6 +2386,10 @@ int steady_launches(sva_batch* b, bool timing_events) {
 // use; falls back to eager launches for good if the runtime cannot capture.
 template <class F>
 int stage_graph(sva_batch* b, hipGraphExec_t* slot, hipStream_t st, F&& body) {
+    if (const int skip = debug_options().pipe_skip) {      // timing diagnostic only (tools/pipe_skip.sh): the chain's work is left out, its events stay
+        const int bit = (slot == &b->gEm[0] || slot == &b->gEm[1]) ? 1 : slot == &b->gV ? 8 : 2;
+        if (skip & bit) return 0;
+    }
     if (!b->stage_graphs) return body();
     if (!*slot) {
         hipGraph_t graph = nullptr;
@@ -2583,7 +2588,8 @@ int steady_pipelined(sva_batch* b) {
     b->stream = sa;
     SVA_TRY(mark(5, sa));
     int rc = 0;
-    if (b->pipe_graph_mode) {
+    if (debug_options().pipe_skip & 4) {
+    } else if (b->pipe_graph_mode) {
         // The AR stage is ~210 launches on ONE stream whose arguments never change (positions, frame counters, noise keys
         // and teacher-forcing flags live in device memory; the code buffer alternates, hence one graph per parity): replaying
         // it as a hipGraph takes those launches off the enqueueing thread, whose launch rate is otherwise as tight a bound

@@ -22,9 +22,11 @@ void set_error(const std::string& msg);
 //                    (tools/make_tune_table.py)
 //   cu_partition=0|1  force the disjoint CU masks of the pipelined mode (AR 96 | encoder + vocoder 160) off / on (default: by stream count)
 //   cu_ar=N           with cu_partition=1: CUs of the AR stream's mask (default: by batch size; A/B only: tools/part_ab2.sh)
+//   pipe_skip=mask    TIMING DIAGNOSTIC (results are garbage): leave out a chain of the pipelined step -- 1 encoder front, 2 side chain
+//                     (downsampler + transformer + BSQ), 4 AR, 8 vocoder (tools/pipe_skip.sh)
 //   f16_weights=0     ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B)
 struct DebugOptions {
-    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0;
+    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0;
     std::string tune_dump;
 };
 const DebugOptions& debug_options();
