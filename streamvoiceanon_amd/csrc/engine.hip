@@ -2387,6 +2387,8 @@ int steady_launches(sva_batch* b, bool timing_events) {
 template <class F>
 int stage_graph(sva_batch* b, hipGraphExec_t* slot, hipStream_t st, F&& body) {
     if (const int skip = debug_options().pipe_skip) {      // timing diagnostic only (tools/pipe_skip.sh): the chain's work is left out, its events stay
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "[sva] SVA_DEBUG=pipe_skip=%d: chains of the pipelined step are LEFT OUT -- timing diagnostic, outputs are garbage\n", skip); }
         const int bit = (slot == &b->gEm[0] || slot == &b->gEm[1]) ? 1 : slot == &b->gV ? 8 : 2;
         if (skip & bit) return 0;
     }
