@@ -224,10 +224,12 @@ int sva_op_attention(sva_engine* e, const float* q, const float* kv, int Lq, int
 int sva_op_geglu(sva_engine* e, const float* h, long ldh, int T, int Dh, float* out, long ldo);
 int sva_op_l2norm(sva_engine* e, const float* x, int T, int C, const float* gamma, float scale, float* y);
 
-/* 1 if the batch decodes with the persistent kernel (ar_decode.hip): <= 6 streams (<= 4 with ar_dtype = 1, whose batched decode on the f16 pipes is faster from 5), reference layer sizes, and the residency check at
- * sva_batch_create passed (all its workgroups fit the AR stream's CUs at once); 0 = the multi-launch decode.  A persistent launch whose
- * workgroups are NOT all resident (GPU shared with another process) times out after ~50 ms: the next sva_sync / sva_step returns an
- * error, every later step fails, and sva_prefill_prompt + sva_streams_begin restart the streams on the multi-launch decode. */
+/* Which decode the batch runs per frame: 1 = the persistent kernel of ar_decode.hip (two streams per launch: <= 6 streams, <= 4 with
+ * ar_dtype = 1), 2 = the batched persistent kernel of ar_batch.hip (every stream of the batch in one launch: the larger batches), 0 = the
+ * multi-launch decode (sampler edits set, layer sizes other than the reference's, or the residency check at sva_batch_create failed:
+ * all workgroups of a persistent launch must fit the AR stream's CUs at once).  A persistent launch whose workgroups are NOT all
+ * resident (GPU shared with another process) times out after ~50 ms: the next sva_sync / sva_step returns an error, every later step
+ * fails, and sva_prefill_prompt + sva_streams_begin restart the streams on the multi-launch decode. */
 int sva_batch_uses_persistent_decode(sva_batch* b);
 /* debug options of the process ("key=value,key=value"; the same keys as the SVA_DEBUG environment variable, the engine's only
  * environment input -- listed in csrc/sva_common.h: ar_timing, pipe_trace, concurrency, ar_persistent, voc_fused_mask, autotune,

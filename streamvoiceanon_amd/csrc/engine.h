@@ -3,6 +3,7 @@
 #include "../../include/sva.h"
 #include "kernels.h"
 #include "ar_decode.h"
+#include "ar_batch.h"
 
 #include <array>
 #include <map>
@@ -213,6 +214,13 @@ struct sva_batch {
     int* d_ar_fail = nullptr;              // [1] timeout code of the persistent kernel (0 = healthy)
     long long* d_ar_dbg = nullptr;         // SVA_AR_TIMING=1: phase timestamps of workgroup 0
     float* kv_fast_mega = nullptr;         // [4][8][2][768] fast-AR K/V scratch of the persistent kernel
+    // batched persistent decode kernel (ar_batch.hip): every stream of the batch in ONE launch per frame
+    bool use_abatch = false;
+    int abatch_G = 0;                      // workgroups of its launch (all co-resident: checked at batch creation)
+    unsigned* d_ab_flags = nullptr;        // hand-off flags, arrays at ab_offs (ar_batch_flag_words)
+    size_t ab_offs[11] = {};
+    unsigned* d_ab_epoch = nullptr;        // [2] running phase counter | exit counter
+    float *ab_qkvf = nullptr, *ab_attf = nullptr, *ab_gf = nullptr, *ab_kvf = nullptr;      // fast-AR activations [B][2304 | 768 | 2304], K/V [4][B][8][1536]
     bool kv_half = false;                  // slow KV cache holds __half (ar_dtype = 1)
     sva::DevPool allocs;
 

@@ -79,6 +79,8 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "pipe_trace") o.pipe_trace = atoi(v.c_str());
             else if (k == "concurrency") o.concurrency = atoi(v.c_str());
             else if (k == "ar_persistent") o.ar_persistent = atoi(v.c_str());
+            else if (k == "ar_batch") o.ar_batch = atoi(v.c_str());
+            else if (k == "ar_batch_wgs") o.ar_batch_wgs = atoi(v.c_str());
             else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());
@@ -111,6 +113,7 @@ static int recover_ar_failure(sva_batch* b) {
     SVA_HIP(hipDeviceSynchronize());
     SVA_HIP(hipMemset(b->d_ar_fail, 0, sizeof(int)));
     b->use_mega = false;
+    b->use_abatch = false;
     for (auto& ge : b->pipe_graph_a) if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
     if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
     std::fill(b->prefilled.begin(), b->prefilled.end(), 0);
@@ -1269,6 +1272,7 @@ namespace {
 int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const long long* codes, int codes_ld, int code_off, int last_pos_inc);
 
 int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_off);
+int ar_decode_frame_batch(sva_batch* b, int ci);
 
 int ar_decode_frame(sva_batch* b, int ci) {
     sva_engine* e = b->e;
@@ -1290,9 +1294,52 @@ int ar_decode_frame(sva_batch* b, int ci) {
     }
     hipLaunchKernelGGL(ar_prepare_step_kernel, dim3(B), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, b->d_codes, b->T2,
                        code_off, b->d_last_pos, D, b->ax, b->d_slot, b->d_pos, b->d_step_content, chunk, ci);
+    if (b->use_abatch && !b->edits_on) return ar_decode_frame_batch(b, ci);          // (sampler edits run on the multi-launch decode, as above)
     SVA_TRY(ar_layers_pass(b, e->ar_layers, 2 * B, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
                            b->kv_slow_slot, c.max_seq_len, b->ax));
     return ar_frame_tail(b, ci, (long)2 * D, (long)D, b->d_codes, b->T2, code_off, 2);
+}
+
+// one decoded frame of EVERY stream of the batch in one launch of the batched persistent kernel (ar_batch.hip); the frame's input
+// tokens are already in b->ax (ar_prepare_step_kernel)
+int ar_decode_frame_batch(sva_batch* b, int ci) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const bool half = c.ar_dtype == 1;
+    ArBatchArgs a;
+    memset(&a, 0, sizeof(a));
+    auto wsel = [&](const Lin& l) -> const void* { return half ? l.Wh : (const void*)l.W; };
+    for (int l = 0; l < AR_SLOW_LAYERS; ++l) {
+        const TrLayer& L = e->ar_layers[l];
+        a.slow[l] = ArLayerW{wsel(L.wqkv), wsel(L.wo), wsel(L.w13), wsel(L.w2), L.attn_norm, L.ffn_norm};
+    }
+    for (int l = 0; l < AR_FAST_LAYERS; ++l) {
+        const TrLayer& L = e->ar_fast_layers[l];
+        a.fast[l] = ArLayerW{wsel(L.wqkv), wsel(L.wo), wsel(L.w13), wsel(L.w2), L.attn_norm, L.ffn_norm};
+    }
+    a.out_w = wsel(e->ar_output); a.out_norm = e->ar_norm; a.fast_out_w = wsel(e->ar_fast_output); a.fast_norm = e->ar_fast_norm;
+    a.codebook_emb = e->codebook_emb; a.fast_emb = e->fast_emb; a.rope_slow = e->rope_ar; a.rope_fast = e->rope_fast;
+    a.B = b->B; a.G = b->abatch_G;
+    a.cached_audio_emb = b->cached_audio_emb; a.last_pos = b->d_last_pos; a.nframes = b->d_nframes; a.seed = b->d_seed;
+    a.kv_slow = b->kv_slow; a.kv_layer_stride = b->kv_slow_layer; a.kv_slot_stride = b->kv_slow_slot; a.S = c.max_seq_len;
+    a.xs = b->ax; a.qkv = b->aqkv; a.att = b->aatt; a.g = b->ag;
+    a.xf = b->xf; a.qkvf = b->ab_qkvf; a.attf = b->ab_attf; a.gf = b->ab_gf; a.kvf = b->ab_kvf;
+    unsigned* F = b->d_ab_flags;
+    const size_t* o = b->ab_offs;
+    a.f_x = F + o[0]; a.f_qkv = F + o[1]; a.f_g = F + o[2]; a.f_att = F + o[3]; a.f_xf = F + o[4]; a.f_qkvf = F + o[5]; a.f_gf = F + o[6];
+    a.f_attf = F + o[7]; a.f_log = F + o[8]; a.f_row = F + o[9]; a.f_sem = F + o[10];
+    a.epoch = b->d_ab_epoch; a.done = b->d_ab_epoch + 1; a.fail = b->d_ar_fail; a.dbg = b->d_ar_dbg;
+    a.slow_logits = b->slow_logits; a.fast_logits = b->fast_logits; a.hidden = b->hidden;
+    a.sem = b->d_sem; a.tok_raw = b->d_tok_raw; a.tok = b->d_tok; a.step_audio = b->d_step_audio; a.pred_hist = b->d_pred_hist;
+    a.hist_cap = b->hist_cap; a.chunk = b->p.chunk_frames; a.ci = ci;
+    const int nstride = c.ar_vocab + c.num_codebooks * c.codebook_size;
+    a.noise = b->noise_on_device ? nullptr : b->d_noise + (long)ci * nstride;
+    a.noise_ld = (long)b->p.chunk_frames * nstride;
+    a.forced = b->d_forced; a.use_forced = b->d_use_forced;
+    const float tclamp = b->p.temperature > 1e-5f ? b->p.temperature : 1e-5f;
+    a.inv_temp = 1.0f / tclamp; a.top_p = b->p.top_p; a.skip_semantic = b->p.skip_semantic;
+    a.vocab = c.ar_vocab; a.codebook_size = c.codebook_size;
+    return launch_ar_batch(a, half ? 1 : 0, b->stream);
 }
 
 // one decoded frame of a one-stream batch in ONE launch of the persistent kernel (ar_decode.hip)
@@ -1754,7 +1801,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // (fp16 AR: the batched decode on the f16 pipes overtakes the persistent kernel at 5 streams -- 2191 vs 1645 frames/s, 6: 2562 vs
         // 2064, 4: 1420 vs 1919; fp32: the persistent kernel wins up to 6 -- tools/part_ab3.sh)
         const int mega_max = c.ar_dtype == 1 ? std::min(4, AR_PERSISTENT_MAX_STREAMS) : AR_PERSISTENT_MAX_STREAMS;
-        const bool will_mega = B <= mega_max && e->mega_ok && debug_options().ar_persistent != 0;
+        const bool will_mega = B <= mega_max && e->mega_ok && debug_options().ar_persistent != 0 && debug_options().ar_batch != 2;
         b->mega_max = mega_max;
         // multi-launch decode (more than 6 streams): its ~265 small launches per frame are a latency chain that the encoder's and
         // vocoder's chip-filling GEMMs would otherwise queue in front of -- disjoint CU masks (AR n | encoder + vocoder 256 - n)
@@ -1954,7 +2001,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     // persistent batch-1 decode kernel (ar_decode.hip): granule buffers, tag epoch, timeout word, fast K/V scratch
     // up to mega_max_b streams decode in ONE launch of it (96 workgroups per stream, each stream's group talks only to itself); the
     // multi-launch chain of the batched path (~200 dependent launches, 2.4-3.3 ms per frame at 2-8 streams) takes over above that
-    b->use_mega = B <= b->mega_max && e->mega_ok && b->fused_decode && debug_options().ar_persistent != 0;
+    b->use_mega = B <= b->mega_max && e->mega_ok && b->fused_decode && debug_options().ar_persistent != 0 && debug_options().ar_batch != 2;
     if (b->use_mega) {
         // every workgroup of a persistent launch must be resident at once: check the launch geometry against the occupancy query and
         // the CUs the AR stream may use, never assume it.  One workgroup per CU is what the kernel is sized for (256 registers, 4 waves);
@@ -1973,6 +2020,33 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         SVA_TRY(dev_alloc(A, &b->d_ar_fail, 1));
         SVA_TRY(dev_alloc(A, &b->kv_fast_mega, (size_t)B * AR_FAST_LAYERS * 8 * 2 * D));
         if (debug_options().ar_timing) SVA_TRY(dev_alloc(A, &b->d_ar_dbg, 1024));
+    }
+    // batched persistent decode kernel (ar_batch.hip): every stream of the batch in one launch per frame.  Takes the batches the
+    // two-streams-per-launch kernel above does not serve; its workgroups must all be resident (same check as above).
+    b->use_abatch = !b->use_mega && e->mega_ok && debug_options().ar_persistent != 0 && debug_options().ar_batch != 0 && B <= AR_BATCH_MAX_STREAMS &&
+                    c.ar_vocab <= 8192 && c.codebook_size <= 1024;
+    if (b->use_abatch) {
+        int per_cu = 0, cus = 0;
+        SVA_TRY(ar_batch_occupancy(c.ar_dtype == 1, B, &per_cu));
+        SVA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+        const int avail = b->ar_partitioned ? std::min(cus, b->ar_cus > 0 ? b->ar_cus : 96) : cus;
+        const int cap = std::min(per_cu, 2) * avail;             // (the occupancy query over-reports by one on SGPR-heavy kernels: never more than 2 relied on)
+        int G = ar_batch_wanted_workgroups(B);
+        if (debug_options().ar_batch_wgs > 0) G = debug_options().ar_batch_wgs;
+        G = std::min(G, cap);
+        if (G < 48) b->use_abatch = false;
+        b->abatch_G = G;
+    }
+    if (b->use_abatch) {
+        const size_t words = ar_batch_flag_words(B, b->ab_offs);
+        SVA_TRY(dev_alloc(A, &b->d_ab_flags, words));
+        SVA_TRY(dev_alloc(A, &b->d_ab_epoch, 2));
+        if (!b->d_ar_fail) SVA_TRY(dev_alloc(A, &b->d_ar_fail, 1));
+        SVA_TRY(dev_alloc(A, &b->ab_qkvf, (size_t)B * 3 * D));
+        SVA_TRY(dev_alloc(A, &b->ab_attf, (size_t)B * D));
+        SVA_TRY(dev_alloc(A, &b->ab_gf, (size_t)B * c.ar_inter));
+        SVA_TRY(dev_alloc(A, &b->ab_kvf, (size_t)AR_FAST_LAYERS * B * 8 * 2 * D));
+        if (debug_options().ar_timing && !b->d_ar_dbg) SVA_TRY(dev_alloc(A, &b->d_ar_dbg, 1024));
     }
     SVA_TRY(dev_alloc(A, &b->cached_audio_emb, (size_t)B * D));
     SVA_TRY(dev_alloc(A, &b->cached_ref_emb, (size_t)B * c.max_delay * D));
@@ -2881,7 +2955,7 @@ extern "C" int sva_stream_chunks(sva_batch* b, const float* pcm_in, float* pcm_o
 // the persistent decode kernel gives up on a hand-off that does not arrive (bounded spin) and records where: surface it at the
 // next synchronisation instead of returning garbage codes
 static int check_ar_fail(sva_batch* b) {
-    if (!b->use_mega || !b->d_ar_fail) return 0;
+    if ((!b->use_mega && !b->use_abatch) || !b->d_ar_fail) return 0;
     int f = 0;
     SVA_HIP(hipMemcpy(&f, b->d_ar_fail, sizeof(int), hipMemcpyDeviceToHost));
     if (f != 0) b->ar_failed = true;
@@ -2901,7 +2975,7 @@ extern "C" int sva_debug_configure(const char* kv) {
 
 // test hook: make the batch look as if its persistent decode kernel had timed out (sets the device-side fail word)
 extern "C" int sva_test_force_ar_timeout(sva_batch* b) {
-    SVA_CHECK(b && b->use_mega && b->d_ar_fail, "sva_test_force_ar_timeout: the batch does not use the persistent decode kernel");
+    SVA_CHECK(b && (b->use_mega || b->use_abatch) && b->d_ar_fail, "sva_test_force_ar_timeout: the batch does not use the persistent decode kernel");
     SVA_HIP(hipSetDevice(b->e->device));
     SVA_TRY(quiesce(b));
     SVA_HIP(hipStreamSynchronize(b->stream));
@@ -2909,7 +2983,7 @@ extern "C" int sva_test_force_ar_timeout(sva_batch* b) {
     SVA_HIP(hipMemcpy(b->d_ar_fail, &code, sizeof(int), hipMemcpyHostToDevice));
     return 0;
 }
-extern "C" int sva_batch_uses_persistent_decode(sva_batch* b) { return b && b->use_mega && !b->edits_on ? 1 : 0; }
+extern "C" int sva_batch_uses_persistent_decode(sva_batch* b) { return b && !b->edits_on ? (b->use_mega ? 1 : b->use_abatch ? 2 : 0) : 0; }
 
 // previous_tokens / repetition_penalty / suppress_tokens of decode_one_token_ar (modules/dual_ar_stream.py:1099-1117, 1175-1213)
 extern "C" int sva_set_sampler_edits(sva_batch* b, const int32_t* previous_tokens, int W, float repetition_penalty, const int32_t* suppress_tokens,

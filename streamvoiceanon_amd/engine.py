@@ -410,8 +410,12 @@ class Batch:
         _check(self.lib.sva_step_device_on(self.h, C.c_void_p(d_in_ptr), C.c_void_p(d_out_ptr), C.c_void_p(stream), int(bool(join_output))),
                "sva_step_device_on")
 
+    def decode_path(self):
+        """0 = multi-launch decode, 1 = persistent kernel (ar_decode.hip, small batches), 2 = batched persistent kernel (ar_batch.hip)."""
+        return int(self.lib.sva_batch_uses_persistent_decode(self.h))
+
     def uses_persistent_decode(self):
-        return bool(self.lib.sva_batch_uses_persistent_decode(self.h))
+        return self.decode_path() != 0
 
     def join_stream(self, stream=None):
         if stream is None:

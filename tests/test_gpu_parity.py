@@ -1156,7 +1156,7 @@ def test_partitioned_pipelining_equals_serial(eng, eng_fp16, B, fp16):
 
     def run(pipeline):
         b = E.Batch(e, n_streams=B, pipeline=pipeline)
-        assert not b.uses_persistent_decode()
+        assert b.decode_path() != 1          # (not the two-streams-per-launch kernel: the batched persistent kernel or the multi-launch chain)
         for i in range(B):
             ac, cc, style, timbre = synth_prompt(2950 + i % 3, 40 + 10 * (i % 3))
             b.prefill_prompt(i, cc, ac, style, timbre, noise_seed=600 + i)

@@ -1,0 +1,134 @@
+"""Batched persistent decode kernel (csrc/ar_batch.hip) against the multi-launch decode on the same streams, plus its phase timeline.
+
+  python tools/ar_batch_check.py [B ...]        AR_DTYPE=0|1   STEPS=12   TIMING=1 (phase table)   PIPE=1 (pipelined throughput too)
+
+Per batch size: the same B streams (distinct prompts / utterances / seeds, device RNG) run three ways -- multi-launch decode
+(SVA_DEBUG ar_batch=0,ar_persistent=0), batched persistent kernel forced (ar_batch=2) free-running, and both teacher-forced on the first
+run's codes -- and are compared: codes equal, top logits / hidden state within fp32 summation order, PCM within 5e-5."""
+import os
+import sys
+import time
+
+if os.environ.get("TIMING", "1") == "1":
+    os.environ["SVA_DEBUG"] = "ar_timing=1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from streamvoiceanon_amd import engine as E, specs, synth_weights as sw
+from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+ar_dtype = int(os.environ.get("AR_DTYPE", "0"))
+steps = int(os.environ.get("STEPS", "12"))
+sizes = [int(x) for x in sys.argv[1:]] or [2, 3, 5, 8, 12, 32, 64]
+W = {k: sw.generate(0, k, shp) for k, shp in specs.all_specs().items()}
+W = {k: v for k, v in W.items() if v is not None}
+eng = E.Engine(W, ar_dtype=ar_dtype)
+lib = E.load_library()
+
+
+def labels():
+    out = ["start"]
+    for l in range(12):
+        out += [f"s.QKV", f"s.ATT", f"s.WO", f"s.W13", f"s.W2"]
+    out.append("SEM")
+    for cb in range(8):
+        for l in range(4):
+            out += ["f.QKV", "f.ATT", "f.WO", "f.W13", "f.W2"]
+        out += ["f.HEAD", "f.SAMPLE"]
+    out.append("FIN")
+    return out
+
+
+def run(B, mode, forced=None, chunk=1, timing=False):
+    lib.sva_debug_configure(mode.encode())
+    b = E.Batch(eng, n_streams=B, chunk_frames=chunk)
+    path = b.decode_path()
+    for s in range(B):
+        ac, cc, style, timbre = synth_prompt(2000 + s % 5, 60 + 7 * (s % 5))
+        b.prefill_prompt(s, cc, ac, style, timbre, noise_seed=1000 + s)
+    b.begin()
+    src = np.stack([synth_utterance(1000 + s % 7, 2048 * chunk * steps) for s in range(B)])
+    n = 2048 * chunk
+    codes, pcm, fast, hid, slow, ar_ms, spans = [], [], [], [], [], [], None
+    nsp = 0
+    for i in range(steps):
+        fc = None if forced is None else forced[i]
+        out = b.step(src[:, i * n:(i + 1) * n], forced_codes=fc)
+        pcm.append(out)
+        codes.append(b.tap("sampled_codes" if forced is not None else "audio_codes", (B, 8) if forced is not None else (B, 8, chunk), np.int32).copy())
+        fast.append(b.tap("fast_logits", (B, 8, 1000)).copy())
+        hid.append(b.tap("hidden", (B, 768)).copy())
+        slow.append(b.tap("slow_logits", (B, 8192)).copy())
+        if i >= 3:
+            ar_ms.append(b.timings()["ar"])
+        if timing and path == 2 and i >= 4:
+            t = b.tap("ar_timing", (1024,), np.int64)[:len(labels())].astype(np.float64) * 0.01
+            d = np.diff(t)
+            spans = d if spans is None else spans + d
+            nsp += 1
+    fail = int(b.tap("ar_fail", (1,), np.int32)[0]) if path else 0
+    b.close()
+    if spans is not None:
+        spans /= nsp
+    return dict(path=path, codes=np.stack(codes), pcm=np.stack(pcm), fast=np.stack(fast), hid=np.stack(hid), slow=np.stack(slow), ar_ms=float(np.median(ar_ms)),
+                fail=fail, spans=spans)
+
+
+def throughput(B, mode, chunk=1, K=60):
+    import torch
+    lib.sva_debug_configure(mode.encode())
+    b = E.Batch(eng, n_streams=B, chunk_frames=chunk, pipeline=True)
+    for s in range(B):
+        ac, cc, style, timbre = synth_prompt(2000 + s % 5, 60 + 7 * (s % 5))
+        b.prefill_prompt(s, cc, ac, style, timbre, noise_seed=1000 + s)
+    b.begin()
+    x = torch.randn(B, 2048 * chunk, device="cuda") * 0.1
+    y = torch.zeros_like(x)
+    for _ in range(10):
+        b.step_device(x.data_ptr(), y.data_ptr())
+    lib.sva_sync(b.h)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        b.step_device(x.data_ptr(), y.data_ptr())
+    lib.sva_sync(b.h)
+    dt = (time.perf_counter() - t0) / K
+    path = b.decode_path()
+    b.close()
+    return dt * 1e3, B * chunk / dt, path
+
+
+ok_all = True
+for B in sizes:
+    ref = run(B, "ar_batch=0,ar_persistent=0")
+    new = run(B, "ar_batch=2,ar_persistent=1", timing=True)
+    # teacher-forced on the reference run's codes: logits of every frame comparable although a near-tie may flip a free-running code
+    forced = [np.ascontiguousarray(ref["codes"][i][:, :, :1]) for i in range(steps)]
+    ref_f = run(B, "ar_batch=0,ar_persistent=0", forced=forced)
+    new_f = run(B, "ar_batch=2,ar_persistent=1", forced=forced)
+    ndiff = int((ref["codes"] != new["codes"]).sum())
+    live = slice(2, None)          # the first `delay` chunks decode nothing
+    dl = float(np.abs(ref_f["fast"][live] - new_f["fast"][live]).max())
+    dh = float(np.abs(ref_f["hid"][live] - new_f["hid"][live]).max())
+    ds = float(np.abs(ref_f["slow"][live] - new_f["slow"][live]).max())
+    dp = float(np.abs(ref["pcm"] - new["pcm"]).max()) if ndiff == 0 else float("nan")
+    fdiff = int((ref_f["codes"] != new_f["codes"]).sum())
+    good = new["path"] == 2 and new["fail"] == 0 and fdiff == 0 and dl <= (2e-2 if ar_dtype else 2e-3) and ndiff == 0
+    ok_all &= good
+    print(f"B={B:3d} ar_dtype={ar_dtype} path={new['path']} fail={new['fail']}  free-running codes differing {ndiff} of {ref['codes'].size}  "
+          f"teacher-forced: raw codes differing {fdiff}, |dlogit| fast {dl:.2e} slow {ds:.2e} |dhidden| {dh:.2e}  |dpcm| {dp:.2e}  "
+          f"AR stage ms: multi-launch {ref['ar_ms']:.3f}  batched-persistent {new['ar_ms']:.3f}   {'OK' if good else 'MISMATCH'}", flush=True)
+    if new["spans"] is not None:
+        kinds = {}
+        lab = labels()
+        for k, v in enumerate(new["spans"]):
+            kinds.setdefault(lab[k + 1], []).append(v)
+        print(f"   phase spans of workgroup 0 (us, mean over frames; frame {new['spans'].sum():.0f} us): " +
+              "  ".join(f"{k} {np.mean(v):.1f}x{len(v)}" for k, v in kinds.items()), flush=True)
+    if os.environ.get("PIPE", "0") == "1":
+        a = throughput(B, "ar_batch=0,ar_persistent=0")
+        c = throughput(B, "ar_batch=1,ar_persistent=1")
+        d = throughput(B, "ar_batch=2,ar_persistent=1")
+        print(f"   pipelined: multi-launch {a[0]:.3f} ms/step {a[1]:.0f} frames/s | default (path {c[2]}) {c[0]:.3f} ms {c[1]:.0f} | batched-persistent {d[0]:.3f} ms {d[1]:.0f}", flush=True)
+lib.sva_debug_configure(b"ar_batch=1,ar_persistent=1")
+print("ALL OK" if ok_all else "SOME MISMATCH")
+sys.exit(0 if ok_all else 1)
