@@ -29,12 +29,13 @@ struct ArBatchArgs {
     void* kv_slow;                // [layer][slot][K|V][H][S][64], float or __half
     long kv_layer_stride, kv_slot_stride;     // elements
     int S;
-    // activations (fp32).  xs holds the frame's 2 B input tokens on entry (ar_prepare_step_kernel)
-    float *xs, *qkv, *att, *g;    // slow: [2B][768], [2B][2304], [2B][768], [2B][2304]
-    float *xf, *qkvf, *attf, *gf; // fast: [B][768], [B][2304], [B][768], [B][2304]
-    float* kvf;                   // [4][B][8][k 768 | v 768] fast-AR K / V of the frame's codebook positions
-    // hand-off flags (one word per produced tile, value = epoch of the producing phase) -- see ar_batch.hip
-    unsigned *f_x, *f_qkv, *f_g, *f_att, *f_xf, *f_qkvf, *f_gf, *f_attf, *f_log, *f_row, *f_sem;
+    const float* xs_in;           // [2B][768] fp32: the frame's 2 B input tokens (ar_prepare_step_kernel)
+    // activations that cross workgroups inside the launch: 8-byte {tag = epoch of the producing phase, fp32 value} granules -- see
+    // ar_batch.hip.  Offsets of the arrays in one allocation: ar_batch_granule_words (same order)
+    unsigned long long *gxs, *gqkv, *gatt, *gg;       // slow: [2B][768], [2B][2304], [2B][768], [2B][2304]
+    unsigned long long *gxf, *gqkvf, *gattf, *ggf;    // fast: [B][768], [B][2304], [B][768], [B][2304]
+    unsigned long long* gkvf;                         // [4][B][8][k 768 | v 768] fast-AR K / V of the frame's codebook positions
+    unsigned long long *glog, *gsem;                  // [B][1024] codebook logits of the current codebook, [B][8192] semantic logits
     unsigned* epoch;              // [1] running phase counter, persists across launches
     unsigned* done;               // [1] exit counter of the launch (the last workgroup out advances *epoch)
     int* fail;                    // [1] set to a phase code if a wait timed out (never in a healthy run)
@@ -54,8 +55,9 @@ struct ArBatchArgs {
 
 // row-tile heights (x 16 rows) of the slow (2 B rows) and fast (B rows) linear phases for a batch size
 void ar_batch_tiles(int B, int* mts, int* mtf);
-// words of the flag block for B streams and the offsets of its arrays (in the order of ArBatchArgs::f_*)
-size_t ar_batch_flag_words(int B, size_t offs[11]);
+// granules (8 bytes each) of the hand-off block for B streams and the offsets of its arrays (in the order of ArBatchArgs::g*)
+constexpr int AR_BATCH_NBUF = 11;
+size_t ar_batch_granule_words(int B, size_t offs[AR_BATCH_NBUF]);
 // workgroups the kernel wants for B streams (one 16-column tile of the widest phase each)
 int ar_batch_wanted_workgroups(int B);
 int ar_batch_occupancy(int wt_half, int B, int* blocks_per_cu);

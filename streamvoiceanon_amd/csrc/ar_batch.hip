@@ -2,27 +2,28 @@
 //
 // decode_one_token_ar (modules/dual_ar_stream.py:1168-1219) for B streams is 12 slow layers on 2 B rows, the semantic head and
 // 8 x (4 fast layers on B rows + codebook head + nucleus sample): ~240 dependent matrix products that each move a few MB of
-// weights.  As separate launches (engine.hip: ar_layers_pass / ar_frame_tail, ~265 kernels of 5-25 us) the frame costs 3.4-3.8 ms
-// at 12-64 streams although the weight stream (0.26 GB fp16 / 0.52 GB fp32) and the matrix work are worth a fraction of that.
-// Here G workgroups stay resident for the whole frame and run a STATIC schedule of phases; phase p of a layer is cut into
-// independent units that workgroup w takes round-robin (unit w, w + G, ...):
-//   * linear phases (wqkv, wo, w1|w3, w2, heads): unit = (row tile of 16 MT rows, 16 output columns).  The K axis is split over
-//     the 4 waves of the workgroup; lanes stream 16-byte weight fragments and 32-byte activation fragments straight from global
-//     memory into MFMA operands (no LDS in the K loop), partial tiles are reduced through LDS once -- the structure of
-//     gemm_f16w.hip.  fp16 weights: v_mfma_f32_16x16x32_f16 with the fp32 activations split exactly into hi + lo halves;
-//     fp32 weights: v_mfma_f32_16x16x4_f32.  RMSNorm is folded in (weight into the operand, 1 / rms onto the accumulators);
-//     RoPE + KV write, residual add and SwiGLU are epilogues.
-//   * slow attention: unit = (stream, head), both new rows against the cached keys (4 waves split the keys, merged in LDS);
+// weights.  As separate launches (engine.hip: ar_layers_pass / ar_frame_tail, ~265 kernels of 5-25 us) the frame costs 2.5-3.8 ms
+// at 8-64 streams although the weight stream (0.26 GB fp16 / 0.52 GB fp32) and the matrix work are worth a fraction of that.
+// Here G workgroups of 8 waves stay resident for the whole frame and run a STATIC schedule of phases; phase p of a layer is cut
+// into independent units that workgroup w takes round-robin (unit w, w + G, ...):
+//   * linear phases (wqkv, wo, w1|w3, w2, heads): unit = (row tile of 16 MT rows, 16 NT output columns).  The K axis is split over
+//     the 8 waves of the workgroup; a wave requests the WHOLE weight slice of its unit (3 or 9 32-wide K blocks per column tile)
+//     BEFORE it looks at its input, so the weight stream's latency overlaps the hand-off of the previous phase's output -- the one
+//     thing a launch boundary cannot do.  Lanes load weight and activation fragments straight into MFMA operands (no LDS in the K
+//     loop), partial tiles are reduced through LDS once.  fp16 weights: v_mfma_f32_16x16x32_f16 with the fp32 activations split
+//     exactly into hi + lo halves; fp32 weights: v_mfma_f32_16x16x4_f32.  RMSNorm is folded in (weight into the operand, 1 / rms
+//     onto the accumulators); RoPE + KV write, residual add and SwiGLU are epilogues.
+//   * slow attention: unit = (stream, head), both new rows against the cached keys (8 waves split the keys, merged in LDS);
 //     fast attention (<= 8 codebook positions): unit = stream; samplers and bookkeeping: unit = stream.
-//   * hand-off between phases (cdna_hip_programming.md Guideline 16, form R1 with sc1 loads in place of the acquire): a unit
-//     stores its output tile write-through (sc1), every wave drains vmcnt, one lane stores the tile's flag = epoch of the phase;
-//     a consuming wave polls exactly the flags of the tiles its K range reads (relaxed agent-scope loads), then reads the
-//     tile with sc1 loads.  Nothing depends on workgroup placement or dispatch order; all waits are bounded (timeout -> *fail,
-//     the kernel runs to its end with garbage instead of hanging).  Every consumer unit's four waves together wait for ALL
-//     column tiles of its row tile, so a buffer is rewritten only after every reader of the previous contents has finished
-//     (the next writer's inputs depend on those readers' outputs).
-// Weight rows of a unit are requested BEFORE its wave waits for the input flags, so the weight stream's latency overlaps the
-// hand-off -- the one thing a launch boundary cannot do.
+//   * hand-off between phases = the data is the flag (cdna_hip_programming.md Guideline 16, form R2, as in ar_decode.hip): every
+//     activation element crosses workgroups as an 8-byte {tag = epoch of the producing phase, value} granule, stored with a relaxed
+//     agent-scope (sc1, write-through) store and read with 16-byte sc1 loads that are repeated until every tag of the wave's
+//     fragment matches.  One memory round trip per edge: no flag words, no drains, no fences; nothing depends on workgroup
+//     placement or dispatch order.  (The first version of this kernel published a flag per tile behind a drain + barrier and polled
+//     the flag before loading the tile: three dependent round trips, 5.5-6 us per phase, 2.2-2.4 ms per frame at 8-12 streams.)
+//     All waits are bounded (timeout -> *fail, the kernel runs to its end with garbage instead of hanging).  A buffer is
+//     rewritten only after every reader of its previous contents has finished: every unit of a consuming phase reads ALL column
+//     tiles of its row tile, and the next writer's inputs depend (transitively) on the outputs of all those units.
 #include "ar_batch.h"
 #include "device_util.h"
 #include "sva_common.h"
@@ -37,52 +38,52 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int SPIN_LIMIT = 1 << 15;                // polls before a wait gives up (tens of ms); a healthy hand-off takes a handful
+constexpr int NWV = 8, NTH = NWV * 64;             // waves / threads per workgroup
+constexpr int SPIN_LIMIT = 1 << 15;                // polls (a memory round trip each) before a wait gives up: tens of ms
 constexpr int QT = 3 * D / 16, XT = D / 16, GT = I / 16;       // column tiles of the qkv (144), x / att (48) and SwiGLU (144) buffers
-constexpr int LOGT = 64, SEMT = 512;                            // flag words per row tile of the codebook / semantic logits
+constexpr int HDR = 64;                            // LDS header (floats): sampled tokens of the workgroup's streams
+constexpr int LOGP = 1024, SEMP = 8192;            // row pitch (granules) of the codebook / semantic logits
 
-__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int ld_sc1(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_g(u64* p, unsigned ep, float v) { store_granule(p, ep, v); }
+__device__ __forceinline__ u64 ld_g(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float g_val(u64 g) { return __uint_as_float((unsigned)g); }
+__device__ __forceinline__ unsigned g_tag(u64 g) { return (unsigned)(g >> 32); }
 
-// one wave: wait until the n (<= 64) consecutive flag words at f have reached epoch `want`
-__device__ __forceinline__ void wait_flags(const unsigned* f, int n, unsigned want, int* fail, int code) {
-    const int lane = threadIdx.x & 63;
-    bool ok = lane >= n;
-    int spins = 0;
-    while (true) {
-        if (!ok) ok = (int)(__hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;
-        if (__all(ok)) break;
-        ++spins;
-        if ((spins & 127) == 0 && *reinterpret_cast<volatile int*>(fail)) break;          // an earlier wait timed out somewhere: run through
-        if (spins > SPIN_LIMIT) { if (lane == 0) *fail = code; break; }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-}
-
-// end of a unit: every wave's write-through stores have completed, then ONE lane publishes the tile's flag
-__device__ __forceinline__ void publish(unsigned* flag, unsigned ep) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// A operand of a linear phase: rows of an fp32 buffer written earlier in this launch (read with sc1 loads)
+// A operand of a linear phase: rows of a granule buffer written earlier in this launch (sc1 loads), or of a plain fp32 buffer
+// written by an earlier launch
 struct ASrc {
     __amdgpu_buffer_rsrc_t rs;
     int row_stride, off;           // bytes
 };
-__device__ __forceinline__ ASrc make_asrc(const float* base, long floats, int row_stride_floats, int off_floats) {
+__device__ __forceinline__ ASrc make_gsrc(const u64* base, long elems, int row_stride_elems, int off_elems) {
     ASrc a;
-    a.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(floats * 4), 0x00020000);
-    a.row_stride = row_stride_floats * 4;
-    a.off = off_floats * 4;
+    a.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(base), 0, (int)(elems * 8), 0x00020000);
+    a.row_stride = row_stride_elems * 8;
+    a.off = off_elems * 8;
     return a;
 }
-__device__ __forceinline__ float4 ld_a16(const ASrc& a, int voff) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a.rs, voff, 0, 16));      // aux 16 = sc1
+__device__ __forceinline__ ASrc make_psrc(const float* base, long elems, int row_stride_elems, int off_elems) {
+    ASrc a;
+    a.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
+    a.row_stride = row_stride_elems * 4;
+    a.off = off_elems * 4;
+    return a;
+}
+__device__ __forceinline__ v4i ld_g16(const __amdgpu_buffer_rsrc_t& rs, int voff) {
+    return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 16));      // aux 16 = sc1
+}
+__device__ __forceinline__ float4 ld_p16(const __amdgpu_buffer_rsrc_t& rs, int voff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+}
+
+// bounded poll bookkeeping of one wave: returns true when the wait must end (timeout, or another wait timed out earlier)
+__device__ __forceinline__ bool spin_over(int& spins, int* fail, int code) {
+    ++spins;
+    if (spins > SPIN_LIMIT) {
+        if ((threadIdx.x & 63) == 0) *fail = code;
+        return true;
+    }
+    return (spins & 7) == 0 && *reinterpret_cast<volatile int*>(fail) != 0;
 }
 
 // eight weights of one row per lane
@@ -165,32 +166,44 @@ __device__ __forceinline__ void mma_block(const AOps<WT, MT>& o, const WReg<WT> 
     }
 }
 
-// Partial tiles of C[m0 .. m0 + 16 MT) x [n0 .. n0 + 16 NT) = A[rows] (x RMSNorm weight) . W[cols]^T, K split over the 4 waves; on return
-// the per-wave partial tiles sit in `red` ([4][MT * NT][64][4] floats, then [4][MT][16] row sums of squares) behind a barrier.
-// waitf() is called by every wave after its first weight fragments are requested and before its first activation load.
-template <typename WT, int MT, int NT, int K, bool RMS, typename WaitF>
-__device__ __forceinline__ void linear_tile(const ASrc& A, int m0, int M, const WT* __restrict__ W, int n0, int N, const float* __restrict__ rms_w,
-                                            WaitF&& waitf, float* red) {
-    constexpr int NKW = K / 128;                   // 32-wide K blocks per wave
-    constexpr int DEP = MT >= 4 ? 2 : 3;           // K blocks in flight per wave
-    static_assert(NKW % DEP == 0 && NKW >= 2 * DEP, "K blocks per wave must be a multiple of the pipeline depth");
+// Partial tiles of C[m0 .. m0 + 16 MT) x [n0 .. n0 + 16 NT) = A[rows] (x RMSNorm weight) . W[cols]^T, K split over the 8 waves; on
+// return the per-wave partial tiles sit in `red` ([8][MT * NT][64][4] floats, then [8][MT][16] row sums of squares) behind a barrier.
+// GRAN: A is a granule buffer whose tags must equal `want`; otherwise plain fp32 rows of an earlier launch.  pre() runs in every
+// wave after its weight loads are requested and before its first activation load (prefetch of what the epilogue needs).
+template <typename WT, int MT, int NT, int K, bool RMS, bool GRAN, typename PreF>
+__device__ __forceinline__ void linear_tile(const ASrc& A, unsigned want, int m0, int M, const WT* __restrict__ W, int n0, int N,
+                                            const float* __restrict__ rms_w, PreF&& pre, float* red, int* fail, int code) {
+    constexpr int NKW = K / (32 * NWV);                 // 32-wide K blocks per wave: 3 (K = 768) or 9 (K = 2304)
+    constexpr int ACH = MT >= 4 ? 1 : 3;                // K blocks of A requested (and validated) together
+    constexpr int ES = GRAN ? 8 : 4;
+    static_assert(K % (32 * NWV) == 0 && NKW % ACH == 0, "K blocks per wave");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fk = lane >> 4;
-    const int kbase = wave * (K / 4) + 8 * fk;
-    const WT* wp[NT];
+    const int kbase = wave * (K / NWV) + 8 * fk;
+    WReg<WT> wv[NKW][NT];
+    float4 nv[NKW][2];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         int n = n0 + 16 * j + fr;
         if (n > N - 1) n = N - 1;
-        wp[j] = W + (long)n * K + kbase;
+        const WT* wp = W + (long)n * K + kbase;
+#pragma unroll
+        for (int it = 0; it < NKW; ++it) wv[it][j].load(wp + it * 32);
+    }
+    if constexpr (RMS) {
+#pragma unroll
+        for (int it = 0; it < NKW; ++it) {
+            nv[it][0] = *reinterpret_cast<const float4*>(rms_w + kbase + it * 32);
+            nv[it][1] = *reinterpret_cast<const float4*>(rms_w + kbase + it * 32 + 4);
+        }
     }
     int aoff[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int m = m0 + 16 * i + fr;
         if (m > M - 1) m = M - 1;
-        aoff[i] = A.off + m * A.row_stride + kbase * 4;
+        aoff[i] = A.off + m * A.row_stride + kbase * ES;
     }
-    const float* np = rms_w + kbase;
+    pre();
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -199,63 +212,61 @@ __device__ __forceinline__ void linear_tile(const ASrc& A, int m0, int M, const 
     float ssq[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) ssq[i] = 0.f;
-    WReg<WT> wv[DEP][NT];
-    float4 av[DEP][MT][2], nv[DEP][2];
-    auto issue_w = [&](int d, int it) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wv[d][j].load(wp[j] + it * 32);
-        if constexpr (RMS) {
-            nv[d][0] = *reinterpret_cast<const float4*>(np + it * 32);
-            nv[d][1] = *reinterpret_cast<const float4*>(np + it * 32 + 4);
-        }
-    };
-    auto issue_a = [&](int d, int it) {
+    for (int c = 0; c < NKW; c += ACH) {
+        float4 av[ACH][MT][2];
+        if constexpr (GRAN) {
+            v4i g[ACH][MT][4];
+            int spins = 0;
+            while (true) {
+                asm volatile("" ::: "memory");          // (the buffer-load builtin is an ordinary read to the optimiser: keep it inside the loop)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            av[d][i][0] = ld_a16(A, aoff[i] + it * 128);
-            av[d][i][1] = ld_a16(A, aoff[i] + it * 128 + 16);
-        }
-    };
+                for (int d = 0; d < ACH; ++d)
 #pragma unroll
-    for (int d = 0; d < DEP; ++d) issue_w(d, d);
-    waitf();
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int d = 0; d < DEP; ++d) issue_a(d, d);
-    // steady state: turn slot d into operands, refill it DEP blocks ahead (no branch around any load), multiply; the last DEP
-    // blocks only consume
-#pragma unroll 1
-    for (int it0 = 0; it0 < NKW - DEP; it0 += DEP) {
+                        for (int q = 0; q < 4; ++q) g[d][i][q] = ld_g16(A.rs, aoff[i] + (c + d) * 256 + q * 16);
+                bool ok = true;
 #pragma unroll
-        for (int d = 0; d < DEP; ++d) {
-            AOps<WT, MT> o;
-            prep_block<WT, MT, RMS>(av[d], nv[d], o, ssq);
-            WReg<WT> wc[NT];
+                for (int d = 0; d < ACH; ++d)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wc[j] = wv[d][j];
-            if constexpr (std::is_same<WT, __half>::value) {
-                issue_w(d, it0 + d + DEP);
-                issue_a(d, it0 + d + DEP);
-                mma_block<WT, MT, NT>(o, wc, acc);
-            } else {            // (fp32 operands stay live through the MFMAs: refill afterwards)
-                mma_block<WT, MT, NT>(o, wc, acc);
-                issue_w(d, it0 + d + DEP);
-                issue_a(d, it0 + d + DEP);
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ok = ok && (unsigned)g[d][i][q].y == want && (unsigned)g[d][i][q].w == want;
+                if (__all(ok)) break;
+                if (spin_over(spins, fail, code)) break;
             }
+#pragma unroll
+            for (int d = 0; d < ACH; ++d)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    av[d][i][0] = make_float4(__int_as_float(g[d][i][0].x), __int_as_float(g[d][i][0].z), __int_as_float(g[d][i][1].x), __int_as_float(g[d][i][1].z));
+                    av[d][i][1] = make_float4(__int_as_float(g[d][i][2].x), __int_as_float(g[d][i][2].z), __int_as_float(g[d][i][3].x), __int_as_float(g[d][i][3].z));
+                }
+        } else {
+#pragma unroll
+            for (int d = 0; d < ACH; ++d)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    av[d][i][0] = ld_p16(A.rs, aoff[i] + (c + d) * 128);
+                    av[d][i][1] = ld_p16(A.rs, aoff[i] + (c + d) * 128 + 16);
+                }
+        }
+#pragma unroll
+        for (int d = 0; d < ACH; ++d) {
+            AOps<WT, MT> o;
+            prep_block<WT, MT, RMS>(av[d], nv[c + d], o, ssq);
+            mma_block<WT, MT, NT>(o, wv[c + d], acc);
         }
     }
-#pragma unroll
-    for (int d = 0; d < DEP; ++d) {
-        AOps<WT, MT> o;
-        prep_block<WT, MT, RMS>(av[d], nv[d], o, ssq);
-        mma_block<WT, MT, NT>(o, wv[d], acc);
-    }
+    __syncthreads();            // the previous unit's epilogue has read `red`
     // cross-wave reduction of the K slices
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&red[((wave * (MT * NT) + i * NT + j) * 64 + lane) * 4]) = acc[i][j];
     if constexpr (RMS) {
-        float* redss = red + 4 * MT * NT * 256;
+        float* redss = red + NWV * MT * NT * 256;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             float v = ssq[i];
@@ -267,34 +278,52 @@ __device__ __forceinline__ void linear_tile(const ASrc& A, int m0, int M, const 
     __syncthreads();
 }
 
-// sum of the four waves' partials of row sub-tile i: t[j][r] = element (row 4 (lane >> 4) + r, column lane & 15) of column tile j
+// sum of the eight waves' partials of row sub-tile i: t[j][r] = element (row 4 (lane >> 4) + r, column lane & 15) of column tile j
 template <int MT, int NT>
 __device__ __forceinline__ void tile_sum(const float* red, int i, int lane, f32x4 (&t)[NT]) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         f32x4 s = *reinterpret_cast<const f32x4*>(&red[((i * NT + j) * 64 + lane) * 4]);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * (MT * NT) + i * NT + j) * 64 + lane) * 4]);
+        for (int w = 1; w < NWV; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * (MT * NT) + i * NT + j) * 64 + lane) * 4]);
         t[j] = s;
     }
 }
 template <int MT, int NT>
 __device__ __forceinline__ float row_inv(const float* red, int i, int row16, int K, float eps) {
-    const float* redss = red + 4 * MT * NT * 256;
+    const float* redss = red + NWV * MT * NT * 256;
     float tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) tot += redss[(w * MT + i) * 16 + row16];
+    for (int w = 0; w < NWV; ++w) tot += redss[(w * MT + i) * 16 + row16];
     return 1.f / sqrtf(tot / (float)K + eps);
 }
 
-constexpr size_t red_floats(int MT, int NT) { return (size_t)4 * MT * NT * 256 + 4 * MT * 16; }
+constexpr size_t red_floats(int MT, int NT) { return (size_t)NWV * MT * NT * 256 + NWV * MT * 16; }
 
-// wo / w2 epilogue: x[m][n] = res[m][n] + acc   (res rows through an ASrc-like (stride, offset) view of a float buffer)
-template <int MT>
-__device__ __forceinline__ void epi_residual(const float* red, int m0, int M, int n0, const float* res, int res_stride, int res_off, float* out,
-                                             float* tap) {
+// residual granules of the lane's four rows of sub-tile i = wave, requested ahead of the unit's K loop (plain fp32 rows of an earlier
+// launch when !GRAN).  They are usually in place by then, but nothing this workgroup has seen proves it: epi_residual checks the tags
+template <int MT, bool GRAN>
+__device__ __forceinline__ void res_prefetch(const void* res, int row_stride, int row_off, int m0, int M, int n0, u64 (&rg)[4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, rq = (lane >> 4) * 4;
-    for (int i = wave; i < MT; i += 4) {
+    if (wave < MT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int m = m0 + 16 * wave + rq + r;
+            if (m > M - 1) m = M - 1;
+            const long e = (long)m * row_stride + row_off + n0 + col;
+            if constexpr (GRAN) rg[r] = ld_g(reinterpret_cast<const u64*>(res) + e);
+            else rg[r] = (u64)__float_as_uint(reinterpret_cast<const float*>(res)[e]);
+        }
+    }
+}
+// wo / w2 epilogue: out[m][n] = res[m][n] + acc.  check: the residual granules must carry tag `want` (re-read until they do: by the
+// time the unit's A operand has been validated they are in place, so this loop does not iterate in practice)
+template <int MT>
+__device__ __forceinline__ void epi_residual(const float* red, int m0, int M, int n0, u64 (&rg)[4], bool check, unsigned want, const u64* res,
+                                             int row_stride, int row_off, u64* out, unsigned ep, float* tap, int* fail) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, rq = (lane >> 4) * 4;
+    if (wave < MT) {
+        const int i = wave;
         f32x4 t[1];
         tile_sum<MT, 1>(red, i, lane, t);
 #pragma unroll
@@ -302,9 +331,17 @@ __device__ __forceinline__ void epi_residual(const float* red, int m0, int M, in
             const int m = m0 + 16 * i + rq + r;
             if (m >= M) continue;
             const int n = n0 + col;
-            const float rv = ld_sc1(res + (long)m * res_stride + res_off + n);
+            u64 g = rg[r];
+            if (check) {
+                int spins = 0;
+                while (g_tag(g) != want) {
+                    g = ld_g(res + (long)m * row_stride + row_off + n);
+                    if (++spins > SPIN_LIMIT) { *fail = 17; break; }
+                }
+            }
+            const float rv = g_val(g);
             if (tap) tap[(long)m * D + n] = rv;
-            st_sc1(out + (long)m * D + n, rv + t[0][r]);
+            st_g(out + (long)m * D + n, ep, rv + t[0][r]);
         }
     }
 }
@@ -312,9 +349,10 @@ __device__ __forceinline__ void epi_residual(const float* red, int m0, int M, in
 #define AB_MARK() do { if (a.dbg && wg == 0 && tid == 0 && nmark < 1000) a.dbg[nmark] = wall_clock64(); ++nmark; } while (0)
 
 template <typename WT, typename KVT, int MTS, int MTF>
-__global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
+__global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* red = lds;
+    int* const toks = reinterpret_cast<int*>(lds);         // [4][8] sampled tokens of the streams this workgroup samples
+    float* const red = lds + HDR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = a.G;
     const int col = lane & 15, rq = (lane >> 4) * 4;
     const int B = a.B, M2 = 2 * B;
@@ -325,13 +363,14 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
     int nmark = 0;
     const int use_forced = *a.use_forced;
     const long SH = (long)a.S * 64;
-    const ASrc AXS = make_asrc(a.xs, (long)M2 * D, D, 0), AATT = make_asrc(a.att, (long)M2 * D, D, 0), AG = make_asrc(a.g, (long)M2 * I, I, 0);
-    const ASrc AHID = make_asrc(a.xs, (long)M2 * D, 2 * D, D);            // content-token rows of the slow residual stream
-    const ASrc AXF = make_asrc(a.xf, (long)B * D, D, 0), AATTF = make_asrc(a.attf, (long)B * D, D, 0), AGF = make_asrc(a.gf, (long)B * I, I, 0);
+    const ASrc AIN = make_psrc(a.xs_in, (long)M2 * D, D, 0);
+    const ASrc AXS = make_gsrc(a.gxs, (long)M2 * D, D, 0), AATT = make_gsrc(a.gatt, (long)M2 * D, D, 0), AG = make_gsrc(a.gg, (long)M2 * I, I, 0);
+    const ASrc AHID = make_gsrc(a.gxs, (long)M2 * D, 2 * D, D);            // content-token rows of the slow residual stream
+    const ASrc AXF = make_gsrc(a.gxf, (long)B * D, D, 0), AATTF = make_gsrc(a.gattf, (long)B * D, D, 0), AGF = make_gsrc(a.ggf, (long)B * I, I, 0);
     AB_MARK();
 
     // ======================================= slow AR: 12 layers on 2 B rows =======================================
-    unsigned e_x = 0;           // epoch at which xs was last published (0: by the previous kernel)
+    unsigned e_x = 0;           // epoch of the phase that last wrote gxs
     for (int l = 0; l < AR_SLOW_LAYERS; ++l) {
         const ArLayerW& L = a.slow[l];
         KVT* const kvl = reinterpret_cast<KVT*>(a.kv_slow) + (long)l * a.kv_layer_stride;
@@ -339,10 +378,11 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
         ++ep;
         for (int u = wg; u < TMS * QT; u += G) {
             const int mi = u / QT, nj = u - mi * QT, m0 = mi * 16 * MTS, n0 = nj * 16;
-            linear_tile<WT, MTS, 1, D, true>(AXS, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm,
-                                             [&] { if (l > 0) wait_flags(a.f_x + mi * XT + 12 * wave, 12, e_x, a.fail, 1); }, red);
+            if (l == 0) linear_tile<WT, MTS, 1, D, true, false>(AIN, 0u, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, [] {}, red, a.fail, 1);
+            else linear_tile<WT, MTS, 1, D, true, true>(AXS, e_x, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, [] {}, red, a.fail, 1);
             const int region = n0 / D, nn = n0 + col - region * D, h = nn >> 6, d = nn & 63;
-            for (int i = wave; i < MTS; i += 4) {
+            if (wave < MTS) {
+                const int i = wave;
                 f32x4 t[1];
                 tile_sum<MTS, 1>(red, i, lane, t);
 #pragma unroll
@@ -356,12 +396,11 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
                         v = (d & 1) ? v * c + pv * sn : v * c - pv * sn;
                     }
                     if (m < M2) {
-                        st_sc1(a.qkv + (long)m * 3 * D + n0 + col, v);
+                        st_g(a.gqkv + (long)m * 3 * D + n0 + col, ep, v);
                         if (region >= 1) st_kv<KVT>(kvl + (long)s * a.kv_slot_stride + ((long)(region - 1) * H + h) * SH + (long)pos * 64 + d, v);
                     }
                 }
             }
-            publish(a.f_qkv + mi * QT + nj, ep);
         }
         AB_MARK();
         // ---- ATT: (stream, head): both new rows against keys 0 .. p0 (+ 1) ----
@@ -372,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
             const int grp = lane >> 4, li = lane & 15;
             const KVT* kc = kvl + (long)s * a.kv_slot_stride + (long)h * SH + li * 4;
             const KVT* vc = kc + (long)H * SH;
-            const int lo = (int)((long)wave * p0 / 4), hi = (int)((long)(wave + 1) * p0 / 4);       // this wave's cached keys
+            const int lo = (int)((long)wave * p0 / NWV), hi = (int)((long)(wave + 1) * p0 / NWV);       // this wave's cached keys
             // cached K / V rows were written by earlier launches: request the first 8 keys of every 16-lane group before waiting for q
             float4 pkk[8], pvv[8];
 #pragma unroll
@@ -383,27 +422,32 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
                 pkk[i] = ld_kv4<KVT>(kc + (long)t * 64);
                 pvv[i] = ld_kv4<KVT>(vc + (long)t * 64);
             }
-            asm volatile("" ::: "memory");
-            {   // q / k / v column tiles of head h of this stream's row tile
-                const int mi = (2 * s) / (16 * MTS);
-                const int reg = lane >> 2, q = lane & 3;
-                const unsigned* f = a.f_qkv + mi * QT + (lane < 12 ? reg * XT + 4 * h + q : 0);
-                bool ok = lane >= 12;
+            // q of both rows (every wave); the frame's own two keys / values (last wave: group 0 = row 0, group 1 = row 1)
+            const __amdgpu_buffer_rsrc_t rq_ = __builtin_amdgcn_make_buffer_rsrc(a.gqkv + (long)(2 * s) * 3 * D, 0, 2 * 3 * D * 8, 0x00020000);
+            const int qo = (h * 64 + li * 4) * 8;
+            const bool newk = wave == NWV - 1 && grp < 2;
+            const int ko = (grp * 3 * D + D + h * 64 + li * 4) * 8;
+            v4i gq[4], gk[4];
+            {
                 int spins = 0;
                 while (true) {
-                    if (!ok) ok = (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ep + 1) >= 0;
+                    asm volatile("" ::: "memory");
+                    gq[0] = ld_g16(rq_, qo); gq[1] = ld_g16(rq_, qo + 16);
+                    gq[2] = ld_g16(rq_, qo + 3 * D * 8); gq[3] = ld_g16(rq_, qo + 3 * D * 8 + 16);
+                    bool ok = (unsigned)gq[0].y == ep - 1 && (unsigned)gq[0].w == ep - 1 && (unsigned)gq[1].y == ep - 1 && (unsigned)gq[1].w == ep - 1 &&
+                              (unsigned)gq[2].y == ep - 1 && (unsigned)gq[2].w == ep - 1 && (unsigned)gq[3].y == ep - 1 && (unsigned)gq[3].w == ep - 1;
+                    if (newk) {
+                        gk[0] = ld_g16(rq_, ko); gk[1] = ld_g16(rq_, ko + 16);
+                        gk[2] = ld_g16(rq_, ko + D * 8); gk[3] = ld_g16(rq_, ko + D * 8 + 16);
+                        ok = ok && (unsigned)gk[0].y == ep - 1 && (unsigned)gk[0].w == ep - 1 && (unsigned)gk[1].y == ep - 1 && (unsigned)gk[1].w == ep - 1 &&
+                             (unsigned)gk[2].y == ep - 1 && (unsigned)gk[2].w == ep - 1 && (unsigned)gk[3].y == ep - 1 && (unsigned)gk[3].w == ep - 1;
+                    }
                     if (__all(ok)) break;
-                    ++spins;
-                    if ((spins & 127) == 0 && *reinterpret_cast<volatile int*>(a.fail)) break;
-                    if (spins > SPIN_LIMIT) { if (lane == 0) *a.fail = 2; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    if (spin_over(spins, a.fail, 2)) break;
                 }
-                asm volatile("" ::: "memory");
             }
-            const float* qrow = a.qkv + (long)(2 * s) * 3 * D + h * 64 + li * 4;
-            float4 q0, q1;
-            q0.x = ld_sc1(qrow) * 0.125f; q0.y = ld_sc1(qrow + 1) * 0.125f; q0.z = ld_sc1(qrow + 2) * 0.125f; q0.w = ld_sc1(qrow + 3) * 0.125f;
-            q1.x = ld_sc1(qrow + 3 * D) * 0.125f; q1.y = ld_sc1(qrow + 3 * D + 1) * 0.125f; q1.z = ld_sc1(qrow + 3 * D + 2) * 0.125f; q1.w = ld_sc1(qrow + 3 * D + 3) * 0.125f;
+            const float4 q0 = make_float4(__int_as_float(gq[0].x) * 0.125f, __int_as_float(gq[0].z) * 0.125f, __int_as_float(gq[1].x) * 0.125f, __int_as_float(gq[1].z) * 0.125f);
+            const float4 q1 = make_float4(__int_as_float(gq[2].x) * 0.125f, __int_as_float(gq[2].z) * 0.125f, __int_as_float(gq[3].x) * 0.125f, __int_as_float(gq[3].z) * 0.125f);
             float mr0 = -INFINITY, ls0 = 0.f, mr1 = -INFINITY, ls1 = 0.f;
             float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
             auto upd = [](float sc, const float4& vv, float& mr, float& ls, float4& o) {
@@ -428,12 +472,10 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
                 const float4 kk = ld_kv4<KVT>(kc + (long)t * 64), vv = ld_kv4<KVT>(vc + (long)t * 64);
                 step2(kk, vv);
             }
-            if (wave == 3 && grp < 2) {
+            if (newk) {
                 // the two keys of this frame, from the freshly published rows: group 0 = key p0 (both rows), group 1 = key p0 + 1 (row 1 only)
-                const float* kr = a.qkv + (long)(2 * s + grp) * 3 * D + D + h * 64 + li * 4;
-                float4 kk, vv;
-                kk.x = ld_sc1(kr); kk.y = ld_sc1(kr + 1); kk.z = ld_sc1(kr + 2); kk.w = ld_sc1(kr + 3);
-                vv.x = ld_sc1(kr + D); vv.y = ld_sc1(kr + D + 1); vv.z = ld_sc1(kr + D + 2); vv.w = ld_sc1(kr + D + 3);
+                const float4 kk = make_float4(__int_as_float(gk[0].x), __int_as_float(gk[0].z), __int_as_float(gk[1].x), __int_as_float(gk[1].z));
+                const float4 vv = make_float4(__int_as_float(gk[2].x), __int_as_float(gk[2].z), __int_as_float(gk[3].x), __int_as_float(gk[3].z));
                 const float s1 = row16_sum(q1.x * kk.x + q1.y * kk.y + q1.z * kk.z + q1.w * kk.w);
                 upd(s1, vv, mr1, ls1, o1);
                 if (grp == 0) {
@@ -441,10 +483,11 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
                     upd(s0, vv, mr0, ls0, o0);
                 }
             }
-            float* part = red;                              // [2][16][68]
+            __syncthreads();                                // the previous unit has read `red`
+            float* part = red;                              // [2][32][68]
             {
                 float* p0_ = part + (wave * 4 + grp) * 68;
-                float* p1_ = part + (16 + wave * 4 + grp) * 68;
+                float* p1_ = part + (4 * NWV + wave * 4 + grp) * 68;
                 *reinterpret_cast<float4*>(p0_ + li * 4) = o0;
                 *reinterpret_cast<float4*>(p1_ + li * 4) = o1;
                 if (li == 0) { p0_[64] = mr0; p0_[65] = ls0; p1_[64] = mr1; p1_[65] = ls1; }
@@ -452,45 +495,43 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
             __syncthreads();
             if (tid < 128) {
                 const int row = tid >> 6, dd = tid & 63;
-                const float* pr = part + row * 16 * 68;
+                const float* pr = part + row * 4 * NWV * 68;
                 float Mx = -INFINITY;
 #pragma unroll
-                for (int g2 = 0; g2 < 16; ++g2)
+                for (int g2 = 0; g2 < 4 * NWV; ++g2)
                     if (pr[g2 * 68 + 65] > 0.f) Mx = fmaxf(Mx, pr[g2 * 68 + 64]);
                 float val = 0.f, den = 0.f;
 #pragma unroll
-                for (int g2 = 0; g2 < 16; ++g2) {
+                for (int g2 = 0; g2 < 4 * NWV; ++g2) {
                     const float lg2 = pr[g2 * 68 + 65];
                     const float wgt = lg2 > 0.f ? expf(pr[g2 * 68 + 64] - Mx) : 0.f;
                     den = fmaf(wgt, lg2, den);
                     val = fmaf(wgt, pr[g2 * 68 + dd], val);
                 }
-                st_sc1(a.att + (long)(2 * s + row) * D + h * 64 + dd, val / den);
+                st_g(a.gatt + (long)(2 * s + row) * D + h * 64 + dd, ep, val / den);
             }
-            publish(a.f_att + h * B + s, ep);
         }
         AB_MARK();
         // ---- WO + residual ----
         ++ep;
         for (int u = wg; u < TMS * XT; u += G) {
             const int mi = u / XT, nj = u - mi * XT, m0 = mi * 16 * MTS, n0 = nj * 16;
-            const int s0 = m0 >> 1, ns = min(8 * MTS, B - s0);
-            linear_tile<WT, MTS, 1, D, false>(AATT, m0, M2, reinterpret_cast<const WT*>(L.wo), n0, D, nullptr,
-                                              [&] {
-#pragma unroll
-                                                  for (int hh = 0; hh < 3; ++hh) wait_flags(a.f_att + (3 * wave + hh) * B + s0, ns, ep - 1, a.fail, 3);
-                                              }, red);
-            epi_residual<MTS>(red, m0, M2, n0, a.xs, D, 0, a.xs, nullptr);
-            publish(a.f_x + mi * XT + nj, ep);
+            u64 rg[4];
+            linear_tile<WT, MTS, 1, D, false, true>(AATT, ep - 1, m0, M2, reinterpret_cast<const WT*>(L.wo), n0, D, nullptr,
+                                                    [&] {
+                                                        if (l == 0) res_prefetch<MTS, false>(a.xs_in, D, 0, m0, M2, n0, rg);
+                                                        else res_prefetch<MTS, true>(a.gxs, D, 0, m0, M2, n0, rg);
+                                                    }, red, a.fail, 3);
+            epi_residual<MTS>(red, m0, M2, n0, rg, l > 0, e_x, a.gxs, D, 0, a.gxs, ep, nullptr, a.fail);
         }
         AB_MARK();
         // ---- W13: RMSNorm + w1 | w3 + SwiGLU ----
         ++ep;
         for (int u = wg; u < TMS * GT; u += G) {
             const int mi = u / GT, nj = u - mi * GT, m0 = mi * 16 * MTS, n0 = nj * 32;
-            linear_tile<WT, MTS, 2, D, true>(AXS, m0, M2, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm,
-                                             [&] { wait_flags(a.f_x + mi * XT + 12 * wave, 12, ep - 1, a.fail, 4); }, red);
-            for (int i = wave; i < MTS; i += 4) {
+            linear_tile<WT, MTS, 2, D, true, true>(AXS, ep - 1, m0, M2, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm, [] {}, red, a.fail, 4);
+            if (wave < MTS) {
+                const int i = wave;
                 f32x4 t[2];
                 tile_sum<MTS, 2>(red, i, lane, t);
 #pragma unroll
@@ -498,29 +539,23 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
                     const int m = m0 + 16 * i + rq + r;
                     if (m >= M2) continue;
                     const float inv = row_inv<MTS, 2>(red, i, rq + r, D, 1e-5f);
-                    st_sc1(a.g + (long)m * I + nj * 16 + col, silu_f(t[0][r] * inv) * (t[1][r] * inv));
+                    st_g(a.gg + (long)m * I + nj * 16 + col, ep, silu_f(t[0][r] * inv) * (t[1][r] * inv));
                 }
             }
-            publish(a.f_g + mi * GT + nj, ep);
         }
         AB_MARK();
         // ---- W2 + residual ----
         ++ep;
         for (int u = wg; u < TMS * XT; u += G) {
             const int mi = u / XT, nj = u - mi * XT, m0 = mi * 16 * MTS, n0 = nj * 16;
-            linear_tile<WT, MTS, 1, I, false>(AG, m0, M2, reinterpret_cast<const WT*>(L.w2), n0, D, nullptr,
-                                              [&] { wait_flags(a.f_g + mi * GT + 36 * wave, 36, ep - 1, a.fail, 5); }, red);
-            epi_residual<MTS>(red, m0, M2, n0, a.xs, D, 0, a.xs, nullptr);
-            publish(a.f_x + mi * XT + nj, ep);
+            u64 rg[4];
+            linear_tile<WT, MTS, 1, I, false, true>(AG, ep - 1, m0, M2, reinterpret_cast<const WT*>(L.w2), n0, D, nullptr,
+                                                    [&] { res_prefetch<MTS, true>(a.gxs, D, 0, m0, M2, n0, rg); }, red, a.fail, 5);
+            epi_residual<MTS>(red, m0, M2, n0, rg, true, ep - 2, a.gxs, D, 0, a.gxs, ep, nullptr, a.fail);
         }
         e_x = ep;
         AB_MARK();
     }
-    // wait for the content-token rows (2 s + 1) of the fast row tile mi: the slow row tiles that hold them
-    auto wait_hidden = [&](int mi) {
-        const int r_lo = 2 * (mi * 16 * MTF), r_hi = min(M2, 2 * (mi * 16 * MTF + 16 * MTF)) - 1;
-        for (int ts = r_lo / (16 * MTS); ts <= r_hi / (16 * MTS); ++ts) wait_flags(a.f_x + ts * XT + 12 * wave, 12, e_x, a.fail, 6);
-    };
     // ---- semantic-token logits (dual_ar_stream.py:1181-1186; the sample is discarded by every caller, :833) ----
     unsigned e_sem = 0;
     if (!a.skip_semantic) {
@@ -528,23 +563,24 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
         e_sem = ep;
         for (int u = wg; u < TMF * ST; u += G) {
             const int mi = u / ST, nj = u - mi * ST, m0 = mi * 16 * MTF, n0 = nj * 16;
-            linear_tile<WT, MTF, 1, D, true>(AHID, m0, B, reinterpret_cast<const WT*>(a.out_w), n0, a.vocab, a.out_norm, [&] { wait_hidden(mi); }, red);
-            for (int i = wave; i < MTF; i += 4) {
+            linear_tile<WT, MTF, 1, D, true, true>(AHID, e_x, m0, B, reinterpret_cast<const WT*>(a.out_w), n0, a.vocab, a.out_norm, [] {}, red, a.fail, 6);
+            if (wave < MTF) {
+                const int i = wave;
                 f32x4 t[1];
                 tile_sum<MTF, 1>(red, i, lane, t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + 16 * i + rq + r, n = n0 + col;
-                    if (m < B && n < a.vocab) st_sc1(a.slow_logits + (long)m * a.vocab + n, t[0][r] * row_inv<MTF, 1>(red, i, rq + r, D, 1e-5f));
+                    if (m < B && n < a.vocab) st_g(a.gsem + (long)m * SEMP + n, ep, t[0][r] * row_inv<MTF, 1>(red, i, rq + r, D, 1e-5f));
                 }
             }
-            publish(a.f_sem + mi * SEMT + nj, ep);
         }
         AB_MARK();
     }
 
     // ======================================= fast AR: 8 codebooks x 4 layers on B rows =======================================
-    unsigned e_row = 0;         // epoch of the previous codebook's sampler (which wrote the xf rows)
+    constexpr unsigned CBP = 5 * AR_FAST_LAYERS + 2;         // phases per codebook
+    unsigned e_row = 0;         // epoch of the previous codebook's sampler (which wrote the gxf rows)
     for (int cb = 0; cb < NCB; ++cb) {
         for (int l = 0; l < AR_FAST_LAYERS; ++l) {
             const ArLayerW& L = a.fast[l];
@@ -553,15 +589,12 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
             ++ep;
             for (int u = wg; u < TMF * QT; u += G) {
                 const int mi = u / QT, nj = u - mi * QT, m0 = mi * 16 * MTF, n0 = nj * 16;
-                auto waitf = [&] {
-                    if (from_slow) wait_hidden(mi);
-                    else if (first) wait_flags(a.f_row + m0, min(16 * MTF, B - m0), e_row, a.fail, 7);
-                    else wait_flags(a.f_xf + mi * XT + 12 * wave, 12, ep - 1, a.fail, 8);
-                };
-                linear_tile<WT, MTF, 1, D, true>(from_slow ? AHID : AXF, m0, B, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, waitf, red);
+                linear_tile<WT, MTF, 1, D, true, true>(from_slow ? AHID : AXF, from_slow ? e_x : first ? e_row : ep - 1, m0, B,
+                                                       reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, [] {}, red, a.fail, 7);
                 const int region = n0 / D, nn = n0 + col - region * D, d = nn & 63;
                 const float c = a.rope_fast[(cb * 32 + (d >> 1)) * 2], sn = a.rope_fast[(cb * 32 + (d >> 1)) * 2 + 1];
-                for (int i = wave; i < MTF; i += 4) {
+                if (wave < MTF) {
+                    const int i = wave;
                     f32x4 t[1];
                     tile_sum<MTF, 1>(red, i, lane, t);
 #pragma unroll
@@ -571,63 +604,75 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
                         const float pv = lane_xor_f<1>(v);
                         if (region < 2) v = (d & 1) ? v * c + pv * sn : v * c - pv * sn;
                         if (m < B) {
-                            st_sc1(a.qkvf + (long)m * 3 * D + n0 + col, v);
-                            if (region >= 1) st_sc1(a.kvf + (((long)l * B + m) * NCB + cb) * 2 * D + (n0 + col - D), v);
+                            st_g(a.gqkvf + (long)m * 3 * D + n0 + col, ep, v);
+                            if (region >= 1) st_g(a.gkvf + (((long)l * B + m) * NCB + cb) * 2 * D + (n0 + col - D), ep, v);
                         }
                     }
                 }
-                publish(a.f_qkvf + mi * QT + nj, ep);
             }
             AB_MARK();
-            // ---- FATT: attention over the <= 8 codebook positions, unit = stream (wave w: heads 3w .. 3w + 2) ----
+            // ---- FATT: attention over the <= 8 codebook positions, unit = stream (wave w: heads w, w + 8) ----
             ++ep;
             for (int u = wg; u < B; u += G) {
-                const int s = u, mi = s / (16 * MTF);
-                wait_flags(a.f_qkvf + mi * QT + 36 * wave, 36, ep - 1, a.fail, 9);
-                __syncthreads();
+                const int s = u;
+                __syncthreads();                   // the previous unit has read `red`
                 float* big = red;                  // [2304] this stream's q | k | v row
-                float* av = red + 3 * D;           // [768]
+                float* hist = red + 3 * D;         // [cb][k 768 | v 768] the earlier positions of this frame
+                float* av = hist + 7 * 2 * D;      // [768]
                 {
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.qkvf + (long)s * 3 * D, 0, 3 * D * 4, 0x00020000);
-                    for (int i = tid; i < 3 * D / 4; i += 256)
-                        *reinterpret_cast<float4*>(big + 4 * i) = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 16));
-                }
-                const float* kvg = a.kvf + (((long)l * B + s) * NCB) * 2 * D;         // [8][k 768 | v 768]
-                const int kg = lane >> 4, kli = lane & 15;
-                unsigned long long pk[3][2][2];
-                float pvv[3][7];
+                    // q | k | v of this position (tag: this layer's FQKV) and K / V of positions t < cb (tag: the same phase, cb - t codebooks ago)
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.gqkvf + (long)s * 3 * D, 0, 3 * D * 8, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.gkvf + (((long)l * B + s) * NCB) * 2 * D, 0, NCB * 2 * D * 8, 0x00020000);
+                    constexpr int NQ = 3 * D / 2, NH1 = 2 * D / 2;       // 16-byte pairs of the row, of one position
+                    const int nh = cb * NH1;
+                    v4i gq[3], gh[11];
+                    int spins = 0;
+                    while (true) {
+                        asm volatile("" ::: "memory");
+                        bool ok = true;
 #pragma unroll
-                for (int hh = 0; hh < 3; ++hh) {
-                    const int hb = (wave * 3 + hh) * 64;
-#pragma unroll
-                    for (int rnd = 0; rnd < 2; ++rnd) {
-                        const int t = kg + 4 * rnd;
-                        if (t < cb) {
-                            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(kvg + (long)t * 2 * D + hb + 4 * kli);
-                            pk[hh][rnd][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            pk[hh][rnd][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int k = 0; k < 3; ++k) {
+                            const int p = tid + k * NTH;
+                            if (p < NQ) {
+                                gq[k] = ld_g16(rs, p * 16);
+                                ok = ok && (unsigned)gq[k].y == ep - 1 && (unsigned)gq[k].w == ep - 1;
+                            }
                         }
+#pragma unroll
+                        for (int k = 0; k < 11; ++k) {
+                            const int p = tid + k * NTH;
+                            if (p < nh) {
+                                gh[k] = ld_g16(rh, p * 16);
+                                const unsigned want = ep - 1 - (unsigned)(cb - p / NH1) * CBP;
+                                ok = ok && (unsigned)gh[k].y == want && (unsigned)gh[k].w == want;
+                            }
+                        }
+                        if (__all(ok)) break;
+                        if (spin_over(spins, a.fail, 9)) break;
                     }
 #pragma unroll
-                    for (int t = 0; t < 7; ++t)
-                        if (t < cb) pvv[hh][t] = ld_sc1(kvg + (long)t * 2 * D + D + hb + lane);
+                    for (int k = 0; k < 3; ++k) {
+                        const int p = tid + k * NTH;
+                        if (p < NQ) *reinterpret_cast<float2*>(big + 2 * p) = make_float2(__int_as_float(gq[k].x), __int_as_float(gq[k].z));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) {
+                        const int p = tid + k * NTH;
+                        if (p < nh) *reinterpret_cast<float2*>(hist + 2 * p) = make_float2(__int_as_float(gh[k].x), __int_as_float(gh[k].z));
+                    }
                 }
                 __syncthreads();
-#pragma unroll
-                for (int hh = 0; hh < 3; ++hh) {
-                    const int hb = (wave * 3 + hh) * 64;
+                const int kg = lane >> 4, kli = lane & 15;
+                for (int h = wave; h < H; h += NWV) {
+                    const int hb = h * 64;
                     const float4 q4 = *reinterpret_cast<const float4*>(big + hb + 4 * kli);
                     float sc2[2];
 #pragma unroll
                     for (int rnd = 0; rnd < 2; ++rnd) {
                         const int t = kg + 4 * rnd;
                         float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (t < cb) {
-                            k4 = make_float4(__uint_as_float((unsigned)pk[hh][rnd][0]), __uint_as_float((unsigned)(pk[hh][rnd][0] >> 32)),
-                                             __uint_as_float((unsigned)pk[hh][rnd][1]), __uint_as_float((unsigned)(pk[hh][rnd][1] >> 32)));
-                        } else if (t == cb) {
-                            k4 = *reinterpret_cast<const float4*>(big + D + hb + 4 * kli);
-                        }
+                        if (t < cb) k4 = *reinterpret_cast<const float4*>(hist + t * 2 * D + hb + 4 * kli);
+                        else if (t == cb) k4 = *reinterpret_cast<const float4*>(big + D + hb + 4 * kli);
                         const float dot = row16_sum(q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w) * 0.125f;
                         sc2[rnd] = t <= cb ? dot : -INFINITY;
                     }
@@ -638,35 +683,36 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
 #pragma unroll
                     for (int t = 0; t < NCB; ++t) {
                         const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (t >> 2) ? e1 : e0), (t & 3) * 16));
-                        const float vd = t < cb ? (t < 7 ? pvv[hh][t < 7 ? t : 0] : 0.f) : big[2 * D + hb + lane];
-                        if (t <= cb) acc = fmaf(e, vd, acc);
+                        if (t <= cb) acc = fmaf(e, t < cb ? hist[t * 2 * D + D + hb + lane] : big[2 * D + hb + lane], acc);
                     }
                     av[hb + lane] = acc * inv;
                 }
                 __syncthreads();
-                for (int i = tid; i < D; i += 256) st_sc1(a.attf + (long)s * D + i, av[i]);
-                publish(a.f_attf + s, ep);
+                for (int i = tid; i < D; i += NTH) st_g(a.gattf + (long)s * D + i, ep, av[i]);
             }
             AB_MARK();
             // ---- FWO + residual ----
             ++ep;
             for (int u = wg; u < TMF * XT; u += G) {
                 const int mi = u / XT, nj = u - mi * XT, m0 = mi * 16 * MTF, n0 = nj * 16;
-                linear_tile<WT, MTF, 1, D, false>(AATTF, m0, B, reinterpret_cast<const WT*>(L.wo), n0, D, nullptr,
-                                                  [&] { wait_flags(a.f_attf + m0, min(16 * MTF, B - m0), ep - 1, a.fail, 10); }, red);
+                u64 rg[4];
+                linear_tile<WT, MTF, 1, D, false, true>(AATTF, ep - 1, m0, B, reinterpret_cast<const WT*>(L.wo), n0, D, nullptr,
+                                                        [&] {
+                                                            if (from_slow) res_prefetch<MTF, true>(a.gxs, 2 * D, D, m0, B, n0, rg);
+                                                            else res_prefetch<MTF, true>(a.gxf, D, 0, m0, B, n0, rg);
+                                                        }, red, a.fail, 10);
                 // hidden = pre-norm state of the content token (forward_generate :340-341): tap, and the fast AR's first input
-                if (from_slow) epi_residual<MTF>(red, m0, B, n0, a.xs, 2 * D, D, a.xf, a.hidden);
-                else epi_residual<MTF>(red, m0, B, n0, a.xf, D, 0, a.xf, nullptr);
-                publish(a.f_xf + mi * XT + nj, ep);
+                if (from_slow) epi_residual<MTF>(red, m0, B, n0, rg, true, e_x, a.gxs, 2 * D, D, a.gxf, ep, a.hidden, a.fail);
+                else epi_residual<MTF>(red, m0, B, n0, rg, true, first ? e_row : ep - 3, a.gxf, D, 0, a.gxf, ep, nullptr, a.fail);
             }
             AB_MARK();
             // ---- FW13 ----
             ++ep;
             for (int u = wg; u < TMF * GT; u += G) {
                 const int mi = u / GT, nj = u - mi * GT, m0 = mi * 16 * MTF, n0 = nj * 32;
-                linear_tile<WT, MTF, 2, D, true>(AXF, m0, B, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm,
-                                                 [&] { wait_flags(a.f_xf + mi * XT + 12 * wave, 12, ep - 1, a.fail, 11); }, red);
-                for (int i = wave; i < MTF; i += 4) {
+                linear_tile<WT, MTF, 2, D, true, true>(AXF, ep - 1, m0, B, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm, [] {}, red, a.fail, 11);
+                if (wave < MTF) {
+                    const int i = wave;
                     f32x4 t[2];
                     tile_sum<MTF, 2>(red, i, lane, t);
 #pragma unroll
@@ -674,20 +720,19 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
                         const int m = m0 + 16 * i + rq + r;
                         if (m >= B) continue;
                         const float inv = row_inv<MTF, 2>(red, i, rq + r, D, 1e-5f);
-                        st_sc1(a.gf + (long)m * I + nj * 16 + col, silu_f(t[0][r] * inv) * (t[1][r] * inv));
+                        st_g(a.ggf + (long)m * I + nj * 16 + col, ep, silu_f(t[0][r] * inv) * (t[1][r] * inv));
                     }
                 }
-                publish(a.f_gf + mi * GT + nj, ep);
             }
             AB_MARK();
             // ---- FW2 + residual ----
             ++ep;
             for (int u = wg; u < TMF * XT; u += G) {
                 const int mi = u / XT, nj = u - mi * XT, m0 = mi * 16 * MTF, n0 = nj * 16;
-                linear_tile<WT, MTF, 1, I, false>(AGF, m0, B, reinterpret_cast<const WT*>(L.w2), n0, D, nullptr,
-                                                  [&] { wait_flags(a.f_gf + mi * GT + 36 * wave, 36, ep - 1, a.fail, 12); }, red);
-                epi_residual<MTF>(red, m0, B, n0, a.xf, D, 0, a.xf, nullptr);
-                publish(a.f_xf + mi * XT + nj, ep);
+                u64 rg[4];
+                linear_tile<WT, MTF, 1, I, false, true>(AGF, ep - 1, m0, B, reinterpret_cast<const WT*>(L.w2), n0, D, nullptr,
+                                                        [&] { res_prefetch<MTF, true>(a.gxf, D, 0, m0, B, n0, rg); }, red, a.fail, 12);
+                epi_residual<MTF>(red, m0, B, n0, rg, true, ep - 2, a.gxf, D, 0, a.gxf, ep, nullptr, a.fail);
             }
             AB_MARK();
         }
@@ -695,73 +740,95 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
         ++ep;
         for (int u = wg; u < TMF * VT; u += G) {
             const int mi = u / VT, nj = u - mi * VT, m0 = mi * 16 * MTF, n0 = nj * 16;
-            linear_tile<WT, MTF, 1, D, true>(AXF, m0, B, reinterpret_cast<const WT*>(a.fast_out_w), n0, V, a.fast_norm,
-                                             [&] { wait_flags(a.f_xf + mi * XT + 12 * wave, 12, ep - 1, a.fail, 13); }, red);
-            for (int i = wave; i < MTF; i += 4) {
+            linear_tile<WT, MTF, 1, D, true, true>(AXF, ep - 1, m0, B, reinterpret_cast<const WT*>(a.fast_out_w), n0, V, a.fast_norm, [] {}, red, a.fail, 13);
+            if (wave < MTF) {
+                const int i = wave;
                 f32x4 t[1];
                 tile_sum<MTF, 1>(red, i, lane, t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + 16 * i + rq + r, n = n0 + col;
-                    if (m < B && n < V) st_sc1(a.fast_logits + ((long)m * NCB + cb) * V + n, t[0][r] * row_inv<MTF, 1>(red, i, rq + r, D, 1e-5f));
+                    if (m < B && n < V) st_g(a.glog + (long)m * LOGP + n, ep, t[0][r] * row_inv<MTF, 1>(red, i, rq + r, D, 1e-5f));
                 }
             }
-            publish(a.f_log + mi * LOGT + nj, ep);
         }
         AB_MARK();
         // ---- SAMPLE: nucleus sample of one stream per unit, next input row = fast_emb[token] ----
         ++ep;
-        for (int u = wg; u < B; u += G) {
-            const int s = u, mi = s / (16 * MTF);
-            wait_flags(a.f_log + mi * LOGT, VT, ep - 1, a.fail, 14);
-            const float* lg = a.fast_logits + ((long)s * NCB + cb) * V;
-            float lv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lv[r] = (tid + 256 * r) < V ? ld_sc1(lg + tid + 256 * r) : -INFINITY;
+        for (int u = wg, k = 0; u < B; u += G, ++k) {
+            const int s = u;
+            float lv[2];
+            {
+                const u64* lg = a.glog + (long)s * LOGP;
+                int spins = 0;
+                while (true) {
+                    u64 g0 = 0, g1 = 0;
+                    bool ok = true;
+                    if (tid < V) { g0 = ld_g(lg + tid); ok = g_tag(g0) == ep - 1; }
+                    if (tid + NTH < V) { g1 = ld_g(lg + tid + NTH); ok = ok && g_tag(g1) == ep - 1; }
+                    lv[0] = tid < V ? g_val(g0) : -INFINITY;
+                    lv[1] = tid + NTH < V ? g_val(g1) : -INFINITY;
+                    if (__all(ok)) break;
+                    if (spin_over(spins, a.fail, 14)) break;
+                }
+            }
+            if (tid < V) a.fast_logits[((long)s * NCB + cb) * V + tid] = lv[0];
+            if (tid + NTH < V) a.fast_logits[((long)s * NCB + cb) * V + tid + NTH] = lv[1];
+            __syncthreads();                   // the previous unit has read `red`
             const float* nz = a.noise ? a.noise + (long)s * a.noise_ld + a.vocab + (long)cb * V : nullptr;
-            const int raw = nucleus_sample<4, 4>(lv, V, tid, nz, a.seed[s], a.nframes[s], 1, cb * V, a.inv_temp, a.top_p, reinterpret_cast<double*>(red));
+            const int raw = nucleus_sample<NWV, 2>(lv, V, tid, nz, a.seed[s], a.nframes[s], 1, cb * V, a.inv_temp, a.top_p, reinterpret_cast<double*>(red));
             int t = raw;
             if (use_forced) t = a.forced[((long)s * NCB + cb) * a.chunk + a.ci];
-            if (tid == 0) { a.tok_raw[s * NCB + cb] = raw; st_sc1(a.tok + s * NCB + cb, t); }
+            if (tid == 0) { a.tok_raw[s * NCB + cb] = raw; a.tok[s * NCB + cb] = t; toks[k * NCB + cb] = t; }
             if (cb + 1 < NCB)
-                for (int i = tid; i < D; i += 256) st_sc1(a.xf + (long)s * D + i, a.fast_emb[(long)t * D + i]);
-            publish(a.f_row + s, ep);
+                for (int i = tid; i < D; i += NTH) st_g(a.gxf + (long)s * D + i, ep, a.fast_emb[(long)t * D + i]);
         }
         e_row = ep;
         AB_MARK();
     }
 
     // ======================================= frame bookkeeping, unit = stream =======================================
-    for (int u = wg; u < B; u += G) {
+    __syncthreads();
+    for (int u = wg, k = 0; u < B; u += G, ++k) {
         const int s = u;
-        wait_flags(a.f_row + s, 1, e_row, a.fail, 15);
-        int* toks = reinterpret_cast<int*>(red + 512);       // (the samplers' scratch sits below)
-        if (tid < NCB) toks[tid] = ld_sc1(a.tok + s * NCB + tid);
-        __syncthreads();
+        const int* tk = toks + k * NCB;
         const int frame = a.nframes[s];
         // cached_new_audio_emb = embed(codes) (dual_ar_stream.py:834, 245-255): codebooks summed in order
-        for (int i = tid; i < D; i += 256) {
+        for (int i = tid; i < D; i += NTH) {
             float acc = 0.f;
 #pragma unroll
-            for (int q = 0; q < NCB; ++q) acc += a.codebook_emb[((long)toks[q] + (long)q * V) * D + i];
+            for (int q = 0; q < NCB; ++q) acc += a.codebook_emb[((long)tk[q] + (long)q * V) * D + i];
             a.cached_audio_emb[(long)s * D + i] = acc;
         }
         if (tid < NCB) {
-            a.pred_hist[((long)s * NCB + tid) * a.hist_cap + (frame & (a.hist_cap - 1))] = toks[tid];
-            a.step_audio[((long)s * NCB + tid) * a.chunk + a.ci] = toks[tid];
+            a.pred_hist[((long)s * NCB + tid) * a.hist_cap + (frame & (a.hist_cap - 1))] = tk[tid];
+            a.step_audio[((long)s * NCB + tid) * a.chunk + a.ci] = tk[tid];
         }
         if (!a.skip_semantic) {
-            const int mi = s / (16 * MTF);
-            for (int k = 0; k < (a.vocab + 15) / 16; k += 64) wait_flags(a.f_sem + mi * SEMT + k, min(64, (a.vocab + 15) / 16 - k), e_sem, a.fail, 16);
-            float lv[32];
+            float lv[16];
+            const u64* lg = a.gsem + (long)s * SEMP;
+            int spins = 0;
+            while (true) {
+                bool ok = true;
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int e = tid + 256 * r;
-                lv[r] = e < a.vocab ? ld_sc1(a.slow_logits + (long)s * a.vocab + e) : -INFINITY;
+                for (int r = 0; r < 16; ++r) {
+                    const int e = tid + NTH * r;
+                    lv[r] = -INFINITY;
+                    if (e < a.vocab) {
+                        const u64 g = ld_g(lg + e);
+                        ok = ok && g_tag(g) == e_sem;
+                        lv[r] = g_val(g);
+                    }
+                }
+                if (__all(ok)) break;
+                if (spin_over(spins, a.fail, 16)) break;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (tid + NTH * r < a.vocab) a.slow_logits[(long)s * a.vocab + tid + NTH * r] = lv[r];
             __syncthreads();
-            const int sm = nucleus_sample<4, 32>(lv, a.vocab, tid, a.noise ? a.noise + (long)s * a.noise_ld : nullptr, a.seed[s], frame, 0, 0, a.inv_temp,
-                                                 a.top_p, reinterpret_cast<double*>(red));
+            const int sm = nucleus_sample<NWV, 16>(lv, a.vocab, tid, a.noise ? a.noise + (long)s * a.noise_ld : nullptr, a.seed[s], frame, 0, 0, a.inv_temp,
+                                                   a.top_p, reinterpret_cast<double*>(red));
             if (tid == 0) a.sem[s] = sm;
         }
         __syncthreads();
@@ -783,26 +850,32 @@ __global__ __launch_bounds__(256, 2) void ar_batch_kernel(const ArBatchArgs a) {
 
 constexpr size_t lds_floats(int MTS, int MTF) {
     const size_t lin = red_floats(MTS > MTF ? MTS : MTF, 2);
-    const size_t att = 2 * 16 * 68, fatt = 4 * D, smp = 256;
+    const size_t att = 2 * 4 * NWV * 68, fatt = 3 * D + 7 * 2 * D + D, smp = 256;
     size_t m = lin;
     if (att > m) m = att;
     if (fatt > m) m = fatt;
     if (smp > m) m = smp;
-    return m;
+    return HDR + m;
 }
 
 template <typename WT, typename KVT, int MTS, int MTF>
 int launch_cfg(const ArBatchArgs& a, hipStream_t st) {
     const size_t smem = lds_floats(MTS, MTF) * sizeof(float);
-    hipLaunchKernelGGL((ar_batch_kernel<WT, KVT, MTS, MTF>), dim3(a.G), dim3(256), smem, st, a);
+    static bool attr_set = false;              // (more than 64 KiB of dynamic LDS needs the opt-in; idempotent, so a race only repeats it)
+    if (!attr_set) {
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_batch_kernel<WT, KVT, MTS, MTF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ar_batch_kernel<WT, KVT, MTS, MTF>), dim3(a.G), dim3(NTH), smem, st, a);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 
 template <typename WT, typename KVT, int MTS, int MTF>
 int occupancy_cfg(int* blocks_per_cu) {
-    SVA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)ar_batch_kernel<WT, KVT, MTS, MTF>, 256,
-                                                         lds_floats(MTS, MTF) * sizeof(float)));
+    const size_t smem = lds_floats(MTS, MTF) * sizeof(float);
+    SVA_HIP(hipFuncSetAttribute((const void*)ar_batch_kernel<WT, KVT, MTS, MTF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    SVA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)ar_batch_kernel<WT, KVT, MTS, MTF>, NTH, smem));
     return 0;
 }
 
@@ -814,15 +887,14 @@ void ar_batch_tiles(int B, int* mts, int* mtf) {
     *mtf = B <= 16 ? 1 : B <= 32 ? 2 : 4;
 }
 
-size_t ar_batch_flag_words(int B, size_t offs[11]) {
-    int mts, mtf;
-    ar_batch_tiles(B, &mts, &mtf);
-    const size_t TMS = (2 * B + 16 * mts - 1) / (16 * mts), TMF = (B + 16 * mtf - 1) / (16 * mtf);
-    const size_t sizes[11] = {TMS * XT, TMS * QT, TMS * GT, (size_t)H * B, TMF * XT, TMF * QT, TMF * GT, (size_t)B, TMF * LOGT, (size_t)B, TMF * SEMT};
+size_t ar_batch_granule_words(int B, size_t offs[AR_BATCH_NBUF]) {
+    const size_t b = (size_t)B;
+    const size_t sizes[AR_BATCH_NBUF] = {2 * b * D, 2 * b * 3 * D, 2 * b * D, 2 * b * I, b * D, b * 3 * D, b * D, b * I,
+                                         (size_t)AR_FAST_LAYERS * b * NCB * 2 * D, b * LOGP, b * SEMP};
     size_t o = 0;
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < AR_BATCH_NBUF; ++i) {
         offs[i] = o;
-        o += (sizes[i] + 63) / 64 * 64;
+        o += (sizes[i] + 31) / 32 * 32;
     }
     return o;
 }
@@ -855,7 +927,8 @@ int ar_batch_occupancy(int wt_half, int B_, int* blocks_per_cu) { AB_DISPATCH(oc
 int launch_ar_batch(const ArBatchArgs& a, int wt_half, hipStream_t st) {
     const int B_ = a.B;
     SVA_CHECK(a.B >= 1 && a.B <= AR_BATCH_MAX_STREAMS && a.G >= 1, "ar_batch: 1..128 streams");
-    SVA_CHECK(a.vocab <= 8192 && a.vocab <= SEMT * 16 && a.codebook_size <= 1024 && a.codebook_size <= LOGT * 16 && (a.hist_cap & (a.hist_cap - 1)) == 0,
+    SVA_CHECK((a.B + a.G - 1) / a.G <= 4, "ar_batch: at most 4 streams per workgroup");
+    SVA_CHECK(a.vocab <= SEMP && a.codebook_size <= 2 * NTH && a.codebook_size <= LOGP && (a.hist_cap & (a.hist_cap - 1)) == 0,
               "ar_batch: unsupported head sizes");
     AB_DISPATCH(launch_cfg, a, st);
 }

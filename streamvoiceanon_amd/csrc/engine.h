@@ -217,10 +217,9 @@ struct sva_batch {
     // batched persistent decode kernel (ar_batch.hip): every stream of the batch in ONE launch per frame
     bool use_abatch = false;
     int abatch_G = 0;                      // workgroups of its launch (all co-resident: checked at batch creation)
-    unsigned* d_ab_flags = nullptr;        // hand-off flags, arrays at ab_offs (ar_batch_flag_words)
+    unsigned long long* d_ab_gran = nullptr;      // hand-off granules, arrays at ab_offs (ar_batch_granule_words)
     size_t ab_offs[11] = {};
     unsigned* d_ab_epoch = nullptr;        // [2] running phase counter | exit counter
-    float *ab_qkvf = nullptr, *ab_attf = nullptr, *ab_gf = nullptr, *ab_kvf = nullptr;      // fast-AR activations [B][2304 | 768 | 2304], K/V [4][B][8][1536]
     bool kv_half = false;                  // slow KV cache holds __half (ar_dtype = 1)
     sva::DevPool allocs;
 

@@ -1322,12 +1322,11 @@ int ar_decode_frame_batch(sva_batch* b, int ci) {
     a.B = b->B; a.G = b->abatch_G;
     a.cached_audio_emb = b->cached_audio_emb; a.last_pos = b->d_last_pos; a.nframes = b->d_nframes; a.seed = b->d_seed;
     a.kv_slow = b->kv_slow; a.kv_layer_stride = b->kv_slow_layer; a.kv_slot_stride = b->kv_slow_slot; a.S = c.max_seq_len;
-    a.xs = b->ax; a.qkv = b->aqkv; a.att = b->aatt; a.g = b->ag;
-    a.xf = b->xf; a.qkvf = b->ab_qkvf; a.attf = b->ab_attf; a.gf = b->ab_gf; a.kvf = b->ab_kvf;
-    unsigned* F = b->d_ab_flags;
+    a.xs_in = b->ax;
+    unsigned long long* Gr = b->d_ab_gran;
     const size_t* o = b->ab_offs;
-    a.f_x = F + o[0]; a.f_qkv = F + o[1]; a.f_g = F + o[2]; a.f_att = F + o[3]; a.f_xf = F + o[4]; a.f_qkvf = F + o[5]; a.f_gf = F + o[6];
-    a.f_attf = F + o[7]; a.f_log = F + o[8]; a.f_row = F + o[9]; a.f_sem = F + o[10];
+    a.gxs = Gr + o[0]; a.gqkv = Gr + o[1]; a.gatt = Gr + o[2]; a.gg = Gr + o[3]; a.gxf = Gr + o[4]; a.gqkvf = Gr + o[5]; a.gattf = Gr + o[6];
+    a.ggf = Gr + o[7]; a.gkvf = Gr + o[8]; a.glog = Gr + o[9]; a.gsem = Gr + o[10];
     a.epoch = b->d_ab_epoch; a.done = b->d_ab_epoch + 1; a.fail = b->d_ar_fail; a.dbg = b->d_ar_dbg;
     a.slow_logits = b->slow_logits; a.fast_logits = b->fast_logits; a.hidden = b->hidden;
     a.sem = b->d_sem; a.tok_raw = b->d_tok_raw; a.tok = b->d_tok; a.step_audio = b->d_step_audio; a.pred_hist = b->d_pred_hist;
@@ -2030,7 +2029,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         SVA_TRY(ar_batch_occupancy(c.ar_dtype == 1, B, &per_cu));
         SVA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
         const int avail = b->ar_partitioned ? std::min(cus, b->ar_cus > 0 ? b->ar_cus : 96) : cus;
-        const int cap = std::min(per_cu, 2) * avail;             // (the occupancy query over-reports by one on SGPR-heavy kernels: never more than 2 relied on)
+        const int cap = std::min(per_cu, 1) * avail;             // 8 waves with up to 256 registers each: one workgroup per CU (the occupancy query's answer beyond 1 is not relied on)
         int G = ar_batch_wanted_workgroups(B);
         if (debug_options().ar_batch_wgs > 0) G = debug_options().ar_batch_wgs;
         G = std::min(G, cap);
@@ -2038,14 +2037,11 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         b->abatch_G = G;
     }
     if (b->use_abatch) {
-        const size_t words = ar_batch_flag_words(B, b->ab_offs);
-        SVA_TRY(dev_alloc(A, &b->d_ab_flags, words));
+        static_assert(AR_BATCH_NBUF == 11, "ab_offs");
+        const size_t words = ar_batch_granule_words(B, b->ab_offs);
+        SVA_TRY(dev_alloc(A, &b->d_ab_gran, words));             // zeroed: tag 0 is never a live epoch (the counter starts at 1)
         SVA_TRY(dev_alloc(A, &b->d_ab_epoch, 2));
         if (!b->d_ar_fail) SVA_TRY(dev_alloc(A, &b->d_ar_fail, 1));
-        SVA_TRY(dev_alloc(A, &b->ab_qkvf, (size_t)B * 3 * D));
-        SVA_TRY(dev_alloc(A, &b->ab_attf, (size_t)B * D));
-        SVA_TRY(dev_alloc(A, &b->ab_gf, (size_t)B * c.ar_inter));
-        SVA_TRY(dev_alloc(A, &b->ab_kvf, (size_t)AR_FAST_LAYERS * B * 8 * 2 * D));
         if (debug_options().ar_timing && !b->d_ar_dbg) SVA_TRY(dev_alloc(A, &b->d_ar_dbg, 1024));
     }
     SVA_TRY(dev_alloc(A, &b->cached_audio_emb, (size_t)B * D));

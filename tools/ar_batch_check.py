@@ -13,7 +13,9 @@ if os.environ.get("TIMING", "1") == "1":
     os.environ["SVA_DEBUG"] = "ar_timing=1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch
 
+torch.cuda.init()          # torch's HIP runtime must see the device before the engine's does
 from streamvoiceanon_amd import engine as E, specs, synth_weights as sw
 from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
 
@@ -75,7 +77,6 @@ def run(B, mode, forced=None, chunk=1, timing=False):
 
 
 def throughput(B, mode, chunk=1, K=60):
-    import torch
     lib.sva_debug_configure(mode.encode())
     b = E.Batch(eng, n_streams=B, chunk_frames=chunk, pipeline=True)
     for s in range(B):
