@@ -21,6 +21,11 @@
 //     fragment matches.  One memory round trip per edge: no flag words, no drains, no fences; nothing depends on workgroup
 //     placement or dispatch order.  (The first version of this kernel published a flag per tile behind a drain + barrier and polled
 //     the flag before loading the tile: three dependent round trips, 5.5-6 us per phase, 2.2-2.4 ms per frame at 8-12 streams.)
+//     Buffers that feed a linear phase are laid out FRAGMENT-MAJOR: element (row m, k) sits at granule
+//     (((k >> 3) * 4 + ((k >> 1) & 3)) * ROWS + m) * 2 + (k & 1), so that one 16-byte load instruction of a wave (lane = row x
+//     k-octet, the MFMA operand layout) reads whole 256-byte runs -- 16 rows x 2 granules -- instead of 16 bytes out of every
+//     64-byte row fragment: every unit of a phase re-reads the whole row tile (48-144 units x 16 MT rows x K x 8 bytes: as many
+//     bytes as the weights from 8 streams on), and these sc1 reads are served past the L2, a cache line at a time.
 //     All waits are bounded (timeout -> *fail, the kernel runs to its end with garbage instead of hanging).  A buffer is
 //     rewritten only after every reader of its previous contents has finished: every unit of a consuming phase reads ALL column
 //     tiles of its row tile, and the next writer's inputs depend (transitively) on the outputs of all those units.
@@ -41,7 +46,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int NWV = 8, NTH = NWV * 64;             // waves / threads per workgroup
 constexpr int SPIN_LIMIT = 1 << 15;                // polls (a memory round trip each) before a wait gives up: tens of ms
 constexpr int QT = 3 * D / 16, XT = D / 16, GT = I / 16;       // column tiles of the qkv (144), x / att (48) and SwiGLU (144) buffers
-constexpr int HDR = 64;                            // LDS header (floats): sampled tokens of the workgroup's streams
+constexpr int HDR = 64 + 2 * AR_BATCH_MAX_STREAMS;  // LDS header (words): sampled tokens of the workgroup's streams [8][8], positions of the 2 B new tokens
 constexpr int LOGP = 1024, SEMP = 8192;            // row pitch (granules) of the codebook / semantic logits
 
 __device__ __forceinline__ void st_g(u64* p, unsigned ep, float v) { store_granule(p, ep, v); }
@@ -49,17 +54,27 @@ __device__ __forceinline__ u64 ld_g(const u64* p) { return __hip_atomic_load(p, 
 __device__ __forceinline__ float g_val(u64 g) { return __uint_as_float((unsigned)g); }
 __device__ __forceinline__ unsigned g_tag(u64 g) { return (unsigned)(g >> 32); }
 
-// A operand of a linear phase: rows of a granule buffer written earlier in this launch (sc1 loads), or of a plain fp32 buffer
-// written by an earlier launch
+// A fragment-major granule buffer of ROWS rows (see the header): logical row m lives at buffer row m * rs + ro
+struct GBuf {
+    u64* p;
+    int rows, rs, ro;
+};
+__device__ __forceinline__ long gidx(const GBuf& b, int m, int k) {
+    return ((long)((k >> 3) * 4 + ((k >> 1) & 3)) * b.rows + (m * b.rs + b.ro)) * 2 + (k & 1);
+}
+// A operand of a linear phase: a fragment-major granule buffer written earlier in this launch (sc1 loads; row_stride / off = bytes of
+// one buffer row / of the view's first row inside a 16-byte column of ROWS pairs, kstep = bytes between consecutive 16-byte pieces of
+// a k-octet), or plain fp32 rows written by an earlier launch (row_stride / off in bytes)
 struct ASrc {
     __amdgpu_buffer_rsrc_t rs;
-    int row_stride, off;           // bytes
+    int row_stride, off, kstep;
 };
-__device__ __forceinline__ ASrc make_gsrc(const u64* base, long elems, int row_stride_elems, int off_elems) {
+__device__ __forceinline__ ASrc make_gsrc(const GBuf& b, int K) {
     ASrc a;
-    a.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(base), 0, (int)(elems * 8), 0x00020000);
-    a.row_stride = row_stride_elems * 8;
-    a.off = off_elems * 8;
+    a.rs = __builtin_amdgcn_make_buffer_rsrc(b.p, 0, (int)((long)b.rows * K * 8), 0x00020000);
+    a.row_stride = b.rs * 16;
+    a.off = b.ro * 16;
+    a.kstep = b.rows * 16;
     return a;
 }
 __device__ __forceinline__ ASrc make_psrc(const float* base, long elems, int row_stride_elems, int off_elems) {
@@ -67,6 +82,7 @@ __device__ __forceinline__ ASrc make_psrc(const float* base, long elems, int row
     a.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
     a.row_stride = row_stride_elems * 4;
     a.off = off_elems * 4;
+    a.kstep = 0;
     return a;
 }
 __device__ __forceinline__ v4i ld_g16(const __amdgpu_buffer_rsrc_t& rs, int voff) {
@@ -74,6 +90,15 @@ __device__ __forceinline__ v4i ld_g16(const __amdgpu_buffer_rsrc_t& rs, int voff
 }
 __device__ __forceinline__ float4 ld_p16(const __amdgpu_buffer_rsrc_t& rs, int voff) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+}
+
+// the thread index as a value the optimiser cannot see through: per-lane offsets derived from it stay inside the phase that uses them
+// (from the plain threadIdx.x they are hoisted out of the layer loops, live through the whole kernel and end up in scratch, where
+// every reload waits for all loads requested before it -- the in-order return that makes the weight prefetches free otherwise)
+__device__ __forceinline__ int otid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
 }
 
 // bounded poll bookkeeping of one wave: returns true when the wait must end (timeout, or another wait timed out earlier)
@@ -84,6 +109,30 @@ __device__ __forceinline__ bool spin_over(int& spins, int* fail, int code) {
         return true;
     }
     return (spins & 7) == 0 && *reinterpret_cast<volatile int*>(fail) != 0;
+}
+
+// L2 prefetch of the weight rows [n0, n0 + ncols) x K of a LATER unit of this workgroup: one 4-byte load per 128-byte line, results
+// never used (kept in pf until the next call: by then a completed poll has proven them landed).  The unit's own 16/32-byte loads then hit
+// this XCD's L2 instead of waiting for HBM on the critical path between two hand-offs.
+struct Pf { int v0 = 0, v1 = 0, v2 = 0; };
+__device__ __forceinline__ void pf_retire(Pf& pf) { asm volatile("" :: "v"(pf.v0), "v"(pf.v1), "v"(pf.v2)); }
+template <typename WT>
+__device__ __forceinline__ void touch_w(Pf& pf, const void* W, int n0, int ncols, int N, int K) {
+    pf_retire(pf);
+    const int t0 = otid();
+    const int lpr = K * (int)sizeof(WT) / 128, total = ncols * lpr;            // <= 32 x 24 or 16 x 72 lines: at most 3 per thread
+    const char* base = reinterpret_cast<const char*>(W);
+    auto one = [&](int i, int& dst) {
+        if (i < total) {
+            const int r = i / lpr, cidx = i - r * lpr;
+            int n = n0 + r;
+            if (n > N - 1) n = N - 1;
+            dst = *reinterpret_cast<const int*>(base + (long)n * K * sizeof(WT) + cidx * 128);
+        }
+    };
+    one(t0, pf.v0);
+    one(t0 + NTH, pf.v1);
+    one(t0 + 2 * NTH, pf.v2);
 }
 
 // eight weights of one row per lane
@@ -166,44 +215,67 @@ __device__ __forceinline__ void mma_block(const AOps<WT, MT>& o, const WReg<WT> 
     }
 }
 
+// SVA_DEBUG=ar_timing=1: stamps of one unit (thread 0 of workgroup 0)
+struct Tm {
+    bool on = false;
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    int sweeps = 0;
+};
+
 // Partial tiles of C[m0 .. m0 + 16 MT) x [n0 .. n0 + 16 NT) = A[rows] (x RMSNorm weight) . W[cols]^T, K split over the 8 waves; on
 // return the per-wave partial tiles sit in `red` ([8][MT * NT][64][4] floats, then [8][MT][16] row sums of squares) behind a barrier.
-// GRAN: A is a granule buffer whose tags must equal `want`; otherwise plain fp32 rows of an earlier launch.  pre() runs in every
-// wave after its weight loads are requested and before its first activation load (prefetch of what the epilogue needs).
-template <typename WT, int MT, int NT, int K, bool RMS, bool GRAN, typename PreF>
+// GRAN: A is a granule buffer whose tags must equal `want`; otherwise plain fp32 rows of an earlier launch.  The wave's K slice is
+// worked in chunks of ACH 32-wide blocks: the weights of the first two chunks are requested up front (BEFORE the input is looked at:
+// they overlap the hand-off; an earlier unit's post() has pulled them into this XCD's L2), chunk c + 2 when chunk c has been
+// multiplied.  pre() runs in every wave after the first weight requests and before the first activation load (prefetch of what the
+// epilogue needs); post() once the wave's last activation chunk has landed (L2 prefetch of a later unit's weights: nothing of this
+// unit may queue behind it -- loads return in order, so the epilogue must not wait for any load of its own).
+template <typename WT, int MT, int NT, int K, bool RMS, bool GRAN, typename PreF, typename PostF>
 __device__ __forceinline__ void linear_tile(const ASrc& A, unsigned want, int m0, int M, const WT* __restrict__ W, int n0, int N,
-                                            const float* __restrict__ rms_w, PreF&& pre, float* red, int* fail, int code) {
+                                            const float* __restrict__ rms_w, PreF&& pre, PostF&& post, float* red, int* fail, int code, Tm& tm) {
+    if (tm.on) tm.t0 = wall_clock64();
     constexpr int NKW = K / (32 * NWV);                 // 32-wide K blocks per wave: 3 (K = 768) or 9 (K = 2304)
     constexpr int ACH = MT >= 4 ? 1 : 3;                // K blocks of A requested (and validated) together
-    constexpr int ES = GRAN ? 8 : 4;
+    constexpr int NCH = NKW / ACH;
     static_assert(K % (32 * NWV) == 0 && NKW % ACH == 0, "K blocks per wave");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fk = lane >> 4;
+    // (an opaque copy of the thread index: otherwise every per-lane offset of every phase is hoisted out of the layer loops and
+    // lives -- spilled to scratch -- through the whole kernel; a scratch reload waits for everything requested before it)
+    const int tid_ = otid();
+    const int lane = tid_ & 63, wave = tid_ >> 6, fr = lane & 15, fk = lane >> 4;
     const int kbase = wave * (K / NWV) + 8 * fk;
-    WReg<WT> wv[NKW][NT];
-    float4 nv[NKW][2];
+    WReg<WT> wv[2][ACH][NT];
+    float4 nv[2][ACH][2];
+    const WT* wp[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         int n = n0 + 16 * j + fr;
         if (n > N - 1) n = N - 1;
-        const WT* wp = W + (long)n * K + kbase;
-#pragma unroll
-        for (int it = 0; it < NKW; ++it) wv[it][j].load(wp + it * 32);
+        wp[j] = W + (long)n * K + kbase;
     }
-    if constexpr (RMS) {
+    auto issue_w = [&](int buf, int ch) {
 #pragma unroll
-        for (int it = 0; it < NKW; ++it) {
-            nv[it][0] = *reinterpret_cast<const float4*>(rms_w + kbase + it * 32);
-            nv[it][1] = *reinterpret_cast<const float4*>(rms_w + kbase + it * 32 + 4);
+        for (int d = 0; d < ACH; ++d) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wv[buf][d][j].load(wp[j] + (ch * ACH + d) * 32);
+            if constexpr (RMS) {
+                nv[buf][d][0] = *reinterpret_cast<const float4*>(rms_w + kbase + (ch * ACH + d) * 32);
+                nv[buf][d][1] = *reinterpret_cast<const float4*>(rms_w + kbase + (ch * ACH + d) * 32 + 4);
+            }
         }
-    }
+    };
+    issue_w(0, 0);
+    if constexpr (NCH > 1) issue_w(1, 1);
     int aoff[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int m = m0 + 16 * i + fr;
         if (m > M - 1) m = M - 1;
-        aoff[i] = A.off + m * A.row_stride + kbase * ES;
+        // granules: piece q of k-octet o at ((o * 4 + q) * ROWS + row) * 16 bytes; this lane's octets: wave * (K / 64) + fk + 4 * block
+        aoff[i] = GRAN ? A.off + m * A.row_stride + (wave * (K / 64) + fk) * 4 * A.kstep : A.off + m * A.row_stride + kbase * 4;
     }
     pre();
+    if (tm.on) tm.t1 = wall_clock64();
+    int sweeps = 0;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -213,7 +285,8 @@ __device__ __forceinline__ void linear_tile(const ASrc& A, unsigned want, int m0
 #pragma unroll
     for (int i = 0; i < MT; ++i) ssq[i] = 0.f;
 #pragma unroll
-    for (int c = 0; c < NKW; c += ACH) {
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = ch * ACH;
         float4 av[ACH][MT][2];
         if constexpr (GRAN) {
             v4i g[ACH][MT][4];
@@ -225,16 +298,29 @@ __device__ __forceinline__ void linear_tile(const ASrc& A, unsigned want, int m0
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) g[d][i][q] = ld_g16(A.rs, aoff[i] + (c + d) * 256 + q * 16);
+                        for (int q = 0; q < 4; ++q) g[d][i][q] = ld_g16(A.rs, aoff[i] + ((c + d) * 16 + q) * A.kstep);
                 bool ok = true;
 #pragma unroll
                 for (int d = 0; d < ACH; ++d)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) ok = ok && (unsigned)g[d][i][q].y == want && (unsigned)g[d][i][q].w == want;
+                        for (int q = 0; q < 4; ++q) ok = ok & ((unsigned)g[d][i][q].y == want) & ((unsigned)g[d][i][q].w == want);
+                if (tm.on && ch == 0 && sweeps == 0) tm.t2 = wall_clock64();
+                ++sweeps;
                 if (__all(ok)) break;
                 if (spin_over(spins, fail, code)) break;
+                // not there yet: wait on ONE piece per lane with pauses (a full sweep per poll from every waiting wave of the chip is
+                // terabytes per second of fabric traffic beside the producers' weight streams), then sweep again
+                bool over = false;
+                while (true) {
+                    __builtin_amdgcn_s_sleep(8);
+                    asm volatile("" ::: "memory");
+                    const v4i t = ld_g16(A.rs, aoff[MT - 1] + ((c + ACH - 1) * 16 + 3) * A.kstep);
+                    if (__all(((unsigned)t.y == want) & ((unsigned)t.w == want))) break;
+                    if (spin_over(spins, fail, code)) { over = true; break; }
+                }
+                if (over) break;
             }
 #pragma unroll
             for (int d = 0; d < ACH; ++d)
@@ -252,12 +338,17 @@ __device__ __forceinline__ void linear_tile(const ASrc& A, unsigned want, int m0
                     av[d][i][1] = ld_p16(A.rs, aoff[i] + (c + d) * 128 + 16);
                 }
         }
+        if (ch == NCH - 1) {
+            if (tm.on) { tm.t3 = wall_clock64(); tm.sweeps = sweeps; }
+            post();
+        }
 #pragma unroll
         for (int d = 0; d < ACH; ++d) {
             AOps<WT, MT> o;
-            prep_block<WT, MT, RMS>(av[d], nv[c + d], o, ssq);
-            mma_block<WT, MT, NT>(o, wv[c + d], acc);
+            prep_block<WT, MT, RMS>(av[d], nv[ch & 1][d], o, ssq);
+            mma_block<WT, MT, NT>(o, wv[ch & 1][d], acc);
         }
+        if (ch + 2 < NCH) issue_w(ch & 1, ch + 2);
     }
     __syncthreads();            // the previous unit's epilogue has read `red`
     // cross-wave reduction of the K slices
@@ -276,6 +367,7 @@ __device__ __forceinline__ void linear_tile(const ASrc& A, unsigned want, int m0
         }
     }
     __syncthreads();
+    if (tm.on) tm.t4 = wall_clock64();
 }
 
 // sum of the eight waves' partials of row sub-tile i: t[j][r] = element (row 4 (lane >> 4) + r, column lane & 15) of column tile j
@@ -302,26 +394,36 @@ constexpr size_t red_floats(int MT, int NT) { return (size_t)NWV * MT * NT * 256
 
 // residual granules of the lane's four rows of sub-tile i = wave, requested ahead of the unit's K loop (plain fp32 rows of an earlier
 // launch when !GRAN).  They are usually in place by then, but nothing this workgroup has seen proves it: epi_residual checks the tags
-template <int MT, bool GRAN>
-__device__ __forceinline__ void res_prefetch(const void* res, int row_stride, int row_off, int m0, int M, int n0, u64 (&rg)[4]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, rq = (lane >> 4) * 4;
+template <int MT>
+__device__ __forceinline__ void res_prefetch(const GBuf& res, int m0, int M, int n0, u64 (&rg)[4]) {
+    const int t_ = otid(), lane = t_ & 63, wave = t_ >> 6, col = lane & 15, rq = (lane >> 4) * 4;
     if (wave < MT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int m = m0 + 16 * wave + rq + r;
             if (m > M - 1) m = M - 1;
-            const long e = (long)m * row_stride + row_off + n0 + col;
-            if constexpr (GRAN) rg[r] = ld_g(reinterpret_cast<const u64*>(res) + e);
-            else rg[r] = (u64)__float_as_uint(reinterpret_cast<const float*>(res)[e]);
+            rg[r] = ld_g(res.p + gidx(res, m, n0 + col));
+        }
+    }
+}
+template <int MT>
+__device__ __forceinline__ void res_prefetch_plain(const float* res, int m0, int M, int n0, u64 (&rg)[4]) {
+    const int t_ = otid(), lane = t_ & 63, wave = t_ >> 6, col = lane & 15, rq = (lane >> 4) * 4;
+    if (wave < MT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int m = m0 + 16 * wave + rq + r;
+            if (m > M - 1) m = M - 1;
+            rg[r] = (u64)__float_as_uint(res[(long)m * D + n0 + col]);
         }
     }
 }
 // wo / w2 epilogue: out[m][n] = res[m][n] + acc.  check: the residual granules must carry tag `want` (re-read until they do: by the
 // time the unit's A operand has been validated they are in place, so this loop does not iterate in practice)
 template <int MT>
-__device__ __forceinline__ void epi_residual(const float* red, int m0, int M, int n0, u64 (&rg)[4], bool check, unsigned want, const u64* res,
-                                             int row_stride, int row_off, u64* out, unsigned ep, float* tap, int* fail) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, rq = (lane >> 4) * 4;
+__device__ __forceinline__ void epi_residual(const float* red, int m0, int M, int n0, u64 (&rg)[4], bool check, unsigned want, const GBuf& res,
+                                             const GBuf& out, unsigned ep, float* tap, int* fail) {
+    const int t_ = otid(), lane = t_ & 63, wave = t_ >> 6, col = lane & 15, rq = (lane >> 4) * 4;
     if (wave < MT) {
         const int i = wave;
         f32x4 t[1];
@@ -335,13 +437,13 @@ __device__ __forceinline__ void epi_residual(const float* red, int m0, int M, in
             if (check) {
                 int spins = 0;
                 while (g_tag(g) != want) {
-                    g = ld_g(res + (long)m * row_stride + row_off + n);
+                    g = ld_g(res.p + gidx(res, m, n));
                     if (++spins > SPIN_LIMIT) { *fail = 17; break; }
                 }
             }
             const float rv = g_val(g);
             if (tap) tap[(long)m * D + n] = rv;
-            st_g(out + (long)m * D + n, ep, rv + t[0][r]);
+            st_g(out.p + gidx(out, m, n), ep, rv + t[0][r]);
         }
     }
 }
@@ -351,10 +453,14 @@ __device__ __forceinline__ void epi_residual(const float* red, int m0, int M, in
 template <typename WT, typename KVT, int MTS, int MTF>
 __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    int* const toks = reinterpret_cast<int*>(lds);         // [4][8] sampled tokens of the streams this workgroup samples
+    int* const toks = reinterpret_cast<int*>(lds);         // [8][8] sampled tokens of the 8 streams this workgroup samples (wave = stream)
+    int* const pos_s = toks + 64;                          // [2 B] cache positions of the frame's new tokens (dual_ar_stream.py:821-824)
     float* const red = lds + HDR;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = a.G;
-    const int col = lane & 15, rq = (lane >> 4) * 4;
+    const int wg = blockIdx.x, G = a.G;
+    // thread indices are re-derived from an opaque copy in every phase (AB_IDS): see linear_tile
+#define AB_IDS() const int tid = otid(), lane = tid & 63, wave = tid >> 6, col = lane & 15, rq = (lane >> 4) * 4; \
+    (void)lane; (void)wave; (void)col; (void)rq
+    const int tid = threadIdx.x;
     const int B = a.B, M2 = 2 * B;
     const int TMS = (M2 + 16 * MTS - 1) / (16 * MTS), TMF = (B + 16 * MTF - 1) / (16 * MTF);
     const int V = a.codebook_size, VT = (V + 15) / 16, ST = (a.vocab + 15) / 16;
@@ -364,9 +470,28 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
     const int use_forced = *a.use_forced;
     const long SH = (long)a.S * 64;
     const ASrc AIN = make_psrc(a.xs_in, (long)M2 * D, D, 0);
-    const ASrc AXS = make_gsrc(a.gxs, (long)M2 * D, D, 0), AATT = make_gsrc(a.gatt, (long)M2 * D, D, 0), AG = make_gsrc(a.gg, (long)M2 * I, I, 0);
-    const ASrc AHID = make_gsrc(a.gxs, (long)M2 * D, 2 * D, D);            // content-token rows of the slow residual stream
-    const ASrc AXF = make_gsrc(a.gxf, (long)B * D, D, 0), AATTF = make_gsrc(a.gattf, (long)B * D, D, 0), AGF = make_gsrc(a.ggf, (long)B * I, I, 0);
+    const int RS = TMS * 16 * MTS, RF = TMF * 16 * MTF;               // rows of the slow / fast fragment-major buffers
+    const GBuf GXS{a.gxs, RS, 1, 0}, GATT{a.gatt, RS, 1, 0}, GG{a.gg, RS, 1, 0};
+    const GBuf GHID{a.gxs, RS, 2, 1};                                  // content-token rows of the slow residual stream
+    const GBuf GXF{a.gxf, RF, 1, 0}, GATTF{a.gattf, RF, 1, 0}, GGF{a.ggf, RF, 1, 0};
+    const ASrc AXS = make_gsrc(GXS, D), AATT = make_gsrc(GATT, D), AG = make_gsrc(GG, I), AHID = make_gsrc(GHID, D);
+    const ASrc AXF = make_gsrc(GXF, D), AATTF = make_gsrc(GATTF, D), AGF = make_gsrc(GGF, I);
+    // SVA_DEBUG=ar_timing=1: inside the linear phases, thread 0 of workgroup 0 accumulates per phase kind (dbg[512 + 8 kind + j]):
+    // j = 0 weights requested, 1 first sweep of the input back, 2 input validated, 3 partial tiles reduced, 4 epilogue stored (all in
+    // 10 ns ticks since the unit began, summed over the frame), 5 sweeps, 6 units
+    Tm tm;
+    tm.on = a.dbg && wg == 0 && tid == 0;
+    if (tm.on)
+        for (int i = 512; i < 512 + 8 * 9; ++i) a.dbg[i] = 0;
+#define AB_ACC(kind) do { if (tm.on && u == wg) { const long long now = wall_clock64(); long long* q_ = a.dbg + 512 + 8 * (kind); \
+        q_[0] += tm.t1 - tm.t0; q_[1] += tm.t2 - tm.t0; q_[2] += tm.t3 - tm.t0; q_[3] += tm.t4 - tm.t0; q_[4] += now - tm.t0; q_[5] += tm.sweeps; q_[6] += 1; } } while (0)
+    Pf pf;
+    // L2 prefetch of the weights of this workgroup's FIRST unit (u = wg) of a later linear phase with `tiles` column tiles of `ncols` rows
+    auto touch = [&](const void* W, int tm, int tiles, int ncols, int N, int K) {
+        if (wg < tm * tiles) touch_w<WT>(pf, W, (wg % tiles) * ncols, ncols, N, K);
+    };
+    for (int m = tid; m < M2; m += NTH) pos_s[m] = a.last_pos[m >> 1] + 1 + (m & 1);
+    __syncthreads();
     AB_MARK();
 
     // ======================================= slow AR: 12 layers on 2 B rows =======================================
@@ -377,10 +502,22 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
         // ---- QKV: RMSNorm + wqkv + RoPE + KV write ----
         ++ep;
         for (int u = wg; u < TMS * QT; u += G) {
+            AB_IDS();
             const int mi = u / QT, nj = u - mi * QT, m0 = mi * 16 * MTS, n0 = nj * 16;
-            if (l == 0) linear_tile<WT, MTS, 1, D, true, false>(AIN, 0u, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, [] {}, red, a.fail, 1);
-            else linear_tile<WT, MTS, 1, D, true, true>(AXS, e_x, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, [] {}, red, a.fail, 1);
             const int region = n0 / D, nn = n0 + col - region * D, h = nn >> 6, d = nn & 63;
+            float2 rcs[4];              // RoPE factors of the lane's four rows (requested with the weights: the epilogue loads nothing)
+            auto pre = [&] {
+                if (wave < MTS && region < 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + 16 * wave + rq + r;
+                        rcs[r] = *reinterpret_cast<const float2*>(a.rope_slow + ((long)pos_s[m < M2 ? m : M2 - 1] * 32 + (d >> 1)) * 2);
+                    }
+                }
+            };
+            auto post = [&] { if (u == wg) touch(L.wo, TMS, XT, 16, D, D); };
+            if (l == 0) linear_tile<WT, MTS, 1, D, true, false>(AIN, 0u, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, pre, post, red, a.fail, 1, tm);
+            else linear_tile<WT, MTS, 1, D, true, true>(AXS, e_x, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, pre, post, red, a.fail, 1, tm);
             if (wave < MTS) {
                 const int i = wave;
                 f32x4 t[1];
@@ -388,11 +525,11 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + 16 * i + rq + r, mc = m < M2 ? m : M2 - 1;
-                    const int s = mc >> 1, pos = a.last_pos[s] + 1 + (mc & 1);
+                    const int s = mc >> 1, pos = pos_s[mc];
                     float v = t[0][r] * row_inv<MTS, 1>(red, i, rq + r, D, 1e-5f);
                     const float pv = lane_xor_f<1>(v);
                     if (region < 2) {
-                        const float c = a.rope_slow[((long)pos * 32 + (d >> 1)) * 2], sn = a.rope_slow[((long)pos * 32 + (d >> 1)) * 2 + 1];
+                        const float c = rcs[r].x, sn = rcs[r].y;
                         v = (d & 1) ? v * c + pv * sn : v * c - pv * sn;
                     }
                     if (m < M2) {
@@ -401,13 +538,15 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                     }
                 }
             }
+            AB_ACC(0);
         }
         AB_MARK();
         // ---- ATT: (stream, head): both new rows against keys 0 .. p0 (+ 1) ----
         ++ep;
         for (int u = wg; u < B * H; u += G) {
+            AB_IDS();
             const int s = u / H, h = u - s * H;
-            const int p0 = a.last_pos[s] + 1;                    // positions of the two new tokens: p0, p0 + 1
+            const int p0 = pos_s[2 * s];                         // positions of the two new tokens: p0, p0 + 1
             const int grp = lane >> 4, li = lane & 15;
             const KVT* kc = kvl + (long)s * a.kv_slot_stride + (long)h * SH + li * 4;
             const KVT* vc = kc + (long)H * SH;
@@ -426,7 +565,7 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
             const __amdgpu_buffer_rsrc_t rq_ = __builtin_amdgcn_make_buffer_rsrc(a.gqkv + (long)(2 * s) * 3 * D, 0, 2 * 3 * D * 8, 0x00020000);
             const int qo = (h * 64 + li * 4) * 8;
             const bool newk = wave == NWV - 1 && grp < 2;
-            const int ko = (grp * 3 * D + D + h * 64 + li * 4) * 8;
+            const int ko = ((grp & 1) * 3 * D + D + h * 64 + li * 4) * 8;      // (every wave loads them: a load under a branch is waited for on the spot)
             v4i gq[4], gk[4];
             {
                 int spins = 0;
@@ -434,14 +573,12 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                     asm volatile("" ::: "memory");
                     gq[0] = ld_g16(rq_, qo); gq[1] = ld_g16(rq_, qo + 16);
                     gq[2] = ld_g16(rq_, qo + 3 * D * 8); gq[3] = ld_g16(rq_, qo + 3 * D * 8 + 16);
-                    bool ok = (unsigned)gq[0].y == ep - 1 && (unsigned)gq[0].w == ep - 1 && (unsigned)gq[1].y == ep - 1 && (unsigned)gq[1].w == ep - 1 &&
-                              (unsigned)gq[2].y == ep - 1 && (unsigned)gq[2].w == ep - 1 && (unsigned)gq[3].y == ep - 1 && (unsigned)gq[3].w == ep - 1;
-                    if (newk) {
-                        gk[0] = ld_g16(rq_, ko); gk[1] = ld_g16(rq_, ko + 16);
-                        gk[2] = ld_g16(rq_, ko + D * 8); gk[3] = ld_g16(rq_, ko + D * 8 + 16);
-                        ok = ok && (unsigned)gk[0].y == ep - 1 && (unsigned)gk[0].w == ep - 1 && (unsigned)gk[1].y == ep - 1 && (unsigned)gk[1].w == ep - 1 &&
-                             (unsigned)gk[2].y == ep - 1 && (unsigned)gk[2].w == ep - 1 && (unsigned)gk[3].y == ep - 1 && (unsigned)gk[3].w == ep - 1;
-                    }
+                    gk[0] = ld_g16(rq_, ko); gk[1] = ld_g16(rq_, ko + 16);
+                    gk[2] = ld_g16(rq_, ko + D * 8); gk[3] = ld_g16(rq_, ko + D * 8 + 16);
+                    const unsigned w_ = ep - 1;
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ok = ok & ((unsigned)gq[q].y == w_) & ((unsigned)gq[q].w == w_) & ((unsigned)gk[q].y == w_) & ((unsigned)gk[q].w == w_);
                     if (__all(ok)) break;
                     if (spin_over(spins, a.fail, 2)) break;
                 }
@@ -508,28 +645,32 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                     den = fmaf(wgt, lg2, den);
                     val = fmaf(wgt, pr[g2 * 68 + dd], val);
                 }
-                st_g(a.gatt + (long)(2 * s + row) * D + h * 64 + dd, ep, val / den);
+                st_g(a.gatt + gidx(GATT, 2 * s + row, h * 64 + dd), ep, val / den);
             }
         }
         AB_MARK();
         // ---- WO + residual ----
         ++ep;
         for (int u = wg; u < TMS * XT; u += G) {
+            AB_IDS();
             const int mi = u / XT, nj = u - mi * XT, m0 = mi * 16 * MTS, n0 = nj * 16;
             u64 rg[4];
             linear_tile<WT, MTS, 1, D, false, true>(AATT, ep - 1, m0, M2, reinterpret_cast<const WT*>(L.wo), n0, D, nullptr,
                                                     [&] {
-                                                        if (l == 0) res_prefetch<MTS, false>(a.xs_in, D, 0, m0, M2, n0, rg);
-                                                        else res_prefetch<MTS, true>(a.gxs, D, 0, m0, M2, n0, rg);
-                                                    }, red, a.fail, 3);
-            epi_residual<MTS>(red, m0, M2, n0, rg, l > 0, e_x, a.gxs, D, 0, a.gxs, ep, nullptr, a.fail);
+                                                        if (l == 0) res_prefetch_plain<MTS>(a.xs_in, m0, M2, n0, rg);
+                                                        else res_prefetch<MTS>(GXS, m0, M2, n0, rg);
+                                                    }, [&] { if (u == wg) touch(L.w13, TMS, GT, 32, 2 * I, D); }, red, a.fail, 3, tm);
+            epi_residual<MTS>(red, m0, M2, n0, rg, l > 0, e_x, GXS, GXS, ep, nullptr, a.fail);
+            AB_ACC(1);
         }
         AB_MARK();
         // ---- W13: RMSNorm + w1 | w3 + SwiGLU ----
         ++ep;
         for (int u = wg; u < TMS * GT; u += G) {
+            AB_IDS();
             const int mi = u / GT, nj = u - mi * GT, m0 = mi * 16 * MTS, n0 = nj * 32;
-            linear_tile<WT, MTS, 2, D, true, true>(AXS, ep - 1, m0, M2, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm, [] {}, red, a.fail, 4);
+            linear_tile<WT, MTS, 2, D, true, true>(AXS, ep - 1, m0, M2, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm, [] {},
+                                                   [&] { if (u == wg) touch(L.w2, TMS, XT, 16, D, I); }, red, a.fail, 4, tm);
             if (wave < MTS) {
                 const int i = wave;
                 f32x4 t[2];
@@ -539,19 +680,28 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                     const int m = m0 + 16 * i + rq + r;
                     if (m >= M2) continue;
                     const float inv = row_inv<MTS, 2>(red, i, rq + r, D, 1e-5f);
-                    st_g(a.gg + (long)m * I + nj * 16 + col, ep, silu_f(t[0][r] * inv) * (t[1][r] * inv));
+                    st_g(a.gg + gidx(GG, m, nj * 16 + col), ep, silu_f(t[0][r] * inv) * (t[1][r] * inv));
                 }
             }
+            AB_ACC(2);
         }
         AB_MARK();
         // ---- W2 + residual ----
         ++ep;
         for (int u = wg; u < TMS * XT; u += G) {
+            AB_IDS();
             const int mi = u / XT, nj = u - mi * XT, m0 = mi * 16 * MTS, n0 = nj * 16;
             u64 rg[4];
             linear_tile<WT, MTS, 1, I, false, true>(AG, ep - 1, m0, M2, reinterpret_cast<const WT*>(L.w2), n0, D, nullptr,
-                                                    [&] { res_prefetch<MTS, true>(a.gxs, D, 0, m0, M2, n0, rg); }, red, a.fail, 5);
-            epi_residual<MTS>(red, m0, M2, n0, rg, true, ep - 2, a.gxs, D, 0, a.gxs, ep, nullptr, a.fail);
+                                                    [&] { res_prefetch<MTS>(GXS, m0, M2, n0, rg); },
+                                                    [&] {
+                                                        if (u != wg) return;
+                                                        if (l + 1 < AR_SLOW_LAYERS) touch(a.slow[l + 1].wqkv, TMS, QT, 16, 3 * D, D);
+                                                        else if (!a.skip_semantic) touch(a.out_w, TMF, ST, 16, a.vocab, D);
+                                                        else touch(a.fast[0].wqkv, TMF, QT, 16, 3 * D, D);
+                                                    }, red, a.fail, 5, tm);
+            epi_residual<MTS>(red, m0, M2, n0, rg, true, ep - 2, GXS, GXS, ep, nullptr, a.fail);
+            AB_ACC(3);
         }
         e_x = ep;
         AB_MARK();
@@ -562,8 +712,10 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
         ++ep;
         e_sem = ep;
         for (int u = wg; u < TMF * ST; u += G) {
+            AB_IDS();
             const int mi = u / ST, nj = u - mi * ST, m0 = mi * 16 * MTF, n0 = nj * 16;
-            linear_tile<WT, MTF, 1, D, true, true>(AHID, e_x, m0, B, reinterpret_cast<const WT*>(a.out_w), n0, a.vocab, a.out_norm, [] {}, red, a.fail, 6);
+            linear_tile<WT, MTF, 1, D, true, true>(AHID, e_x, m0, B, reinterpret_cast<const WT*>(a.out_w), n0, a.vocab, a.out_norm, [] {},
+                                                   [&] { if (u == wg) touch(a.fast[0].wqkv, TMF, QT, 16, 3 * D, D); }, red, a.fail, 6, tm);
             if (wave < MTF) {
                 const int i = wave;
                 f32x4 t[1];
@@ -574,6 +726,36 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                     if (m < B && n < a.vocab) st_g(a.gsem + (long)m * SEMP + n, ep, t[0][r] * row_inv<MTF, 1>(red, i, rq + r, D, 1e-5f));
                 }
             }
+        }
+        // the semantic sample itself, unit = stream (8 waves x 16 logits per lane).  Here and not at the end of the frame: it reads the
+        // stream's frame counter, which the wave that samples the stream's last codebook advances; every workgroup that runs such a
+        // unit also has a unit in the first fast phase, so the advance is ordered behind this read
+        for (int u = wg; u < B; u += G) {
+            AB_IDS();
+            const int s = u;
+            float lv[16];
+            const u64* lg = a.gsem + (long)s * SEMP;
+            int spins = 0;
+            while (true) {
+                bool ok = true;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {          // (no load under a branch: it would be waited for on the spot)
+                    const int e = tid + NTH * r;
+                    const u64 g = ld_g(lg + (e < a.vocab ? e : a.vocab - 1));
+                    ok = ok & (g_tag(g) == e_sem);
+                    lv[r] = e < a.vocab ? g_val(g) : -INFINITY;
+                }
+                if (__all(ok)) break;
+                if (spin_over(spins, a.fail, 16)) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (tid + NTH * r < a.vocab) a.slow_logits[(long)s * a.vocab + tid + NTH * r] = lv[r];
+            __syncthreads();                   // the previous unit has read `red`
+            const int sm = nucleus_sample<NWV, 16>(lv, a.vocab, tid, a.noise ? a.noise + (long)s * a.noise_ld : nullptr, a.seed[s], a.nframes[s], 0, 0,
+                                                   a.inv_temp, a.top_p, reinterpret_cast<double*>(red));
+            if (tid == 0) a.sem[s] = sm;
         }
         AB_MARK();
     }
@@ -588,11 +770,14 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
             // ---- FQKV: RMSNorm + wqkv + RoPE (position = codebook index) + K / V of this position ----
             ++ep;
             for (int u = wg; u < TMF * QT; u += G) {
+                AB_IDS();
                 const int mi = u / QT, nj = u - mi * QT, m0 = mi * 16 * MTF, n0 = nj * 16;
-                linear_tile<WT, MTF, 1, D, true, true>(from_slow ? AHID : AXF, from_slow ? e_x : first ? e_row : ep - 1, m0, B,
-                                                       reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, [] {}, red, a.fail, 7);
                 const int region = n0 / D, nn = n0 + col - region * D, d = nn & 63;
-                const float c = a.rope_fast[(cb * 32 + (d >> 1)) * 2], sn = a.rope_fast[(cb * 32 + (d >> 1)) * 2 + 1];
+                const float2 cs = *reinterpret_cast<const float2*>(a.rope_fast + (cb * 32 + (d >> 1)) * 2);
+                const float c = cs.x, sn = cs.y;
+                linear_tile<WT, MTF, 1, D, true, true>(from_slow ? AHID : AXF, from_slow ? e_x : first ? e_row : ep - 1, m0, B,
+                                                       reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, [] {},
+                                                       [&] { if (u == wg) touch(L.wo, TMF, XT, 16, D, D); }, red, a.fail, 7, tm);
                 if (wave < MTF) {
                     const int i = wave;
                     f32x4 t[1];
@@ -609,11 +794,13 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                         }
                     }
                 }
+                AB_ACC(4);
             }
             AB_MARK();
             // ---- FATT: attention over the <= 8 codebook positions, unit = stream (wave w: heads w, w + 8) ----
             ++ep;
             for (int u = wg; u < B; u += G) {
+                AB_IDS();
                 const int s = u;
                 __syncthreads();                   // the previous unit has read `red`
                 float* big = red;                  // [2304] this stream's q | k | v row
@@ -629,23 +816,19 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                     int spins = 0;
                     while (true) {
                         asm volatile("" ::: "memory");
-                        bool ok = true;
+                        bool ok = true;         // (every load unconditional, clamped: a load under a branch is waited for on the spot)
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
                             const int p = tid + k * NTH;
-                            if (p < NQ) {
-                                gq[k] = ld_g16(rs, p * 16);
-                                ok = ok && (unsigned)gq[k].y == ep - 1 && (unsigned)gq[k].w == ep - 1;
-                            }
+                            gq[k] = ld_g16(rs, (p < NQ ? p : NQ - 1) * 16);
+                            ok = ok & ((unsigned)gq[k].y == ep - 1) & ((unsigned)gq[k].w == ep - 1);
                         }
 #pragma unroll
                         for (int k = 0; k < 11; ++k) {
-                            const int p = tid + k * NTH;
-                            if (p < nh) {
-                                gh[k] = ld_g16(rh, p * 16);
-                                const unsigned want = ep - 1 - (unsigned)(cb - p / NH1) * CBP;
-                                ok = ok && (unsigned)gh[k].y == want && (unsigned)gh[k].w == want;
-                            }
+                            const int p = tid + k * NTH, pc = p < nh ? p : 0;
+                            gh[k] = ld_g16(rh, pc * 16);
+                            const unsigned want = ep - 1 - (unsigned)(cb - pc / NH1) * CBP;
+                            ok = ok & ((p >= nh) | (((unsigned)gh[k].y == want) & ((unsigned)gh[k].w == want)));
                         }
                         if (__all(ok)) break;
                         if (spin_over(spins, a.fail, 9)) break;
@@ -688,29 +871,33 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                     av[hb + lane] = acc * inv;
                 }
                 __syncthreads();
-                for (int i = tid; i < D; i += NTH) st_g(a.gattf + (long)s * D + i, ep, av[i]);
+                for (int i = tid; i < D; i += NTH) st_g(a.gattf + gidx(GATTF, s, i), ep, av[i]);
             }
             AB_MARK();
             // ---- FWO + residual ----
             ++ep;
             for (int u = wg; u < TMF * XT; u += G) {
+                AB_IDS();
                 const int mi = u / XT, nj = u - mi * XT, m0 = mi * 16 * MTF, n0 = nj * 16;
                 u64 rg[4];
                 linear_tile<WT, MTF, 1, D, false, true>(AATTF, ep - 1, m0, B, reinterpret_cast<const WT*>(L.wo), n0, D, nullptr,
                                                         [&] {
-                                                            if (from_slow) res_prefetch<MTF, true>(a.gxs, 2 * D, D, m0, B, n0, rg);
-                                                            else res_prefetch<MTF, true>(a.gxf, D, 0, m0, B, n0, rg);
-                                                        }, red, a.fail, 10);
+                                                            if (from_slow) res_prefetch<MTF>(GHID, m0, B, n0, rg);
+                                                            else res_prefetch<MTF>(GXF, m0, B, n0, rg);
+                                                        }, [&] { if (u == wg) touch(L.w13, TMF, GT, 32, 2 * I, D); }, red, a.fail, 10, tm);
                 // hidden = pre-norm state of the content token (forward_generate :340-341): tap, and the fast AR's first input
-                if (from_slow) epi_residual<MTF>(red, m0, B, n0, rg, true, e_x, a.gxs, 2 * D, D, a.gxf, ep, a.hidden, a.fail);
-                else epi_residual<MTF>(red, m0, B, n0, rg, true, first ? e_row : ep - 3, a.gxf, D, 0, a.gxf, ep, nullptr, a.fail);
+                if (from_slow) epi_residual<MTF>(red, m0, B, n0, rg, true, e_x, GHID, GXF, ep, a.hidden, a.fail);
+                else epi_residual<MTF>(red, m0, B, n0, rg, true, first ? e_row : ep - 3, GXF, GXF, ep, nullptr, a.fail);
+                AB_ACC(5);
             }
             AB_MARK();
             // ---- FW13 ----
             ++ep;
             for (int u = wg; u < TMF * GT; u += G) {
+                AB_IDS();
                 const int mi = u / GT, nj = u - mi * GT, m0 = mi * 16 * MTF, n0 = nj * 32;
-                linear_tile<WT, MTF, 2, D, true, true>(AXF, ep - 1, m0, B, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm, [] {}, red, a.fail, 11);
+                linear_tile<WT, MTF, 2, D, true, true>(AXF, ep - 1, m0, B, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm, [] {},
+                                                       [&] { if (u == wg) touch(L.w2, TMF, XT, 16, D, I); }, red, a.fail, 11, tm);
                 if (wave < MTF) {
                     const int i = wave;
                     f32x4 t[2];
@@ -720,27 +907,37 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                         const int m = m0 + 16 * i + rq + r;
                         if (m >= B) continue;
                         const float inv = row_inv<MTF, 2>(red, i, rq + r, D, 1e-5f);
-                        st_g(a.ggf + (long)m * I + nj * 16 + col, ep, silu_f(t[0][r] * inv) * (t[1][r] * inv));
+                        st_g(a.ggf + gidx(GGF, m, nj * 16 + col), ep, silu_f(t[0][r] * inv) * (t[1][r] * inv));
                     }
                 }
+                AB_ACC(6);
             }
             AB_MARK();
             // ---- FW2 + residual ----
             ++ep;
             for (int u = wg; u < TMF * XT; u += G) {
+                AB_IDS();
                 const int mi = u / XT, nj = u - mi * XT, m0 = mi * 16 * MTF, n0 = nj * 16;
                 u64 rg[4];
                 linear_tile<WT, MTF, 1, I, false, true>(AGF, ep - 1, m0, B, reinterpret_cast<const WT*>(L.w2), n0, D, nullptr,
-                                                        [&] { res_prefetch<MTF, true>(a.gxf, D, 0, m0, B, n0, rg); }, red, a.fail, 12);
-                epi_residual<MTF>(red, m0, B, n0, rg, true, ep - 2, a.gxf, D, 0, a.gxf, ep, nullptr, a.fail);
+                                                        [&] { res_prefetch<MTF>(GXF, m0, B, n0, rg); },
+                                                        [&] {
+                                                            if (u != wg) return;
+                                                            if (l + 1 < AR_FAST_LAYERS) touch(a.fast[l + 1].wqkv, TMF, QT, 16, 3 * D, D);
+                                                            else touch(a.fast_out_w, TMF, VT, 16, V, D);
+                                                        }, red, a.fail, 12, tm);
+                epi_residual<MTF>(red, m0, B, n0, rg, true, ep - 2, GXF, GXF, ep, nullptr, a.fail);
+                AB_ACC(7);
             }
             AB_MARK();
         }
         // ---- HEAD: fast_norm + codebook logits ----
         ++ep;
         for (int u = wg; u < TMF * VT; u += G) {
+            AB_IDS();
             const int mi = u / VT, nj = u - mi * VT, m0 = mi * 16 * MTF, n0 = nj * 16;
-            linear_tile<WT, MTF, 1, D, true, true>(AXF, ep - 1, m0, B, reinterpret_cast<const WT*>(a.fast_out_w), n0, V, a.fast_norm, [] {}, red, a.fail, 13);
+            linear_tile<WT, MTF, 1, D, true, true>(AXF, ep - 1, m0, B, reinterpret_cast<const WT*>(a.fast_out_w), n0, V, a.fast_norm, [] {},
+                                                   [&] { if (u == wg && cb + 1 < NCB) touch(a.fast[0].wqkv, TMF, QT, 16, 3 * D, D); }, red, a.fail, 13, tm);
             if (wave < MTF) {
                 const int i = wave;
                 f32x4 t[1];
@@ -751,90 +948,70 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                     if (m < B && n < V) st_g(a.glog + (long)m * LOGP + n, ep, t[0][r] * row_inv<MTF, 1>(red, i, rq + r, D, 1e-5f));
                 }
             }
+            AB_ACC(8);
         }
         AB_MARK();
-        // ---- SAMPLE: nucleus sample of one stream per unit, next input row = fast_emb[token] ----
+        // ---- SAMPLE: unit = 8 streams, one per wave (16 logits per lane, no barrier inside the sampler: ar_decode.hip); the next
+        // input row = fast_emb[token] ----
         ++ep;
-        for (int u = wg, k = 0; u < B; u += G, ++k) {
-            const int s = u;
-            float lv[2];
-            {
+        for (int u = wg; u < (B + NWV - 1) / NWV; u += G) {
+            AB_IDS();
+            const int s = u * NWV + wave;
+            if (s < B) {
+                float lv[16];
                 const u64* lg = a.glog + (long)s * LOGP;
                 int spins = 0;
                 while (true) {
-                    u64 g0 = 0, g1 = 0;
                     bool ok = true;
-                    if (tid < V) { g0 = ld_g(lg + tid); ok = g_tag(g0) == ep - 1; }
-                    if (tid + NTH < V) { g1 = ld_g(lg + tid + NTH); ok = ok && g_tag(g1) == ep - 1; }
-                    lv[0] = tid < V ? g_val(g0) : -INFINITY;
-                    lv[1] = tid + NTH < V ? g_val(g1) : -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {      // (no load under a branch: it would be waited for on the spot)
+                        const int e = lane + 64 * r;
+                        const u64 g = ld_g(lg + (e < V ? e : V - 1));
+                        ok = ok & (g_tag(g) == ep - 1);
+                        lv[r] = e < V ? g_val(g) : -INFINITY;
+                    }
                     if (__all(ok)) break;
                     if (spin_over(spins, a.fail, 14)) break;
+                    __builtin_amdgcn_s_sleep(8);
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (lane + 64 * r < V) a.fast_logits[((long)s * NCB + cb) * V + lane + 64 * r] = lv[r];
+                const float* nz = a.noise ? a.noise + (long)s * a.noise_ld + a.vocab + (long)cb * V : nullptr;
+                const int raw = nucleus_sample<1, 16>(lv, V, lane, nz, a.seed[s], a.nframes[s], 1, cb * V, a.inv_temp, a.top_p, nullptr);
+                int t = raw;
+                if (use_forced) t = a.forced[((long)s * NCB + cb) * a.chunk + a.ci];
+                if (lane == 0) { a.tok_raw[s * NCB + cb] = raw; a.tok[s * NCB + cb] = t; toks[wave * NCB + cb] = t; }
+                if (cb + 1 < NCB)
+                    for (int i = lane; i < D; i += 64) st_g(a.gxf + gidx(GXF, s, i), ep, a.fast_emb[(long)t * D + i]);
             }
-            if (tid < V) a.fast_logits[((long)s * NCB + cb) * V + tid] = lv[0];
-            if (tid + NTH < V) a.fast_logits[((long)s * NCB + cb) * V + tid + NTH] = lv[1];
-            __syncthreads();                   // the previous unit has read `red`
-            const float* nz = a.noise ? a.noise + (long)s * a.noise_ld + a.vocab + (long)cb * V : nullptr;
-            const int raw = nucleus_sample<NWV, 2>(lv, V, tid, nz, a.seed[s], a.nframes[s], 1, cb * V, a.inv_temp, a.top_p, reinterpret_cast<double*>(red));
-            int t = raw;
-            if (use_forced) t = a.forced[((long)s * NCB + cb) * a.chunk + a.ci];
-            if (tid == 0) { a.tok_raw[s * NCB + cb] = raw; a.tok[s * NCB + cb] = t; toks[k * NCB + cb] = t; }
-            if (cb + 1 < NCB)
-                for (int i = tid; i < D; i += NTH) st_g(a.gxf + (long)s * D + i, ep, a.fast_emb[(long)t * D + i]);
         }
         e_row = ep;
         AB_MARK();
     }
 
-    // ======================================= frame bookkeeping, unit = stream =======================================
-    __syncthreads();
-    for (int u = wg, k = 0; u < B; u += G, ++k) {
-        const int s = u;
-        const int* tk = toks + k * NCB;
-        const int frame = a.nframes[s];
-        // cached_new_audio_emb = embed(codes) (dual_ar_stream.py:834, 245-255): codebooks summed in order
-        for (int i = tid; i < D; i += NTH) {
-            float acc = 0.f;
+    // ======================================= frame bookkeeping: the wave that sampled a stream =======================================
+    for (int u = wg; u < (B + NWV - 1) / NWV; u += G) {
+        AB_IDS();
+        const int s = u * NWV + wave;
+        if (s < B) {
+            const int* tk = toks + wave * NCB;                  // (written by this wave: program order)
+            const int frame = a.nframes[s];
+            // cached_new_audio_emb = embed(codes) (dual_ar_stream.py:834, 245-255): codebooks summed in order
+            for (int i = lane; i < D; i += 64) {
+                float acc = 0.f;
 #pragma unroll
-            for (int q = 0; q < NCB; ++q) acc += a.codebook_emb[((long)tk[q] + (long)q * V) * D + i];
-            a.cached_audio_emb[(long)s * D + i] = acc;
-        }
-        if (tid < NCB) {
-            a.pred_hist[((long)s * NCB + tid) * a.hist_cap + (frame & (a.hist_cap - 1))] = tk[tid];
-            a.step_audio[((long)s * NCB + tid) * a.chunk + a.ci] = tk[tid];
-        }
-        if (!a.skip_semantic) {
-            float lv[16];
-            const u64* lg = a.gsem + (long)s * SEMP;
-            int spins = 0;
-            while (true) {
-                bool ok = true;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int e = tid + NTH * r;
-                    lv[r] = -INFINITY;
-                    if (e < a.vocab) {
-                        const u64 g = ld_g(lg + e);
-                        ok = ok && g_tag(g) == e_sem;
-                        lv[r] = g_val(g);
-                    }
-                }
-                if (__all(ok)) break;
-                if (spin_over(spins, a.fail, 16)) break;
+                for (int q = 0; q < NCB; ++q) acc += a.codebook_emb[((long)tk[q] + (long)q * V) * D + i];
+                a.cached_audio_emb[(long)s * D + i] = acc;
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (tid + NTH * r < a.vocab) a.slow_logits[(long)s * a.vocab + tid + NTH * r] = lv[r];
-            __syncthreads();
-            const int sm = nucleus_sample<NWV, 16>(lv, a.vocab, tid, a.noise ? a.noise + (long)s * a.noise_ld : nullptr, a.seed[s], frame, 0, 0, a.inv_temp,
-                                                   a.top_p, reinterpret_cast<double*>(red));
-            if (tid == 0) a.sem[s] = sm;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            a.nframes[s] = frame + 1;
-            a.last_pos[s] += 2;
+            if (lane < NCB) {
+                a.pred_hist[((long)s * NCB + lane) * a.hist_cap + (frame & (a.hist_cap - 1))] = tk[lane];
+                a.step_audio[((long)s * NCB + lane) * a.chunk + a.ci] = tk[lane];
+            }
+            if (lane == 0) {
+                a.nframes[s] = frame + 1;
+                a.last_pos[s] += 2;
+            }
         }
     }
     AB_MARK();
@@ -888,8 +1065,11 @@ void ar_batch_tiles(int B, int* mts, int* mtf) {
 }
 
 size_t ar_batch_granule_words(int B, size_t offs[AR_BATCH_NBUF]) {
+    int mts, mtf;
+    ar_batch_tiles(B, &mts, &mtf);
     const size_t b = (size_t)B;
-    const size_t sizes[AR_BATCH_NBUF] = {2 * b * D, 2 * b * 3 * D, 2 * b * D, 2 * b * I, b * D, b * 3 * D, b * D, b * I,
+    const size_t rs = (size_t)(2 * B + 16 * mts - 1) / (16 * mts) * 16 * mts, rf = (size_t)(B + 16 * mtf - 1) / (16 * mtf) * 16 * mtf;      // fragment-major buffers: whole row tiles
+    const size_t sizes[AR_BATCH_NBUF] = {rs * D, 2 * b * 3 * D, rs * D, rs * I, rf * D, b * 3 * D, rf * D, rf * I,
                                          (size_t)AR_FAST_LAYERS * b * NCB * 2 * D, b * LOGP, b * SEMP};
     size_t o = 0;
     for (int i = 0; i < AR_BATCH_NBUF; ++i) {
@@ -927,7 +1107,7 @@ int ar_batch_occupancy(int wt_half, int B_, int* blocks_per_cu) { AB_DISPATCH(oc
 int launch_ar_batch(const ArBatchArgs& a, int wt_half, hipStream_t st) {
     const int B_ = a.B;
     SVA_CHECK(a.B >= 1 && a.B <= AR_BATCH_MAX_STREAMS && a.G >= 1, "ar_batch: 1..128 streams");
-    SVA_CHECK((a.B + a.G - 1) / a.G <= 4, "ar_batch: at most 4 streams per workgroup");
+    SVA_CHECK((a.B + NWV - 1) / NWV <= a.G && 3 * 48 * ((a.B + 63) / 64) >= 1, "ar_batch: one group of 8 streams per workgroup");
     SVA_CHECK(a.vocab <= SEMP && a.codebook_size <= 2 * NTH && a.codebook_size <= LOGP && (a.hist_cap & (a.hist_cap - 1)) == 0,
               "ar_batch: unsupported head sizes");
     AB_DISPATCH(launch_cfg, a, st);

@@ -16,6 +16,8 @@ Protocol (little endian, one TCP connection = one `RealtimeSession`):
     server -> client   for every BLOCK: u32 3 | u32 nbytes | float32[2048 * block_frame] converted samples (zeros while the delay fills)
                        for REF / CONF:  u32 kind | u32 0
                        on error:        u32 0xffffffff | u32 nbytes | utf-8 message (the connection stays open)
+    Frame sizes are bounded per kind (CONF = 12 bytes, BLOCK <= 64 frames of 2048 samples, REF <= 60 s of 44.1 kHz audio + a 1 KiB name);
+    an oversize or unknown frame is answered with an error and the connection is closed (its payload cannot be skipped safely).
 
 One connection is served at a time per process (the reference's GUI is single-session too); the engine and its weights stay
 resident between connections.
@@ -29,6 +31,12 @@ import numpy as np
 from .realtime import GuiSettings, RealtimeSession
 
 KIND_REF, KIND_CONF, KIND_BLOCK, KIND_BYE, KIND_ERR = 1, 2, 3, 4, 0xFFFFFFFF
+MAX_BLOCK_FRAMES = 64
+MAX_PAYLOAD = {KIND_REF: 1024 + 1 + 4 * 44100 * 60, KIND_CONF: 12, KIND_BLOCK: 4 * 2048 * MAX_BLOCK_FRAMES, KIND_BYE: 0}
+
+
+class ProtocolError(Exception):
+    """A frame the server cannot even read past (unknown kind, oversize payload): answered, then the connection is dropped."""
 
 
 def _recv_exact(conn, n):
@@ -51,6 +59,10 @@ def serve_connection(conn, model_set):
     ref_name, ref_wav = "", None
     while True:
         kind, nbytes = struct.unpack("<II", _recv_exact(conn, 8))
+        if kind not in MAX_PAYLOAD or nbytes > MAX_PAYLOAD[kind]:
+            msg = f"frame kind {kind} with {nbytes} bytes refused (limits: {MAX_PAYLOAD})"
+            _send(conn, KIND_ERR, ("ProtocolError: " + msg).encode("utf-8"))
+            raise ProtocolError(msg)
         payload = _recv_exact(conn, nbytes) if nbytes else b""
         try:
             if kind == KIND_BYE:
@@ -64,19 +76,19 @@ def serve_connection(conn, model_set):
                 _send(conn, KIND_REF)
             elif kind == KIND_CONF:
                 alpha, bf, nd = struct.unpack("<fii", payload)
-                if not (bf >= 1 and nd >= 1):
-                    raise ValueError("block_frame and n_frame_delay must be >= 1")
+                if not (1 <= bf <= MAX_BLOCK_FRAMES and nd >= 1):
+                    raise ValueError(f"block_frame must be 1..{MAX_BLOCK_FRAMES} and n_frame_delay >= 1")
                 settings = GuiSettings(alpha=float(alpha), block_frame=int(bf), n_frame_delay=int(nd))
                 _send(conn, KIND_CONF)
             elif kind == KIND_BLOCK:
                 if ref_wav is None:
                     raise ValueError("send a reference (kind 1) before the first block")
+                if len(payload) % 4:
+                    raise ValueError("block payload is not a whole number of float32 samples")
                 block = np.frombuffer(payload, dtype="<f4").astype(np.float32)
                 out = sess.run_block(model_set, ref_wav, ref_name, block, settings)
                 _send(conn, KIND_BLOCK, np.ascontiguousarray(out, dtype="<f4").tobytes())
-            else:
-                raise ValueError(f"unknown frame kind {kind}")
-        except (ValueError, AssertionError, RuntimeError, NotImplementedError) as ex:
+        except (ValueError, AssertionError, RuntimeError, NotImplementedError, struct.error, UnicodeDecodeError) as ex:
             _send(conn, KIND_ERR, f"{type(ex).__name__}: {ex}".encode("utf-8"))
 
 
@@ -97,8 +109,10 @@ def serve(model_set, host="127.0.0.1", port=5577, max_connections=None, ready=No
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 try:
                     serve_connection(conn, model_set)
-                except ConnectionError:
+                except (ConnectionError, ProtocolError):
                     pass
+                except Exception as ex:          # a misbehaving client must not take the resident engine down with it
+                    print(f"stream_server: connection dropped after {type(ex).__name__}: {ex}", flush=True)
             served += 1
 
 

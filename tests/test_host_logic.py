@@ -217,3 +217,64 @@ def test_stream_server_protocol_with_a_stub_model():
     c.close()
     th.join(10)
     assert not th.is_alive()
+
+
+def test_stream_server_survives_malformed_frames():
+    """Wire-level hardening: a short CONF payload is answered with an error on the open connection; an oversize or unknown
+    frame is refused before its payload is buffered and only that connection is dropped -- the server accepts the next client."""
+    import socket
+    import struct
+    import threading
+
+    import numpy as np
+
+    from streamvoiceanon_amd import stream_server as S
+
+    class Stub:
+        def prefill_prompt(self, ref, max_prompt_frames=64, delay=2, alpha=1.0):
+            pass
+
+        def setup_stream_caches(self, **kw):
+            pass
+
+        def process_one_chunk(self, block):
+            return np.asarray(block)
+
+    ready = threading.Event()
+    th = threading.Thread(target=S.serve, args=(Stub(), "127.0.0.1", 0, 3, ready), daemon=True)
+    th.start()
+    assert ready.wait(10)
+
+    def read_frame(sock):
+        k, n = struct.unpack("<II", S._recv_exact(sock, 8))
+        return k, S._recv_exact(sock, n) if n else b""
+
+    # 1: a CONF frame of the wrong length -> struct.error is reported, the connection keeps working
+    c = S.Client(port=ready.port)
+    S._send(c.sock, S.KIND_CONF, b"\x00" * 5)
+    k, body = read_frame(c.sock)
+    assert k == S.KIND_ERR and b"error" in body.lower()
+    c.set_reference("r", np.ones(2048 * 4, np.float32))
+    c.configure(block_frame=1)
+    assert c.convert(np.zeros(2048, np.float32)).shape == (2048,)
+    try:
+        c.configure(block_frame=S.MAX_BLOCK_FRAMES + 1)
+        raise AssertionError("an oversize block_frame must be refused")
+    except RuntimeError:
+        pass
+    c.close()
+    # 2: a 3 GiB BLOCK header: refused without reading the payload, connection closed by the server
+    s2 = socket.create_connection(("127.0.0.1", ready.port))
+    s2.sendall(struct.pack("<II", S.KIND_BLOCK, 3 << 30))
+    k, body = read_frame(s2)
+    assert k == S.KIND_ERR and b"refused" in body
+    assert s2.recv(1) == b""
+    s2.close()
+    # 3: an unknown kind, then a well-behaved client is still served
+    s3 = socket.create_connection(("127.0.0.1", ready.port))
+    s3.sendall(struct.pack("<II", 77, 0))
+    k, body = read_frame(s3)
+    assert k == S.KIND_ERR
+    s3.close()
+    th.join(10)
+    assert not th.is_alive()

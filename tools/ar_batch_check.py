@@ -53,6 +53,7 @@ def run(B, mode, forced=None, chunk=1, timing=False):
     n = 2048 * chunk
     codes, pcm, fast, hid, slow, ar_ms, spans = [], [], [], [], [], [], None
     nsp = 0
+    inner_sum = None
     for i in range(steps):
         fc = None if forced is None else forced[i]
         out = b.step(src[:, i * n:(i + 1) * n], forced_codes=fc)
@@ -64,16 +65,21 @@ def run(B, mode, forced=None, chunk=1, timing=False):
         if i >= 3:
             ar_ms.append(b.timings()["ar"])
         if timing and path == 2 and i >= 4:
-            t = b.tap("ar_timing", (1024,), np.int64)[:len(labels())].astype(np.float64) * 0.01
+            raw = b.tap("ar_timing", (1024,), np.int64)
+            t = raw[:len(labels())].astype(np.float64) * 0.01
+            inner = raw[512:512 + 72].reshape(9, 8).astype(np.float64)
             d = np.diff(t)
             spans = d if spans is None else spans + d
+            inner_sum = inner if nsp == 0 else inner_sum + inner
             nsp += 1
     fail = int(b.tap("ar_fail", (1,), np.int32)[0]) if path else 0
     b.close()
+    inner_out = None
     if spans is not None:
         spans /= nsp
+        inner_out = inner_sum
     return dict(path=path, codes=np.stack(codes), pcm=np.stack(pcm), fast=np.stack(fast), hid=np.stack(hid), slow=np.stack(slow), ar_ms=float(np.median(ar_ms)),
-                fail=fail, spans=spans)
+                fail=fail, spans=spans, inner=inner_out)
 
 
 def throughput(B, mode, chunk=1, K=60):
@@ -113,6 +119,22 @@ for B in sizes:
     ds = float(np.abs(ref_f["slow"][live] - new_f["slow"][live]).max())
     dp = float(np.abs(ref["pcm"] - new["pcm"]).max()) if ndiff == 0 else float("nan")
     fdiff = int((ref_f["codes"] != new_f["codes"]).sum())
+    for (i, sidx, cb) in list(zip(*np.nonzero(ref_f["codes"][..., 0] != new_f["codes"][..., 0] if ref_f["codes"].ndim == 4 else ref_f["codes"] != new_f["codes"])))[:4]:
+        ca, cn = int(ref_f["codes"].reshape(steps, B, 8)[i, sidx, cb]), int(new_f["codes"].reshape(steps, B, 8)[i, sidx, cb])
+        la, ln = ref_f["fast"][i, sidx, cb], new_f["fast"][i, sidx, cb]
+        pa = np.exp(la.astype(np.float64) - la.max()); pa /= pa.sum()
+        order = np.argsort(-pa); cum = np.cumsum(pa[order])
+        ra, rn = int(np.nonzero(order == ca)[0][0]), int(np.nonzero(order == cn)[0][0])
+        from streamvoiceanon_amd.synth_audio import frame_noise
+        qn = frame_noise(1000 + int(sidx), int(i) - 2)[1][cb].astype(np.float64)
+        def ratios(lg):
+            z = lg.astype(np.float64) / 0.7
+            e = np.exp(z - z.max())
+            return e[ca] / qn[ca], e[cn] / qn[cn]
+        r_a, r_n = ratios(la), ratios(ln)
+        print(f"      p^(1/T)/q of ({ca}, {cn}): multi-launch logits {r_a[0]:.9e} {r_a[1]:.9e} (rel gap {(r_a[0] - r_a[1]) / r_a[0]:.2e}); batched logits {r_n[0]:.9e} {r_n[1]:.9e} (rel gap {(r_n[0] - r_n[1]) / r_n[0]:.2e})")
+        print(f"   raw-code flip at step {i} stream {sidx} codebook {cb}: multi-launch {ca} (rank {ra}, p {pa[ca]:.3e}, cum before {cum[ra] - pa[ca]:.9f}) vs batched {cn} "
+              f"(rank {rn}, p {pa[cn]:.3e}, cum before {cum[rn] - pa[cn]:.9f}); |dlogit| there {abs(la[ca] - ln[ca]):.2e} {abs(la[cn] - ln[cn]):.2e}; max |dlogit| row {np.abs(la - ln).max():.2e}")
     good = new["path"] == 2 and new["fail"] == 0 and fdiff == 0 and dl <= (2e-2 if ar_dtype else 2e-3) and ndiff == 0
     ok_all &= good
     print(f"B={B:3d} ar_dtype={ar_dtype} path={new['path']} fail={new['fail']}  free-running codes differing {ndiff} of {ref['codes'].size}  "
@@ -125,6 +147,13 @@ for B in sizes:
             kinds.setdefault(lab[k + 1], []).append(v)
         print(f"   phase spans of workgroup 0 (us, mean over frames; frame {new['spans'].sum():.0f} us): " +
               "  ".join(f"{k} {np.mean(v):.1f}x{len(v)}" for k, v in kinds.items()), flush=True)
+    if new.get("inner") is not None:
+        names = ["s.QKV", "s.WO", "s.W13", "s.W2", "f.QKV", "f.WO", "f.W13", "f.W2", "f.HEAD"]
+        print("   inside the first unit of workgroup 0, us since the unit began (mean per unit): weights requested | first input sweep back | input valid | partials reduced | epilogue stored | sweeps")
+        for k, nm in enumerate(names):
+            r = new["inner"][k]
+            if r[6] > 0:
+                print(f"      {nm:7s} {r[0] / r[6] * 0.01:5.2f} | {r[1] / r[6] * 0.01:5.2f} | {r[2] / r[6] * 0.01:5.2f} | {r[3] / r[6] * 0.01:5.2f} | {r[4] / r[6] * 0.01:5.2f} | {r[5] / r[6]:.2f}")
     if os.environ.get("PIPE", "0") == "1":
         a = throughput(B, "ar_batch=0,ar_persistent=0")
         c = throughput(B, "ar_batch=1,ar_persistent=1")
