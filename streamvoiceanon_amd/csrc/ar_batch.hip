@@ -230,7 +230,7 @@ struct Tm {
 // multiplied.  pre() runs in every wave after the first weight requests and before the first activation load (prefetch of what the
 // epilogue needs); post() once the wave's last activation chunk has landed (L2 prefetch of a later unit's weights: nothing of this
 // unit may queue behind it -- loads return in order, so the epilogue must not wait for any load of its own).
-template <typename WT, int MT, int NT, int K, bool RMS, bool GRAN, typename PreF, typename PostF>
+template <typename WT, int MT, int NT, int K, bool RMS, bool GRAN, int NP = 1, typename PreF, typename PostF>
 __device__ __forceinline__ void linear_tile(const ASrc& A, unsigned want, int m0, int M, const WT* __restrict__ W, int n0, int N,
                                             const float* __restrict__ rms_w, PreF&& pre, PostF&& post, float* red, int* fail, int code, Tm& tm) {
     if (tm.on) tm.t0 = wall_clock64();
@@ -238,12 +238,16 @@ __device__ __forceinline__ void linear_tile(const ASrc& A, unsigned want, int m0
     constexpr int ACH = MT >= 4 ? 1 : 3;                // K blocks of A requested (and validated) together
     constexpr int NCH = NKW / ACH;
     static_assert(K % (32 * NWV) == 0 && NKW % ACH == 0, "K blocks per wave");
+    // NP = 2 (single-chunk K only): the NT column tiles are multiplied in two passes of NT / 2 against the same landed A operands, the
+    // second pass's weights requested while the first multiplies -- twice the columns per unit without twice the weight registers
+    constexpr int NTC = NT / NP;
+    static_assert(NP == 1 || (NP == 2 && NCH == 1 && NT % 2 == 0), "two column passes need a single K chunk");
     // (an opaque copy of the thread index: otherwise every per-lane offset of every phase is hoisted out of the layer loops and
     // lives -- spilled to scratch -- through the whole kernel; a scratch reload waits for everything requested before it)
     const int tid_ = otid();
     const int lane = tid_ & 63, wave = tid_ >> 6, fr = lane & 15, fk = lane >> 4;
     const int kbase = wave * (K / NWV) + 8 * fk;
-    WReg<WT> wv[2][ACH][NT];
+    WReg<WT> wv[2][ACH][NTC];
     float4 nv[2][ACH][2];
     const WT* wp[NT];
 #pragma unroll
@@ -252,19 +256,21 @@ __device__ __forceinline__ void linear_tile(const ASrc& A, unsigned want, int m0
         if (n > N - 1) n = N - 1;
         wp[j] = W + (long)n * K + kbase;
     }
-    auto issue_w = [&](int buf, int ch) {
+    auto issue_w = [&](int buf, int ch, int pass) {
 #pragma unroll
         for (int d = 0; d < ACH; ++d) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wv[buf][d][j].load(wp[j] + (ch * ACH + d) * 32);
+            for (int j = 0; j < NTC; ++j) wv[buf][d][j].load(wp[pass * NTC + j] + (ch * ACH + d) * 32);
             if constexpr (RMS) {
-                nv[buf][d][0] = *reinterpret_cast<const float4*>(rms_w + kbase + (ch * ACH + d) * 32);
-                nv[buf][d][1] = *reinterpret_cast<const float4*>(rms_w + kbase + (ch * ACH + d) * 32 + 4);
+                if (pass == 0) {
+                    nv[buf][d][0] = *reinterpret_cast<const float4*>(rms_w + kbase + (ch * ACH + d) * 32);
+                    nv[buf][d][1] = *reinterpret_cast<const float4*>(rms_w + kbase + (ch * ACH + d) * 32 + 4);
+                }
             }
         }
     };
-    issue_w(0, 0);
-    if constexpr (NCH > 1) issue_w(1, 1);
+    issue_w(0, 0, 0);
+    if constexpr (NCH > 1) issue_w(1, 1, 0);
     int aoff[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -342,13 +348,34 @@ __device__ __forceinline__ void linear_tile(const ASrc& A, unsigned want, int m0
             if (tm.on) { tm.t3 = wall_clock64(); tm.sweeps = sweeps; }
             post();
         }
+        if constexpr (NP == 1) {
 #pragma unroll
-        for (int d = 0; d < ACH; ++d) {
-            AOps<WT, MT> o;
-            prep_block<WT, MT, RMS>(av[d], nv[ch & 1][d], o, ssq);
-            mma_block<WT, MT, NT>(o, wv[ch & 1][d], acc);
+            for (int d = 0; d < ACH; ++d) {
+                AOps<WT, MT> o;
+                prep_block<WT, MT, RMS>(av[d], nv[ch & 1][d], o, ssq);
+                mma_block<WT, MT, NT>(o, wv[ch & 1][d], acc);
+            }
+            if (ch + 2 < NCH) issue_w(ch & 1, ch + 2, 0);
+        } else {
+            issue_w(1, 0, 1);
+            AOps<WT, MT> o[ACH];
+#pragma unroll
+            for (int d = 0; d < ACH; ++d) prep_block<WT, MT, RMS>(av[d], nv[0][d], o[d], ssq);
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                f32x4 accp[MT][NTC];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTC; ++j) accp[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int d = 0; d < ACH; ++d) mma_block<WT, MT, NTC>(o[d], wv[pass][d], accp);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTC; ++j) acc[i][pass * NTC + j] = accp[i][j];
+            }
         }
-        if (ch + 2 < NCH) issue_w(ch & 1, ch + 2);
     }
     __syncthreads();            // the previous unit's epilogue has read `red`
     // cross-wave reduction of the K slices
@@ -464,6 +491,10 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
     const int B = a.B, M2 = 2 * B;
     const int TMS = (M2 + 16 * MTS - 1) / (16 * MTS), TMF = (B + 16 * MTF - 1) / (16 * MTF);
     const int V = a.codebook_size, VT = (V + 15) / 16, ST = (a.vocab + 15) / 16;
+    // column tiles per unit of the wide phases (wqkv: 144 tiles, w1 | w3: 144 gate / up pairs): two each up to 32 rows, so that EVERY
+    // linear phase has at most 72 units per row tile and a launch of 72-96 workgroups takes each phase in one round
+    constexpr int QNS = MTS >= 4 ? 1 : 2, GNS = MTS >= 4 ? 1 : 2, QNF = MTF >= 4 ? 1 : 2, GNF = MTF >= 4 ? 1 : 2;
+    constexpr int QUS = QT / QNS, GUS = GT / GNS, QUF = QT / QNF, GUF = GT / GNF;
     __builtin_amdgcn_s_setprio(3);
     unsigned ep = *a.epoch;
     int nmark = 0;
@@ -501,40 +532,47 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
         KVT* const kvl = reinterpret_cast<KVT*>(a.kv_slow) + (long)l * a.kv_layer_stride;
         // ---- QKV: RMSNorm + wqkv + RoPE + KV write ----
         ++ep;
-        for (int u = wg; u < TMS * QT; u += G) {
+        for (int u = wg; u < TMS * QUS; u += G) {
             AB_IDS();
-            const int mi = u / QT, nj = u - mi * QT, m0 = mi * 16 * MTS, n0 = nj * 16;
-            const int region = n0 / D, nn = n0 + col - region * D, h = nn >> 6, d = nn & 63;
-            float2 rcs[4];              // RoPE factors of the lane's four rows (requested with the weights: the epilogue loads nothing)
+            const int mi = u / QUS, nj = u - mi * QUS, m0 = mi * 16 * MTS, n0 = nj * 16 * QNS;
+            float2 rcs[QNS][4];         // RoPE factors of the lane's rows (requested with the weights: the epilogue loads nothing)
             auto pre = [&] {
-                if (wave < MTS && region < 2) {
+                if (wave < MTS) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + 16 * wave + rq + r;
-                        rcs[r] = *reinterpret_cast<const float2*>(a.rope_slow + ((long)pos_s[m < M2 ? m : M2 - 1] * 32 + (d >> 1)) * 2);
+                    for (int j = 0; j < QNS; ++j) {
+                        const int nt = n0 + 16 * j, region = nt / D, d = (nt + col - region * D) & 63;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = m0 + 16 * wave + rq + r;
+                            rcs[j][r] = *reinterpret_cast<const float2*>(a.rope_slow + ((long)pos_s[m < M2 ? m : M2 - 1] * 32 + (d >> 1)) * 2);
+                        }
                     }
                 }
             };
             auto post = [&] { if (u == wg) touch(L.wo, TMS, XT, 16, D, D); };
-            if (l == 0) linear_tile<WT, MTS, 1, D, true, false>(AIN, 0u, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, pre, post, red, a.fail, 1, tm);
-            else linear_tile<WT, MTS, 1, D, true, true>(AXS, e_x, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, pre, post, red, a.fail, 1, tm);
+            if (l == 0) linear_tile<WT, MTS, QNS, D, true, false, QNS>(AIN, 0u, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, pre, post, red, a.fail, 1, tm);
+            else linear_tile<WT, MTS, QNS, D, true, true, QNS>(AXS, e_x, m0, M2, reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, pre, post, red, a.fail, 1, tm);
             if (wave < MTS) {
                 const int i = wave;
-                f32x4 t[1];
-                tile_sum<MTS, 1>(red, i, lane, t);
+                f32x4 t[QNS];
+                tile_sum<MTS, QNS>(red, i, lane, t);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 16 * i + rq + r, mc = m < M2 ? m : M2 - 1;
-                    const int s = mc >> 1, pos = pos_s[mc];
-                    float v = t[0][r] * row_inv<MTS, 1>(red, i, rq + r, D, 1e-5f);
-                    const float pv = lane_xor_f<1>(v);
-                    if (region < 2) {
-                        const float c = rcs[r].x, sn = rcs[r].y;
-                        v = (d & 1) ? v * c + pv * sn : v * c - pv * sn;
-                    }
-                    if (m < M2) {
-                        st_g(a.gqkv + (long)m * 3 * D + n0 + col, ep, v);
-                        if (region >= 1) st_kv<KVT>(kvl + (long)s * a.kv_slot_stride + ((long)(region - 1) * H + h) * SH + (long)pos * 64 + d, v);
+                for (int j = 0; j < QNS; ++j) {
+                    const int nt = n0 + 16 * j, region = nt / D, nn = nt + col - region * D, h = nn >> 6, d = nn & 63;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + 16 * i + rq + r, mc = m < M2 ? m : M2 - 1;
+                        const int s = mc >> 1, pos = pos_s[mc];
+                        float v = t[j][r] * row_inv<MTS, QNS>(red, i, rq + r, D, 1e-5f);
+                        const float pv = lane_xor_f<1>(v);
+                        if (region < 2) {
+                            const float c = rcs[j][r].x, sn = rcs[j][r].y;
+                            v = (d & 1) ? v * c + pv * sn : v * c - pv * sn;
+                        }
+                        if (m < M2) {
+                            st_g(a.gqkv + (long)m * 3 * D + nt + col, ep, v);
+                            if (region >= 1) st_kv<KVT>(kvl + (long)s * a.kv_slot_stride + ((long)(region - 1) * H + h) * SH + (long)pos * 64 + d, v);
+                        }
                     }
                 }
             }
@@ -659,28 +697,30 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                                                     [&] {
                                                         if (l == 0) res_prefetch_plain<MTS>(a.xs_in, m0, M2, n0, rg);
                                                         else res_prefetch<MTS>(GXS, m0, M2, n0, rg);
-                                                    }, [&] { if (u == wg) touch(L.w13, TMS, GT, 32, 2 * I, D); }, red, a.fail, 3, tm);
+                                                    }, [&] { if (u == wg) touch(L.w13, TMS, GUS, 32 * GNS, 2 * I, D); }, red, a.fail, 3, tm);
             epi_residual<MTS>(red, m0, M2, n0, rg, l > 0, e_x, GXS, GXS, ep, nullptr, a.fail);
             AB_ACC(1);
         }
         AB_MARK();
         // ---- W13: RMSNorm + w1 | w3 + SwiGLU ----
         ++ep;
-        for (int u = wg; u < TMS * GT; u += G) {
+        for (int u = wg; u < TMS * GUS; u += G) {
             AB_IDS();
-            const int mi = u / GT, nj = u - mi * GT, m0 = mi * 16 * MTS, n0 = nj * 32;
-            linear_tile<WT, MTS, 2, D, true, true>(AXS, ep - 1, m0, M2, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm, [] {},
-                                                   [&] { if (u == wg) touch(L.w2, TMS, XT, 16, D, I); }, red, a.fail, 4, tm);
+            const int mi = u / GUS, nj = u - mi * GUS, m0 = mi * 16 * MTS, n0 = nj * 32 * GNS;
+            linear_tile<WT, MTS, 2 * GNS, D, true, true, GNS>(AXS, ep - 1, m0, M2, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm, [] {},
+                                                         [&] { if (u == wg) touch(L.w2, TMS, XT, 16, D, I); }, red, a.fail, 4, tm);
             if (wave < MTS) {
                 const int i = wave;
-                f32x4 t[2];
-                tile_sum<MTS, 2>(red, i, lane, t);
+                f32x4 t[2 * GNS];
+                tile_sum<MTS, 2 * GNS>(red, i, lane, t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + 16 * i + rq + r;
                     if (m >= M2) continue;
-                    const float inv = row_inv<MTS, 2>(red, i, rq + r, D, 1e-5f);
-                    st_g(a.gg + gidx(GG, m, nj * 16 + col), ep, silu_f(t[0][r] * inv) * (t[1][r] * inv));
+                    const float inv = row_inv<MTS, 2 * GNS>(red, i, rq + r, D, 1e-5f);
+#pragma unroll
+                    for (int j = 0; j < GNS; ++j)
+                        st_g(a.gg + gidx(GG, m, (nj * GNS + j) * 16 + col), ep, silu_f(t[2 * j][r] * inv) * (t[2 * j + 1][r] * inv));
                 }
             }
             AB_ACC(2);
@@ -696,9 +736,9 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                                                     [&] { res_prefetch<MTS>(GXS, m0, M2, n0, rg); },
                                                     [&] {
                                                         if (u != wg) return;
-                                                        if (l + 1 < AR_SLOW_LAYERS) touch(a.slow[l + 1].wqkv, TMS, QT, 16, 3 * D, D);
+                                                        if (l + 1 < AR_SLOW_LAYERS) touch(a.slow[l + 1].wqkv, TMS, QUS, 16 * QNS, 3 * D, D);
                                                         else if (!a.skip_semantic) touch(a.out_w, TMF, ST, 16, a.vocab, D);
-                                                        else touch(a.fast[0].wqkv, TMF, QT, 16, 3 * D, D);
+                                                        else touch(a.fast[0].wqkv, TMF, QUF, 16 * QNF, 3 * D, D);
                                                     }, red, a.fail, 5, tm);
             epi_residual<MTS>(red, m0, M2, n0, rg, true, ep - 2, GXS, GXS, ep, nullptr, a.fail);
             AB_ACC(3);
@@ -715,7 +755,7 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
             AB_IDS();
             const int mi = u / ST, nj = u - mi * ST, m0 = mi * 16 * MTF, n0 = nj * 16;
             linear_tile<WT, MTF, 1, D, true, true>(AHID, e_x, m0, B, reinterpret_cast<const WT*>(a.out_w), n0, a.vocab, a.out_norm, [] {},
-                                                   [&] { if (u == wg) touch(a.fast[0].wqkv, TMF, QT, 16, 3 * D, D); }, red, a.fail, 6, tm);
+                                                   [&] { if (u == wg) touch(a.fast[0].wqkv, TMF, QUF, 16 * QNF, 3 * D, D); }, red, a.fail, 6, tm);
             if (wave < MTF) {
                 const int i = wave;
                 f32x4 t[1];
@@ -769,28 +809,36 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
             const bool first = l == 0, from_slow = first && cb == 0;
             // ---- FQKV: RMSNorm + wqkv + RoPE (position = codebook index) + K / V of this position ----
             ++ep;
-            for (int u = wg; u < TMF * QT; u += G) {
+            for (int u = wg; u < TMF * QUF; u += G) {
                 AB_IDS();
-                const int mi = u / QT, nj = u - mi * QT, m0 = mi * 16 * MTF, n0 = nj * 16;
-                const int region = n0 / D, nn = n0 + col - region * D, d = nn & 63;
-                const float2 cs = *reinterpret_cast<const float2*>(a.rope_fast + (cb * 32 + (d >> 1)) * 2);
-                const float c = cs.x, sn = cs.y;
-                linear_tile<WT, MTF, 1, D, true, true>(from_slow ? AHID : AXF, from_slow ? e_x : first ? e_row : ep - 1, m0, B,
-                                                       reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, [] {},
-                                                       [&] { if (u == wg) touch(L.wo, TMF, XT, 16, D, D); }, red, a.fail, 7, tm);
+                const int mi = u / QUF, nj = u - mi * QUF, m0 = mi * 16 * MTF, n0 = nj * 16 * QNF;
+                float2 cs[QNF];
+#pragma unroll
+                for (int j = 0; j < QNF; ++j) {
+                    const int nt = n0 + 16 * j, region = nt / D, d = (nt + col - region * D) & 63;
+                    cs[j] = *reinterpret_cast<const float2*>(a.rope_fast + (cb * 32 + (d >> 1)) * 2);
+                }
+                linear_tile<WT, MTF, QNF, D, true, true, QNF>(from_slow ? AHID : AXF, from_slow ? e_x : first ? e_row : ep - 1, m0, B,
+                                                         reinterpret_cast<const WT*>(L.wqkv), n0, 3 * D, L.attn_norm, [] {},
+                                                         [&] { if (u == wg) touch(L.wo, TMF, XT, 16, D, D); }, red, a.fail, 7, tm);
                 if (wave < MTF) {
                     const int i = wave;
-                    f32x4 t[1];
-                    tile_sum<MTF, 1>(red, i, lane, t);
+                    f32x4 t[QNF];
+                    tile_sum<MTF, QNF>(red, i, lane, t);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + 16 * i + rq + r;
-                        float v = t[0][r] * row_inv<MTF, 1>(red, i, rq + r, D, 1e-5f);
-                        const float pv = lane_xor_f<1>(v);
-                        if (region < 2) v = (d & 1) ? v * c + pv * sn : v * c - pv * sn;
-                        if (m < B) {
-                            st_g(a.gqkvf + (long)m * 3 * D + n0 + col, ep, v);
-                            if (region >= 1) st_g(a.gkvf + (((long)l * B + m) * NCB + cb) * 2 * D + (n0 + col - D), ep, v);
+                    for (int j = 0; j < QNF; ++j) {
+                        const int nt = n0 + 16 * j, region = nt / D, d = (nt + col - region * D) & 63;
+                        const float c = cs[j].x, sn = cs[j].y;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = m0 + 16 * i + rq + r;
+                            float v = t[j][r] * row_inv<MTF, QNF>(red, i, rq + r, D, 1e-5f);
+                            const float pv = lane_xor_f<1>(v);
+                            if (region < 2) v = (d & 1) ? v * c + pv * sn : v * c - pv * sn;
+                            if (m < B) {
+                                st_g(a.gqkvf + (long)m * 3 * D + nt + col, ep, v);
+                                if (region >= 1) st_g(a.gkvf + (((long)l * B + m) * NCB + cb) * 2 * D + (nt + col - D), ep, v);
+                            }
                         }
                     }
                 }
@@ -884,7 +932,7 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                                                         [&] {
                                                             if (from_slow) res_prefetch<MTF>(GHID, m0, B, n0, rg);
                                                             else res_prefetch<MTF>(GXF, m0, B, n0, rg);
-                                                        }, [&] { if (u == wg) touch(L.w13, TMF, GT, 32, 2 * I, D); }, red, a.fail, 10, tm);
+                                                        }, [&] { if (u == wg) touch(L.w13, TMF, GUF, 32 * GNF, 2 * I, D); }, red, a.fail, 10, tm);
                 // hidden = pre-norm state of the content token (forward_generate :340-341): tap, and the fast AR's first input
                 if (from_slow) epi_residual<MTF>(red, m0, B, n0, rg, true, e_x, GHID, GXF, ep, a.hidden, a.fail);
                 else epi_residual<MTF>(red, m0, B, n0, rg, true, first ? e_row : ep - 3, GXF, GXF, ep, nullptr, a.fail);
@@ -893,21 +941,23 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
             AB_MARK();
             // ---- FW13 ----
             ++ep;
-            for (int u = wg; u < TMF * GT; u += G) {
+            for (int u = wg; u < TMF * GUF; u += G) {
                 AB_IDS();
-                const int mi = u / GT, nj = u - mi * GT, m0 = mi * 16 * MTF, n0 = nj * 32;
-                linear_tile<WT, MTF, 2, D, true, true>(AXF, ep - 1, m0, B, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm, [] {},
-                                                       [&] { if (u == wg) touch(L.w2, TMF, XT, 16, D, I); }, red, a.fail, 11, tm);
+                const int mi = u / GUF, nj = u - mi * GUF, m0 = mi * 16 * MTF, n0 = nj * 32 * GNF;
+                linear_tile<WT, MTF, 2 * GNF, D, true, true, GNF>(AXF, ep - 1, m0, B, reinterpret_cast<const WT*>(L.w13), n0, 2 * I, L.ffn_norm, [] {},
+                                                             [&] { if (u == wg) touch(L.w2, TMF, XT, 16, D, I); }, red, a.fail, 11, tm);
                 if (wave < MTF) {
                     const int i = wave;
-                    f32x4 t[2];
-                    tile_sum<MTF, 2>(red, i, lane, t);
+                    f32x4 t[2 * GNF];
+                    tile_sum<MTF, 2 * GNF>(red, i, lane, t);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int m = m0 + 16 * i + rq + r;
                         if (m >= B) continue;
-                        const float inv = row_inv<MTF, 2>(red, i, rq + r, D, 1e-5f);
-                        st_g(a.ggf + gidx(GGF, m, nj * 16 + col), ep, silu_f(t[0][r] * inv) * (t[1][r] * inv));
+                        const float inv = row_inv<MTF, 2 * GNF>(red, i, rq + r, D, 1e-5f);
+#pragma unroll
+                        for (int j = 0; j < GNF; ++j)
+                            st_g(a.ggf + gidx(GGF, m, (nj * GNF + j) * 16 + col), ep, silu_f(t[2 * j][r] * inv) * (t[2 * j + 1][r] * inv));
                     }
                 }
                 AB_ACC(6);
@@ -923,7 +973,7 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
                                                         [&] { res_prefetch<MTF>(GXF, m0, B, n0, rg); },
                                                         [&] {
                                                             if (u != wg) return;
-                                                            if (l + 1 < AR_FAST_LAYERS) touch(a.fast[l + 1].wqkv, TMF, QT, 16, 3 * D, D);
+                                                            if (l + 1 < AR_FAST_LAYERS) touch(a.fast[l + 1].wqkv, TMF, QUF, 16 * QNF, 3 * D, D);
                                                             else touch(a.fast_out_w, TMF, VT, 16, V, D);
                                                         }, red, a.fail, 12, tm);
                 epi_residual<MTF>(red, m0, B, n0, rg, true, ep - 2, GXF, GXF, ep, nullptr, a.fail);
@@ -937,7 +987,7 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
             AB_IDS();
             const int mi = u / VT, nj = u - mi * VT, m0 = mi * 16 * MTF, n0 = nj * 16;
             linear_tile<WT, MTF, 1, D, true, true>(AXF, ep - 1, m0, B, reinterpret_cast<const WT*>(a.fast_out_w), n0, V, a.fast_norm, [] {},
-                                                   [&] { if (u == wg && cb + 1 < NCB) touch(a.fast[0].wqkv, TMF, QT, 16, 3 * D, D); }, red, a.fail, 13, tm);
+                                                   [&] { if (u == wg && cb + 1 < NCB) touch(a.fast[0].wqkv, TMF, QUF, 16 * QNF, 3 * D, D); }, red, a.fail, 13, tm);
             if (wave < MTF) {
                 const int i = wave;
                 f32x4 t[1];
@@ -1026,7 +1076,8 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
 }
 
 constexpr size_t lds_floats(int MTS, int MTF) {
-    const size_t lin = red_floats(MTS > MTF ? MTS : MTF, 2);
+    const int mt = MTS > MTF ? MTS : MTF;
+    const size_t lin = red_floats(mt, mt >= 4 ? 2 : 4);
     const size_t att = 2 * 4 * NWV * 68, fatt = 3 * D + 7 * 2 * D + D, smp = 256;
     size_t m = lin;
     if (att > m) m = att;
@@ -1083,7 +1134,7 @@ int ar_batch_wanted_workgroups(int B) {
     int mts, mtf;
     ar_batch_tiles(B, &mts, &mtf);
     const int TMS = (2 * B + 16 * mts - 1) / (16 * mts);
-    return QT * TMS;
+    return (mts >= 4 ? QT : QT / 2) * TMS;
 }
 
 #define AB_DISPATCH(FN, ...)                                                                                   \

@@ -1757,6 +1757,16 @@ int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSe
 }
 }  // namespace
 
+// batch sizes the batched persistent decode kernel (ar_batch.hip) serves: where it beats both the two-streams-per-launch kernel
+// (ar_decode.hip, below) and the multi-launch decode (above) in the pipelined mode -- fp32 AR 7-24 streams, fp16 AR 5-11
+// (profiles/r04_abatch_sweep.txt); SVA_DEBUG ar_batch=0 never, ar_batch=2 every size it can run (A/B, parity tests)
+static bool abatch_serves(int B, int ar_dtype) {
+    const int mode = debug_options().ar_batch;
+    if (mode == 0 || B > AR_BATCH_MAX_STREAMS) return false;
+    if (mode == 2) return true;
+    return ar_dtype == 1 ? (B >= 5 && B <= 11) : (B >= 7 && B <= 24);
+}
+
 static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batch* b);
 
 extern "C" int sva_batch_create(sva_engine* e, const sva_stream_params* p, sva_batch** out) {
@@ -1808,8 +1818,14 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // profiles/r03_partition_ab.txt -- fp32 AR: 8 streams 1873 unpartitioned / 2206 with 96 CUs / 2497 with 128; 12: 2683 / 3422
         // with 96; 24: 3960 / 4312 with 64; 32: 5008 / 5322 with 64; 48: 5725 / 5628.  fp16 AR: 12: 3053 / 3989 with 64; 16: 3682 /
         // 4234; 24: 4415 / 4884; 32: 5337 / 5421).  Round 2 partitioned 7-8 streams only, always 96 | 160.
+        // batched persistent decode kernel (ar_batch.hip; the range it serves: batch_create_impl): no CU partition either -- its 72
+        // workgroups of 8 waves x 256 registers fill 72 CUs by themselves and leave the other 184 to the encoder and the vocoder
+        // (pipelined, fp32 AR, unpartitioned vs the multi-launch decode on its best partition: 8 streams 3066-3169 vs 2538 frames/s,
+        // 12: 3761-3795 vs 3463, 16: 4465 vs 4166, 24: 4839 vs 4223, 32: 5288 vs 5419; on 64 / 96 / 128-CU partitions it loses 3-20 %;
+        // fp16 AR: 6 streams 2989 vs 2664, 8: 3440 vs 3197, 12: 4059 vs 4110 -- profiles/r04_abatch_sweep.txt)
+        const bool will_abatch = !will_mega && abatch_serves(B, c.ar_dtype) && e->mega_ok && debug_options().ar_persistent != 0;
         int ar_cus = 96, part_streams = 0;
-        if (b->p.pipeline && !will_mega && B <= (p->chunk_frames > 1 ? 16 : 32)) {      // (chunk 4: 16 streams +11 %, 32 streams -15 %: tools/part_ab4.sh)
+        if (b->p.pipeline && !will_mega && !will_abatch && B <= (p->chunk_frames > 1 ? 16 : 32)) {      // (chunk 4: 16 streams +11 %, 32 streams -15 %: tools/part_ab4.sh)
             part_streams = B;
             if (B >= 2) ar_cus = c.ar_dtype == 1 ? (B <= 8 ? 96 : 64) : (B <= 8 ? 128 : B <= 20 ? 96 : 64);
         }
@@ -2022,8 +2038,8 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     }
     // batched persistent decode kernel (ar_batch.hip): every stream of the batch in one launch per frame.  Takes the batches the
     // two-streams-per-launch kernel above does not serve; its workgroups must all be resident (same check as above).
-    b->use_abatch = !b->use_mega && e->mega_ok && debug_options().ar_persistent != 0 && debug_options().ar_batch != 0 && B <= AR_BATCH_MAX_STREAMS &&
-                    c.ar_vocab <= 8192 && c.codebook_size <= 1024;
+    b->use_abatch = !b->use_mega && e->mega_ok && debug_options().ar_persistent != 0 && abatch_serves(B, c.ar_dtype) && c.ar_vocab <= 8192 &&
+                    c.codebook_size <= 1024;
     if (b->use_abatch) {
         int per_cu = 0, cus = 0;
         SVA_TRY(ar_batch_occupancy(c.ar_dtype == 1, B, &per_cu));

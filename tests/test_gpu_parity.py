@@ -1663,3 +1663,88 @@ def test_stream_server_equals_custom_infer(weights0):
     c.close()
     th.join(30)
     w_srv.engine.close(); w_ref.engine.close()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_rccl_gather_of_engine_results(world):
+    """SURVEY 8e / VERDICT r03 item 6: the utterance shards of every rank go through the REAL engine and their codes are gathered to rank 0
+    over RCCL (torch.distributed "nccl", sharding.gather_results -> dist.gather); the gathered codes, put back into global utterance
+    order, equal the codes of the same utterances decoded by one process with no communication.  world = 1 exercises the RCCL path
+    on a single device (a forced one-rank group); world = 2 runs when the box has two devices."""
+    import os
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"{world} HIP devices needed, {torch.cuda.device_count()} visible")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_gather_worker.py")
+    env = dict(os.environ)
+    env.pop("SVA_DEBUG", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + world), worker]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("GATHER")]
+    assert line, r.stdout[-1000:]
+    parts = line[-1].split()
+    assert parts[1] == str(world) and parts[-2] == parts[-1], line[-1]
+
+
+@pytest.mark.parametrize("B,fp16", [(2, False), (3, False), (5, False), (8, False), (12, False), (32, False), (64, False), (5, True), (8, True), (33, True)])
+def test_batched_persistent_decode_equals_multi_launch(eng, eng_fp16, B, fp16):
+    """the batched persistent decode kernel (csrc/ar_batch.hip: every stream of the batch in ONE launch per frame,
+    {epoch, value} granule hand-offs, MFMA tiles over the 2 B / B rows) against the multi-launch decode of the same batch, at every
+    row-tile shape of the kernel (16 / 32 / 64-row slow tiles, one and two row tiles) and beyond the sizes it serves by default
+    (SVA_DEBUG ar_batch=2 forces it).  Teacher-forced on the multi-launch run's codes: top logits within fp32 summation order
+    (fp16 weights: 2e-3), hidden state alike, raw sampled codes equal except where the two candidates' sampling ratios
+    p^(1/T) / q are closer than 1e-4 relative (a genuine near-tie: the kernels sum K in a different order).  Free-running codes and
+    PCM are compared when no near-tie flipped a code."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    e, steps, lib = (eng_fp16 if fp16 else eng), 9, E.load_library()
+
+    def run(mode, forced=None):
+        lib.sva_debug_configure(mode.encode())          # (read at batch creation)
+        try:
+            b = E.Batch(e, n_streams=B)
+        finally:
+            lib.sva_debug_configure(b"ar_batch=1,ar_persistent=1")
+        path = b.decode_path()
+        for s in range(B):
+            ac, cc, style, timbre = synth_prompt(2000 + s % 5, 60 + 7 * (s % 5))
+            b.prefill_prompt(s, cc, ac, style, timbre, noise_seed=1000 + s)
+        b.begin()
+        src = np.stack([synth_utterance(1000 + s % 7, 2048 * steps) for s in range(B)])
+        codes, pcm, fast, hid = [], [], [], []
+        for i in range(steps):
+            pcm.append(b.step(src[:, i * 2048:(i + 1) * 2048], forced_codes=None if forced is None else forced[i]))
+            codes.append(b.tap("sampled_codes", (B, 8), np.int32).copy() if forced is not None else b.tap("audio_codes", (B, 8, 1), np.int32)[:, :, 0].copy())
+            fast.append(b.tap("fast_logits", (B, 8, 1000)).copy())
+            hid.append(b.tap("hidden", (B, 768)).copy())
+        fail = int(b.tap("ar_fail", (1,), np.int32)[0]) if path else 0
+        b.close()
+        return path, fail, np.stack(codes), np.stack(pcm), np.stack(fast), np.stack(hid)
+
+    p0, _, codes0, pcm0, _, _ = run("ar_batch=0,ar_persistent=0")
+    p2, fail2, codes2, pcm2, _, _ = run("ar_batch=2,ar_persistent=1")
+    assert p0 == 0 and p2 == 2 and fail2 == 0
+    forced = [np.ascontiguousarray(codes0[i][:, :, None]) for i in range(steps)]
+    _, _, raw0, _, fast0, hid0 = run("ar_batch=0,ar_persistent=0", forced)
+    _, fail2f, raw2, _, fast2, hid2 = run("ar_batch=2,ar_persistent=1", forced)
+    assert fail2f == 0
+    live = slice(2, None)                                  # the first `delay` chunks decode nothing
+    tol = 2e-3 if fp16 else 2e-4
+    assert np.abs(fast0[live] - fast2[live]).max() <= tol and np.abs(hid0[live] - hid2[live]).max() <= tol
+    flips = 0
+    for i, s, cb in zip(*np.nonzero(raw0 != raw2)):
+        q = frame_noise(1000 + int(s), int(i) - 2)[1][cb].astype(np.float64)
+        z = fast0[i, s, cb].astype(np.float64) / 0.7
+        r = np.exp(z - z.max()) / q
+        ca, cn = int(raw0[i, s, cb]), int(raw2[i, s, cb])
+        assert abs(r[ca] - r[cn]) <= 1e-4 * max(r[ca], r[cn]), f"codes differ without a near-tie at step {i} stream {s} codebook {cb}: {ca} vs {cn}"
+        flips += 1
+    if flips == 0:
+        np.testing.assert_array_equal(codes0, codes2)
+        assert np.abs(pcm0 - pcm2).max() <= PCM_TOL

@@ -104,10 +104,34 @@ def throughput(B, mode, chunk=1, K=60):
     return dt * 1e3, B * chunk / dt, path
 
 
+if os.environ.get("SWEEP", "0") == "2":
+    # pipelined throughput against the number of workgroups of the persistent launch (no CU partition)
+    for B in sizes:
+        row = []
+        for g in (48, 56, 64, 72, 80, 96, 144):
+            ms, fps, path = throughput(B, f"ar_batch=1,ar_persistent=1,cu_partition=0,ar_batch_wgs={g}", K=80)
+            row.append(f"{g}: {fps:.0f} (p{path})")
+        ms, fps, path = throughput(B, "ar_batch=0,ar_persistent=0,cu_partition=-1", K=80)
+        print(f"B={B:3d} frames/s by workgroups  " + "  ".join(row) + f"  | multi-launch, default partition: {fps:.0f}", flush=True)
+    lib.sva_debug_configure(b"ar_batch=1,ar_persistent=1,cu_partition=-1,ar_batch_wgs=0")
+    sys.exit(0)
+if os.environ.get("SWEEP", "0") == "1":
+    # pipelined throughput of the batched persistent decode against the CU partition of the AR stream
+    for B in sizes:
+        row = []
+        for cfg in ["cu_partition=0"] + [f"cu_partition=1,cu_ar={n}" for n in (64, 96, 128)]:
+            try:
+                ms, fps, path = throughput(B, "ar_batch=1,ar_persistent=1," + cfg, K=80)
+                row.append(f"{cfg.split('=')[-1] if 'cu_ar' in cfg else 'none'}: {fps:.0f} (p{path})")
+            except RuntimeError as ex:
+                row.append(f"{cfg}: {str(ex)[:40]}")
+        ms, fps, path = throughput(B, "ar_batch=0,ar_persistent=0,cu_partition=-1", K=80)
+        print(f"B={B:3d} frames/s by AR CUs  " + "  ".join(row) + f"  | multi-launch, default partition: {fps:.0f}", flush=True)
+    sys.exit(0)
 ok_all = True
 for B in sizes:
     ref = run(B, "ar_batch=0,ar_persistent=0")
-    new = run(B, "ar_batch=2,ar_persistent=1", timing=True)
+    new = run(B, "ar_batch=2,ar_persistent=1", timing=os.environ.get("TIMING", "1") == "1")
     # teacher-forced on the reference run's codes: logits of every frame comparable although a near-tie may flip a free-running code
     forced = [np.ascontiguousarray(ref["codes"][i][:, :, :1]) for i in range(steps)]
     ref_f = run(B, "ar_batch=0,ar_persistent=0", forced=forced)
