@@ -55,6 +55,12 @@ typedef struct sva_config {
     int ar_dtype;          /* 0: fp32 AR weights + fp32 KV (parity mode); 1: fp16 AR weights (streamed as fp16 by the batch-1 decode kernel;
                             * the batched / prefill GEMMs use the same fp16-rounded values) + fp16 slow KV cache, as the reference
                             * decodes under torch.autocast(fp16) with fp16 caches (evaluations/infer_arvc.py:55-59, 483, 493) */
+    int mm_mode;           /* batch-scale GEMMs (>= 2048 rows) of the encoder / vocoder, csrc/gemm_planes.hip: 0 = fp32-grade from three bf16
+                            * planes per operand (six part products; any fp32 range), 1 = fp32-grade from two fp16 planes (three part
+                            * products, half the matrix work; operands inside the fp16 range, which torch.autocast(fp16) -- infer_arvc.py:493 --
+                            * demands of the reference too), -1 = the round-3 kernel that splits operands inside its K loop (A/B) */
+    int voc_dtype;         /* 0: vocoder (firefly.decode) GEMMs in the mm_mode grade; 1: fp16 operands, fp32 accumulate -- the reference's
+                            * own precision for this stage (torch.autocast(fp16) around code2wav_fn, infer_arvc.py:493, 571-590) */
 } sva_config;
 
 /* evaluations/infer_arvc.py setup_stream_caches (:443-460) + stream_infer defaults (:598-613) */
@@ -263,6 +269,13 @@ int sva_test_gemm_choice(int device, int M, int N, int K, const float* A, const 
  * iters > 0 also returns the average microseconds per launch. */
 int sva_test_gemm_f16w(int device, int M, int N, int K, const float* A, const float* W, const float* bias, const float* rms_w,
                        const float* res, int mode, float* C, int iters, float* out_us);
+/* conv-GEMM fed from pre-split 16-bit operand planes (csrc/gemm_planes.hip; the Linear layers of firefly.py:421-440 and
+ * windowed_transformer.py:134-143 at batch scale): mode 0 = three bf16 planes / six products (fp32-grade), 1 = two fp16 planes /
+ * three products (fp32-grade inside the fp16 range), 2 = one fp16 plane (torch.autocast(fp16), evaluations/infer_arvc.py:493);
+ * variant = tile variant 0..5; flags: 1 = A handed over as planes, 2 = C leaves as planes only (summed back to fp32 for the caller),
+ * 4 = GELU epilogue, 8 = SiLU on load; iters > 0 also returns the average microseconds per launch. */
+int sva_test_gemm_planes(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int mode,
+                         int variant, int flags, int iters, float* out_us);
 /* Prefill attention of the slow AR (modules/dual_ar_stream.py:338-356 with causal_mask[kv_pos]): M query rows [M][H*64] at positions
  * pos0 .. pos0 + M - 1 against keys / values [pos0 + M][H*64] placed in a cache of S positions (fp32, or fp16 when half_kv).
  * out_ref: the per-row kernel, out_mfma: the flash-style MFMA kernel; us[2] their launch times when iters > 0. */

@@ -41,6 +41,9 @@ struct Lin {
     void* Wh = nullptr;          // fp16 copy in the same [N][K] layout (AR layers of an ar_dtype = 1 engine)
     float* b = nullptr;
     int N = 0, K = 0;
+    unsigned short* Wp = nullptr;    // pre-split 16-bit planes [planes][N][K] of W * 2^e (gemm_planes.hip), wp_inv = 2^-e, pmode = their PlanesMode
+    float wp_inv = 1.f;
+    int pmode = -1;
 };
 
 // ConvNeXtBlock (modules/vqgan/modules/firefly.py:375-440)

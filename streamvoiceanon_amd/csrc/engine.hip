@@ -136,7 +136,7 @@ extern "C" int sva_config_default(sva_config* c) {
     c->tr_layers = 8; c->tr_heads = 8; c->tr_dim = 512; c->tr_inter = 1536; c->bsq_bits = 13;
     c->ar_dim = 768; c->ar_heads = 12; c->ar_layers = 12; c->ar_fast_layers = 4; c->ar_inter = 2304;
     c->ar_vocab = 8192; c->codebook_size = 1000; c->num_codebooks = 8; c->max_delay = 8; c->max_seq_len = 2048;
-    c->timbre_dim = 128; c->timbre_tokens = 32; c->style_dim = 192; c->voc_dim = 512; c->ar_dtype = 0;
+    c->timbre_dim = 128; c->timbre_tokens = 32; c->style_dim = 192; c->voc_dim = 512; c->ar_dtype = 0; c->mm_mode = 0; c->voc_dtype = 0;
     return 0;
 }
 extern "C" int sva_stream_params_default(sva_stream_params* p) {
@@ -563,6 +563,45 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
         SVA_TRY(upload(e->allocs, &e->post_w, pt));
         SVA_TRY(P.vec(h + "conv_post.conv.bias", &e->post_b, 1));
     }
+    // ---- pre-split operand planes of the encoder / vocoder weights (gemm_planes.hip) ----
+    {
+        const int enc_mode = c.mm_mode == 1 ? PLANES_H3 : c.mm_mode == 0 ? PLANES_S6 : -1;
+        const int voc_mode = c.voc_dtype == 1 ? PLANES_H1 : enc_mode;
+        SVA_CHECK(c.mm_mode >= -1 && c.mm_mode <= 1 && (c.voc_dtype == 0 || c.voc_dtype == 1), "bad mm_mode / voc_dtype");
+        std::vector<float> host;
+        auto planes = [&](Lin& l, int mode) -> int {
+            if (mode < 0 || !l.W || l.N < 64 || l.K % 32 != 0) return 0;
+            const long n = (long)l.N * l.K;
+            host.resize(n);
+            SVA_HIP(hipMemcpy(host.data(), l.W, sizeof(float) * n, hipMemcpyDeviceToHost));
+            float mx = 0.f;
+            for (long i = 0; i < n; ++i) mx = std::max(mx, fabsf(host[i]));
+            SVA_TRY(dev_alloc(e->allocs, &l.Wp, (size_t)planes_count(mode) * n, false));
+            SVA_TRY(make_weight_planes(l.W, n, mx, mode, l.Wp, &l.wp_inv, 0));
+            l.pmode = mode;
+            return 0;
+        };
+        auto front = [&](EncFront& F, int mode) -> int {
+            if (!F.loaded) return 0;
+            SVA_TRY(planes(F.stem, mode));
+            for (int i = 0; i < 4; ++i) {
+                SVA_TRY(planes(F.trans[i], mode));
+                for (auto& cx : F.stages[i]) { SVA_TRY(planes(cx.pw1, mode)); SVA_TRY(planes(cx.pw2, mode)); }
+            }
+            for (int i = 0; i < 2; ++i) { SVA_TRY(planes(F.ds_conv[i], mode)); SVA_TRY(planes(F.ds_cnx[i].pw1, mode)); SVA_TRY(planes(F.ds_cnx[i].pw2, mode)); }
+            return 0;
+        };
+        SVA_TRY(front(e->tokf, enc_mode));
+        SVA_TRY(front(e->vocf, enc_mode));           // firefly.encode of the prompt produces FSQ indices: encoder grade
+        for (auto& L : e->tr) { SVA_TRY(planes(L.wqkv, enc_mode)); SVA_TRY(planes(L.wo, enc_mode)); SVA_TRY(planes(L.w13, enc_mode)); SVA_TRY(planes(L.w2, enc_mode)); }
+        for (int i = 0; i < 2; ++i) { SVA_TRY(planes(e->up_conv[i], voc_mode)); SVA_TRY(planes(e->up_cnx[i].pw1, voc_mode)); SVA_TRY(planes(e->up_cnx[i].pw2, voc_mode)); }
+        SVA_TRY(planes(e->conv_pre, voc_mode));
+        for (int i = 0; i < 5; ++i) {
+            SVA_TRY(planes(e->ups[i], voc_mode));
+            for (int bb = 0; bb < 3; ++bb)
+                for (int j = 0; j < 3; ++j) { SVA_TRY(planes(e->res[i][bb][j].c1, voc_mode)); SVA_TRY(planes(e->res[i][bb][j].c2, voc_mode)); }
+        }
+    }
     e->host.clear();
     e->finalized = true;
     SVA_HIP(hipDeviceSynchronize());
@@ -583,7 +622,10 @@ int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda,
     g.A = A; g.a_bstride = a_bstride; g.a_off = a_off; g.lda = lda;
     g.T = T; g.M = nb * T; g.stride = stride; g.dil = dil; g.taps = taps; g.Cin = Cin;
     g.W = w.W; g.Wh = w.Wh; g.N = w.N; g.bias = w.b;
+    g.Wp = w.Wp; g.wp_pstride = (long)w.N * w.K; g.wp_inv = w.wp_inv; g.pmode = w.pmode;
     g.C = C; g.c_bstride = c_bstride; g.c_off = c_off; g.ldc = ldc;
+    if (g.Ap) g.A = nullptr;        // operand planes replace the fp32 tensor (cnx_block_t / enc_transformer hand-overs)
+    if (g.Cp) g.C = nullptr;
     SVA_CHECK(w.K == taps * Cin, "gemm_call: weight K mismatch");
     b->gemm_flops += 2.0 * g.M * (double)g.N * w.K;
     b->gemm_launches += 1;
@@ -633,6 +675,7 @@ int conv_desc(sva_batch* b, const Act& in, int T_out, int dil, int taps, const L
     g.A = in.p; g.a_bstride = in.bstride; g.a_off = (long)(in.H - padL) * in.C; g.lda = in.C;
     g.T = T_out; g.M = b->B * T_out; g.stride = 1; g.dil = dil; g.taps = taps; g.Cin = in.C;
     g.W = w.W; g.N = w.N; g.bias = w.b;
+    g.Wp = w.Wp; g.wp_pstride = (long)w.N * w.K; g.wp_inv = w.wp_inv; g.pmode = w.pmode;
     g.C = out.p; g.c_bstride = out.bstride; g.c_off = (long)out.H * out.C; g.ldc = out.C;
     return 0;
 }
@@ -683,6 +726,14 @@ __global__ void mean3_kernel(const float* __restrict__ y0, const float* __restri
     reinterpret_cast<float4*>(out + (long)b * o_bstride + o_off)[i] = r;
 }
 
+// Two chained GEMMs of `rows` rows can hand their intermediate tensor over as operand planes (gemm_planes.hip) when both weights carry
+// planes of one fp16 format -- two fp16 planes (or one) fill exactly the bytes (half the bytes) of the fp32 tensor they replace, so
+// they live in its buffer -- and the problem is at the scale where the planes kernel is the dispatcher's choice anyway.
+bool planes_edge(const Lin& producer, const Lin& consumer, long rows) {
+    return rows >= 2048 && producer.Wp && consumer.Wp && producer.pmode == consumer.pmode && (producer.pmode == PLANES_H3 || producer.pmode == PLANES_H1) &&
+           producer.N % 8 == 0;
+}
+
 // ConvNeXtBlock (firefly.py:421-440) on x rows [x.H, x.H+T); result into `out` rows [out.H, out.H+T)
 // (out == nullptr: in place).  Streaming users must NOT run in place: the dwconv history of the next step is the
 // block INPUT, while downstream convs need history of the block OUTPUT.  h1 / h2 = scratch with batch strides.
@@ -694,6 +745,12 @@ int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs
     SVA_CHECK(o.C == C, "cnx_block: bad output activation");
     ConvGemm p1;
     p1.act = ACT_GELU;
+    ConvGemm p2;
+    // batch scale: the hidden tensor goes from pwconv1's GELU epilogue to pwconv2 as operand planes, in the scratch buffer's own memory
+    if (planes_edge(c.pw1, c.pw2, b->B * T)) {
+        p1.Cp = reinterpret_cast<unsigned short*>(h2); p1.cp_pstride = h2_bs * b->B;
+        p2.Ap = p1.Cp; p2.ap_pstride = p1.cp_pstride;
+    }
     if (b->B * T <= 16 && C <= 512) {
         // a handful of rows (streaming pass, upsampler at small B): depthwise conv + LayerNorm happen in the prologue of the
         // pointwise GEMM (every column block recomputes them -- a few thousand FMAs -- instead of a launch of their own)
@@ -703,7 +760,6 @@ int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs
         SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, h1_bs, b->stream));
         SVA_TRY(gemm_call(b, h1, h1_bs, 0, C, b->B, T, 1, 1, 1, C, c.pw1, h2, h2_bs, 0, 4 * C, p1));
     }
-    ConvGemm p2;
     p2.gamma = c.gamma;
     p2.skip_lo = skip_lo; p2.skip_hi = skip_hi;
     p2.res = x.p; p2.r_bstride = x.bstride; p2.r_off = (long)x.H * C; p2.ldr = C;
@@ -964,6 +1020,11 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows, int part = 0) {
         xr = xw; xr_bs = xw_bs; xr_off = 0;
         ConvGemm pg;
         pg.w13 = 1;
+        ConvGemm pd;
+        if (planes_edge(L.w13, L.w2, (long)B * Tr)) {          // SwiGLU output -> w2 as operand planes, in tr_g's memory
+            pg.Cp = reinterpret_cast<unsigned short*>(b->tr_g); pg.cp_pstride = (long)B * T2 * I;
+            pd.Ap = pg.Cp; pd.ap_pstride = pg.cp_pstride;
+        }
         if (conv_gemm_can_fuse_rms(B * Tr, 2 * I)) {
             pg.rms_w = L.ffn_norm; pg.rms_eps = 1e-5f;
             SVA_TRY(gemm_call(b, xw, xw_bs, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, (long)r0 * I, I, pg));
@@ -971,7 +1032,6 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows, int part = 0) {
             SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, (long)r0 * D, D, B, Tr, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, (long)r0 * D, D, st));
             SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, (long)r0 * I, I, pg));
         }
-        ConvGemm pd;
         pd.gamma = L.ls_ffn;
         pd.res = xw; pd.r_bstride = xw_bs; pd.r_off = (long)r0 * D; pd.ldr = D;
         SVA_TRY(gemm_call(b, b->tr_g, (long)T2 * I, (long)r0 * I, I, B, Tr, 1, 1, 1, I, L.w2, xw, xw_bs, (long)r0 * D, D, pd));
@@ -1808,13 +1868,13 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // mostly wait on hand-offs, so the AR chain no longer queues behind the other stages' workgroups, and the encoder /
         // vocoder GEMMs want the whole chip (measured 1.41 ms per step with the 96 | 128 | 32 split, 1.13 without)
         // (fp16 AR: the batched decode on the f16 pipes overtakes the persistent kernel at 5 streams -- 2191 vs 1645 frames/s, 6: 2562 vs
-        // 2064, 4: 1420 vs 1919; fp32: the persistent kernel wins up to 6 -- tools/part_ab3.sh)
+        // 2064, 4: 1420 vs 1919; fp32: the persistent kernel wins up to 6 -- the round-3 partition A/B scripts, git history)
         const int mega_max = c.ar_dtype == 1 ? std::min(4, AR_PERSISTENT_MAX_STREAMS) : AR_PERSISTENT_MAX_STREAMS;
         const bool will_mega = B <= mega_max && e->mega_ok && debug_options().ar_persistent != 0 && debug_options().ar_batch != 2;
         b->mega_max = mega_max;
         // multi-launch decode (more than 6 streams): its ~265 small launches per frame are a latency chain that the encoder's and
         // vocoder's chip-filling GEMMs would otherwise queue in front of -- disjoint CU masks (AR n | encoder + vocoder 256 - n)
-        // win up to 32 streams, with a smaller AR share as the batch grows (tools/part_ab.sh, part_ab2.sh;
+        // win up to 32 streams, with a smaller AR share as the batch grows (the round-3 partition A/B scripts, git history, round-3 A/B;
         // profiles/r03_partition_ab.txt -- fp32 AR: 8 streams 1873 unpartitioned / 2206 with 96 CUs / 2497 with 128; 12: 2683 / 3422
         // with 96; 24: 3960 / 4312 with 64; 32: 5008 / 5322 with 64; 48: 5725 / 5628.  fp16 AR: 12: 3053 / 3989 with 64; 16: 3682 /
         // 4234; 24: 4415 / 4884; 32: 5337 / 5421).  Round 2 partitioned 7-8 streams only, always 96 | 160.
@@ -1825,7 +1885,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // fp16 AR: 6 streams 2989 vs 2664, 8: 3440 vs 3197, 12: 4059 vs 4110 -- profiles/r04_abatch_sweep.txt)
         const bool will_abatch = !will_mega && abatch_serves(B, c.ar_dtype) && e->mega_ok && debug_options().ar_persistent != 0;
         int ar_cus = 96, part_streams = 0;
-        if (b->p.pipeline && !will_mega && !will_abatch && B <= (p->chunk_frames > 1 ? 16 : 32)) {      // (chunk 4: 16 streams +11 %, 32 streams -15 %: tools/part_ab4.sh)
+        if (b->p.pipeline && !will_mega && !will_abatch && B <= (p->chunk_frames > 1 ? 16 : 32)) {      // (chunk 4: 16 streams +11 %, 32 streams -15 %: the round-3 partition A/B scripts, git history)
             part_streams = B;
             if (B >= 2) ar_cus = c.ar_dtype == 1 ? (B <= 8 ? 96 : 64) : (B <= 8 ? 128 : B <= 20 ? 96 : 64);
         }

@@ -686,12 +686,21 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
 // tiles per wave); kind 1 = LDS-tiled kernel (a: 0 = 64x64, 1 = 128x128, 2 = 128x32, 3 = 256x16, 4 = 128x64, 5 = 64x128,
 // 6 = 256x64, 7 = 256x128 on 8 waves; 4..7 are reached through the autotuner only).
 struct Choice { int kind, a, b, c; int z = 1; };      // z: grid-level K split of the small-M kernel
+static thread_local int t_planes_mode = -1;              // set by launch_choice when the planes kernel took a kind-4 choice
 static thread_local int t_last_kind = -1;                // kernel family of this thread's latest dispatch (bench.py: per-pipe roofline)
 
 static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
     if (ch.kind == 4) {                 // fp32 on the bf16 matrix pipes, six-product split (gemm_split.hip), a = tile variant
         ConvGemmGroup gg;
         if (t_group) gg = *t_group; else gg.g[0] = g;
+        // weights that carry pre-split planes: the same tile shapes fed from the planes, in the planes' precision (gemm_planes.hip; a >= 8: its own variant a - 8)
+        bool planes = true;
+        for (int i = 0; i < gg.n; ++i) planes = planes && planes_gemm_supported(gg.g[i]);
+        if (planes) {
+            t_planes_mode = g.pmode;
+            return launch_planes_gemm(gg, ch.a >= 8 ? ch.a - 8 : ch.a == 4 ? 0 : ch.a, st);
+        }
+        SVA_CHECK(!g.Ap && !g.Cp && ch.a < 8, "conv_gemm: operand planes need weight planes");
         return launch_split_gemm(gg, ch.a, st);
     }
     if (ch.kind == 2) {                 // LDS-DMA ring kernel (gemm_pipe.hip), a = tile variant
@@ -981,8 +990,11 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
             }
         }
     }
-    t_last_kind = ch.kind;
+    // operand planes exist only for the planes kernel: a problem that carries them takes that kernel whatever the table says for the shape
+    if ((g.Ap || g.Cp) && ch.kind != 4) ch = Choice{4, g.N < 128 || g.M < 128 ? 3 : 0, 0, 0};
+    t_planes_mode = -1;
     SVA_TRY_RC(launch_choice(g, st, ch));
+    t_last_kind = t_planes_mode >= 0 ? 6 + t_planes_mode : ch.kind;       // 6 / 7 / 8: planes kernel in S6 / H3 / H1
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -995,6 +1007,12 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
     if (kind == 2) {
         SVA_CHECK(pipe_gemm_supported(g) && a >= 0 && a <= 6, "conv_gemm_choice: the pipelined kernel needs Cin % 64 == 0 and 16-byte aligned operands");
         SVA_TRY_RC(launch_choice(g, st, Choice{2, a, 0, 0}));
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
+    if (kind == 6) {                    // the planes kernel (gemm_planes.hip), a = its tile variant
+        SVA_CHECK(planes_gemm_supported(g) && a >= 0 && a <= 5 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the planes kernel needs weight planes, Cin % 32 == 0 and 16-byte aligned C rows");
+        SVA_TRY_RC(launch_choice(g, st, Choice{4, 8 + a, 0, 0}));
         SVA_HIP(hipGetLastError());
         return 0;
     }

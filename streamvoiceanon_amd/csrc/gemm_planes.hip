@@ -1,0 +1,430 @@
+// conv-GEMM on the 16-bit matrix pipes from PRE-SPLIT operand planes.
+//
+// gemm_split.hip splits every fp32 element of both operands into three bf16 parts while staging each tile, once per tile that
+// touches it (a weight element M / 128 times, an activation element N / 128 times): 2.6 VALU instructions per MFMA, 49 % issue
+// stalls (profiles/r03_split_gemm_pmc_*).  Here the split is done ONCE per element, by whoever produces it:
+//   * weights at engine finalize (make_weight_planes below), stored as NPL 16-bit planes [NPL][N][K], scaled by a power of two so
+//     that the low parts of ordinary weights stay normal numbers (undone on the accumulator, exactly);
+//   * activations by the epilogue of the producing GEMM (ConvGemm::Cp: the Linear -> GELU -> Linear pair of a ConvNeXt block,
+//     firefly.py:421-440, and w1|w3 -> w2 of the window transformer, windowed_transformer.py:134-143, hand their hidden tensor
+//     over as planes and never store it as fp32) or by to_planes_kernel after a non-GEMM producer; an A operand that only exists
+//     as fp32 is split while it is staged, as before (APL = false).
+// Three precisions (ConvGemm::pmode), all accumulating in fp32 on v_mfma_f32_16x16x32_{bf16,f16}:
+//   S6: x = hi + mid + lo in bf16 (3 x 8 bits), six part products >= 2^-16 of the leading one -- fp32-grade for any fp32 range
+//       (the arithmetic of gemm_split.hip);
+//   H3: x = hi + lo in fp16 (2 x 11 bits, |x - hi - lo| <= 2^-23 |x|), three products hi.hi + hi.lo + lo.hi; the dropped lo.lo is
+//       <= 2^-24 of the leading one -- fp32-grade with HALF the matrix work and two planes instead of three, for operands inside the
+//       fp16 range (the reference runs this path under torch.autocast(fp16), evaluations/infer_arvc.py:493, so its own
+//       activations are);
+//   H1: x = fp16(x), one product -- the reference's own precision (autocast), a sixth of the matrix work.
+//
+// LDS image (both operands, every path): a K tile is cut into 1 KiB PIECES = 16 rows x 32 k of one plane, stored chunk-major --
+// lane l = (k-chunk l >> 4, row l & 15) of the piece owns bytes [16 l, 16 l + 16).  That is the order the MFMA fragment wants
+// (lane (fr, fk) supplies k = 8 fk .. 8 fk + 7 of row fr), so a fragment read is ONE lane-linear ds_read_b128 per piece, free of
+// bank conflicts in all four lane groups of the instruction (MI355X_MICROARCH.md, LDS table), and staging a piece is one 16-byte
+// load + one ds_write_b128 per lane.  Double-buffered, one barrier per K tile; tile k + 2 is requested from memory while tile k
+// multiplies and tile k + 1 is being written.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "sva_common.h"
+
+namespace sva {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+template <int MODE> struct PM;
+template <> struct PM<PLANES_S6> { static constexpr int NPL = 3; };
+template <> struct PM<PLANES_H3> { static constexpr int NPL = 2; };
+template <> struct PM<PLANES_H1> { static constexpr int NPL = 1; };
+
+// two fp32 -> one packed pair per plane
+template <int MODE>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[PM<MODE>::NPL]) {
+    if constexpr (MODE == PLANES_S6) {
+        const f32x2 v = {a, b};
+        o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        const f32x2 r1 = {a - __uint_as_float(o[0] << 16), b - __uint_as_float(o[0] & 0xffff0000u)};
+        o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+        const f32x2 r2 = {r1.x - __uint_as_float(o[1] << 16), r1.y - __uint_as_float(o[1] & 0xffff0000u)};
+        o[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+    } else {
+        const f32x2 v = {a, b};
+        f16x2 h = __builtin_convertvector(v, f16x2);
+        o[0] = __builtin_bit_cast(unsigned, h);
+        if constexpr (MODE == PLANES_H3) {
+            // (an opaque copy of hi: the residual must be taken from the ROUNDED value, whatever the optimiser makes of the casts -- gemm_f16w.hip: split8)
+            asm("" : "+v"(o[0]));
+            const f16x2 hq = __builtin_bit_cast(f16x2, o[0]);
+            const f32x2 r = {a - (float)hq.x, b - (float)hq.y};
+            o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+        }
+    }
+}
+// eight consecutive k of one row -> one 16-byte chunk per plane
+template <int MODE>
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4 (&o)[PM<MODE>::NPL]) {
+    constexpr int NPL = PM<MODE>::NPL;
+    unsigned p0[NPL], p1[NPL], p2[NPL], p3[NPL];
+    split_pair<MODE>(v0.x, v0.y, p0);
+    split_pair<MODE>(v0.z, v0.w, p1);
+    split_pair<MODE>(v1.x, v1.y, p2);
+    split_pair<MODE>(v1.z, v1.w, p3);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) o[p] = (u32x4){p0[p], p1[p], p2[p], p3[p]};
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x4 mma1(const u32x4& a, const u32x4& b, const f32x4& c) {
+    if constexpr (MODE == PLANES_S6) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// BM x BN tile, 4 waves (2 x 2), BK = 32 KB k per tile.  APL: the A operand comes as planes (g.Ap), otherwise as fp32 (g.A) and is
+// split while it is staged
+template <int MODE, int BM, int BN, int KB, bool APL>
+__global__ __launch_bounds__(256, (MODE == PLANES_S6 && BM + BN > 192) ? 1 : 2) void planes_gemm_kernel(const ConvGemmGroup gg) {
+    constexpr int NTH = 256, BK = 32 * KB, WM = 2, WN = 2, NPL = PM<MODE>::NPL;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int RBA = BM / 16, RBB = BN / 16;                 // row blocks (pieces per plane and k block) of the A / B tile
+    constexpr int A_BYTES = KB * NPL * RBA * 1024, B_BYTES = KB * NPL * RBB * 1024, STAGE = A_BYTES + B_BYTES;
+    constexpr int IA = RBA / 4, IB = RBB / 4;                   // row blocks per wave
+    static_assert(RBA % 4 == 0 && RBB % 4 == 0, "tile rows in blocks of 64");
+    const ConvGemm& g = gg.g[blockIdx.z];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int tbx = blockIdx.x, tby = blockIdx.y;
+    xcd_tile(gg.xcd_swz, gridDim.x, gridDim.y, tbx, tby);
+    const int bm0 = tby * BM, bn0 = tbx * BN;
+    const int prow = lane & 15, pchunk = lane >> 4;            // this lane's (row, k-chunk) inside a piece
+
+    // ---- operand pointers of the pieces this thread stages: row blocks wave, wave + 4, ... ----
+    const float* a_f32[IA];
+    const unsigned short* a_pl[IA];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        int m = bm0 + (wave + 4 * i) * 16 + prow;
+        if (m > g.M - 1) m = g.M - 1;
+        const int b = m / g.T, t = m - b * g.T;
+        const long off = (long)b * g.a_bstride + g.a_off + (long)t * g.stride * g.lda + pchunk * 8;
+        a_f32[i] = g.A + off;
+        a_pl[i] = g.Ap + off;
+    }
+    const long Kt = (long)g.taps * g.Cin;
+    const unsigned short* b_pl[IB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        int n = bn0 + (wave + 4 * i) * 16 + prow;
+        if (n > g.N - 1) n = g.N - 1;
+        b_pl[i] = g.Wp + (long)n * Kt + pchunk * 8;
+    }
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int kc_tiles = g.Cin / BK;
+    const int nk = g.taps * kc_tiles;
+
+    // registers of one K tile in flight
+    f32x4 ra[APL ? 1 : KB][APL ? 1 : IA][2];
+    u32x4 rap[APL ? KB : 1][APL ? IA : 1][NPL];
+    u32x4 rb[KB][IB][NPL];
+    auto gload = [&](int kt) {
+        const int tap = kt / kc_tiles;
+        const int kc = (kt - tap * kc_tiles) * BK;
+        const long aoff = (long)tap * g.dil * g.lda + kc;
+        const long boff = (long)tap * g.Cin + kc;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                if constexpr (APL) {
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) rap[kb][i][p] = *reinterpret_cast<const u32x4*>(a_pl[i] + (long)p * g.ap_pstride + aoff + kb * 32);
+                } else {
+                    ra[kb][i][0] = *reinterpret_cast<const f32x4*>(a_f32[i] + aoff + kb * 32);
+                    ra[kb][i][1] = *reinterpret_cast<const f32x4*>(a_f32[i] + aoff + kb * 32 + 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) rb[kb][i][p] = *reinterpret_cast<const u32x4*>(b_pl[i] + (long)p * g.wp_pstride + boff + kb * 32);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* const st = lds + buf * STAGE + lane * 16;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                u32x4 o[NPL];
+                if constexpr (APL) {
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) o[p] = rap[kb][i][p];
+                } else {
+                    f32x4 v0 = ra[kb][i][0], v1 = ra[kb][i][1];
+                    if (g.a_silu) {
+                        v0.x = silu_f(v0.x); v0.y = silu_f(v0.y); v0.z = silu_f(v0.z); v0.w = silu_f(v0.w);
+                        v1.x = silu_f(v1.x); v1.y = silu_f(v1.y); v1.z = silu_f(v1.z); v1.w = silu_f(v1.w);
+                    }
+                    split8<MODE>(v0, v1, o);
+                }
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(st + ((kb * NPL + p) * RBA + wave + 4 * i) * 1024) = o[p];
+            }
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(st + A_BYTES + ((kb * NPL + p) * RBB + wave + 4 * i) * 1024) = rb[kb][i][p];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    if (nk > 1) gload(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                    // tile kt is in buffer kt & 1; nobody still reads the other buffer
+        if (kt + 1 < nk) {
+            lstore((kt + 1) & 1);
+            if (kt + 2 < nk) gload(kt + 2);
+        }
+        const char* const sa = lds + (kt & 1) * STAGE + lane * 16 + (wm * MI) * 1024;
+        const char* const sb = lds + (kt & 1) * STAGE + A_BYTES + lane * 16 + (wn * NI) * 1024;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            u32x4 af[MI][NPL], bf[NI][NPL];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(sa + ((kb * NPL + p) * RBA + i) * 1024);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) bf[j][p] = *reinterpret_cast<const u32x4*>(sb + ((kb * NPL + p) * RBB + j) * 1024);
+            // small products first
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                if constexpr (MODE == PLANES_S6) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][2], bf[j][0], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][0], bf[j][2], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][1], bf[j][1], acc[i][j]);
+                }
+                if constexpr (MODE != PLANES_H1) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][1], bf[j][0], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][0], bf[j][1], acc[i][j]);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][0], bf[j][0], acc[i][j]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue (as conv_gemm_kernel / split_gemm_kernel: accumulators staged through LDS for whole 16-byte row accesses) ----
+    constexpr int CS = BN + 4;
+    float* Cs = smem;                              // [BM][CS]
+    const int col = lane & 15, rq = (lane >> 4) * 4;
+    const float winv = g.wp_inv;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(wm * TM + i * 16 + rq + r) * CS + wn * TN + j * 16 + col] = acc[i][j][r] * winv;
+    __syncthreads();
+    auto store4 = [&](const float4& v, long idx) {
+        if (g.C) *reinterpret_cast<float4*>(g.C + idx) = v;
+        if (g.Cp) {
+            unsigned p0[NPL], p1[NPL];
+            split_pair<MODE>(v.x, v.y, p0);
+            split_pair<MODE>(v.z, v.w, p1);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x2*>(g.Cp + (long)p * g.cp_pstride + idx) = (u32x2){p0[p], p1[p]};
+        }
+    };
+    if (g.w13) {
+        // SwiGLU: tile columns alternate 16 x w1 | 16 x w3; output column (n0 >> 1) + c
+        constexpr int OC4 = BN / 8;                // float4 chunks of output per row
+        for (int idx = tid; idx < BM * OC4; idx += NTH) {
+            const int row = idx / OC4, q = idx - row * OC4;
+            const int m = bm0 + row;
+            const int grp = q >> 2, c4 = (q & 3) * 4;       // 16-wide group, offset inside it
+            const int n = bn0 + grp * 32 + c4;              // w1 column
+            if (m >= g.M || n >= g.N) continue;
+            const int b = m / g.T, t = m - b * g.T;
+            if (t >= g.skip_lo && t < g.skip_hi) continue;
+            const float4 a = *reinterpret_cast<const float4*>(&Cs[row * CS + grp * 32 + c4]);
+            const float4 w = *reinterpret_cast<const float4*>(&Cs[row * CS + grp * 32 + 16 + c4]);
+            float4 o;
+            o.x = silu_f(a.x) * w.x; o.y = silu_f(a.y) * w.y; o.z = silu_f(a.z) * w.z; o.w = silu_f(a.w) * w.w;
+            store4(o, (long)b * g.c_bstride + g.c_off + (long)t * g.ldc + ((bn0 + grp * 32) >> 1) + c4);
+        }
+        return;
+    }
+    constexpr int C4 = BN / 4;
+    for (int idx = tid; idx < BM * C4; idx += NTH) {
+        const int row = idx / C4, c4 = (idx - row * C4) * 4;
+        const int m = bm0 + row, n = bn0 + c4;
+        if (m >= g.M || n >= g.N) continue;
+        const int b = m / g.T, t = m - b * g.T;
+        if (t >= g.skip_lo && t < g.skip_hi) continue;
+        float4 v = *reinterpret_cast<const float4*>(&Cs[row * CS + c4]);
+        if (g.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (g.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        else if (g.act == ACT_LOGCLAMP) { v.x = __logf(fmaxf(v.x, 1e-5f)); v.y = __logf(fmaxf(v.y, 1e-5f)); v.z = __logf(fmaxf(v.z, 1e-5f)); v.w = __logf(fmaxf(v.w, 1e-5f)); }
+        if (g.gamma) {
+            const float4 gm = *reinterpret_cast<const float4*>(g.gamma + n);
+            v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
+        }
+        if (g.res) {
+            const float4 rr = *reinterpret_cast<const float4*>(g.res + (long)b * g.r_bstride + g.r_off + (long)t * g.ldr + n);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        v.x *= g.scale; v.y *= g.scale; v.z *= g.scale; v.w *= g.scale;
+        const long ci = (long)b * g.c_bstride + g.c_off + (long)t * g.ldc + n;
+        if (g.accumulate) {
+            const float4 cc = *reinterpret_cast<const float4*>(g.C + ci);
+            v.x += cc.x; v.y += cc.y; v.z += cc.z; v.w += cc.w;
+        }
+        store4(v, ci);
+    }
+}
+
+template <int MODE, int BM, int BN, int KB, bool APL>
+int launch_planes_t(const ConvGemmGroup& gg_in, hipStream_t st) {
+    ConvGemmGroup gg = gg_in;
+    const ConvGemm& g = gg.g[0];
+    constexpr size_t smem_ab = (size_t)2 * KB * PM<MODE>::NPL * (BM + BN) / 16 * 1024;
+    constexpr size_t smem_c = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t smem = smem_ab > smem_c ? smem_ab : smem_c;
+    static DeviceOnce attr_set;
+    if (attr_set.needed() && smem > 48 * 1024) {
+        SVA_HIP(hipFuncSetAttribute((const void*)planes_gemm_kernel<MODE, BM, BN, KB, APL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set.done();
+    }
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, gg.n);
+    gg.xcd_swz = xcd_swizzle_for(grid.x, grid.y);
+    hipLaunchKernelGGL((planes_gemm_kernel<MODE, BM, BN, KB, APL>), grid, dim3(256), smem, st, gg);
+    return 0;
+}
+
+template <int MODE, bool APL>
+int launch_planes_m(const ConvGemmGroup& gg, int variant, hipStream_t st) {
+    const bool k64 = gg.g[0].Cin % 64 == 0;
+    switch (variant) {
+        case 0: return launch_planes_t<MODE, 128, 128, 1, APL>(gg, st);
+        case 1: return launch_planes_t<MODE, 128, 64, 1, APL>(gg, st);
+        case 2: return launch_planes_t<MODE, 64, 128, 1, APL>(gg, st);
+        case 3: return launch_planes_t<MODE, 64, 64, 1, APL>(gg, st);
+        // 64-deep K tiles (half the barriers; the tile's stage is twice as large)
+        case 4: if (k64) return launch_planes_t<MODE, 128, 128, 2, APL>(gg, st); return launch_planes_t<MODE, 128, 128, 1, APL>(gg, st);
+        case 5: if (k64) return launch_planes_t<MODE, 64, 64, 2, APL>(gg, st); return launch_planes_t<MODE, 64, 64, 1, APL>(gg, st);
+    }
+    set_error("planes_gemm: bad variant");
+    return -1;
+}
+
+// fp32 rows -> planes (a non-GEMM producer's output that feeds a planes GEMM as its A operand): element index space of `src` kept
+template <int MODE>
+__global__ void to_planes_kernel(const float* __restrict__ src, long n8, unsigned short* __restrict__ dst, long pstride, float scale, int silu) {
+    constexpr int NPL = PM<MODE>::NPL;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(src + i * 8), v1 = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+        v0 *= scale; v1 *= scale;
+        if (silu) {
+            v0.x = silu_f(v0.x); v0.y = silu_f(v0.y); v0.z = silu_f(v0.z); v0.w = silu_f(v0.w);
+            v1.x = silu_f(v1.x); v1.y = silu_f(v1.y); v1.z = silu_f(v1.z); v1.w = silu_f(v1.w);
+        }
+        u32x4 o[NPL];
+        split8<MODE>(v0, v1, o);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dst + (long)p * pstride + i * 8) = o[p];
+    }
+}
+
+}  // namespace
+
+int planes_count(int mode) { return mode == PLANES_S6 ? 3 : mode == PLANES_H3 ? 2 : 1; }
+
+// channels in whole 32-wide K tiles, planes of the weights present; the tiled epilogue's conditions (16-byte aligned C rows) are the caller's
+bool planes_gemm_supported(const ConvGemm& g) {
+    return g.Wp && g.pmode >= 0 && g.pmode <= 2 && g.Cin % 32 == 0 && g.stride >= 1 && !g.rms_w && !g.dw_wT && (g.C || g.Cp) && !(g.accumulate && !g.C) &&
+           (g.A || g.Ap) && (!g.Ap || (g.lda % 8 == 0 && g.a_off % 8 == 0 && g.a_bstride % 8 == 0 && g.ap_pstride % 8 == 0)) &&
+           (!g.Cp || (g.ldc % 4 == 0 && g.c_off % 4 == 0 && g.c_bstride % 4 == 0 && g.cp_pstride % 4 == 0));
+}
+
+int launch_planes_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st) {
+    const ConvGemm& g = gg.g[0];
+    SVA_CHECK(planes_gemm_supported(g), "planes_gemm: unsupported problem");
+    for (int i = 1; i < gg.n; ++i)
+        SVA_CHECK(planes_gemm_supported(gg.g[i]) && gg.g[i].pmode == g.pmode && !gg.g[i].Ap == !g.Ap, "planes_gemm: group members differ");
+    if (g.Ap) {
+        SVA_CHECK(!g.a_silu, "planes_gemm: SiLU belongs to the producer of the planes");
+        switch (g.pmode) {
+            case PLANES_S6: return launch_planes_m<PLANES_S6, true>(gg, variant, st);
+            case PLANES_H3: return launch_planes_m<PLANES_H3, true>(gg, variant, st);
+            default: return launch_planes_m<PLANES_H1, true>(gg, variant, st);
+        }
+    }
+    switch (g.pmode) {
+        case PLANES_S6: return launch_planes_m<PLANES_S6, false>(gg, variant, st);
+        case PLANES_H3: return launch_planes_m<PLANES_H3, false>(gg, variant, st);
+        default: return launch_planes_m<PLANES_H1, false>(gg, variant, st);
+    }
+}
+
+int launch_to_planes(const float* src, long n, unsigned short* dst, long pstride, int mode, float scale, int silu, hipStream_t st) {
+    SVA_CHECK(n % 8 == 0 && mode >= 0 && mode <= 2, "to_planes: whole 8-element chunks");
+    const long n8 = n / 8;
+    const int blocks = (int)std::min<long>((n8 + 255) / 256, 2048);
+    if (mode == PLANES_S6) hipLaunchKernelGGL(to_planes_kernel<PLANES_S6>, dim3(blocks), dim3(256), 0, st, src, n8, dst, pstride, scale, silu);
+    else if (mode == PLANES_H3) hipLaunchKernelGGL(to_planes_kernel<PLANES_H3>, dim3(blocks), dim3(256), 0, st, src, n8, dst, pstride, scale, silu);
+    else hipLaunchKernelGGL(to_planes_kernel<PLANES_H1>, dim3(blocks), dim3(256), 0, st, src, n8, dst, pstride, scale, silu);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// Planes of a weight matrix W [n elements] already on the device: dst = [NPL][n] 16-bit, element = part of W * 2^e with e chosen so
+// that max |W| 2^e lies in [2^7, 2^8) in the fp16 modes (the low part of a weight 2^-9 of the largest is still a normal fp16; far
+// from the fp16 overflow threshold) and e = 0 for bf16 (fp32's exponent range).  *inv = 2^-e for the accumulator.
+int make_weight_planes(const float* dW, long n, float max_abs, int mode, unsigned short* dst, float* inv, hipStream_t st) {
+    int e = 0;
+    if (mode != PLANES_S6 && max_abs > 0.f && std::isfinite(max_abs)) {
+        int ex;
+        (void)frexpf(max_abs, &ex);            // max_abs = f * 2^ex, f in [0.5, 1)
+        e = 8 - ex;
+    }
+    *inv = ldexpf(1.f, -e);
+    return launch_to_planes(dW, n, dst, n, mode, ldexpf(1.f, e), 0, st);
+}
+
+}  // namespace sva

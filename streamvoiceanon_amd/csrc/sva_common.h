@@ -23,7 +23,7 @@ void set_error(const std::string& msg);
 //   autotune=1, tune_log=1, tune_table=0, tune_dump=PATH   timed search / its log / ignore the compiled-in table / dump the choices
 //                    (tools/make_tune_table.py)
 //   cu_partition=0|1  force the disjoint CU masks of the pipelined mode (AR 96 | encoder + vocoder 160) off / on (default: by stream count)
-//   cu_ar=N           with cu_partition=1: CUs of the AR stream's mask (default: by batch size; A/B only: tools/part_ab2.sh)
+//   cu_ar=N           with cu_partition=1: CUs of the AR stream's mask (default: by batch size; A/B only: the round-3 partition A/B scripts, git history)
 //   pipe_skip=mask    TIMING DIAGNOSTIC (results are garbage): leave out a chain of the pipelined step -- 1 encoder front, 2 side chain
 //                     (downsampler + transformer + BSQ), 4 AR, 8 vocoder (tools/pipe_skip.sh)
 //   f16_weights=0     ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B)
@@ -77,6 +77,9 @@ struct DeviceOnce {
 // is the same GEMM with N = stride*Cout and 2 (or 1) taps -- see DESIGN.md.
 // ---------------------------------------------------------------------------------------
 enum ActKind : int { ACT_NONE = 0, ACT_GELU = 1, ACT_LOGCLAMP = 2 };
+// operand-plane formats of gemm_planes.hip (sva_config::mm_mode): S6 = 3 bf16 planes / six products (fp32-grade, any range),
+// H3 = 2 fp16 planes / three products (fp32-grade inside the fp16 range), H1 = 1 fp16 plane / one product (torch.autocast(fp16))
+enum PlanesMode : int { PLANES_S6 = 0, PLANES_H3 = 1, PLANES_H1 = 2 };
 
 struct ConvGemm {
     const float* A = nullptr;   // element (b, r, k): A[b*a_bstride + a_off + r*lda + k]
@@ -118,6 +121,16 @@ struct ConvGemm {
     float ln_eps = 1e-6f;
     const float* rms_w = nullptr;   // [Cin] fused RMSNorm of the A rows (taps == 1): A' = A * rms_w * rsqrt(mean(A^2) + rms_eps);
     float rms_eps = 1e-5f;          //       only on the small-M path -- ask conv_gemm_can_fuse_rms() first
+    // pre-split 16-bit operand planes (gemm_planes.hip).  Wp: [planes][N][taps*Cin] parts of W * 2^e, wp_inv = 2^-e; Ap / Cp: planes
+    // of the A / C tensor in the SAME element index space as A / C (plane p at + p * pstride elements).  C may be null when Cp is set.
+    const unsigned short* Wp = nullptr;
+    long wp_pstride = 0;
+    float wp_inv = 1.f;
+    int pmode = -1;                 // PlanesMode of Wp (and of Ap / Cp)
+    const unsigned short* Ap = nullptr;
+    long ap_pstride = 0;
+    unsigned short* Cp = nullptr;
+    long cp_pstride = 0;
 };
 
 // up to three independent problems of identical shape (M, N, Cin, stride, epilogue flags; taps / dilation / pointers may
@@ -156,6 +169,12 @@ bool split_gemm_supported(const ConvGemm& g);
 int launch_split_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 bool pipe_gemm_supported(const ConvGemm& g);
 int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
+// gemm_planes.hip: 16-bit matrix pipes fed from pre-split operand planes (variant 0..3 = 128x128, 128x64, 64x128, 64x64; 4 / 5 = 128x128 / 64x64 with 64-deep K tiles)
+int planes_count(int mode);
+bool planes_gemm_supported(const ConvGemm& g);
+int launch_planes_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
+int launch_to_planes(const float* src, long n, unsigned short* dst, long pstride, int mode, float scale, int silu, hipStream_t st);
+int make_weight_planes(const float* dW, long n, float max_abs, int mode, unsigned short* dst, float* inv, hipStream_t st);
 // gemm_f16w.hip: fp16 weights on the f16 matrix pipes (fp32 activations split hi + lo), plain linear layers of the AR chain
 bool f16w_gemm_supported(const ConvGemm& g);
 int launch_f16w_gemm(const ConvGemm& g, hipStream_t st);

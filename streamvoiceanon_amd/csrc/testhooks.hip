@@ -10,6 +10,12 @@
 
 using namespace sva;
 
+#define SVA_TRY(expr)            \
+    do {                         \
+        const int _rc = (expr);  \
+        if (_rc) return _rc;     \
+    } while (0)
+
 static int test_gemm_impl(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, const int* choice);
 extern "C" int sva_test_gemm(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C) {
     return test_gemm_impl(device, M, N, K, A, W, bias, C, nullptr);
@@ -268,5 +274,80 @@ extern "C" int sva_host_launch_cost(int device, int iters, float* us_per_launch)
     const auto t1 = std::chrono::steady_clock::now();
     SVA_HIP(hipStreamSynchronize(r.first));
     *us_per_launch = (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
+    return 0;
+}
+
+// The planes GEMM (gemm_planes.hip) on one problem: weights split on the device as the engine does at finalize.  mode = PlanesMode,
+// variant = tile variant; flags: 1 = the A operand as planes (to_planes pass first), 2 = the result leaves as planes only (summed back
+// to fp32 here), 4 = GELU epilogue, 8 = SiLU on load (fp32 A only).  iters > 0 also times it (out_us[0] = microseconds per launch).
+extern "C" int sva_test_gemm_planes(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int mode,
+                                    int variant, int flags, int iters, float* out_us) {
+    SVA_HIP(hipSetDevice(device));
+    SVA_CHECK(mode >= 0 && mode <= 2 && K % 32 == 0 && N % 4 == 0, "test_gemm_planes: bad arguments");
+    const int npl = planes_count(mode);
+    float *dA, *dW, *dB = nullptr, *dC;
+    unsigned short *dWp, *dAp = nullptr, *dCp = nullptr;
+    SVA_HIP(hipMalloc(&dA, sizeof(float) * (size_t)M * K));
+    SVA_HIP(hipMalloc(&dW, sizeof(float) * (size_t)N * K));
+    SVA_HIP(hipMalloc(&dC, sizeof(float) * (size_t)M * N));
+    SVA_HIP(hipMalloc(&dWp, 2 * (size_t)npl * N * K));
+    SVA_HIP(hipMemcpy(dA, A, sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(dW, W, sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
+    if (bias) {
+        SVA_HIP(hipMalloc(&dB, sizeof(float) * N));
+        SVA_HIP(hipMemcpy(dB, bias, sizeof(float) * N, hipMemcpyHostToDevice));
+    }
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)N * K; ++i) mx = std::max(mx, fabsf(W[i]));
+    ConvGemm g;
+    g.A = dA; g.a_bstride = (long)M * K; g.lda = K; g.T = M; g.M = M; g.Cin = K; g.taps = 1;
+    g.W = dW; g.N = N; g.bias = dB; g.C = dC; g.c_bstride = (long)M * N; g.ldc = N;
+    g.Wp = dWp; g.wp_pstride = (long)N * K; g.pmode = mode;
+    SVA_TRY(make_weight_planes(dW, (long)N * K, mx, mode, dWp, &g.wp_inv, 0));
+    if (flags & 1) {
+        SVA_HIP(hipMalloc(&dAp, 2 * (size_t)npl * M * K));
+        SVA_TRY(launch_to_planes(dA, (long)M * K, dAp, (long)M * K, mode, 1.f, 0, 0));
+        g.Ap = dAp; g.ap_pstride = (long)M * K; g.A = nullptr;
+    }
+    if (flags & 2) {
+        SVA_HIP(hipMalloc(&dCp, 2 * (size_t)npl * M * N));
+        g.Cp = dCp; g.cp_pstride = (long)M * N; g.C = nullptr;
+    }
+    if (flags & 4) g.act = ACT_GELU;
+    if ((flags & 8) && !(flags & 1)) g.a_silu = 1;
+    SVA_TRY(launch_conv_gemm_choice(g, 0, 6, variant, 0, 0));
+    SVA_HIP(hipDeviceSynchronize());
+    if (flags & 2) {
+        std::vector<uint16_t> hp((size_t)npl * M * N);
+        SVA_HIP(hipMemcpy(hp.data(), dCp, hp.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < (size_t)M * N; ++i) {
+            float s = 0.f;
+            for (int p = npl - 1; p >= 0; --p) {
+                const uint16_t bits = hp[(size_t)p * M * N + i];
+                if (mode == PLANES_S6) { const uint32_t u = (uint32_t)bits << 16; float f; memcpy(&f, &u, 4); s += f; }
+                else { _Float16 h; memcpy(&h, &bits, 2); s += (float)h; }
+            }
+            C[i] = s;
+        }
+    } else {
+        SVA_HIP(hipMemcpy(C, dC, sizeof(float) * (size_t)M * N, hipMemcpyDeviceToHost));
+    }
+    if (iters > 0 && out_us) {
+        hipEvent_t e0, e1;
+        SVA_HIP(hipEventCreate(&e0));
+        SVA_HIP(hipEventCreate(&e1));
+        SVA_HIP(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) SVA_TRY(launch_conv_gemm_choice(g, 0, 6, variant, 0, 0));
+        SVA_HIP(hipEventRecord(e1, 0));
+        SVA_HIP(hipDeviceSynchronize());
+        float ms = 0;
+        SVA_HIP(hipEventElapsedTime(&ms, e0, e1));
+        out_us[0] = ms * 1e3f / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); (void)hipFree(dWp);
+    if (dB) (void)hipFree(dB);
+    if (dAp) (void)hipFree(dAp);
+    if (dCp) (void)hipFree(dCp);
     return 0;
 }

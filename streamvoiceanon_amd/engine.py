@@ -30,7 +30,7 @@ class SvaConfig(C.Structure):
         ("ar_dim", C.c_int), ("ar_heads", C.c_int), ("ar_layers", C.c_int), ("ar_fast_layers", C.c_int), ("ar_inter", C.c_int),
         ("ar_vocab", C.c_int), ("codebook_size", C.c_int), ("num_codebooks", C.c_int), ("max_delay", C.c_int),
         ("max_seq_len", C.c_int), ("timbre_dim", C.c_int), ("timbre_tokens", C.c_int), ("style_dim", C.c_int),
-        ("voc_dim", C.c_int), ("ar_dtype", C.c_int),
+        ("voc_dim", C.c_int), ("ar_dtype", C.c_int), ("mm_mode", C.c_int), ("voc_dtype", C.c_int),
     ]
 
 
@@ -105,6 +105,7 @@ def load_library():
     lib.sva_set_sampler_edits.argtypes = [vp, vp, i32, C.c_float, vp, i32]
     lib.sva_test_prefill_attention.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]
     lib.sva_test_gemm_f16w.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp]
+    lib.sva_test_gemm_planes.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.sva_host_launch_cost.argtypes = [i32, i32, f32p]
     lib.sva_test_sampler.argtypes = [i32, i32, i32, i32, vp, vp, C.c_float, C.c_float, vp, i32, f32p]
     _lib = lib
@@ -119,7 +120,7 @@ EXPORTED_SYMBOLS = [
     "sva_dev_alloc", "sva_dev_free", "sva_dev_upload", "sva_dev_download", "sva_op_conv", "sva_op_affine", "sva_op_unary", "sva_op_colstats",
     "sva_op_cam_context", "sva_op_mul", "sva_op_add", "sva_op_conv2d", "sva_op_cf_to_rows", "sva_op_fbank_power", "sva_op_stft_mag", "sva_op_attention",
     "sva_op_geglu", "sva_op_l2norm",
-    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_test_prefill_attention", "sva_set_sampler_edits", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
+    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_test_gemm_planes", "sva_test_prefill_attention", "sva_set_sampler_edits", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
 ]
 
 
@@ -193,11 +194,17 @@ class Engine:
     """Weights on one MI355X.  `weights`: dict name -> array-like (numpy / torch CPU tensor) keyed by the
     reference state-dict names prefixed with 'arvc.' / 'tok.' / 'voc.'."""
 
-    def __init__(self, weights: dict, device: int = 0, ar_dtype: int = 0):
+    def __init__(self, weights: dict, device: int = 0, ar_dtype: int = 0, mm_mode: int = None, voc_dtype: int = None):
+        """mm_mode / voc_dtype: sva_config fields of the same names (None = the library's default): precision format of the batch-scale
+        encoder / vocoder GEMMs (csrc/gemm_planes.hip) and the reference-precision (fp16 operand) vocoder."""
         self.lib = load_library()
         self.cfg = SvaConfig()
         _check(self.lib.sva_config_default(C.byref(self.cfg)), "sva_config_default")
         self.cfg.ar_dtype = ar_dtype
+        if mm_mode is not None:
+            self.cfg.mm_mode = mm_mode
+        if voc_dtype is not None:
+            self.cfg.voc_dtype = voc_dtype
         self.h = C.c_void_p()
         _check(self.lib.sva_engine_create(C.byref(self.cfg), device, C.byref(self.h)), "sva_engine_create")
         self.device = device
@@ -490,6 +497,22 @@ def test_gemm_f16w(A, W, bias=None, rms_w=None, res=None, swiglu=False, iters=0,
     us = np.zeros(1, dtype=np.float32)
     mode = (1 if nw is not None else 0) | (2 if r is not None else 0) | (4 if swiglu else 0)
     _check(lib.sva_test_gemm_f16w(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(nw), _ptr(r), mode, _ptr(out), int(iters), _ptr(us)), "sva_test_gemm_f16w")
+    return out, float(us[0])
+
+
+def test_gemm_planes(A, W, bias=None, mode=1, variant=0, a_planes=False, c_planes=False, gelu=False, silu=False, iters=0, device=0):
+    """The planes GEMM (csrc/gemm_planes.hip): epi(A @ W.T) with both operands as pre-split 16-bit planes.  Returns (C, us_per_launch)."""
+    lib = load_library()
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    M, K = A.shape
+    N = W.shape[0]
+    out = np.empty((M, N), dtype=np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    us = np.zeros(1, dtype=np.float32)
+    flags = (1 if a_planes else 0) | (2 if c_planes else 0) | (4 if gelu else 0) | (8 if silu else 0)
+    _check(lib.sva_test_gemm_planes(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out), int(mode), int(variant), flags, int(iters), _ptr(us)),
+           "sva_test_gemm_planes")
     return out, float(us[0])
 
 

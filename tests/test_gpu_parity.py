@@ -1748,3 +1748,98 @@ def test_batched_persistent_decode_equals_multi_launch(eng, eng_fp16, B, fp16):
     if flips == 0:
         np.testing.assert_array_equal(codes0, codes2)
         assert np.abs(pcm0 - pcm2).max() <= PCM_TOL
+
+
+def test_planes_gemm_every_mode_vs_fp64():
+    """csrc/gemm_planes.hip: every precision format x tile variant x operand form (A as fp32 or as planes, C as fp32 or as planes
+    only) against an fp64 product on ragged shapes.  S6 (three bf16 planes, six products) and H3 (two fp16 planes, three products)
+    are fp32-grade; H1 (one fp16 plane) is the reference's torch.autocast(fp16) precision."""
+    from streamvoiceanon_amd import engine as E
+
+    rng = np.random.default_rng(11)
+    for (M, N, K) in ((200, 192, 256), (515, 288, 128), (160, 320, 384), (1030, 132, 96)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
+        scale = np.abs(ref).max()
+        for mode in (0, 1, 2):
+            for variant in range(6):
+                if (variant in (0, 1, 4) and M < 128) or (variant in (0, 2, 4) and N < 128):
+                    continue
+                for ap in (False, True):
+                    for cp in (False, True):
+                        out, _ = E.test_gemm_planes(A, W, bias=bias, mode=mode, variant=variant, a_planes=ap, c_planes=cp)
+                        err = np.abs(out - ref).max() / scale
+                        # fp32-grade: a few fp32 roundings of the largest output; planes-only output adds its own 2^-23 / 2^-24 split error.
+                        # H1: 2^-11 per operand, averaged over K; planes-only output rounds the result to fp16 as well
+                        tol = (4e-3 if cp else 2e-3) if mode == 2 else 3e-6
+                        assert err <= tol, (M, N, K, mode, variant, ap, cp, err)
+    # epilogue / prologue forms the engine uses at batch scale
+    A = rng.standard_normal((300, 256)).astype(np.float32)
+    W = (rng.standard_normal((192, 256)) * 0.06).astype(np.float32)
+    a64, w64 = A.astype(np.float64), W.astype(np.float64)
+    g64 = a64 @ w64.T
+    gel = 0.5 * g64 * (1.0 + torch.erf(torch.from_numpy(g64) / np.sqrt(2.0)).numpy())
+    sil = (a64 / (1.0 + np.exp(-a64))) @ w64.T
+    for mode in (0, 1):
+        out, _ = E.test_gemm_planes(A, W, mode=mode, variant=3, gelu=True, c_planes=True)
+        assert np.abs(out - gel).max() / np.abs(gel).max() <= 3e-6, mode
+        out, _ = E.test_gemm_planes(A, W, mode=mode, variant=3, silu=True)
+        assert np.abs(out - sil).max() / np.abs(sil).max() <= 3e-6, mode
+
+
+@pytest.mark.parametrize("mm_mode", [-1, 0, 1])
+def test_mm_modes_batch16_vs_reference_golden(weights0, mm_mode):
+    """The batch-scale GEMM formats of sva_config.mm_mode (-1 in-loop bf16 split of round 3, 0 pre-split bf16 planes / six products,
+    1 pre-split fp16 planes / three products with the ConvNeXt and FFN hidden tensors handed over as planes): 16 copies of the
+    fixture utterance in one batch (2720-row encoder passes, 2048-row transformer passes) reproduce the reference fixture --
+    content codes and audio codes identical, PCM within the fp32 tolerance."""
+    from streamvoiceanon_amd import engine as E
+
+    e = E.Engine(weights0, mm_mode=mm_mode)
+    try:
+        g, outs, content, audio, slow, fast, _ = _stream_vs_golden(e, weights0, "stream_s0", n_streams=16, slot=15, n_limit=12)
+    finally:
+        e.close()
+    np.testing.assert_array_equal(content, g["content_codes"][:content.shape[0]])
+    np.testing.assert_array_equal(audio, g["audio_codes"][:, :audio.shape[1]])
+    checked = 0
+    for k, idx in enumerate(g["pcm_full_idx"]):
+        if int(idx) < len(outs):
+            np.testing.assert_allclose(outs[int(idx)], g["pcm_full"][k], atol=PCM_TOL)
+            checked += 1
+    sums = np.array([float(o.astype(np.float64).sum()) for o in outs])
+    np.testing.assert_allclose(sums, g["pcm_sum"][:len(outs)], atol=5e-2)
+    assert checked >= 1
+
+
+def test_voc_dtype_fp16_vocoder_vs_reference(weights0, record_property):
+    """sva_config.voc_dtype = 1: the vocoder's batch-scale GEMMs take fp16 operands with fp32 accumulation -- the reference's own
+    precision for code2wav_fn under torch.autocast(fp16) (evaluations/infer_arvc.py:493, 571-590).  Gate: PCM within 1e-3 of the fp32
+    reference fixture (SURVEY 8c's vocoder tolerance) on the 64-frame window and on a 16-stream streaming run whose codes stay
+    identical (the AR and the encoder do not change)."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+
+    e = E.Engine(weights0, voc_dtype=1)
+    try:
+        g = load_golden("vocoder_s0")
+        codes = g["codes"].astype(np.int32)
+        b = E.Batch(e, n_streams=1, voc_max_frames=64)
+        pcm = b.vocode_window(codes)
+        b.close()
+        ref = O.vocode_window(torch.from_numpy(g["codes"]), weights0)[:, 0].numpy()
+        err_w = float(np.abs(pcm - ref).max())
+        record_property("voc_fp16_window_max_abs_err", err_w)
+        assert err_w <= 1e-3
+        np.testing.assert_allclose(pcm[0, -2048:], g["pcm_last_frame"], atol=1e-3)
+        gs, outs, content, audio, *_ = _stream_vs_golden(e, weights0, "stream_s0", n_streams=16, slot=3, n_limit=12)
+    finally:
+        e.close()
+    np.testing.assert_array_equal(content, gs["content_codes"][:content.shape[0]])
+    np.testing.assert_array_equal(audio, gs["audio_codes"][:, :audio.shape[1]])
+    errs = [float(np.abs(outs[int(idx)] - gs["pcm_full"][k]).max()) for k, idx in enumerate(gs["pcm_full_idx"]) if int(idx) < len(outs)]
+    record_property("voc_fp16_stream_max_abs_err", max(errs))
+    assert errs and max(errs) <= 1e-3
+    assert max(err_w, max(errs)) > 1e-6          # (the fp16 path really ran: an fp32-grade result would sit at ~1e-6)
