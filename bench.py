@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--ar-dtype", type=int, default=0, choices=(0, 1),
                     help="0: fp32 AR weights + fp32 KV (parity mode, the headline); 1: fp16 AR weights + fp16 slow KV cache, as the "
                          "reference decodes under torch.autocast(fp16) (evaluations/infer_arvc.py:55-59, 483)")
+    ap.add_argument("--mm-mode", type=int, default=None, choices=(0, 1, 2),
+                    help="sva_config.mm_mode (default: the library's): batch-scale encoder / vocoder GEMM format, csrc/gemm_planes.hip")
+    ap.add_argument("--voc-dtype", type=int, default=None, choices=(0, 1),
+                    help="sva_config.voc_dtype: 1 = fp16-operand vocoder GEMMs, the reference's autocast precision (infer_arvc.py:493)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=60, help="CPU-baseline sample size (chunk-steps)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -508,7 +512,7 @@ def main():
     B, c = args.streams, args.chunk
     n = 2048 * c
     W = synth_weights.generate_all(0, specs.all_specs())
-    eng = E.Engine(W, device=local_rank, ar_dtype=args.ar_dtype)
+    eng = E.Engine(W, device=local_rank, ar_dtype=args.ar_dtype, mm_mode=args.mm_mode, voc_dtype=args.voc_dtype)
     pin_info = {}
     cpus_at_start = os.sched_getaffinity(0)
 
@@ -624,10 +628,14 @@ def main():
             tot_ms, nl = batch.gemm_profile()
             tm_prof = batch.timings()          # stage times of this serial, event-bracketed step
             tab = batch.gemm_profile_table()
-            pipes = {"f32_mfma": [0.0, 0.0, 0], "bf16_split": [0.0, 0.0, 0], "f16_weights": [0.0, 0.0, 0]}       # flops, us, launches
+            pipes = {"f32_mfma": [0.0, 0.0, 0], "bf16_split": [0.0, 0.0, 0], "f16_weights": [0.0, 0.0, 0], "planes_bf16x3": [0.0, 0.0, 0],
+                     "planes_f16x2": [0.0, 0.0, 0], "planes_f16x1": [0.0, 0.0, 0]}       # flops, us, launches
+            KIND_PIPE = {4: "bf16_split", 5: "f16_weights", 6: "planes_bf16x3", 7: "planes_f16x2", 8: "planes_f16x1"}
             for M_, N_, K_, taps_, mode_, us in tab:
-                kind = (int(mode_) >> 8) - 1            # 0 small-M, 1 tiled, 2 pipelined: v_mfma_f32_16x16x4_f32;  4: six bf16 part products;
-                pp = pipes["bf16_split" if kind == 4 else "f16_weights" if kind == 5 else "f32_mfma"]      # 5: fp16 weights x (hi + lo) fp16 activations
+                # 0 small-M, 1 tiled, 2 pipelined: v_mfma_f32_16x16x4_f32; 4: six bf16 part products split in the K loop; 5: fp16 weights x (hi + lo)
+                # fp16 activations; 6 / 7 / 8: pre-split operand planes (gemm_planes.hip): bf16 x 3 (six products), fp16 x 2 (three), fp16 x 1 (one)
+                kind = (int(mode_) >> 8) - 1
+                pp = pipes[KIND_PIPE.get(kind, "f32_mfma")]
                 pp[0] += 2.0 * M_ * N_ * K_; pp[1] += us; pp[2] += 1
             if os.environ.get("SVA_GEMM_TABLE"):
                 agg = {}
@@ -660,15 +668,17 @@ def main():
             by_pipe = {}
             for name, (fl, us, cnt) in pipes.items():
                 if cnt:
-                    pk = PEAK_F32_MFMA_TFLOPS if name == "f32_mfma" else PEAK_SPLIT if name == "bf16_split" else PEAK_F16W
+                    pk = {"f32_mfma": PEAK_F32_MFMA_TFLOPS, "bf16_split": PEAK_SPLIT, "planes_bf16x3": PEAK_SPLIT, "planes_f16x2": 2500.0 / 3.0,
+                          "planes_f16x1": 2500.0, "f16_weights": PEAK_F16W}[name]
                     by_pipe[name] = {"launches": cnt, "ms": round(us * 1e-3, 4), "gflop": round(fl / 1e9, 3), "achieved": round(fl / us / 1e6, 3),
                                      "peak": round(pk, 1), "frac": round(fl / us / 1e6 / pk, 5)}
             # the fraction of what the launches COULD have done in their own time on the pipes they ran on
             cap = sum(v["ms"] * v["peak"] for v in by_pipe.values())
             frac_own = (flops / 1e9) / cap if cap > 0 else 0.0
             roof = {"bound": "mfma", "kernel": "conv-GEMM family: pipe_gemm_kernel / conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32) and split_gemm_kernel / "
-                              "split_ws_kernel (the same fp32 problems as six bf16 part products on v_mfma_f32_16x16x32_bf16, fp32-grade results; the "
-                              "per-shape table picks)",
+                              "planes_gemm_kernel (the same fp32 problems on the 16-bit pipes from pre-split operand planes: six bf16 part products, or three "
+                              "fp16 part products with sva_config.mm_mode = 1 -- fp32-grade results either way; one fp16 product for a voc_dtype = 1 vocoder; "
+                              "the per-shape table picks)",
                     "peak_note": "peak = 157.3 TF/s, the dense f32-MFMA peak (the arithmetic the path is specified in) -- `frac` = achieved / 157.3 as the contract "
                                  "defines it; launches of the split-bf16 kernel run on the bf16 pipes, whose ceiling for this work is 2500 / 6 = 416.7 TF/s: `by_pipe` "
                                  "prices each kernel family against its own pipe and `frac_of_own_pipes` is the time-weighted combination (the honest figure when "
@@ -706,7 +716,9 @@ def main():
                                f"encode window 128 / vocoder window 64 frames, synthetic 44.1 kHz speech-like audio, "
                                f"synthetic prompt R={args.prompt_frames}, random-init weights of the reference architecture",
                    "streams_per_gpu": B, "chunk_frames": c, "parallelism": f"utterance-parallel x{world}",
-                   "hipgraph": bool(args.graph), "stage_pipelining": bool(args.pipeline) and not args.graph,
+                   "hipgraph": ("whole step as one captured graph" if args.graph else
+                                "one captured graph per stage chain (encoder front, side chain, AR, vocoder), replayed every step" if args.pipeline else "none (eager launches)"),
+                   "stage_pipelining": bool(args.pipeline) and not args.graph, "mm_mode": int(eng.cfg.mm_mode), "voc_dtype": int(eng.cfg.voc_dtype),
                    "enqueue_thread": pin_info or None},
         "rtf": round(ms * 1e-3 / (c * FRAME_S), 5), "x_realtime": round(fps * FRAME_S, 2),
         "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm.items()},
@@ -783,6 +795,12 @@ def main():
             out["torch_gpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         _t.cuda.empty_cache()
         out["torch_compile_gpu_baseline"] = compiled_baseline(args)
+    if "batched_64_streams" in out:
+        # compact configs[2] figures as the LAST key of the line (a log tail keeps them)
+        b64 = out["batched_64_streams"]
+        r64 = b64.get("roofline") or {}
+        out["b64"] = {"ms_per_step": b64["ms_per_step"], "value": b64["value"], "unit": "frames/s", "frac_of_own_pipes": r64.get("frac_of_own_pipes"),
+                      "stage_ms": b64["stage_ms_last_step"]}
     print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -55,10 +55,11 @@ typedef struct sva_config {
     int ar_dtype;          /* 0: fp32 AR weights + fp32 KV (parity mode); 1: fp16 AR weights (streamed as fp16 by the batch-1 decode kernel;
                             * the batched / prefill GEMMs use the same fp16-rounded values) + fp16 slow KV cache, as the reference
                             * decodes under torch.autocast(fp16) with fp16 caches (evaluations/infer_arvc.py:55-59, 483, 493) */
-    int mm_mode;           /* batch-scale GEMMs (>= 2048 rows) of the encoder / vocoder, csrc/gemm_planes.hip: 0 = fp32-grade from three bf16
-                            * planes per operand (six part products; any fp32 range), 1 = fp32-grade from two fp16 planes (three part
-                            * products, half the matrix work; operands inside the fp16 range, which torch.autocast(fp16) -- infer_arvc.py:493 --
-                            * demands of the reference too), -1 = the round-3 kernel that splits operands inside its K loop (A/B) */
+    int mm_mode;           /* fp32-grade batch-scale GEMMs (>= 4096 rows) of the encoder / vocoder: 1 (default) = two pre-split fp16 planes per
+                            * operand, three part products (csrc/gemm_planes.hip): half the matrix work of 0, for operands inside the fp16
+                            * range -- which torch.autocast(fp16), infer_arvc.py:493, demands of the reference too; 0 = three bf16 parts split
+                            * inside the K loop, six products (csrc/gemm_split.hip, the round-3 kernel): any fp32 range; 2 = three pre-split
+                            * bf16 planes, six products (A/B: slower than 0, its planes are 6 bytes per element) */
     int voc_dtype;         /* 0: vocoder (firefly.decode) GEMMs in the mm_mode grade; 1: fp16 operands, fp32 accumulate -- the reference's
                             * own precision for this stage (torch.autocast(fp16) around code2wav_fn, infer_arvc.py:493, 571-590) */
 } sva_config;

@@ -39,6 +39,7 @@ struct ArBatchArgs {
     unsigned* epoch;              // [1] running phase counter, persists across launches
     unsigned* done;               // [1] exit counter of the launch (the last workgroup out advances *epoch)
     int* fail;                    // [1] set to a phase code if a wait timed out (never in a healthy run)
+    int* fail_host;               // null, or a host-mapped mirror of *fail: written at the end of a launch that saw the flag set (callers that never synchronise)
     long long* dbg;               // null, or [1024] phase timestamps of workgroup 0 (SVA_DEBUG=ar_timing=1)
     // taps / outputs
     float *slow_logits, *fast_logits, *hidden;

@@ -1071,6 +1071,10 @@ __global__ __launch_bounds__(NTH, 2) void ar_batch_kernel(const ArBatchArgs a) {
         if (old == (unsigned)G - 1) {
             __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.epoch, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.fail_host) {      // a timeout of this launch reaches the host without a synchronising call (sva_step_device_on)
+                const int f = *reinterpret_cast<volatile int*>(a.fail);
+                if (f) *reinterpret_cast<volatile int*>(a.fail_host) = f;
+            }
         }
     }
 }

@@ -40,6 +40,7 @@ struct ArDecodeArgs {
     unsigned long long *gx, *gbig, *gatt, *glog, *ga;     // granule buffers: [2][768], [2][2304], [96][66], [1024], [2][768]
     unsigned* epoch;              // [1] running phase counter (tags), persists across launches
     int* fail;                    // [1] set to a phase code if a gather timed out (never in a healthy run)
+    int* fail_host;               // null, or a host-mapped mirror of *fail: written at the end of a launch that saw the flag set (callers that never synchronise)
     long long* dbg;               // null, or [1024] phase timestamps of workgroup 0 (SVA_AR_TIMING=1)
     // taps / outputs
     float *slow_logits, *fast_logits, *hidden;

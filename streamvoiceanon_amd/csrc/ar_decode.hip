@@ -607,6 +607,10 @@ __global__ __launch_bounds__(256, 1) void ar_decode_kernel(const ArDecodeArgs a)
         *s_nframes = frame + 1;
         *s_last_pos = p0 + 1;
         *s_epoch = ep;
+        if (a.fail_host) {          // a timeout seen by the end of this launch reaches the host without a synchronising call (sva_step_device_on)
+            const int f = *reinterpret_cast<volatile int*>(a.fail);
+            if (f) *reinterpret_cast<volatile int*>(a.fail_host) = f;
+        }
     }
     if (!a.skip_semantic) {
         float l[32];

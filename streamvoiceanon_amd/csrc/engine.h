@@ -215,6 +215,8 @@ struct sva_batch {
     unsigned long long* d_gran = nullptr;  // its granule buffers (gx | gbig | gatt | glog)
     unsigned* d_epoch = nullptr;           // [1] running phase counter of the granule tags
     int* d_ar_fail = nullptr;              // [1] timeout code of the persistent kernel (0 = healthy)
+    int* h_ar_fail = nullptr;              // host-mapped mirror of *d_ar_fail (written by the kernels at the end of a launch that saw it set)
+    int* d_ar_fail_host = nullptr;         //   ... its device address
     long long* d_ar_dbg = nullptr;         // SVA_AR_TIMING=1: phase timestamps of workgroup 0
     float* kv_fast_mega = nullptr;         // [4][8][2][768] fast-AR K/V scratch of the persistent kernel
     // batched persistent decode kernel (ar_batch.hip): every stream of the batch in ONE launch per frame
@@ -277,6 +279,7 @@ struct sva_batch {
     long kv_slow_slot = 0, kv_slow_layer = 0, kv_fast_slot = 0, kv_fast_layer = 0;
     float* cached_audio_emb = nullptr;     // [B][dim]
     float* cached_ref_emb = nullptr;       // [B][max_delay][dim]
+    int* d_ref_tail = nullptr;             // [B][8][max_delay] last frames of the stored prompt's audio codes (device-side re-prefill)
     float* spk = nullptr;                  // [33][dim] scratch
     float *d_style = nullptr, *d_timbre = nullptr;     // [B][192], [B][32][128]
     int* d_sem = nullptr;                  // [B] semantic token (discarded by callers)

@@ -81,6 +81,8 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "ar_persistent") o.ar_persistent = atoi(v.c_str());
             else if (k == "ar_batch") o.ar_batch = atoi(v.c_str());
             else if (k == "ar_batch_wgs") o.ar_batch_wgs = atoi(v.c_str());
+            else if (k == "planes_dbg") o.planes_dbg = atoi(v.c_str());
+            else if (k == "reprefill") o.reprefill = atoi(v.c_str());
             else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());
@@ -112,6 +114,7 @@ static int recover_ar_failure(sva_batch* b) {
     if (!b->ar_failed) return 0;
     SVA_HIP(hipDeviceSynchronize());
     SVA_HIP(hipMemset(b->d_ar_fail, 0, sizeof(int)));
+    if (b->h_ar_fail) *b->h_ar_fail = 0;
     b->use_mega = false;
     b->use_abatch = false;
     for (auto& ge : b->pipe_graph_a) if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
@@ -136,7 +139,7 @@ extern "C" int sva_config_default(sva_config* c) {
     c->tr_layers = 8; c->tr_heads = 8; c->tr_dim = 512; c->tr_inter = 1536; c->bsq_bits = 13;
     c->ar_dim = 768; c->ar_heads = 12; c->ar_layers = 12; c->ar_fast_layers = 4; c->ar_inter = 2304;
     c->ar_vocab = 8192; c->codebook_size = 1000; c->num_codebooks = 8; c->max_delay = 8; c->max_seq_len = 2048;
-    c->timbre_dim = 128; c->timbre_tokens = 32; c->style_dim = 192; c->voc_dim = 512; c->ar_dtype = 0; c->mm_mode = 0; c->voc_dtype = 0;
+    c->timbre_dim = 128; c->timbre_tokens = 32; c->style_dim = 192; c->voc_dim = 512; c->ar_dtype = 0; c->mm_mode = 1; c->voc_dtype = 0;
     return 0;
 }
 extern "C" int sva_stream_params_default(sva_stream_params* p) {
@@ -565,12 +568,12 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
     }
     // ---- pre-split operand planes of the encoder / vocoder weights (gemm_planes.hip) ----
     {
-        const int enc_mode = c.mm_mode == 1 ? PLANES_H3 : c.mm_mode == 0 ? PLANES_S6 : -1;
+        const int enc_mode = c.mm_mode == 1 ? PLANES_H3 : c.mm_mode == 2 ? PLANES_S6 : -1;
         const int voc_mode = c.voc_dtype == 1 ? PLANES_H1 : enc_mode;
-        SVA_CHECK(c.mm_mode >= -1 && c.mm_mode <= 1 && (c.voc_dtype == 0 || c.voc_dtype == 1), "bad mm_mode / voc_dtype");
+        SVA_CHECK(c.mm_mode >= 0 && c.mm_mode <= 2 && (c.voc_dtype == 0 || c.voc_dtype == 1), "bad mm_mode / voc_dtype");
         std::vector<float> host;
         auto planes = [&](Lin& l, int mode) -> int {
-            if (mode < 0 || !l.W || l.N < 64 || l.K % 32 != 0) return 0;
+            if (mode < 0 || !l.W || l.N < (mode == PLANES_H1 ? 32 : 64) || l.K % 32 != 0) return 0;
             const long n = (long)l.N * l.K;
             host.resize(n);
             SVA_HIP(hipMemcpy(host.data(), l.W, sizeof(float) * n, hipMemcpyDeviceToHost));
@@ -730,7 +733,7 @@ __global__ void mean3_kernel(const float* __restrict__ y0, const float* __restri
 // planes of one fp16 format -- two fp16 planes (or one) fill exactly the bytes (half the bytes) of the fp32 tensor they replace, so
 // they live in its buffer -- and the problem is at the scale where the planes kernel is the dispatcher's choice anyway.
 bool planes_edge(const Lin& producer, const Lin& consumer, long rows) {
-    return rows >= 2048 && producer.Wp && consumer.Wp && producer.pmode == consumer.pmode && (producer.pmode == PLANES_H3 || producer.pmode == PLANES_H1) &&
+    return rows >= 6144 && producer.Wp && consumer.Wp && producer.pmode == consumer.pmode && (producer.pmode == PLANES_H3 || producer.pmode == PLANES_H1) &&
            producer.N % 8 == 0;
 }
 
@@ -1317,6 +1320,69 @@ __global__ void build_delayfill_kernel(const float* __restrict__ content_emb, co
         pos[li * rows + r] = last_pos[b] + 1 + r;
     }
 }
+// Re-prefill of the due slots of a batch in ONE pass (infer_arvc.py:547-564: prompt <- [ref (truncated), last buffer_frames predicted
+// frames] / [ref content, src content[-buffer-d:-d]]).  The attention is causal, so the K / V rows of the reference part of that prompt
+// -- positions 0 .. 32 + 2 Rt -- are the ones the slot's cache has held since its first prefill: only the 2 na rows of the appended
+// frames are new.  They are built here from the device-resident history rings (no host round trip) for every due slot and then run
+// through the layers as one (sum of rows)-row pass against the cached prefix.  Row layout per slot, i = Rt .. Rt + na - 1:
+//   position 33 + 2 i = content_emb[content_hist[c_lo + i - Rt]],  34 + 2 i = audio_embed(ac'[:, i - d]),
+//   ac'[:, j] = ref_audio[:, j] for j < Rt (the last d reference frames: ref_tail) and pred_hist[nf - na + j - Rt] beyond.
+struct ReprefillArgs {
+    int n;
+    int slot[128], Rt[128], nf[128], na[128], row_off[129];
+};
+__global__ void build_reprefill_kernel(const ReprefillArgs a, const float* __restrict__ content_emb, const float* __restrict__ codebook_emb,
+                                       const int* __restrict__ content_hist, const int* __restrict__ pred_hist, int hist_cap, int ncontent,
+                                       const int* __restrict__ ref_tail, int max_delay, int d, int ncb, int cbsize, int D, int nspk,
+                                       float* __restrict__ x, int* __restrict__ slot_out, int* __restrict__ pos_out) {
+    const int row = blockIdx.x;
+    int li = 0;
+    while (li + 1 < a.n && row >= a.row_off[li + 1]) ++li;
+    const int r = row - a.row_off[li], b = a.slot[li], Rt = a.Rt[li], nf = a.nf[li], na = a.na[li];
+    const int i = Rt + (r >> 1);
+    float* o = x + (long)row * D;
+    const int mask = hist_cap - 1;
+    if ((r & 1) == 0) {
+        const int c_lo = ncontent - d - na;                      // src_content_codes[-buffer-d:-d]
+        const int code = content_hist[(long)b * hist_cap + ((c_lo + (i - Rt)) & mask)];
+        for (int k = threadIdx.x; k < D; k += blockDim.x) o[k] = content_emb[(long)code * D + k];
+    } else {
+        const int j = i - d;                                     // frame of the concatenated audio codes
+        int code[8];
+        for (int q = 0; q < ncb; ++q)
+            code[q] = j < Rt ? ref_tail[((long)b * ncb + q) * max_delay + (max_delay - (Rt - j))]
+                             : pred_hist[((long)b * ncb + q) * hist_cap + ((nf - na + (j - Rt)) & mask)];
+        for (int k = threadIdx.x; k < D; k += blockDim.x) {
+            float acc = 0.f;
+            for (int q = 0; q < ncb; ++q) acc += codebook_emb[((long)code[q] + (long)q * cbsize) * D + k];      // codebooks summed in order (build_prompt_kernel)
+            o[k] = acc;
+        }
+    }
+    if (threadIdx.x == 0) {
+        slot_out[row] = b;
+        pos_out[row] = nspk + 2 * Rt + r;
+    }
+}
+// cached_ref_emb = embed(ac')[-d:] of the new prompt (dual_ar_stream.py:775) and last_pos = its last position, per due slot
+__global__ void finish_reprefill_kernel(const ReprefillArgs a, const float* __restrict__ codebook_emb, const int* __restrict__ pred_hist, int hist_cap,
+                                        const int* __restrict__ ref_tail, int max_delay, int d, int ncb, int cbsize, int D, int nspk,
+                                        float* __restrict__ cached_ref_emb, int* __restrict__ last_pos) {
+    const int li = blockIdx.x / d, jj = blockIdx.x % d;
+    const int b = a.slot[li], Rt = a.Rt[li], nf = a.nf[li], na = a.na[li];
+    const int j = Rt + na - d + jj;
+    const int mask = hist_cap - 1;
+    int code[8];
+    for (int q = 0; q < ncb; ++q)
+        code[q] = j < Rt ? ref_tail[((long)b * ncb + q) * max_delay + (max_delay - (Rt - j))]
+                         : pred_hist[((long)b * ncb + q) * hist_cap + ((nf - na + (j - Rt)) & mask)];
+    for (int k = threadIdx.x; k < D; k += blockDim.x) {
+        float acc = 0.f;
+        for (int q = 0; q < ncb; ++q) acc += codebook_emb[((long)code[q] + (long)q * cbsize) * D + k];
+        cached_ref_emb[((long)b * max_delay + jj) * D + k] = acc;
+    }
+    if (jj == 0 && threadIdx.x == 0) last_pos[b] = nspk + 2 * (Rt + na) - 1;
+}
+
 __global__ void add_list_kernel(int* p, const int* list, int n, int v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[list[i]] += v;
@@ -1387,7 +1453,7 @@ int ar_decode_frame_batch(sva_batch* b, int ci) {
     const size_t* o = b->ab_offs;
     a.gxs = Gr + o[0]; a.gqkv = Gr + o[1]; a.gatt = Gr + o[2]; a.gg = Gr + o[3]; a.gxf = Gr + o[4]; a.gqkvf = Gr + o[5]; a.gattf = Gr + o[6];
     a.ggf = Gr + o[7]; a.gkvf = Gr + o[8]; a.glog = Gr + o[9]; a.gsem = Gr + o[10];
-    a.epoch = b->d_ab_epoch; a.done = b->d_ab_epoch + 1; a.fail = b->d_ar_fail; a.dbg = b->d_ar_dbg;
+    a.epoch = b->d_ab_epoch; a.done = b->d_ab_epoch + 1; a.fail = b->d_ar_fail; a.fail_host = b->d_ar_fail_host; a.dbg = b->d_ar_dbg;
     a.slow_logits = b->slow_logits; a.fast_logits = b->fast_logits; a.hidden = b->hidden;
     a.sem = b->d_sem; a.tok_raw = b->d_tok_raw; a.tok = b->d_tok; a.step_audio = b->d_step_audio; a.pred_hist = b->d_pred_hist;
     a.hist_cap = b->hist_cap; a.chunk = b->p.chunk_frames; a.ci = ci;
@@ -1421,7 +1487,7 @@ int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_
     a.cached_audio_emb = b->cached_audio_emb; a.last_pos = b->d_last_pos; a.nframes = b->d_nframes; a.seed = b->d_seed;
     a.kv_slow = b->kv_slow; a.kv_layer_stride = b->kv_slow_layer; a.S = c.max_seq_len; a.kv_fast = b->kv_fast_mega;
     a.gx = b->d_gran; a.gbig = a.gx + 2 * 768; a.gatt = a.gbig + 2 * 2304; a.glog = a.gatt + AR_WGS * 66; a.ga = a.glog + 1024;
-    a.epoch = b->d_epoch; a.fail = b->d_ar_fail; a.dbg = b->d_ar_dbg;
+    a.epoch = b->d_epoch; a.fail = b->d_ar_fail; a.fail_host = b->d_ar_fail_host; a.dbg = b->d_ar_dbg;
     a.slow_logits = b->slow_logits; a.fast_logits = b->fast_logits; a.hidden = b->hidden;
     a.sem = b->d_sem; a.tok_raw = b->d_tok_raw; a.tok = b->d_tok; a.step_audio = b->d_step_audio; a.pred_hist = b->d_pred_hist;
     a.step_content = b->d_step_content; a.hist_cap = b->hist_cap; a.chunk = b->p.chunk_frames; a.ci = ci;
@@ -2039,7 +2105,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     SVA_TRY(dev_alloc(A, &b->d_u, (size_t)B * T2 * c.bsq_bits));
     // AR
     const int D = c.ar_dim, S = c.max_seq_len, H = c.ar_heads, ncb = c.num_codebooks;
-    b->Mmax = std::max(std::max(2 * B, B * (2 * c.max_delay - 1)), S);
+    b->Mmax = std::max(std::max(std::max(2 * B, B * (2 * c.max_delay - 1)), S), std::min(B, 128) * 2 * p->buffer_frames);    // (last: a whole batch re-prefilling at once)
     SVA_TRY(dev_alloc(A, &b->ax, (size_t)b->Mmax * D));
     SVA_TRY(dev_alloc(A, &b->ahn, (size_t)b->Mmax * D));
     SVA_TRY(dev_alloc(A, &b->aqkv, (size_t)b->Mmax * 3 * D));
@@ -2120,8 +2186,14 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         if (!b->d_ar_fail) SVA_TRY(dev_alloc(A, &b->d_ar_fail, 1));
         if (debug_options().ar_timing && !b->d_ar_dbg) SVA_TRY(dev_alloc(A, &b->d_ar_dbg, 1024));
     }
+    if (b->d_ar_fail) {     // host-visible mirror of the timeout flag (the stream-ordered API never synchronises, so nothing read d_ar_fail)
+        SVA_HIP(hipHostMalloc((void**)&b->h_ar_fail, sizeof(int), hipHostMallocMapped));
+        *b->h_ar_fail = 0;
+        SVA_HIP(hipHostGetDevicePointer((void**)&b->d_ar_fail_host, b->h_ar_fail, 0));
+    }
     SVA_TRY(dev_alloc(A, &b->cached_audio_emb, (size_t)B * D));
     SVA_TRY(dev_alloc(A, &b->cached_ref_emb, (size_t)B * c.max_delay * D));
+    SVA_TRY(dev_alloc(A, &b->d_ref_tail, (size_t)B * c.num_codebooks * c.max_delay));
     SVA_TRY(dev_alloc(A, &b->spk, (size_t)(c.timbre_tokens + 1) * D));
     SVA_TRY(dev_alloc(A, &b->d_style, (size_t)B * c.style_dim));
     SVA_TRY(dev_alloc(A, &b->d_timbre, (size_t)B * c.timbre_tokens * c.timbre_dim));
@@ -2222,6 +2294,7 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     for (auto& ge : b->pipe_graph_a) if (ge) (void)hipGraphExecDestroy(ge);
     for (hipGraphExec_t ge : {b->gEm[0], b->gEm[1], b->gEs[0], b->gEs[1], b->gE, b->gE2, b->gT0, b->gT1[0], b->gT1[1], b->gV}) if (ge) (void)hipGraphExecDestroy(ge);
     for (void* p : b->allocs.chunks) (void)hipFree(p);
+    if (b->h_ar_fail) (void)hipHostFree(b->h_ar_fail);
     if (b->hp_in) (void)hipHostFree(b->hp_in);
     if (b->hp_out) (void)hipHostFree(b->hp_out);
     for (int i = 0; i < 5; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
@@ -2281,6 +2354,14 @@ extern "C" int sva_prefill_prompt(sva_batch* b, int slot, const int64_t* ref_con
     for (int q = 0; q < ncb; ++q)
         for (int i = 0; i < Rt; ++i) b->ref_audio[slot][(size_t)q * Rt + i] = ac[(size_t)q * R + i];
     b->ref_len[slot] = Rt;
+    {   // the last max_delay frames of the stored prompt's audio codes, for the device-side re-prefill (right-aligned; a shorter prompt leaves the front unused)
+        const int md = c.max_delay;
+        std::vector<int32_t> tail((size_t)ncb * md, 0);
+        for (int q = 0; q < ncb; ++q)
+            for (int j = 0; j < md; ++j)
+                if (Rt - md + j >= 0) tail[(size_t)q * md + j] = ac[(size_t)q * R + (Rt - md + j)];
+        SVA_TRY(h2d(b, b->d_ref_tail + (long)slot * ncb * md, tail.data(), sizeof(int32_t) * tail.size()));
+    }
     b->prefilled[slot] = 1;
     return 0;
 }
@@ -2467,6 +2548,41 @@ extern "C" int sva_streams_begin(sva_batch* b) {
 // the per-chunk step
 // ============================================================================================
 namespace {
+
+// every due slot in one pass over the layers, no host synchronisation (see build_reprefill_kernel)
+int reprefill_slots(sva_batch* b, const std::vector<int>& due) {
+    sva_engine* e = b->e;
+    const sva_config& c = e->cfg;
+    const int ncb = c.num_codebooks, d = b->p.delay, bf = b->p.buffer_frames, D = c.ar_dim, nspk = c.timbre_tokens + 1;
+    hipStream_t st = b->stream;
+    for (size_t lo = 0; lo < due.size(); lo += 128) {
+        ReprefillArgs a;
+        a.n = (int)std::min<size_t>(128, due.size() - lo);
+        a.row_off[0] = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const int slot = due[lo + i];
+            const int nf = b->h_nframes[slot], ncon = b->h_ncontent;
+            const int na = std::min(bf, nf);
+            SVA_CHECK(na == std::max(0, (ncon - d) - std::max(0, ncon - bf - d)) && na >= d, "re-prefill: content/audio history length mismatch");
+            a.slot[i] = slot; a.Rt[i] = b->ref_len[slot]; a.nf[i] = nf; a.na[i] = na;
+            a.row_off[i + 1] = a.row_off[i] + 2 * na;
+        }
+        const int M = a.row_off[a.n];
+        SVA_CHECK(M <= b->Mmax, "re-prefill: more rows than the AR scratch holds");
+        hipLaunchKernelGGL(build_reprefill_kernel, dim3(M), dim3(256), 0, st, a, e->content_emb, e->codebook_emb, b->d_content_hist, b->d_pred_hist,
+                           b->hist_cap, b->h_ncontent, b->d_ref_tail, c.max_delay, d, ncb, c.codebook_size, D, nspk, b->ax, b->d_slot, b->d_pos);
+        SVA_TRY(ar_layers_pass(b, e->ar_layers, M, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer, b->kv_slow_slot,
+                               c.max_seq_len, b->ax));
+        hipLaunchKernelGGL(finish_reprefill_kernel, dim3(a.n * d), dim3(256), 0, st, a, e->codebook_emb, b->d_pred_hist, b->hist_cap, b->d_ref_tail,
+                           c.max_delay, d, ncb, c.codebook_size, D, nspk, b->cached_ref_emb, b->d_last_pos);
+        SVA_HIP(hipGetLastError());
+        for (int i = 0; i < a.n; ++i) {
+            SVA_CHECK(nspk + 2 * (a.Rt[i] + a.na[i]) <= c.max_seq_len, "re-prefill: prompt too long for the KV cache");
+            b->h_last_pos[a.slot[i]] = nspk + 2 * (a.Rt[i] + a.na[i]) - 1;
+        }
+    }
+    return 0;
+}
 
 int reprefill_slot(sva_batch* b, int slot) {
     // infer_arvc.py:547-564: prompt <- [ref (truncated), last buffer_frames predicted frames] /
@@ -2814,6 +2930,7 @@ int quiesce(sva_batch* b) {
 int step_body(sva_batch* b) {
     sva_engine* e = b->e;
     (void)e;
+    if (b->h_ar_fail && *reinterpret_cast<volatile int*>(b->h_ar_fail) != 0) b->ar_failed = true;      // (a launch of an earlier step saw a wait time out)
     SVA_CHECK(!b->ar_failed, "this batch's persistent AR decode kernel timed out earlier: call sva_streams_begin to restart its streams");
     const int B = b->B, chunk = b->p.chunk_frames, d = b->p.delay, n = 2048 * chunk;
     hipStream_t st = b->stream;
@@ -2858,8 +2975,14 @@ int step_body(sva_batch* b) {
         std::vector<int> redo;
         if (b->pipe_dirty) b->stream = b->sa;  // pipelined: the KV rewrite belongs to the AR stream (it already waited for E of this step)
         int rrc = 0;
-        for (int i = 0; i < B && !rrc; ++i)
-            if (b->h_last_pos[i] / 2 >= b->p.max_seq_frames) { rrc = reprefill_slot(b, i); redo.push_back(i); }
+        for (int i = 0; i < B; ++i)
+            if (b->h_last_pos[i] / 2 >= b->p.max_seq_frames) redo.push_back(i);
+        if (!redo.empty()) {
+            // one pass for all due slots against the cached prompt prefix (reprefill_slots); SVA_DEBUG reprefill=0: the round-3 path, one
+            // whole-prompt prefill per slot behind a host synchronisation (A/B, parity of the two)
+            if (debug_options().reprefill) rrc = reprefill_slots(b, redo);
+            else for (size_t i = 0; i < redo.size() && !rrc; ++i) rrc = reprefill_slot(b, redo[i]);
+        }
         if (!rrc) rrc = ar_delay_fill(b, redo);       // prefill_src_condition4delay(src_content_codes[-d:]) for those slots only
         if (b->pipe_dirty) {
             b->stream = b->main_stream;

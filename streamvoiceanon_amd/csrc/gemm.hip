@@ -689,18 +689,33 @@ struct Choice { int kind, a, b, c; int z = 1; };      // z: grid-level K split o
 static thread_local int t_planes_mode = -1;              // set by launch_choice when the planes kernel took a kind-4 choice
 static thread_local int t_last_kind = -1;                // kernel family of this thread's latest dispatch (bench.py: per-pipe roofline)
 
+// Tile variant of the planes kernel (gemm_planes.hip) for a problem.  The candidates that ever win on the encoder's / vocoder's shapes
+// (tools/planes_bench.py, profiles/r04_planes_bench.txt) are 128 x 128 (two workgroups per CU) and 256 x 128 (eight waves, one per CU,
+// two thirds of the operand traffic); which one is a matter of how the tile count quantises over the 256 CUs.  In units of the time
+// T a CU needs for one 128 x 128 tile's worth of work when it is full: a round of 512 small tiles costs 2 T, a last round of <= 256
+// of them (one per CU) 1.3 T, a round of 256 large tiles 1.7 T.  The rule reproduces the measured winner of the two on all ten shapes.
+static int planes_variant(const ConvGemm& g, int group_n) {
+    if (g.N < 128) return g.M >= 128 ? 1 : 3;
+    if (g.M < 128) return 2;
+    const long wg0 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * group_n, wg6 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * group_n;
+    if (wg0 < 224) return 3;                // too few 128 x 128 tiles for the chip: 64 x 64 (the mid-size shapes of profiles/r04_planes_bench_small.txt)
+    if (g.M < 256) return 0;
+    const long rem = wg0 % 512;
+    const double t0 = (double)(wg0 / 512) * 2.0 + (rem == 0 ? 0.0 : rem <= 256 ? 1.3 : 2.0);
+    const double t6 = (double)((wg6 + 255) / 256) * 1.7;
+    if (t6 < t0) return 6;
+    return wg0 <= 768 ? 7 : 0;              // up to a round and a half of tiles: the 8-wave form of the same tile (four waves per SIMD overlap its phases better)
+}
+
 static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
     if (ch.kind == 4) {                 // fp32 on the bf16 matrix pipes, six-product split (gemm_split.hip), a = tile variant
         ConvGemmGroup gg;
         if (t_group) gg = *t_group; else gg.g[0] = g;
-        // weights that carry pre-split planes: the same tile shapes fed from the planes, in the planes' precision (gemm_planes.hip; a >= 8: its own variant a - 8)
-        bool planes = true;
-        for (int i = 0; i < gg.n; ++i) planes = planes && planes_gemm_supported(gg.g[i]);
-        if (planes) {
+        if (ch.a >= 8) {                // the kernel fed from pre-split operand planes (gemm_planes.hip), its tile variant a - 8
             t_planes_mode = g.pmode;
-            return launch_planes_gemm(gg, ch.a >= 8 ? ch.a - 8 : ch.a == 4 ? 0 : ch.a, st);
+            return launch_planes_gemm(gg, ch.a - 8, st);
         }
-        SVA_CHECK(!g.Ap && !g.Cp && ch.a < 8, "conv_gemm: operand planes need weight planes");
+        SVA_CHECK(!g.Ap && !g.Cp, "conv_gemm: operand planes need the planes kernel");
         return launch_split_gemm(gg, ch.a, st);
     }
     if (ch.kind == 2) {                 // LDS-DMA ring kernel (gemm_pipe.hip), a = tile variant
@@ -990,8 +1005,19 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
             }
         }
     }
-    // operand planes exist only for the planes kernel: a problem that carries them takes that kernel whatever the table says for the shape
-    if ((g.Ap || g.Cp) && ch.kind != 4) ch = Choice{4, g.N < 128 || g.M < 128 ? 3 : 0, 0, 0};
+    // Weights that carry pre-split planes (gemm_planes.hip).  fp16 x 1 (a voc_dtype = 1 vocoder): one product per block instead of the
+    // six or eight of any fp32-grade kernel -- every problem with enough rows to fill its tiles.  fp32-grade planes (fp16 x 2, bf16 x 3):
+    // where the split kernels are the choice anyway and the batch is large enough for the 128-row tiles to fill the chip (measured:
+    // +9 / +12 % frames/s at 64 / 128 streams, -2 % at 32 against the tuned in-loop split kernels, profiles/r04_mm_mode_ab.txt: from 6144 rows).  A
+    // problem whose operands only exist as planes has no other kernel.
+    {
+        bool planes = c_vec;
+        if (t_group) { for (int i = 0; i < t_group->n; ++i) planes = planes && planes_gemm_supported(t_group->g[i]); }
+        else planes = planes && planes_gemm_supported(g);
+        const bool want = g.Ap || g.Cp || (g.pmode == PLANES_H1 ? g.M >= 1024 : (ch.kind == 4 && g.M >= 6144));
+        if (planes && want) ch = Choice{4, 8 + planes_variant(g, group_n), 0, 0};
+        else SVA_CHECK(!g.Ap && !g.Cp, "conv_gemm: operand planes handed to a problem the planes kernel does not take");
+    }
     t_planes_mode = -1;
     SVA_TRY_RC(launch_choice(g, st, ch));
     t_last_kind = t_planes_mode >= 0 ? 6 + t_planes_mode : ch.kind;       // 6 / 7 / 8: planes kernel in S6 / H3 / H1
@@ -1011,7 +1037,7 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
         return 0;
     }
     if (kind == 6) {                    // the planes kernel (gemm_planes.hip), a = its tile variant
-        SVA_CHECK(planes_gemm_supported(g) && a >= 0 && a <= 5 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the planes kernel needs weight planes, Cin % 32 == 0 and 16-byte aligned C rows");
+        SVA_CHECK(planes_gemm_supported(g) && a >= 0 && a <= 7 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the planes kernel needs weight planes, Cin % 32 == 0 and 16-byte aligned C rows");
         SVA_TRY_RC(launch_choice(g, st, Choice{4, 8 + a, 0, 0}));
         SVA_HIP(hipGetLastError());
         return 0;

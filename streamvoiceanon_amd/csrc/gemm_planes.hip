@@ -28,6 +28,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "sva_common.h"
@@ -94,16 +95,17 @@ __device__ __forceinline__ f32x4 mma1(const u32x4& a, const u32x4& b, const f32x
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// BM x BN tile, 4 waves (2 x 2), BK = 32 KB k per tile.  APL: the A operand comes as planes (g.Ap), otherwise as fp32 (g.A) and is
-// split while it is staged
-template <int MODE, int BM, int BN, int KB, bool APL>
-__global__ __launch_bounds__(256, (MODE == PLANES_S6 && BM + BN > 192) ? 1 : 2) void planes_gemm_kernel(const ConvGemmGroup gg) {
-    constexpr int NTH = 256, BK = 32 * KB, WM = 2, WN = 2, NPL = PM<MODE>::NPL;
+// BM x BN tile, WM x WN waves of 64 x 64 (or smaller) wave tiles, BK = 32 KB k per tile.  APL: the A operand comes as planes (g.Ap),
+// otherwise as fp32 (g.A) and is split while it is staged
+template <int MODE, int BM, int BN, int KB, bool APL, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, ((WM * WN > 4 && BM > 128) || (MODE == PLANES_S6 && BM + BN > 192)) ? 1 : 2) void planes_gemm_kernel(const ConvGemmGroup gg) {
+    constexpr int NW = WM * WN, NTH = 64 * NW, BK = 32 * KB, NPL = PM<MODE>::NPL;
+    constexpr int NS = KB == 1 ? 3 : 2;                         // register stages of global loads in flight
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
     constexpr int RBA = BM / 16, RBB = BN / 16;                 // row blocks (pieces per plane and k block) of the A / B tile
     constexpr int A_BYTES = KB * NPL * RBA * 1024, B_BYTES = KB * NPL * RBB * 1024, STAGE = A_BYTES + B_BYTES;
-    constexpr int IA = RBA / 4, IB = RBB / 4;                   // row blocks per wave
-    static_assert(RBA % 4 == 0 && RBB % 4 == 0, "tile rows in blocks of 64");
+    constexpr int IA = RBA / NW, IB = RBB / NW;                 // row blocks per wave
+    static_assert(RBA % NW == 0 && RBB % NW == 0 && IA >= 1 && IB >= 1, "tile rows: whole row blocks per wave");
     const ConvGemm& g = gg.g[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256, (MODE == PLANES_S6 && BM + BN > 192) ? 1 : 2) 
     const unsigned short* a_pl[IA];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-        int m = bm0 + (wave + 4 * i) * 16 + prow;
+        int m = bm0 + (wave + NW * i) * 16 + prow;
         if (m > g.M - 1) m = g.M - 1;
         const int b = m / g.T, t = m - b * g.T;
         const long off = (long)b * g.a_bstride + g.a_off + (long)t * g.stride * g.lda + pchunk * 8;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, (MODE == PLANES_S6 && BM + BN > 192) ? 1 : 2) 
     const unsigned short* b_pl[IB];
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-        int n = bn0 + (wave + 4 * i) * 16 + prow;
+        int n = bn0 + (wave + NW * i) * 16 + prow;
         if (n > g.N - 1) n = g.N - 1;
         b_pl[i] = g.Wp + (long)n * Kt + pchunk * 8;
     }
@@ -144,35 +146,45 @@ __global__ __launch_bounds__(256, (MODE == PLANES_S6 && BM + BN > 192) ? 1 : 2) 
 
     const int kc_tiles = g.Cin / BK;
     const int nk = g.taps * kc_tiles;
+    const int dbg = gg.xcd_swz >> 8;            // TIMING EXPERIMENT (results are garbage): 1 no global loads in the K loop, 2 no LDS stores, 4 no MFMAs, 8 no epilogue
+    // (kernel-argument fields the K loop needs, as values)
+    const long g_tapstep = (long)g.dil * g.lda, g_ap_ps = g.ap_pstride, g_wp_ps = g.wp_pstride;
+    const int g_cin = g.Cin, g_silu = g.a_silu;
 
-    // registers of one K tile in flight
-    f32x4 ra[APL ? 1 : KB][APL ? 1 : IA][2];
-    u32x4 rap[APL ? KB : 1][APL ? IA : 1][NPL];
-    u32x4 rb[KB][IB][NPL];
-    auto gload = [&](int kt) {
+    // NS register stages: the loads of tiles k + 2 .. k + NS are in flight while tile k multiplies and tile k + 1 is written to LDS
+    // (one stage ahead -- the first version -- left a tile's loads ~0.3 us, one tile's worth of MFMAs, to cover a 1-2 us trip to
+    // L2 / HBM: every variant and precision ran at the same ~5.5 TB/s of operand traffic, 12-26 % of its matrix pipe)
+    constexpr int AV = APL ? NPL : 2;                           // 16-byte loads per staged A piece
+    constexpr int LPS = KB * (IA * AV + IB * NPL);              // loads per thread and K tile
+    struct Regs {
+        u32x4 a[KB][IA][AV];
+        u32x4 b[KB][IB][NPL];
+    };
+    Regs rg[NS];
+    auto gload = [&](int kt, Regs& r) {
         const int tap = kt / kc_tiles;
         const int kc = (kt - tap * kc_tiles) * BK;
-        const long aoff = (long)tap * g.dil * g.lda + kc;
-        const long boff = (long)tap * g.Cin + kc;
+        const long aoff = (long)tap * g_tapstep + kc;
+        const long boff = (long)tap * g_cin + kc;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
                 if constexpr (APL) {
 #pragma unroll
-                    for (int p = 0; p < NPL; ++p) rap[kb][i][p] = *reinterpret_cast<const u32x4*>(a_pl[i] + (long)p * g.ap_pstride + aoff + kb * 32);
+                    for (int p = 0; p < NPL; ++p) r.a[kb][i][p] = *reinterpret_cast<const u32x4*>(a_pl[i] + (long)p * g_ap_ps + aoff + kb * 32);
                 } else {
-                    ra[kb][i][0] = *reinterpret_cast<const f32x4*>(a_f32[i] + aoff + kb * 32);
-                    ra[kb][i][1] = *reinterpret_cast<const f32x4*>(a_f32[i] + aoff + kb * 32 + 4);
+                    r.a[kb][i][0] = *reinterpret_cast<const u32x4*>(a_f32[i] + aoff + kb * 32);
+                    r.a[kb][i][1] = *reinterpret_cast<const u32x4*>(a_f32[i] + aoff + kb * 32 + 4);
                 }
             }
 #pragma unroll
             for (int i = 0; i < IB; ++i)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) rb[kb][i][p] = *reinterpret_cast<const u32x4*>(b_pl[i] + (long)p * g.wp_pstride + boff + kb * 32);
+                for (int p = 0; p < NPL; ++p) r.b[kb][i][p] = *reinterpret_cast<const u32x4*>(b_pl[i] + (long)p * g_wp_ps + boff + kb * 32);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const Regs& r) {
         char* const st = lds + buf * STAGE + lane * 16;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
@@ -181,71 +193,94 @@ __global__ __launch_bounds__(256, (MODE == PLANES_S6 && BM + BN > 192) ? 1 : 2) 
                 u32x4 o[NPL];
                 if constexpr (APL) {
 #pragma unroll
-                    for (int p = 0; p < NPL; ++p) o[p] = rap[kb][i][p];
+                    for (int p = 0; p < NPL; ++p) o[p] = r.a[kb][i][p];
                 } else {
-                    f32x4 v0 = ra[kb][i][0], v1 = ra[kb][i][1];
-                    if (g.a_silu) {
+                    f32x4 v0 = __builtin_bit_cast(f32x4, r.a[kb][i][0]), v1 = __builtin_bit_cast(f32x4, r.a[kb][i][1]);
+                    if (g_silu) {
                         v0.x = silu_f(v0.x); v0.y = silu_f(v0.y); v0.z = silu_f(v0.z); v0.w = silu_f(v0.w);
                         v1.x = silu_f(v1.x); v1.y = silu_f(v1.y); v1.z = silu_f(v1.z); v1.w = silu_f(v1.w);
                     }
                     split8<MODE>(v0, v1, o);
                 }
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(st + ((kb * NPL + p) * RBA + wave + 4 * i) * 1024) = o[p];
+                for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(st + ((kb * NPL + p) * RBA + wave + NW * i) * 1024) = o[p];
             }
 #pragma unroll
             for (int i = 0; i < IB; ++i)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(st + A_BYTES + ((kb * NPL + p) * RBB + wave + 4 * i) * 1024) = rb[kb][i][p];
+                for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(st + A_BYTES + ((kb * NPL + p) * RBB + wave + NW * i) * 1024) = r.b[kb][i][p];
+        }
+    };
+    // fragments of one 32-wide k block of the staged tile, and its products for the column sub-tiles [j0, j1)
+    struct Frags { u32x4 a[MI][NPL], b[NI][NPL]; };
+    auto load_frags = [&](int buf, int kb, Frags& f) {
+        const char* const sa = lds + buf * STAGE + lane * 16 + (wm * MI) * 1024;
+        const char* const sb = lds + buf * STAGE + A_BYTES + lane * 16 + (wn * NI) * 1024;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) f.a[i][p] = *reinterpret_cast<const u32x4*>(sa + ((kb * NPL + p) * RBA + i) * 1024);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) f.b[j][p] = *reinterpret_cast<const u32x4*>(sb + ((kb * NPL + p) * RBB + j) * 1024);
+    };
+    auto mma = [&](const Frags& f, int j0, int j1) {
+        // small products first
+#pragma unroll
+        for (int j = j0; j < j1; ++j) {
+            if constexpr (MODE == PLANES_S6) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(f.a[i][2], f.b[j][0], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(f.a[i][0], f.b[j][2], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(f.a[i][1], f.b[j][1], acc[i][j]);
+            }
+            if constexpr (MODE != PLANES_H1) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(f.a[i][1], f.b[j][0], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(f.a[i][0], f.b[j][1], acc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(f.a[i][0], f.b[j][0], acc[i][j]);
         }
     };
 
-    gload(0);
-    lstore(0);
-    if (nk > 1) gload(1);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                    // tile kt is in buffer kt & 1; nobody still reads the other buffer
-        if (kt + 1 < nk) {
-            lstore((kt + 1) & 1);
-            if (kt + 2 < nk) gload(kt + 2);
-        }
-        const char* const sa = lds + (kt & 1) * STAGE + lane * 16 + (wm * MI) * 1024;
-        const char* const sb = lds + (kt & 1) * STAGE + A_BYTES + lane * 16 + (wn * NI) * 1024;
+    // tile 0 -> LDS stage 0; tiles 1 .. NS in flight (tile s in register stage s % NS).  Every iteration stores and requests
+    // unconditionally (beyond the last tile: a clamped re-read of it, stored into the stage nobody reads any more), so the queue
+    // always holds NS stages in issue order when a stage is waited for
+    gload(0, rg[0]);
+    lstore(0, rg[0]);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            u32x4 af[MI][NPL], bf[NI][NPL];
+    for (int s_ = 1; s_ <= NS; ++s_) gload(s_ < nk ? s_ : nk - 1, rg[s_ % NS]);
+    for (int kt = 0; kt < nk; kt += NS) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+        for (int u = 0; u < NS; ++u) {
+            const int k = kt + u;
+            if (k >= nk) goto k_done;
+            __syncthreads();                    // tile k is in LDS stage k & 1; nobody still reads the other stage
+            // this tile's fragment reads go to the LDS queue FIRST and half of its products are issued before the wave stops at
+            // the wait for tile k + 1's global loads and stores that tile: the stores drain behind the reads while the matrix pipe
+            // works (stores first -- the first version -- put them, and the wait in front of them, on every tile's critical path)
+            Frags f;
+            load_frags(k & 1, 0, f);
+            if (!(dbg & 4)) mma(f, 0, NI / 2);
+            if (!(dbg & 2)) lstore((k + 1) & 1, rg[(u + 1) % NS]);
+            if (!(dbg & 1)) gload(k + 1 + NS < nk ? k + 1 + NS : nk - 1, rg[(u + 1) % NS]);
+            if (!(dbg & 4)) mma(f, NI / 2, NI);
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(sa + ((kb * NPL + p) * RBA + i) * 1024);
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) bf[j][p] = *reinterpret_cast<const u32x4*>(sb + ((kb * NPL + p) * RBB + j) * 1024);
-            // small products first
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                if constexpr (MODE == PLANES_S6) {
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][2], bf[j][0], acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][0], bf[j][2], acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][1], bf[j][1], acc[i][j]);
-                }
-                if constexpr (MODE != PLANES_H1) {
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][1], bf[j][0], acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][0], bf[j][1], acc[i][j]);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(af[i][0], bf[j][0], acc[i][j]);
+            for (int kb = 1; kb < KB; ++kb) {
+                load_frags(k & 1, kb, f);
+                mma(f, 0, NI);
             }
         }
     }
+k_done:
     __syncthreads();
 
+    if (dbg & 8) { if (acc[0][0][0] == 123.456f) g.C[0] = 1.f; return; }
     // ---- epilogue (as conv_gemm_kernel / split_gemm_kernel: accumulators staged through LDS for whole 16-byte row accesses) ----
     constexpr int CS = BN + 4;
     float* Cs = smem;                              // [BM][CS]
@@ -271,13 +306,15 @@ __global__ __launch_bounds__(256, (MODE == PLANES_S6 && BM + BN > 192) ? 1 : 2) 
     if (g.w13) {
         // SwiGLU: tile columns alternate 16 x w1 | 16 x w3; output column (n0 >> 1) + c
         constexpr int OC4 = BN / 8;                // float4 chunks of output per row
+        const int eb0w = bm0 / g.T, et0w = bm0 - eb0w * g.T;
         for (int idx = tid; idx < BM * OC4; idx += NTH) {
             const int row = idx / OC4, q = idx - row * OC4;
             const int m = bm0 + row;
             const int grp = q >> 2, c4 = (q & 3) * 4;       // 16-wide group, offset inside it
             const int n = bn0 + grp * 32 + c4;              // w1 column
             if (m >= g.M || n >= g.N) continue;
-            const int b = m / g.T, t = m - b * g.T;
+            int b = eb0w, t = et0w + row;
+            if (t >= g.T) { t -= g.T; ++b; if (t >= g.T) { b += t / g.T; t %= g.T; } }
             if (t >= g.skip_lo && t < g.skip_hi) continue;
             const float4 a = *reinterpret_cast<const float4*>(&Cs[row * CS + grp * 32 + c4]);
             const float4 w = *reinterpret_cast<const float4*>(&Cs[row * CS + grp * 32 + 16 + c4]);
@@ -288,11 +325,13 @@ __global__ __launch_bounds__(256, (MODE == PLANES_S6 && BM + BN > 192) ? 1 : 2) 
         return;
     }
     constexpr int C4 = BN / 4;
+    const int eb0 = bm0 / g.T, et0 = bm0 - eb0 * g.T;          // (one division per workgroup; a tile rarely spans more than two batch items)
     for (int idx = tid; idx < BM * C4; idx += NTH) {
         const int row = idx / C4, c4 = (idx - row * C4) * 4;
         const int m = bm0 + row, n = bn0 + c4;
         if (m >= g.M || n >= g.N) continue;
-        const int b = m / g.T, t = m - b * g.T;
+        int b = eb0, t = et0 + row;
+        if (t >= g.T) { t -= g.T; ++b; if (t >= g.T) { b += t / g.T; t %= g.T; } }
         if (t >= g.skip_lo && t < g.skip_hi) continue;
         float4 v = *reinterpret_cast<const float4*>(&Cs[row * CS + c4]);
         if (g.bias) {
@@ -319,21 +358,22 @@ __global__ __launch_bounds__(256, (MODE == PLANES_S6 && BM + BN > 192) ? 1 : 2) 
     }
 }
 
-template <int MODE, int BM, int BN, int KB, bool APL>
+template <int MODE, int BM, int BN, int KB, bool APL, int WM = 2, int WN = 2>
 int launch_planes_t(const ConvGemmGroup& gg_in, hipStream_t st) {
     ConvGemmGroup gg = gg_in;
     const ConvGemm& g = gg.g[0];
     constexpr size_t smem_ab = (size_t)2 * KB * PM<MODE>::NPL * (BM + BN) / 16 * 1024;
     constexpr size_t smem_c = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t smem = smem_ab > smem_c ? smem_ab : smem_c;
+    static_assert(smem <= 160 * 1024, "LDS of one CU");
     static DeviceOnce attr_set;
     if (attr_set.needed() && smem > 48 * 1024) {
-        SVA_HIP(hipFuncSetAttribute((const void*)planes_gemm_kernel<MODE, BM, BN, KB, APL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        SVA_HIP(hipFuncSetAttribute((const void*)planes_gemm_kernel<MODE, BM, BN, KB, APL, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set.done();
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, gg.n);
-    gg.xcd_swz = xcd_swizzle_for(grid.x, grid.y);
-    hipLaunchKernelGGL((planes_gemm_kernel<MODE, BM, BN, KB, APL>), grid, dim3(256), smem, st, gg);
+    gg.xcd_swz = xcd_swizzle_for(grid.x, grid.y) | (debug_options().planes_dbg << 8);
+    hipLaunchKernelGGL((planes_gemm_kernel<MODE, BM, BN, KB, APL, WM, WN>), grid, dim3(64 * WM * WN), smem, st, gg);
     return 0;
 }
 
@@ -346,8 +386,15 @@ int launch_planes_m(const ConvGemmGroup& gg, int variant, hipStream_t st) {
         case 2: return launch_planes_t<MODE, 64, 128, 1, APL>(gg, st);
         case 3: return launch_planes_t<MODE, 64, 64, 1, APL>(gg, st);
         // 64-deep K tiles (half the barriers; the tile's stage is twice as large)
-        case 4: if (k64) return launch_planes_t<MODE, 128, 128, 2, APL>(gg, st); return launch_planes_t<MODE, 128, 128, 1, APL>(gg, st);
+        case 4:             // (three planes x 2 stages x 64 k of a 128 x 128 tile would need 192 KiB of LDS)
+            if constexpr (MODE != PLANES_S6) { if (k64) return launch_planes_t<MODE, 128, 128, 2, APL>(gg, st); }
+            return launch_planes_t<MODE, 128, 128, 1, APL>(gg, st);
         case 5: if (k64) return launch_planes_t<MODE, 64, 64, 2, APL>(gg, st); return launch_planes_t<MODE, 64, 64, 1, APL>(gg, st);
+        // 8 waves: 256 x 128 (each weight tile feeds twice the rows: two thirds of the operand traffic per flop of 128 x 128)
+        case 6: return launch_planes_t<MODE, 256, 128, 1, APL, 4, 2>(gg, st);
+        // 128 x 128 on 8 waves of 32 x 64: four waves per SIMD with two workgroups per CU (more independent instruction streams to
+        // overlap a tile's load / LDS-store / fragment-read / MFMA phases, for 1.5 x the fragment reads)
+        case 7: return launch_planes_t<MODE, 128, 128, 1, APL, 4, 2>(gg, st);
     }
     set_error("planes_gemm: bad variant");
     return -1;

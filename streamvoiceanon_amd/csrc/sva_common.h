@@ -26,9 +26,13 @@ void set_error(const std::string& msg);
 //   cu_ar=N           with cu_partition=1: CUs of the AR stream's mask (default: by batch size; A/B only: the round-3 partition A/B scripts, git history)
 //   pipe_skip=mask    TIMING DIAGNOSTIC (results are garbage): leave out a chain of the pipelined step -- 1 encoder front, 2 side chain
 //                     (downsampler + transformer + BSQ), 4 AR, 8 vocoder (tools/pipe_skip.sh)
+//   planes_dbg=mask   TIMING DIAGNOSTIC (results are garbage): leave parts of the planes GEMM out -- 1 global loads of its K loop, 2 LDS stores, 4 MFMAs,
+//                     8 epilogue (tools/planes_probe.py)
+//   reprefill=0       re-prefill as one whole-prompt prefill per slot behind a host synchronisation (round 3) instead of one pass over the
+//                     appended rows of all due slots against the cached prompt prefix (A/B, parity)
 //   f16_weights=0     ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B)
 struct DebugOptions {
-    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0;
+    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1;
     std::string tune_dump;
 };
 const DebugOptions& debug_options();

@@ -23,8 +23,8 @@ def accuracy():
         bias = rng.standard_normal(N).astype(np.float32)
         ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
         for mode in MODES:
-            for variant in range(6):
-                if (variant in (0, 1, 4) and M < 128) or (variant in (0, 2, 4) and N < 128):
+            for variant in range(8):
+                if (variant in (0, 1, 4, 7) and M < 128) or (variant in (0, 2, 4, 6, 7) and N < 128) or (variant == 6 and M < 256):
                     continue
                 for ap in (False, True):
                     for cp in (False, True):
@@ -52,7 +52,10 @@ def accuracy():
 
 
 def timings():
-    shapes = [(8192, 3072, 512), (10880, 1536, 384), (10880, 384, 1536), (8192, 1536, 512), (8192, 512, 1536), (10880, 2048, 512), (10880, 512, 2048),
+    if os.environ.get("SHAPES"):            # "M,N,K M,N,K ..."
+        shapes = [tuple(int(x) for x in t.split(",")) for t in os.environ["SHAPES"].split()]
+    else:
+      shapes = [(8192, 3072, 512), (10880, 1536, 384), (10880, 384, 1536), (8192, 1536, 512), (8192, 512, 1536), (10880, 2048, 512), (10880, 512, 2048),
               (8192, 512, 512), (10880, 1024, 256), (10880, 256, 1024)]
     for (M, N, K) in shapes:
         A = rng.standard_normal((M, K)).astype(np.float32)
@@ -61,7 +64,7 @@ def timings():
         row = ["M %5d N %4d K %4d" % (M, N, K)]
         for mode in (0, 1, 2):
             best = None
-            for variant in (0, 1, 2, 3, 4, 5):
+            for variant in (0, 1, 2, 3, 4, 5, 6, 7):
                 for ap in (False, True):
                     _, us = E.test_gemm_planes(A, W, mode=mode, variant=variant, a_planes=ap, iters=20)
                     if best is None or us < best[0]:
@@ -73,5 +76,6 @@ def timings():
 
 
 if __name__ == "__main__":
-    accuracy()
+    if not os.environ.get("SHAPES"):
+        accuracy()
     timings()
