@@ -438,6 +438,35 @@ def prompt_latency_block(w):
     return res
 
 
+def reprefill_block(eng, B=64):
+    """A whole batch re-prefilling on the same step (evaluations/infer_arvc.py:547-564; equal prompts, so every stream falls due together:
+    SURVEY 8d config 3's re-prefill situation): synchronous step latency of the steady steps and of the re-prefill steps."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    R, msf, n = 107, 160, 50
+    b = E.Batch(eng, n_streams=B, max_seq_frames=msf, buffer_frames=32, pipeline=True)
+    ac, cc, style, timbre = synth_prompt(2000, R)
+    for s_ in range(B):
+        b.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=1 + s_)
+    b.begin()
+    src = np.stack([synth_utterance(1000 + s_ % 5, 2048 * n) for s_ in range(B)])
+    lat, pos = [], []
+    for i in range(n):
+        t1 = time.perf_counter()
+        b.step(src[:, i * 2048:(i + 1) * 2048])
+        b.sync()
+        lat.append((time.perf_counter() - t1) * 1e3)
+        pos.append(int(b.tap("last_pos", (B,), np.int32)[0]))
+    b.close()
+    re = [i for i in range(1, n) if pos[i] < pos[i - 1]]
+    base = float(np.median(lat[10:]))
+    worst = max(lat[i] for i in re) if re else None
+    return {"streams": B, "prompt_frames": R, "max_seq_frames": msf, "steady_sync_step_ms": round(base, 3), "reprefill_steps": len(re),
+            "reprefill_step_ms": round(worst, 3) if worst else None, "over_steady": round(worst / base, 3) if worst else None,
+            "note": "all streams due on the same step: one pass over the 2 x 32 appended rows of every stream against the cached prompt prefix, no host synchronisation"}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the contract's
     torch.distributed.run line on 127.0.0.1 with a free port) and pass their exit status on.  Fails loudly when the box has fewer
@@ -763,6 +792,11 @@ def main():
                                      "x_realtime": round(64 * c * 10 / dt2 * FRAME_S, 2),
                                      "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm2.items()},
                                      "roofline": ({**roof2, **stage_rates(64, ms2, tm2, roof2["algorithmic_gflop_per_step"])} if roof2 else None), **extra2}
+    if world == 1 and B == 1 and not args.no_batched:
+        try:
+            out["reprefill_64_streams"] = reprefill_block(eng)
+        except Exception as ex:
+            out["reprefill_64_streams"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if world == 1 and args.offline:
         import traceback
         wrap = None

@@ -1862,7 +1862,7 @@ def test_batched_reprefill_equals_per_slot_reprefill(eng, weights0):
     from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
 
     lib = E.load_library()
-    B, n_chunks, msf = 6, 70, 110
+    B, n_chunks, msf = 6, 150, 160           # (a re-prefilled prompt -- reference + 32 frames -- must stay below max_seq_frames)
     lens = [60, 60, 75, 75, 90, 60]
     src = np.stack([synth_utterance(1500 + s, 2048 * n_chunks) for s in range(B)])
 
@@ -1902,7 +1902,7 @@ def test_reprefill_whole_batch_at_once_64_streams(weights0, ar_dtype):
 
     lib = E.load_library()
     e = E.Engine(weights0, ar_dtype=ar_dtype)
-    B, n_chunks, msf = 64, 40, 95
+    B, n_chunks, msf = 64, 80, 130
     src = np.stack([synth_utterance(1600 + s % 4, 2048 * n_chunks) for s in range(B)])
     ac, cc, style, timbre = synth_prompt(2200, 64)
 
