@@ -1884,13 +1884,19 @@ int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSe
 }  // namespace
 
 // batch sizes the batched persistent decode kernel (ar_batch.hip) serves: where it beats both the two-streams-per-launch kernel
-// (ar_decode.hip, below) and the multi-launch decode (above) in the pipelined mode -- fp32 AR 7-24 streams, fp16 AR 5-11
-// (profiles/r04_abatch_sweep.txt); SVA_DEBUG ar_batch=0 never, ar_batch=2 every size it can run (A/B, parity tests)
-static bool abatch_serves(int B, int ar_dtype) {
+// (ar_decode.hip, below) and the multi-launch decode (above).  Pipelined (throughput) mode, fp32 AR: 4-24 streams (4: 1681 vs 1632
+// frames/s, 5: 2064 vs 1654, 6: 2421 vs 1914, 8: 2949 vs 2508, 16: 4439 vs 4133, 32: 5288 vs 5419); fp16 AR: 3-11 (3: 1624 vs 1487, 4: 2071
+// vs 1914, 8: 3440 vs 3197, 12: 4059 vs 4110); with several frames per step (chunk > 1) the decode is the step's longest stage and the
+// kernel serves up to 32 streams (32 x chunk 4: 7763 vs 6341 frames/s).  A caller that synchronises every chunk sees the kernel's
+// ~2.1-2.3 ms frame against 1.75 ms for two launches of the two-stream kernel: there it starts at 5 streams
+// (profiles/r04_small_batch_ab.txt, r04_abatch_sweep in the comments above).  SVA_DEBUG ar_batch=0 never, ar_batch=2 every size it can run
+static int abatch_lo(int ar_dtype, bool pipelined) { return pipelined ? (ar_dtype == 1 ? 3 : 4) : 5; }
+static bool abatch_serves(int B, int ar_dtype, bool pipelined, int chunk) {
     const int mode = debug_options().ar_batch;
     if (mode == 0 || B > AR_BATCH_MAX_STREAMS) return false;
     if (mode == 2) return true;
-    return ar_dtype == 1 ? (B >= 5 && B <= 11) : (B >= 7 && B <= 24);
+    const int hi = chunk > 1 ? 32 : (ar_dtype == 1 ? 11 : 24);
+    return B >= abatch_lo(ar_dtype, pipelined) && B <= hi;
 }
 
 static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batch* b);
@@ -1935,7 +1941,8 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // vocoder GEMMs want the whole chip (measured 1.41 ms per step with the 96 | 128 | 32 split, 1.13 without)
         // (fp16 AR: the batched decode on the f16 pipes overtakes the persistent kernel at 5 streams -- 2191 vs 1645 frames/s, 6: 2562 vs
         // 2064, 4: 1420 vs 1919; fp32: the persistent kernel wins up to 6 -- the round-3 partition A/B scripts, git history)
-        const int mega_max = c.ar_dtype == 1 ? std::min(4, AR_PERSISTENT_MAX_STREAMS) : AR_PERSISTENT_MAX_STREAMS;
+        const int mega_max = debug_options().ar_batch == 0 ? (c.ar_dtype == 1 ? std::min(4, AR_PERSISTENT_MAX_STREAMS) : AR_PERSISTENT_MAX_STREAMS)
+                                                           : std::min(abatch_lo(c.ar_dtype, b->p.pipeline != 0) - 1, AR_PERSISTENT_MAX_STREAMS);
         const bool will_mega = B <= mega_max && e->mega_ok && debug_options().ar_persistent != 0 && debug_options().ar_batch != 2;
         b->mega_max = mega_max;
         // multi-launch decode (more than 6 streams): its ~265 small launches per frame are a latency chain that the encoder's and
@@ -1949,7 +1956,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // (pipelined, fp32 AR, unpartitioned vs the multi-launch decode on its best partition: 8 streams 3066-3169 vs 2538 frames/s,
         // 12: 3761-3795 vs 3463, 16: 4465 vs 4166, 24: 4839 vs 4223, 32: 5288 vs 5419; on 64 / 96 / 128-CU partitions it loses 3-20 %;
         // fp16 AR: 6 streams 2989 vs 2664, 8: 3440 vs 3197, 12: 4059 vs 4110 -- profiles/r04_abatch_sweep.txt)
-        const bool will_abatch = !will_mega && abatch_serves(B, c.ar_dtype) && e->mega_ok && debug_options().ar_persistent != 0;
+        const bool will_abatch = !will_mega && abatch_serves(B, c.ar_dtype, b->p.pipeline != 0, p->chunk_frames) && e->mega_ok && debug_options().ar_persistent != 0;
         int ar_cus = 96, part_streams = 0;
         if (b->p.pipeline && !will_mega && !will_abatch && B <= (p->chunk_frames > 1 ? 16 : 32)) {      // (chunk 4: 16 streams +11 %, 32 streams -15 %: the round-3 partition A/B scripts, git history)
             part_streams = B;
@@ -2164,7 +2171,7 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     }
     // batched persistent decode kernel (ar_batch.hip): every stream of the batch in one launch per frame.  Takes the batches the
     // two-streams-per-launch kernel above does not serve; its workgroups must all be resident (same check as above).
-    b->use_abatch = !b->use_mega && e->mega_ok && debug_options().ar_persistent != 0 && abatch_serves(B, c.ar_dtype) && c.ar_vocab <= 8192 &&
+    b->use_abatch = !b->use_mega && e->mega_ok && debug_options().ar_persistent != 0 && abatch_serves(B, c.ar_dtype, b->p.pipeline != 0, b->p.chunk_frames) && c.ar_vocab <= 8192 &&
                     c.codebook_size <= 1024;
     if (b->use_abatch) {
         int per_cu = 0, cus = 0;
