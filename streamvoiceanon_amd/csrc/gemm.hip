@@ -1014,7 +1014,11 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
         bool planes = c_vec;
         if (t_group) { for (int i = 0; i < t_group->n; ++i) planes = planes && planes_gemm_supported(t_group->g[i]); }
         else planes = planes && planes_gemm_supported(g);
-        const bool want = g.Ap || g.Cp || (g.pmode == PLANES_H1 ? g.M >= 1024 : (ch.kind == 4 && g.M >= 6144));
+        // (and the few 2048+-row problems of a 64-stream batch that the table gives to the f32-MFMA kernels: the C = 256 HiFiGAN level's
+        // grouped convs -- 5.6 GFLOP per launch at ~60 TF/s there)
+        const double gflop = 2e-9 * g.M * (double)g.N * g.taps * g.Cin * group_n;
+        const bool want = g.Ap || g.Cp ||
+                          (g.pmode == PLANES_H1 ? g.M >= 1024 : ((ch.kind == 4 && g.M >= 6144) || (ch.kind != 4 && g.M >= 2048 && g.N >= 128 && gflop >= 2.0)));
         if (planes && want) ch = Choice{4, 8 + planes_variant(g, group_n), 0, 0};
         else SVA_CHECK(!g.Ap && !g.Cp, "conv_gemm: operand planes handed to a problem the planes kernel does not take");
     }
