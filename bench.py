@@ -56,6 +56,9 @@ def parse():
                     help="sva_config.mm_mode (default: the library's): batch-scale encoder / vocoder GEMM format, csrc/gemm_planes.hip")
     ap.add_argument("--voc-dtype", type=int, default=None, choices=(0, 1),
                     help="sva_config.voc_dtype: 1 = fp16-operand vocoder GEMMs, the reference's autocast precision (infer_arvc.py:493)")
+    ap.add_argument("--skip-semantic", action="store_true",
+                    help="sva_stream_params.skip_semantic: leave out the semantic-token head and its sample, which every caller of the reference "
+                         "discards (modules/dual_ar_stream.py:833); off by default -- the headline computes everything the reference computes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=60, help="CPU-baseline sample size (chunk-steps)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -548,7 +551,7 @@ def main():
     def run_workload(B, steps, warmup, want_roofline):
         """B streams per rank; returns (seconds for `steps` steps [max over ranks], stage timings, gathered count, roofline)"""
         pipelined = bool(args.pipeline) and not args.graph
-        batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=args.graph, pipeline=pipelined)
+        batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=args.graph, pipeline=pipelined, skip_semantic=args.skip_semantic)
         # utterances are global ids sharded over ranks (weak scaling: B per rank)
         my_utts = shard_utterances(list(range(world * B)), world)[rank]
         for s_, u in enumerate(my_utts):
@@ -747,7 +750,7 @@ def main():
                    "streams_per_gpu": B, "chunk_frames": c, "parallelism": f"utterance-parallel x{world}",
                    "hipgraph": ("whole step as one captured graph" if args.graph else
                                 "one captured graph per stage chain (encoder front, side chain, AR, vocoder), replayed every step" if args.pipeline else "none (eager launches)"),
-                   "stage_pipelining": bool(args.pipeline) and not args.graph, "mm_mode": int(eng.cfg.mm_mode), "voc_dtype": int(eng.cfg.voc_dtype),
+                   "stage_pipelining": bool(args.pipeline) and not args.graph, "mm_mode": int(eng.cfg.mm_mode), "voc_dtype": int(eng.cfg.voc_dtype), "skip_semantic_head": bool(args.skip_semantic),
                    "enqueue_thread": pin_info or None},
         "rtf": round(ms * 1e-3 / (c * FRAME_S), 5), "x_realtime": round(fps * FRAME_S, 2),
         "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm.items()},

@@ -7,6 +7,7 @@
 
 #include <array>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -135,9 +136,10 @@ struct sva_engine {
     int device = 0;
     // persistent AR decode launches of DIFFERENT batches of this engine are chained (event): two half-resident persistent grids
     // waiting for each other's CUs would only end at their spin timeouts
-    hipEvent_t mega_ev = nullptr;
+    hipEvent_t mega_ev = nullptr;          // created by sva_engine_finalize, destroyed with the engine
     bool mega_ev_valid = false;
-    const void* mega_last = nullptr;
+    const void* mega_last = nullptr;       // (cleared when that batch is destroyed)
+    std::mutex mega_mu;                    // batches of one engine may be driven by different host threads
     bool finalized = false;
     std::unordered_map<std::string, sva::HostTensor> host;
     sva::DevPool allocs;

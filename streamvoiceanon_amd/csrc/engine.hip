@@ -548,6 +548,10 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->e->device);
     (void)quiesce(b);
+    {   // (a later batch may be allocated at this address: the chain's "same batch, no wait" test must not match it)
+        std::lock_guard<std::mutex> lk(b->e->mega_mu);
+        if (b->e->mega_last == b) b->e->mega_last = nullptr;
+    }
     if (b->main_stream) (void)hipStreamSynchronize(b->main_stream);
     for (int i = 0; i < 2; ++i) if (b->aux[i]) (void)hipStreamSynchronize(b->aux[i]);
     if (b->sa) (void)hipStreamSynchronize(b->sa);

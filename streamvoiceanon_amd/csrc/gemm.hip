@@ -544,7 +544,14 @@ int conv_gemm_check_errors() {
         if (!kv.second.cnt) continue;
         unsigned v = 0;
         SVA_HIP(hipMemcpy(&v, kv.second.cnt + KS_ERR_WORD, sizeof(unsigned), hipMemcpyDeviceToHost));
-        SVA_CHECK(v == 0, "split-K GEMM: a partial tile never arrived (hand-off fault)");
+        if (v != 0) {
+            // reported once (the word used to stay set, so every later sva_sync of every batch failed): the fault word and the
+            // whole hand-off scratch of that stream are cleared -- a partial that arrives late must not be consumed as a stale tile
+            SVA_HIP(hipDeviceSynchronize());
+            SVA_HIP(hipMemset(kv.second.ws, 0, KS_WS_FLOATS * 8));
+            SVA_HIP(hipMemset(kv.second.cnt, 0, KS_CNT * sizeof(unsigned)));
+            SVA_CHECK(false, "split-K GEMM: a partial tile never arrived (hand-off fault); the results of the steps since the last sva_sync are invalid");
+        }
     }
     return 0;
 }

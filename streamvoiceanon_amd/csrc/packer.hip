@@ -60,6 +60,7 @@ extern "C" void sva_engine_destroy(sva_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     for (void* p : e->allocs.chunks) hipFree(p);
+    if (e->mega_ev) (void)hipEventDestroy(e->mega_ev);
     delete e;
 }
 
@@ -481,6 +482,7 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
                 for (int j = 0; j < 3; ++j) { SVA_TRY(planes(e->res[i][bb][j].c1, voc_mode)); SVA_TRY(planes(e->res[i][bb][j].c2, voc_mode)); }
         }
     }
+    SVA_HIP(hipEventCreateWithFlags(&e->mega_ev, hipEventDisableTiming));      // chains persistent decode launches of different batches (stages.hip)
     e->host.clear();
     e->finalized = true;
     SVA_HIP(hipDeviceSynchronize());

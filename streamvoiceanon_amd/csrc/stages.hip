@@ -584,10 +584,11 @@ int ar_decode_frame(sva_batch* b, int ci) {
     if (b->use_mega && !b->edits_on) {          // (sampler edits run on the multi-launch decode: same KV, positions and counters)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool eager = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;     // (events of other batches cannot enter a capture)
+        std::unique_lock<std::mutex> lk(e->mega_mu, std::defer_lock);
+        if (eager) lk.lock();
         if (eager && e->mega_ev_valid && e->mega_last != b) SVA_HIP(hipStreamWaitEvent(st, e->mega_ev, 0));
         SVA_TRY(ar_decode_frame_mega(b, ci, b->d_codes, code_off));
-        if (eager) {
-            if (!e->mega_ev) SVA_HIP(hipEventCreateWithFlags(&e->mega_ev, hipEventDisableTiming));
+        if (eager && e->mega_ev) {
             SVA_HIP(hipEventRecord(e->mega_ev, st));
             e->mega_ev_valid = true; e->mega_last = b;
         }

@@ -1966,3 +1966,20 @@ def test_persistent_decode_timeout_reaches_a_caller_that_never_synchronises(eng)
     assert raised is not None and "timed out" in raised[1] and raised[0] <= 6, raised
     torch.cuda.synchronize()
     b.close()
+
+
+def test_f16w_stress_tool_is_clean():
+    """the fp16-weight GEMM of the batched fp16 decode (csrc/gemm_f16w.hip) carries compiler-specific workarounds (opaque copies,
+    a plain FMA chain for the row norms) whose only guard was a tool outside the test run.  The tool's full sweep -- shapes x epilogues x
+    seeds against float64 on the rounded weights, plus launch-to-launch bit equality -- now runs with the GPU tests (normal build; the
+    -amdgpu-waitcnt-forcezero build stays with tools/waitcnt_audit.sh)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "f16w_stress.py")], capture_output=True, text=True, timeout=900)
+    last = [ln for ln in r.stdout.splitlines() if ln.endswith("bad")]
+    assert r.returncode == 0 and last, r.stdout[-2000:] + r.stderr[-2000:]
+    n, bad = int(last[-1].split()[0]), int(last[-1].split()[2])
+    assert n >= 1000 and bad == 0, r.stdout[-2000:]
