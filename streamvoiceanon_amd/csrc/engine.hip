@@ -45,6 +45,7 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "ar_batch_wgs") o.ar_batch_wgs = atoi(v.c_str());
             else if (k == "planes_dbg") o.planes_dbg = atoi(v.c_str());
             else if (k == "reprefill") o.reprefill = atoi(v.c_str());
+            else if (k == "ar_group") o.ar_group = atoi(v.c_str());
             else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());
@@ -157,7 +158,16 @@ int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSe
 // kernel serves up to 32 streams (32 x chunk 4: 7763 vs 6341 frames/s).  A caller that synchronises every chunk sees the kernel's
 // ~2.1-2.3 ms frame against 1.75 ms for two launches of the two-stream kernel: there it starts at 5 streams
 // (profiles/r04_small_batch_ab.txt, r04_abatch_sweep in the comments above).  SVA_DEBUG ar_batch=0 never, ar_batch=2 every size it can run
-static int abatch_lo(int ar_dtype, bool pipelined) { return pipelined ? (ar_dtype == 1 ? 3 : 4) : 5; }
+// streams per group of the group form of the persistent kernel (ar_group.hip: 2-4 streams share every phase's weight registers and
+// hand-offs on ONE set of 96 workgroups), 0 = not served.  SVA_DEBUG ar_group=0 off, ar_group=2 also 6 streams as two groups of three
+static int group_ns(int B) {
+    const int mode = debug_options().ar_group;
+    if (mode == 0) return 0;
+    if (B >= 2 && B <= 4) return B;
+    if (B == 6 && mode == 2) return 3;
+    return 0;
+}
+static int abatch_lo(int ar_dtype, bool pipelined) { return debug_options().ar_group ? 5 : pipelined ? (ar_dtype == 1 ? 3 : 4) : 5; }
 static bool abatch_serves(int B, int ar_dtype, bool pipelined, int chunk) {
     const int mode = debug_options().ar_batch;
     if (mode == 0 || B > AR_BATCH_MAX_STREAMS) return false;
@@ -208,8 +218,9 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // vocoder GEMMs want the whole chip (measured 1.41 ms per step with the 96 | 128 | 32 split, 1.13 without)
         // (fp16 AR: the batched decode on the f16 pipes overtakes the persistent kernel at 5 streams -- 2191 vs 1645 frames/s, 6: 2562 vs
         // 2064, 4: 1420 vs 1919; fp32: the persistent kernel wins up to 6 -- the round-3 partition A/B scripts, git history)
-        const int mega_max = debug_options().ar_batch == 0 ? (c.ar_dtype == 1 ? std::min(4, AR_PERSISTENT_MAX_STREAMS) : AR_PERSISTENT_MAX_STREAMS)
-                                                           : std::min(abatch_lo(c.ar_dtype, b->p.pipeline != 0) - 1, AR_PERSISTENT_MAX_STREAMS);
+        int mega_max = debug_options().ar_batch == 0 ? (c.ar_dtype == 1 ? std::min(4, AR_PERSISTENT_MAX_STREAMS) : AR_PERSISTENT_MAX_STREAMS)
+                                                     : std::min(abatch_lo(c.ar_dtype, b->p.pipeline != 0) - 1, AR_PERSISTENT_MAX_STREAMS);
+        if (group_ns(B) > 0) mega_max = std::max(mega_max, B);
         const bool will_mega = B <= mega_max && e->mega_ok && debug_options().ar_persistent != 0 && debug_options().ar_batch != 2;
         b->mega_max = mega_max;
         // multi-launch decode (more than 6 streams): its ~265 small launches per frame are a latency chain that the encoder's and
@@ -428,6 +439,12 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         const int wgs = AR_WGS;
         b->mega_per_launch = (avail >= 2 * wgs && !b->ar_partitioned) ? 2 : 1;
         if (per_cu < 1 || avail < wgs) b->use_mega = false;                // fall back to the multi-launch decode
+        // groups of 2-4 streams on one set of 96 workgroups each (ar_group.hip; more than half of a CU's LDS per workgroup: one per CU)
+        b->mega_group_ns = (b->use_mega && (c.ar_dtype == 1) == b->kv_half && !b->ar_partitioned) ? group_ns(B) : 0;
+        if (b->mega_group_ns > 0 && avail < wgs * (B / b->mega_group_ns)) b->mega_group_ns = 0;
+        if (b->mega_group_ns == 0 && B > (debug_options().ar_batch == 0 ? AR_PERSISTENT_MAX_STREAMS : abatch_lo(c.ar_dtype, b->p.pipeline != 0) - 1) &&
+            abatch_serves(B, c.ar_dtype, b->p.pipeline != 0, b->p.chunk_frames))
+            b->use_mega = false;                                           // (the group form was the reason this size came here)
     }
     if (b->use_mega) {
         SVA_TRY(dev_alloc(A, &b->d_gran, ar_decode_granule_words() * B));

@@ -686,6 +686,10 @@ int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_
     // at most two streams per launch: 192 workgroups find a CU each and leave half of every register file to the other stages'
     // kernels; four streams in one launch (two 256-register workgroups on half of the CUs) measured 1.75 ms for the frame AND
     // locked the encoder / vocoder kernels out of those CUs (2.69 ms per pipelined step against 1.9 with two launches of two)
+    if (b->mega_group_ns > 0) {         // groups of streams that share each phase's weights and hand-offs (ar_group.hip)
+        a.slot_base = 0;
+        return launch_ar_group(a, c.ar_dtype == 1, b->kv_half, b->mega_group_ns, b->B / b->mega_group_ns, b->stream);
+    }
     const int per_launch = b->mega_per_launch;
     for (int s0 = 0; s0 < b->B; s0 += per_launch) {
         a.slot_base = s0;

@@ -1983,3 +1983,40 @@ def test_f16w_stress_tool_is_clean():
     assert r.returncode == 0 and last, r.stdout[-2000:] + r.stderr[-2000:]
     n, bad = int(last[-1].split()[0]), int(last[-1].split()[2])
     assert n >= 1000 and bad == 0, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("B", [2, 3, 4])
+def test_group_form_of_the_persistent_decode_equals_the_default_path(eng, B):
+    """csrc/ar_group.hip (SVA_DEBUG ar_group=1: 2-4 streams share each phase's weight registers and hand-offs on one set of 96
+    workgroups; measured slower than the default policy and therefore off) computes per stream exactly what ar_decode.hip computes:
+    codes and PCM of a batch identical to the default path's, bit for bit."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    lib, n_chunks = E.load_library(), 8
+    src = np.stack([synth_utterance(1700 + s, 2048 * n_chunks) for s in range(B)])
+
+    def run(mode):
+        lib.sva_debug_configure(f"ar_group={mode}".encode())          # (read at batch creation)
+        try:
+            b = E.Batch(eng, n_streams=B)
+        finally:
+            lib.sva_debug_configure(b"ar_group=0")
+        for s in range(B):
+            ac, cc, style, timbre = synth_prompt(2300 + s, 50 + 9 * s)
+            b.prefill_prompt(s, cc, ac, style, timbre, noise_seed=1700 + s)
+        b.begin()
+        pcm = [b.step(src[:, i * 2048:(i + 1) * 2048]) for i in range(n_chunks)]
+        codes = np.stack([b.pred_codes(s) for s in range(B)])
+        path = b.decode_path()
+        b.close()
+        return np.concatenate(pcm, axis=1), codes, path
+
+    p1, c1, path1 = run(1)
+    p0, c0, _ = run(0)
+    assert path1 == 1 and c1.shape[-1] >= n_chunks - 2
+    np.testing.assert_array_equal(c1, c0)
+    if B == 2:          # the default path at 2 streams is ar_decode.hip itself: the same arithmetic, so the same bits
+        np.testing.assert_array_equal(p1, p0)
+    else:
+        assert np.abs(p1 - p0).max() <= PCM_TOL
