@@ -274,7 +274,8 @@ int sva_test_gemm_f16w(int device, int M, int N, int K, const float* A, const fl
  * windowed_transformer.py:134-143 at batch scale): mode 0 = three bf16 planes / six products (fp32-grade), 1 = two fp16 planes /
  * three products (fp32-grade inside the fp16 range), 2 = one fp16 plane (torch.autocast(fp16), evaluations/infer_arvc.py:493);
  * variant = tile variant 0..5; flags: 1 = A handed over as planes, 2 = C leaves as planes only (summed back to fp32 for the caller),
- * 4 = GELU epilogue, 8 = SiLU on load; iters > 0 also returns the average microseconds per launch. */
+ * 4 = GELU epilogue, 8 = SiLU on load, 16 = range check (a non-finite output of the fp16 formats fails the call, as sva_sync does for a batch);
+ * iters > 0 also returns the average microseconds per launch. */
 int sva_test_gemm_planes(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int mode,
                          int variant, int flags, int iters, float* out_us);
 /* Prefill attention of the slow AR (modules/dual_ar_stream.py:338-356 with causal_mask[kv_pos]): M query rows [M][H*64] at positions

@@ -218,6 +218,8 @@ struct sva_batch {
     unsigned long long* d_gran = nullptr;  // its granule buffers (gx | gbig | gatt | glog)
     unsigned* d_epoch = nullptr;           // [1] running phase counter of the granule tags
     int* d_ar_fail = nullptr;              // [1] timeout code of the persistent kernel (0 = healthy)
+    int* h_mm_ovf = nullptr;               // host-mapped: an fp16-planes GEMM of this batch produced a non-finite output (gemm_planes.hip)
+    int* d_mm_ovf = nullptr;               //   ... its device address
     int* h_ar_fail = nullptr;              // host-mapped mirror of *d_ar_fail (written by the kernels at the end of a launch that saw it set)
     int* d_ar_fail_host = nullptr;         //   ... its device address
     long long* d_ar_dbg = nullptr;         // SVA_AR_TIMING=1: phase timestamps of workgroup 0

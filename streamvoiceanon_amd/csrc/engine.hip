@@ -477,6 +477,11 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         if (!b->d_ar_fail) SVA_TRY(dev_alloc(A, &b->d_ar_fail, 1));
         if (debug_options().ar_timing && !b->d_ar_dbg) SVA_TRY(dev_alloc(A, &b->d_ar_dbg, 1024));
     }
+    if (c.mm_mode == 1 || c.voc_dtype == 1) {       // fp16 operand planes: their range check reports here (checked by sva_sync)
+        SVA_HIP(hipHostMalloc((void**)&b->h_mm_ovf, sizeof(int), hipHostMallocMapped));
+        *b->h_mm_ovf = 0;
+        SVA_HIP(hipHostGetDevicePointer((void**)&b->d_mm_ovf, b->h_mm_ovf, 0));
+    }
     if (b->d_ar_fail) {     // host-visible mirror of the timeout flag (the stream-ordered API never synchronises, so nothing read d_ar_fail)
         SVA_HIP(hipHostMalloc((void**)&b->h_ar_fail, sizeof(int), hipHostMallocMapped));
         *b->h_ar_fail = 0;
@@ -590,6 +595,7 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     for (hipGraphExec_t ge : {b->gEm[0], b->gEm[1], b->gEs[0], b->gEs[1], b->gE, b->gE2, b->gT0, b->gT1[0], b->gT1[1], b->gV}) if (ge) (void)hipGraphExecDestroy(ge);
     for (void* p : b->allocs.chunks) (void)hipFree(p);
     if (b->h_ar_fail) (void)hipHostFree(b->h_ar_fail);
+    if (b->h_mm_ovf) (void)hipHostFree(b->h_mm_ovf);
     if (b->hp_in) (void)hipHostFree(b->hp_in);
     if (b->hp_out) (void)hipHostFree(b->hp_out);
     for (int i = 0; i < 5; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
@@ -1519,6 +1525,12 @@ extern "C" int sva_sync(sva_batch* b) {
     SVA_HIP(hipStreamSynchronize(b->stream));
     SVA_TRY(check_ar_fail(b));
     SVA_TRY(conv_gemm_check_errors());
+    if (b->h_mm_ovf && *reinterpret_cast<volatile int*>(b->h_mm_ovf) != 0) {
+        *b->h_mm_ovf = 0;
+        SVA_CHECK(false, "a batch-scale GEMM on fp16 operand planes produced a non-finite output: an activation or weight is outside the fp16 range "
+                         "(as it would be for the reference under torch.autocast(fp16)); create the engine with sva_config.mm_mode = 0 (and voc_dtype = 0) "
+                         "for the range-safe bf16 kernels -- the results since the last sva_sync are invalid");
+    }
     float t;
     if (!b->graph_step)
         for (int i = 0; i < 3; ++i)

@@ -294,6 +294,11 @@ k_done:
             for (int r = 0; r < 4; ++r) Cs[(wm * TM + i * 16 + rq + r) * CS + wn * TN + j * 16 + col] = acc[i][j][r] * winv;
     __syncthreads();
     auto store4 = [&](const float4& v, long idx) {
+        if constexpr (MODE != PLANES_S6) {
+            // fp16 parts have fp16's range: an operand beyond +-65504 turns into inf and the output into inf / nan.  The reference
+            // (torch.autocast(fp16)) has the same limit; here it is REPORTED (sva_sync fails, naming mm_mode = 0) instead of propagating
+            if (g.ovf && !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < INFINITY)) *reinterpret_cast<volatile int*>(g.ovf) = 1;
+        }
         if (g.C) *reinterpret_cast<float4*>(g.C + idx) = v;
         if (g.Cp) {
             unsigned p0[NPL], p1[NPL];

@@ -20,7 +20,7 @@ int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda,
     g.A = A; g.a_bstride = a_bstride; g.a_off = a_off; g.lda = lda;
     g.T = T; g.M = nb * T; g.stride = stride; g.dil = dil; g.taps = taps; g.Cin = Cin;
     g.W = w.W; g.Wh = w.Wh; g.N = w.N; g.bias = w.b;
-    g.Wp = w.Wp; g.wp_pstride = (long)w.N * w.K; g.wp_inv = w.wp_inv; g.pmode = w.pmode;
+    g.Wp = w.Wp; g.wp_pstride = (long)w.N * w.K; g.wp_inv = w.wp_inv; g.pmode = w.pmode; g.ovf = b->d_mm_ovf;
     g.C = C; g.c_bstride = c_bstride; g.c_off = c_off; g.ldc = ldc;
     if (g.Ap) g.A = nullptr;        // operand planes replace the fp32 tensor (cnx_block_t / enc_transformer hand-overs)
     if (g.Cp) g.C = nullptr;
@@ -73,7 +73,7 @@ int conv_desc(sva_batch* b, const Act& in, int T_out, int dil, int taps, const L
     g.A = in.p; g.a_bstride = in.bstride; g.a_off = (long)(in.H - padL) * in.C; g.lda = in.C;
     g.T = T_out; g.M = b->B * T_out; g.stride = 1; g.dil = dil; g.taps = taps; g.Cin = in.C;
     g.W = w.W; g.N = w.N; g.bias = w.b;
-    g.Wp = w.Wp; g.wp_pstride = (long)w.N * w.K; g.wp_inv = w.wp_inv; g.pmode = w.pmode;
+    g.Wp = w.Wp; g.wp_pstride = (long)w.N * w.K; g.wp_inv = w.wp_inv; g.pmode = w.pmode; g.ovf = b->d_mm_ovf;
     g.C = out.p; g.c_bstride = out.bstride; g.c_off = (long)out.H * out.C; g.ldc = out.C;
     return 0;
 }

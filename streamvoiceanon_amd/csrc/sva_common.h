@@ -137,6 +137,7 @@ struct ConvGemm {
     long ap_pstride = 0;
     unsigned short* Cp = nullptr;
     long cp_pstride = 0;
+    int* ovf = nullptr;             // fp16 planes only: set to 1 when an output is not finite (an operand outside the fp16 range); host-mapped
 };
 
 // up to three independent problems of identical shape (M, N, Cin, stride, epilogue flags; taps / dilation / pointers may

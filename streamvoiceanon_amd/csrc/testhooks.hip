@@ -315,8 +315,20 @@ extern "C" int sva_test_gemm_planes(int device, int M, int N, int K, const float
     }
     if (flags & 4) g.act = ACT_GELU;
     if ((flags & 8) && !(flags & 1)) g.a_silu = 1;
+    int* h_ovf = nullptr;
+    if (flags & 16) {       // the range check of the fp16 formats: a non-finite output is an error of the call
+        SVA_HIP(hipHostMalloc((void**)&h_ovf, sizeof(int), hipHostMallocMapped));
+        *h_ovf = 0;
+        SVA_HIP(hipHostGetDevicePointer((void**)&g.ovf, h_ovf, 0));
+    }
     SVA_TRY(launch_conv_gemm_choice(g, 0, 6, variant, 0, 0));
     SVA_HIP(hipDeviceSynchronize());
+    if (h_ovf) {
+        const int o = *reinterpret_cast<volatile int*>(h_ovf);
+        (void)hipHostFree(h_ovf);
+        g.ovf = nullptr;
+        if (o) { set_error("planes GEMM: non-finite output (an operand outside the fp16 range)"); return -3; }
+    }
     if (flags & 2) {
         std::vector<uint16_t> hp((size_t)npl * M * N);
         SVA_HIP(hipMemcpy(hp.data(), dCp, hp.size() * 2, hipMemcpyDeviceToHost));

@@ -500,7 +500,7 @@ def test_gemm_f16w(A, W, bias=None, rms_w=None, res=None, swiglu=False, iters=0,
     return out, float(us[0])
 
 
-def test_gemm_planes(A, W, bias=None, mode=1, variant=0, a_planes=False, c_planes=False, gelu=False, silu=False, iters=0, device=0):
+def test_gemm_planes(A, W, bias=None, mode=1, variant=0, a_planes=False, c_planes=False, gelu=False, silu=False, iters=0, device=0, range_check=False):
     """The planes GEMM (csrc/gemm_planes.hip): epi(A @ W.T) with both operands as pre-split 16-bit planes.  Returns (C, us_per_launch)."""
     lib = load_library()
     A = np.ascontiguousarray(A, dtype=np.float32)
@@ -510,7 +510,7 @@ def test_gemm_planes(A, W, bias=None, mode=1, variant=0, a_planes=False, c_plane
     out = np.empty((M, N), dtype=np.float32)
     b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
     us = np.zeros(1, dtype=np.float32)
-    flags = (1 if a_planes else 0) | (2 if c_planes else 0) | (4 if gelu else 0) | (8 if silu else 0)
+    flags = (1 if a_planes else 0) | (2 if c_planes else 0) | (4 if gelu else 0) | (8 if silu else 0) | (16 if range_check else 0)
     _check(lib.sva_test_gemm_planes(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out), int(mode), int(variant), flags, int(iters), _ptr(us)),
            "sva_test_gemm_planes")
     return out, float(us[0])

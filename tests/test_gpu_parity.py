@@ -2020,3 +2020,23 @@ def test_group_form_of_the_persistent_decode_equals_the_default_path(eng, B):
         np.testing.assert_array_equal(p1, p0)
     else:
         assert np.abs(p1 - p0).max() <= PCM_TOL
+
+
+def test_fp16_planes_range_check_reports_an_operand_beyond_the_fp16_range():
+    """The default batch-scale GEMM format (sva_config.mm_mode = 1: fp16 operand planes) has fp16's range, like the reference under
+    torch.autocast(fp16).  An operand beyond +-65504 must not propagate silently: the kernel raises a host-visible flag on a non-finite
+    output (sva_sync of a batch fails and names mm_mode = 0; here through the unit hook).  The bf16 format takes the same operand."""
+    from streamvoiceanon_amd import engine as E
+
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((256, 128)).astype(np.float32)
+    W = (rng.standard_normal((128, 128)) * 0.05).astype(np.float32)
+    out, _ = E.test_gemm_planes(A, W, mode=1, variant=3, range_check=True)          # in range: fine
+    assert np.isfinite(out).all()
+    A[17, 5] = 1.0e5
+    for mode in (1, 2):
+        with pytest.raises(RuntimeError, match="non-finite"):
+            E.test_gemm_planes(A, W, mode=mode, variant=3, range_check=True)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    out, _ = E.test_gemm_planes(A, W, mode=0, variant=3, range_check=True)          # bf16 x 3: fp32's range
+    assert np.abs(out - ref).max() <= 3e-6 * np.abs(ref).max()
