@@ -866,7 +866,8 @@ int launch_conv_gemm_group(const ConvGemm* gs, int n, hipStream_t st) {
 static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n) {
     SVA_CHECK(g.Cin % 16 == 0 && g.Cin > 0, "conv_gemm: Cin must be a multiple of 16");
     // decode-sized linear layers of an fp16-weight AR: stream the fp16 weights (half the bytes of the fp32 copy) through the f16 pipes
-    if (g.Wh && group_n == 1 && g.M <= 256 && debug_options().f16_weights && f16w_gemm_supported(g)) {
+    if (g.Wh && group_n == 1 && g.M <= 256 && debug_options().f16_weights && (f16w_gemm_validated_compiler() || debug_options().f16_weights == 2) &&
+        f16w_gemm_supported(g)) {
         t_last_kind = 5;
         return launch_f16w_gemm(g, st);
     }

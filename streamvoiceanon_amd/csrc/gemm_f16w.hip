@@ -224,6 +224,18 @@ int launch_cfg(const ConvGemm& g, const _Float16* Wh, hipStream_t st) {
 
 }  // namespace
 
+// This kernel carries compiler-specific workarounds (opaque copies of the A fragments, a plain FMA chain for the row norms: see the header
+// and DESIGN.md section 4) that were validated -- tools/f16w_stress.py under the normal and the -amdgpu-waitcnt-forcezero build, inside the
+// GPU tests -- with the compiler of ROCm 7.2 (AMD clang 22.0, HIP 7.2).  Built with anything else the dispatcher does not pick it by
+// default: the fp32 copy of the rounded weights runs instead until the stress sweep has been repeated and this check updated.
+bool f16w_gemm_validated_compiler() {
+#if defined(__clang_major__) && __clang_major__ == 22 && defined(HIP_VERSION_MAJOR) && HIP_VERSION_MAJOR == 7 && HIP_VERSION_MINOR == 2
+    return true;
+#else
+    return false;
+#endif
+}
+
 // plain linear layers: one tap, unit stride, K a multiple of 32 with 16-byte aligned rows, the epilogues of the AR chain only
 bool f16w_gemm_supported(const ConvGemm& g) {
     return g.Wh && g.taps == 1 && g.stride == 1 && g.Cin % 32 == 0 && g.lda % 4 == 0 && g.a_off % 4 == 0 && g.a_bstride % 4 == 0 && !g.a_silu && !g.dw_wT &&

@@ -32,7 +32,8 @@ void set_error(const std::string& msg);
 //                     8 epilogue (tools/planes_probe.py)
 //   reprefill=0       re-prefill as one whole-prompt prefill per slot behind a host synchronisation (round 3) instead of one pass over the
 //                     appended rows of all due slots against the cached prompt prefix (A/B, parity)
-//   f16_weights=0     ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B)
+//   f16_weights=0|2   ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B) / on gemm_f16w.hip even when
+//                     the library was built with a compiler the kernel was not validated with
 struct DebugOptions {
     int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1, ar_group = 0;
     std::string tune_dump;
@@ -184,6 +185,7 @@ int launch_to_planes(const float* src, long n, unsigned short* dst, long pstride
 int make_weight_planes(const float* dW, long n, float max_abs, int mode, unsigned short* dst, float* inv, hipStream_t st);
 // gemm_f16w.hip: fp16 weights on the f16 matrix pipes (fp32 activations split hi + lo), plain linear layers of the AR chain
 bool f16w_gemm_supported(const ConvGemm& g);
+bool f16w_gemm_validated_compiler();      // built with the compiler the kernel's workarounds were validated with
 int launch_f16w_gemm(const ConvGemm& g, hipStream_t st);
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
 int conv_gemm_last_kind();          // kernel family the calling thread's latest launch_conv_gemm[_group] picked: 0 small-M, 1 tiled, 2 pipelined (f32 MFMA), 4 split-bf16, 5 fp16 weights (f16 MFMA)
