@@ -701,7 +701,19 @@ static thread_local int t_last_kind = -1;                // kernel family of thi
 // two thirds of the operand traffic); which one is a matter of how the tile count quantises over the 256 CUs.  In units of the time
 // T a CU needs for one 128 x 128 tile's worth of work when it is full: a round of 512 small tiles costs 2 T, a last round of <= 256
 // of them (one per CU) 1.3 T, a round of 256 large tiles 1.7 T.  The rule reproduces the measured winner of the two on all ten shapes.
+struct PlanesRow { int M, N, K, variant; };
+static const PlanesRow g_planes_table[] = {
+#include "planes_table.inc"
+};
 static int planes_variant(const ConvGemm& g, int group_n) {
+    // measured winners for the encoder's shapes (tools/planes_tune.py -> planes_table.inc; every variant computes the same bits, the K
+    // loop is the same): the row with this (N, K) whose M is nearest, if within a quarter of it
+    if (group_n == 1 && g.taps == 1) {
+        const PlanesRow* best = nullptr;
+        for (const PlanesRow& r : g_planes_table)
+            if (r.N == g.N && r.K == g.Cin && (!best || std::abs(r.M - g.M) < std::abs(best->M - g.M))) best = &r;
+        if (best && std::abs(best->M - g.M) * 4 <= g.M && (best->variant != 6 || g.M >= 256) && (g.M >= 128 || best->variant == 2 || best->variant == 3)) return best->variant;
+    }
     if (g.N < 128) return g.M >= 128 ? 1 : 3;
     if (g.M < 128) return 2;
     const long wg0 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * group_n, wg6 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * group_n;
@@ -1016,7 +1028,8 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
     // Weights that carry pre-split planes (gemm_planes.hip).  fp16 x 1 (a voc_dtype = 1 vocoder): one product per block instead of the
     // six or eight of any fp32-grade kernel -- every problem with enough rows to fill its tiles.  fp32-grade planes (fp16 x 2, bf16 x 3):
     // where the split kernels are the choice anyway and the batch is large enough for the 128-row tiles to fill the chip (measured:
-    // +9 / +12 % frames/s at 64 / 128 streams, -2 % at 32 against the tuned in-loop split kernels, profiles/r04_mm_mode_ab.txt: from 6144 rows).  A
+    // with its tile variant from the measured table it beats the tuned in-loop split kernels on 38 of 40 mid-size shapes, by 5-60 %:
+    // profiles/r04_old_vs_planes.txt (full chip); from 3072 rows = 24 streams -- below that the pipelined mode runs the encoder on a CU partition the old table was tuned for: 16 streams -2.6 %, 24 / 32 / 48 streams +1 / +1 / +8 %).  A
     // problem whose operands only exist as planes has no other kernel.
     {
         bool planes = c_vec;
@@ -1026,7 +1039,7 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
         // grouped convs -- 5.6 GFLOP per launch at ~60 TF/s there)
         const double gflop = 2e-9 * g.M * (double)g.N * g.taps * g.Cin * group_n;
         const bool want = g.Ap || g.Cp ||
-                          (g.pmode == PLANES_H1 ? g.M >= 1024 : ((ch.kind == 4 && g.M >= 6144) || (ch.kind != 4 && g.M >= 2048 && g.N >= 128 && gflop >= 2.0)));
+                          (g.pmode == PLANES_H1 ? g.M >= 1024 : ((ch.kind == 4 && g.M >= 3072) || (ch.kind != 4 && g.M >= 2048 && g.N >= 128 && gflop >= 2.0)));
         if (planes && want) ch = Choice{4, 8 + planes_variant(g, group_n), 0, 0};
         else SVA_CHECK(!g.Ap && !g.Cp, "conv_gemm: operand planes handed to a problem the planes kernel does not take");
     }

@@ -128,7 +128,7 @@ __global__ void mean3_kernel(const float* __restrict__ y0, const float* __restri
 // planes of one fp16 format -- two fp16 planes (or one) fill exactly the bytes (half the bytes) of the fp32 tensor they replace, so
 // they live in its buffer -- and the problem is at the scale where the planes kernel is the dispatcher's choice anyway.
 bool planes_edge(const Lin& producer, const Lin& consumer, long rows) {
-    return rows >= 6144 && producer.Wp && consumer.Wp && producer.pmode == consumer.pmode && (producer.pmode == PLANES_H3 || producer.pmode == PLANES_H1) &&
+    return rows >= 3072 && producer.Wp && consumer.Wp && producer.pmode == consumer.pmode && (producer.pmode == PLANES_H3 || producer.pmode == PLANES_H1) &&
            producer.N % 8 == 0;
 }
 
