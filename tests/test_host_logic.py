@@ -278,3 +278,18 @@ def test_stream_server_survives_malformed_frames():
     s3.close()
     th.join(10)
     assert not th.is_alive()
+
+
+def test_planes_variant_table_is_well_formed():
+    """csrc/planes_table.inc (tools/planes_tune.py): rows {M, N, K, variant} that csrc/gemm.hip includes verbatim -- one row per
+    (M, N, K), variants the launcher knows, shapes the planes kernel accepts (K in whole 32-wide tiles, N in 16-byte rows)."""
+    import os
+    import re
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "streamvoiceanon_amd", "csrc", "planes_table.inc")
+    rows = [tuple(int(x) for x in m.groups()) for m in re.finditer(r"^\{(\d+), (\d+), (\d+), (\d+)\},$", open(path).read(), re.M)]
+    assert len(rows) >= 100
+    assert len({r[:3] for r in rows}) == len(rows)
+    for M, N, K, v in rows:
+        assert v in (0, 1, 2, 3, 6, 7) and K % 32 == 0 and N % 4 == 0 and M >= 1024
+        assert not (v in (0, 2, 6, 7) and N < 128) and not (v == 6 and M < 256)
