@@ -1281,7 +1281,10 @@ int step_body(sva_batch* b) {
         if (!redo.empty()) {
             // one pass for all due slots against the cached prompt prefix (reprefill_slots); SVA_DEBUG reprefill=0: the round-3 path, one
             // whole-prompt prefill per slot behind a host synchronisation (A/B, parity of the two)
-            if (debug_options().reprefill) rrc = reprefill_slots(b, redo);
+            // (a stream that has decoded fewer than `delay` frames -- a prompt about as long as max_seq_frames -- keeps the general form)
+            bool one_pass = debug_options().reprefill != 0;
+            for (int s_ : redo) one_pass = one_pass && std::min(b->p.buffer_frames, b->h_nframes[s_]) >= b->p.delay;
+            if (one_pass) rrc = reprefill_slots(b, redo);
             else for (size_t i = 0; i < redo.size() && !rrc; ++i) rrc = reprefill_slot(b, redo[i]);
         }
         if (!rrc) rrc = ar_delay_fill(b, redo);       // prefill_src_condition4delay(src_content_codes[-d:]) for those slots only
