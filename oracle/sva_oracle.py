@@ -625,13 +625,20 @@ class StreamSession:
         self.n_reprefill = 0
         self.trace = []
 
-    def process_one_chunk(self, chunk: torch.Tensor, forced_codes: torch.Tensor | None = None) -> torch.Tensor:
-        """chunk [1, 2048*c] -> [1, 2048*c] (:492-596).  forced_codes [8, c] teacher-forces the AR."""
+    def process_one_chunk(self, chunk: torch.Tensor, forced_codes: torch.Tensor | None = None,
+                          content_override: torch.Tensor | None = None, vocode: bool = True) -> torch.Tensor:
+        """chunk [1, 2048*c] -> [1, 2048*c] (:492-596).  forced_codes [8, c] teacher-forces the AR.
+        Test-time shortcuts for LONG replays (tests/test_oracle_golden.py, the 672-chunk fixture): content_override [c] takes the
+        step's content codes from a fixture instead of re-encoding the 128-frame window (the encoder is pinned by its own fixtures),
+        vocode=False skips the 64-frame vocoder window of a chunk whose PCM nobody checks (returns zeros)."""
         n = chunk.shape[-1]
         c = self.chunk
         self.window = torch.cat([self.window[:, n:], chunk], dim=-1)                      # :495-496
-        codes = encode_window(self.window, self.W)[0, 0]                                  # :505-508
-        new_codes = codes[-c:]
+        if content_override is None:
+            codes = encode_window(self.window, self.W)[0, 0]                              # :505-508
+            new_codes = codes[-c:]
+        else:
+            new_codes = content_override.long().reshape(c)
         self.src_content_codes = torch.cat([self.src_content_codes, new_codes])           # :518
         rec = dict(content=new_codes.clone(), audio=None, hidden=[], slow_logits=[], fast_logits=[])
         self.trace.append(rec)
@@ -658,6 +665,10 @@ class StreamSession:
             self.ar.prefill_prompt(ext_content, ext_audio, self.style, self.timbre, d)
             self.ar.prefill_src_condition4delay(self.src_content_codes[-d:])
             self.n_reprefill += 1
+        if not vocode:
+            self.pred_codes = self.pred_codes[:, -SAMPLES_PER_FRAME:]
+            self.src_content_codes = self.src_content_codes[-SAMPLES_PER_FRAME:]
+            return torch.zeros_like(chunk)
         win = self.pred_codes[:, -self.Wd:]                                               # :567-571
         pad = self.Wd - win.shape[-1]
         if pad > 0:

@@ -65,9 +65,6 @@ struct ArDecodeArgs {
 // one_per_cu: pad the LDS request so that no two of the 96 workgroups share a CU
 // n_slots: streams decoded by this launch (grid 96 x n_slots; all 96 n_slots workgroups must be co-resident)
 int launch_ar_decode(const ArDecodeArgs& a, int wt_half, int kv_half, bool one_per_cu, hipStream_t st, int n_slots = 1);
-// ar_group.hip: the same frame for GROUPS of ns = 2..4 streams that share each phase's weight registers and hand-offs (grid 96 x n_groups;
-// slots a.slot_base .. a.slot_base + ns * n_groups - 1); per stream the arithmetic of launch_ar_decode
-int launch_ar_group(const ArDecodeArgs& a, int wt_half, int kv_half, int ns, int n_groups, hipStream_t st);
 // blocks of the kernel the runtime says fit one CU at the launch's LDS size (hipOccupancyMaxActiveBlocksPerMultiprocessor)
 int ar_decode_occupancy(int wt_half, int kv_half, int* blocks_per_cu);
 size_t ar_decode_granule_words();     // u64 words of a stream's granule block (gx | gbig | gatt | glog | ga, in this order)

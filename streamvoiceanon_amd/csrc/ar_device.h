@@ -155,8 +155,12 @@ __device__ __forceinline__ unsigned umax_wave(unsigned v) {
 // logits per thread of NW waves (element of slot r: e0 + r * NW * 64); the sort-free threshold search of
 // sampler_bisect_kernel (kernels.hip) with interpolated, key-snapped probes.  NW == 1: no barrier at all.  Returns the
 // token in every participating thread.  red: LDS scratch of >= 64 doubles (NW > 1 only).
+// ALWAYS inlined: as a called function its logits array lives in scratch memory, and -- what kept ar_batch.hip out of the two-build
+// audit in round 4 -- hipcc's -amdgpu-waitcnt-forcezero mode puts an s_waitcnt between the s_getpc_b64 / s_add_u32 @rel32@lo+4 /
+// s_addc_u32 @rel32@hi+12 of every call sequence, whose +4 / +12 assume adjacency: the s_swappc lands 4 bytes in front of the callee
+// (HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION; /tmp disassembly).  No calls, no call sequences.
 template <int NW, int PER>
-__device__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float* noise, unsigned long long seed, int frame, int kind,
+__device__ __forceinline__ int nucleus_sample(const float (&l)[PER], int V, int e0, const float* noise, unsigned long long seed, int frame, int kind,
                               int noise_elem_off, float inv_temp, float top_p, double* red, long long* dbg = nullptr) {
 #define NS_MARK(k) do { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); } while (0)
     NS_MARK(0);

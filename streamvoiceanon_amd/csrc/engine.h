@@ -213,7 +213,6 @@ struct sva_batch {
     bool ar_failed = false;                // a persistent launch timed out: every step fails until sva_streams_begin, which falls back to the multi-launch decode
     bool use_mega = false;                 // B == 1: one persistent kernel per decoded frame (ar_decode.hip)
     int mega_per_launch = 1;               // streams per persistent launch (2 when 192 workgroups find a CU each)
-    int mega_group_ns = 0;                 // > 0: streams per GROUP of the group form (ar_group.hip), B / mega_group_ns groups in one launch
     bool ar_partitioned = false;           // the AR stream has a CU partition of its own
     unsigned long long* d_gran = nullptr;  // its granule buffers (gx | gbig | gatt | glog)
     unsigned* d_epoch = nullptr;           // [1] running phase counter of the granule tags

@@ -45,7 +45,6 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "ar_batch_wgs") o.ar_batch_wgs = atoi(v.c_str());
             else if (k == "planes_dbg") o.planes_dbg = atoi(v.c_str());
             else if (k == "reprefill") o.reprefill = atoi(v.c_str());
-            else if (k == "ar_group") o.ar_group = atoi(v.c_str());
             else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());
@@ -158,16 +157,9 @@ int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSe
 // kernel serves up to 32 streams (32 x chunk 4: 7763 vs 6341 frames/s).  A caller that synchronises every chunk sees the kernel's
 // ~2.1-2.3 ms frame against 1.75 ms for two launches of the two-stream kernel: there it starts at 5 streams
 // (profiles/r04_small_batch_ab.txt, r04_abatch_sweep in the comments above).  SVA_DEBUG ar_batch=0 never, ar_batch=2 every size it can run
-// streams per group of the group form of the persistent kernel (ar_group.hip: 2-4 streams share every phase's weight registers and
-// hand-offs on ONE set of 96 workgroups), 0 = not served.  SVA_DEBUG ar_group=0 off, ar_group=2 also 6 streams as two groups of three
-static int group_ns(int B) {
-    const int mode = debug_options().ar_group;
-    if (mode == 0) return 0;
-    if (B >= 2 && B <= 4) return B;
-    if (B == 6 && mode == 2) return 3;
-    return 0;
-}
-static int abatch_lo(int ar_dtype, bool pipelined) { return debug_options().ar_group ? 5 : pipelined ? (ar_dtype == 1 ? 3 : 4) : 5; }
+// (a GROUP form of the persistent kernel -- 2-4 streams sharing each phase's weight registers and hand-offs on one set of 96 workgroups --
+// was built in round 4, measured slower than this policy at every size and removed in round 5: profiles/r04_group_ab.txt, git history)
+static int abatch_lo(int ar_dtype, bool pipelined) { return pipelined ? (ar_dtype == 1 ? 3 : 4) : 5; }
 static bool abatch_serves(int B, int ar_dtype, bool pipelined, int chunk) {
     const int mode = debug_options().ar_batch;
     if (mode == 0 || B > AR_BATCH_MAX_STREAMS) return false;
@@ -202,6 +194,9 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     b->p = *p;
     const int B = b->B = p->n_streams;
     SVA_CHECK(B >= 1 && p->chunk_frames >= 1 && p->delay >= 1 && p->delay <= c.max_delay, "bad stream params (delay 0 is broken upstream too)");
+    // a re-prefill rebuilds [speaker prefix | 2 x (truncated prompt + buffer_frames)] + the delay fill in one slot's cache (infer_arvc.py:547-564)
+    SVA_CHECK(c.timbre_tokens + 1 + 2 * (p->max_prompt_frames + p->buffer_frames) + 2 * p->delay <= c.max_seq_len,
+              "max_prompt_frames + buffer_frames do not fit the KV cache: a re-prefill would overrun the slot");
     SVA_CHECK(p->encode_window_frames % 1 == 0 && p->encode_window_frames >= p->chunk_frames, "bad encode window");
     if (b->p.voc_max_frames < p->chunk_frames) b->p.voc_max_frames = p->chunk_frames;
     // Streams come from a process-wide set per device, created once in a fixed order (main, encoder side stream, AR,
@@ -220,7 +215,6 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         // 2064, 4: 1420 vs 1919; fp32: the persistent kernel wins up to 6 -- the round-3 partition A/B scripts, git history)
         int mega_max = debug_options().ar_batch == 0 ? (c.ar_dtype == 1 ? std::min(4, AR_PERSISTENT_MAX_STREAMS) : AR_PERSISTENT_MAX_STREAMS)
                                                      : std::min(abatch_lo(c.ar_dtype, b->p.pipeline != 0) - 1, AR_PERSISTENT_MAX_STREAMS);
-        if (group_ns(B) > 0) mega_max = std::max(mega_max, B);
         const bool will_mega = B <= mega_max && e->mega_ok && debug_options().ar_persistent != 0 && debug_options().ar_batch != 2;
         b->mega_max = mega_max;
         // multi-launch decode (more than 6 streams): its ~265 small launches per frame are a latency chain that the encoder's and
@@ -439,12 +433,6 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         const int wgs = AR_WGS;
         b->mega_per_launch = (avail >= 2 * wgs && !b->ar_partitioned) ? 2 : 1;
         if (per_cu < 1 || avail < wgs) b->use_mega = false;                // fall back to the multi-launch decode
-        // groups of 2-4 streams on one set of 96 workgroups each (ar_group.hip; more than half of a CU's LDS per workgroup: one per CU)
-        b->mega_group_ns = (b->use_mega && (c.ar_dtype == 1) == b->kv_half && !b->ar_partitioned) ? group_ns(B) : 0;
-        if (b->mega_group_ns > 0 && avail < wgs * (B / b->mega_group_ns)) b->mega_group_ns = 0;
-        if (b->mega_group_ns == 0 && B > (debug_options().ar_batch == 0 ? AR_PERSISTENT_MAX_STREAMS : abatch_lo(c.ar_dtype, b->p.pipeline != 0) - 1) &&
-            abatch_serves(B, c.ar_dtype, b->p.pipeline != 0, b->p.chunk_frames))
-            b->use_mega = false;                                           // (the group form was the reason this size came here)
     }
     if (b->use_mega) {
         SVA_TRY(dev_alloc(A, &b->d_gran, ar_decode_granule_words() * B));
@@ -850,6 +838,16 @@ extern "C" int sva_streams_begin(sva_batch* b) {
 // ============================================================================================
 namespace {
 
+int check_mm_overflow(sva_batch* b) {
+    if (b->h_mm_ovf && *reinterpret_cast<volatile int*>(b->h_mm_ovf) != 0) {
+        *b->h_mm_ovf = 0;
+        SVA_CHECK(false, "a batch-scale GEMM on fp16 operand planes produced a non-finite output: an activation or weight is outside the fp16 range "
+                         "(as it would be for the reference under torch.autocast(fp16)); create the engine with sva_config.mm_mode = 0 (and voc_dtype = 0) "
+                         "for the range-safe bf16 kernels -- the results since the last synchronisation are invalid");
+    }
+    return 0;
+}
+
 // every due slot in one pass over the layers, no host synchronisation (see build_reprefill_kernel)
 int reprefill_slots(sva_batch* b, const std::vector<int>& due) {
     sva_engine* e = b->e;
@@ -867,6 +865,8 @@ int reprefill_slots(sva_batch* b, const std::vector<int>& due) {
             SVA_CHECK(na == std::max(0, (ncon - d) - std::max(0, ncon - bf - d)) && na >= d, "re-prefill: content/audio history length mismatch");
             a.slot[i] = slot; a.Rt[i] = b->ref_len[slot]; a.nf[i] = nf; a.na[i] = na;
             a.row_off[i + 1] = a.row_off[i] + 2 * na;
+            // BEFORE anything is enqueued: rows past the slot's cache would land in the next slot's
+            SVA_CHECK(nspk + 2 * (a.Rt[i] + na) + 2 * d <= c.max_seq_len, "re-prefill: prompt too long for the KV cache");
         }
         const int M = a.row_off[a.n];
         SVA_CHECK(M <= b->Mmax, "re-prefill: more rows than the AR scratch holds");
@@ -877,10 +877,7 @@ int reprefill_slots(sva_batch* b, const std::vector<int>& due) {
         hipLaunchKernelGGL(finish_reprefill_kernel, dim3(a.n * d), dim3(256), 0, st, a, e->codebook_emb, b->d_pred_hist, b->hist_cap, b->d_ref_tail,
                            c.max_delay, d, ncb, c.codebook_size, D, nspk, b->cached_ref_emb, b->d_last_pos);
         SVA_HIP(hipGetLastError());
-        for (int i = 0; i < a.n; ++i) {
-            SVA_CHECK(nspk + 2 * (a.Rt[i] + a.na[i]) <= c.max_seq_len, "re-prefill: prompt too long for the KV cache");
-            b->h_last_pos[a.slot[i]] = nspk + 2 * (a.Rt[i] + a.na[i]) - 1;
-        }
+        for (int i = 0; i < a.n; ++i) b->h_last_pos[a.slot[i]] = nspk + 2 * (a.Rt[i] + a.na[i]) - 1;
     }
     return 0;
 }
@@ -1172,8 +1169,15 @@ int steady_pipelined(sva_batch* b) {
             }
             if (graph) (void)hipGraphDestroy(graph);
         }
-        if (b->pipe_graph_a[par]) SVA_HIP(hipGraphLaunch(b->pipe_graph_a[par], sa));
-        else for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
+        if (b->pipe_graph_a[par]) {
+            // the captured stage's persistent launches carry no cross-batch ordering of their own: chain the replay as a whole
+            PersistentChain chain(b, sa, (b->use_mega || b->use_abatch) && !b->edits_on);
+            rc = chain.rc;
+            if (!rc) {
+                SVA_HIP(hipGraphLaunch(b->pipe_graph_a[par], sa));
+                rc = chain.finish();
+            }
+        } else for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
     } else {
         for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
     }
@@ -1233,6 +1237,8 @@ int step_body(sva_batch* b) {
     (void)e;
     if (b->h_ar_fail && *reinterpret_cast<volatile int*>(b->h_ar_fail) != 0) b->ar_failed = true;      // (a launch of an earlier step saw a wait time out)
     SVA_CHECK(!b->ar_failed, "this batch's persistent AR decode kernel timed out earlier: call sva_streams_begin to restart its streams");
+    // callers of the stream-ordered API may never call sva_sync: the fp16-planes overflow flag is polled here too
+    SVA_TRY(check_mm_overflow(b));
     const int B = b->B, chunk = b->p.chunk_frames, d = b->p.delay, n = 2048 * chunk;
     hipStream_t st = b->stream;
     const bool steady = b->delay_filled && (b->h_ncontent + chunk >= d);
@@ -1259,7 +1265,12 @@ int step_body(sva_batch* b) {
                 b->graph_ready = true;
             }
             SVA_HIP(hipEventRecord(b->ev[0], st));
-            SVA_HIP(hipGraphLaunch(b->graph_exec, st));
+            {
+                PersistentChain chain(b, st, (b->use_mega || b->use_abatch) && !b->edits_on);       // (as for the captured AR stage of the pipelined mode)
+                SVA_TRY(chain.rc);
+                SVA_HIP(hipGraphLaunch(b->graph_exec, st));
+                SVA_TRY(chain.finish());
+            }
             SVA_HIP(hipEventRecord(b->ev[3], st));
             b->graph_step = true;
         } else {
@@ -1528,12 +1539,7 @@ extern "C" int sva_sync(sva_batch* b) {
     SVA_HIP(hipStreamSynchronize(b->stream));
     SVA_TRY(check_ar_fail(b));
     SVA_TRY(conv_gemm_check_errors());
-    if (b->h_mm_ovf && *reinterpret_cast<volatile int*>(b->h_mm_ovf) != 0) {
-        *b->h_mm_ovf = 0;
-        SVA_CHECK(false, "a batch-scale GEMM on fp16 operand planes produced a non-finite output: an activation or weight is outside the fp16 range "
-                         "(as it would be for the reference under torch.autocast(fp16)); create the engine with sva_config.mm_mode = 0 (and voc_dtype = 0) "
-                         "for the range-safe bf16 kernels -- the results since the last sva_sync are invalid");
-    }
+    SVA_TRY(check_mm_overflow(b));
     float t;
     if (!b->graph_step)
         for (int i = 0; i < 3; ++i)

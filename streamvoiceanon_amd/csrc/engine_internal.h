@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,16 @@ int encode(sva_batch* b, const int* step_ptr, int n_chunk, int add);
 int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add, bool transformer_too = true);
 int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int* d_slot, const int* d_pos, const float* rope, float* kv, long kv_layer, long kv_slot, int S, float* x, int run_slot = -1, int run_pos0 = 0);
 int ar_decode_frame(sva_batch* b, int ci);
+// orders the persistent decode launches of different batches of one engine (stages.hip)
+struct PersistentChain {
+    sva_batch* b;
+    hipStream_t st;
+    bool active;
+    int rc = 0;
+    std::unique_lock<std::mutex> lk;
+    PersistentChain(sva_batch* b, hipStream_t st, bool active);
+    int finish();          // records the engine's event behind the launches enqueued since construction
+};
 int ar_decode_frame_batch(sva_batch* b, int ci);
 int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_off);
 int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const long long* codes, int codes_ld, int code_off, int last_pos_inc);

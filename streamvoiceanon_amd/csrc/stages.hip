@@ -575,28 +575,53 @@ int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const lon
 int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_off);
 int ar_decode_frame_batch(sva_batch* b, int ci);
 
+// Persistent decode kernels (ar_decode.hip, ar_batch.hip) need every workgroup of their grid resident at once: one 8-wave /
+// 256-register workgroup per CU.  Two batches of one engine on different streams (a pipelined batch next to a synchronous one, an
+// ar_decode batch next to an ar_batch batch) would otherwise co-schedule two such grids, both half-resident, both spinning into their
+// timeout -- so EVERY persistent launch of an engine (eager, or the replay of a captured AR stage) is chained behind the previous one
+// of another batch by an event, under the engine's mutex (batches may be driven by different host threads).
+PersistentChain::PersistentChain(sva_batch* b_, hipStream_t st_, bool active_) : b(b_), st(st_), active(active_), lk(b_->e->mega_mu, std::defer_lock) {
+    if (!active) return;
+    lk.lock();
+    sva_engine* e = b->e;
+    if (e->mega_ev_valid && e->mega_last != b && hipStreamWaitEvent(st, e->mega_ev, 0) != hipSuccess) {
+        set_error("PersistentChain: hipStreamWaitEvent failed");
+        rc = 1;
+    }
+}
+int PersistentChain::finish() {
+    if (!active) return 0;
+    sva_engine* e = b->e;
+    if (e->mega_ev) {
+        SVA_HIP(hipEventRecord(e->mega_ev, st));
+        e->mega_ev_valid = true; e->mega_last = b;
+    }
+    return 0;
+}
+
 int ar_decode_frame(sva_batch* b, int ci) {
     sva_engine* e = b->e;
     const sva_config& c = e->cfg;
     const int B = b->B, D = c.ar_dim, chunk = b->p.chunk_frames;
     hipStream_t st = b->stream;
     const int code_off = b->T2 - chunk + ci;
-    if (b->use_mega && !b->edits_on) {          // (sampler edits run on the multi-launch decode: same KV, positions and counters)
+    const bool persistent = (b->use_mega || b->use_abatch) && !b->edits_on;     // (sampler edits run on the multi-launch decode: same KV, positions and counters)
+    if (persistent) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        const bool eager = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;     // (events of other batches cannot enter a capture)
-        std::unique_lock<std::mutex> lk(e->mega_mu, std::defer_lock);
-        if (eager) lk.lock();
-        if (eager && e->mega_ev_valid && e->mega_last != b) SVA_HIP(hipStreamWaitEvent(st, e->mega_ev, 0));
-        SVA_TRY(ar_decode_frame_mega(b, ci, b->d_codes, code_off));
-        if (eager && e->mega_ev) {
-            SVA_HIP(hipEventRecord(e->mega_ev, st));
-            e->mega_ev_valid = true; e->mega_last = b;
+        const bool eager = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;     // (events of other batches cannot enter a capture:
+        PersistentChain chain(b, st, eager);                                                                     //  the replay of a captured AR stage is chained as a whole, engine.hip)
+        SVA_TRY(chain.rc);
+        if (b->use_mega) {
+            SVA_TRY(ar_decode_frame_mega(b, ci, b->d_codes, code_off));
+        } else {
+            hipLaunchKernelGGL(ar_prepare_step_kernel, dim3(B), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, b->d_codes, b->T2,
+                               code_off, b->d_last_pos, D, b->ax, b->d_slot, b->d_pos, b->d_step_content, chunk, ci);
+            SVA_TRY(ar_decode_frame_batch(b, ci));
         }
-        return 0;
+        return chain.finish();
     }
     hipLaunchKernelGGL(ar_prepare_step_kernel, dim3(B), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, b->d_codes, b->T2,
                        code_off, b->d_last_pos, D, b->ax, b->d_slot, b->d_pos, b->d_step_content, chunk, ci);
-    if (b->use_abatch && !b->edits_on) return ar_decode_frame_batch(b, ci);          // (sampler edits run on the multi-launch decode, as above)
     SVA_TRY(ar_layers_pass(b, e->ar_layers, 2 * B, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
                            b->kv_slow_slot, c.max_seq_len, b->ax));
     return ar_frame_tail(b, ci, (long)2 * D, (long)D, b->d_codes, b->T2, code_off, 2);
@@ -686,10 +711,6 @@ int ar_decode_frame_mega(sva_batch* b, int ci, const long long* codes, int code_
     // at most two streams per launch: 192 workgroups find a CU each and leave half of every register file to the other stages'
     // kernels; four streams in one launch (two 256-register workgroups on half of the CUs) measured 1.75 ms for the frame AND
     // locked the encoder / vocoder kernels out of those CUs (2.69 ms per pipelined step against 1.9 with two launches of two)
-    if (b->mega_group_ns > 0) {         // groups of streams that share each phase's weights and hand-offs (ar_group.hip)
-        a.slot_base = 0;
-        return launch_ar_group(a, c.ar_dtype == 1, b->kv_half, b->mega_group_ns, b->B / b->mega_group_ns, b->stream);
-    }
     const int per_launch = b->mega_per_launch;
     for (int s0 = 0; s0 < b->B; s0 += per_launch) {
         a.slot_base = s0;

@@ -18,8 +18,6 @@ void set_error(const std::string& msg);
 //   concurrency=0    one stream for everything (rocprofv3 --pmc serialises dispatches: tools/pmc.sh, bench.py's traffic passes)
 //   ar_persistent=0  multi-launch AR decode instead of the persistent kernel (A/B, parity of the fallback)
 //   ar_batch=0|2     batched persistent decode kernel (ar_batch.hip) off / for every batch size incl. the ones ar_decode.hip serves (A/B, parity)
-//   ar_group=1|2     group form of the persistent kernel (ar_group.hip: 2-4 streams per set of 96 workgroups; off by default, see its header) on / also for
-//                    6 streams as two groups of three (A/B, parity)
 //   ar_batch_wgs=N   workgroups of its launch (default: one per 16-column tile of the widest phase, capped by what is resident)
 //   voc_fused_mask=M which narrow HiFiGAN levels run as the fused kernel (bit 0: C = 16, bit 1: C = 32; parity tests)
 //   autotune=1, tune_log=1, tune_table=0, tune_dump=PATH   timed search / its log / ignore the compiled-in table / dump the choices
@@ -35,7 +33,7 @@ void set_error(const std::string& msg);
 //   f16_weights=0|2   ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B) / on gemm_f16w.hip even when
 //                     the library was built with a compiler the kernel was not validated with
 struct DebugOptions {
-    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1, ar_group = 0;
+    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1;
     std::string tune_dump;
 };
 const DebugOptions& debug_options();

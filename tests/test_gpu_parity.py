@@ -134,7 +134,8 @@ def _stream_vs_golden(eng, W, name, forced=False, device_rng=False, n_limit=None
                 buffer_frames=int(g["buffer_frames"]), use_graph=use_graph)
     for s_ in range(B):
         b.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=useed)
-    extra = dict(prefill_logits=b.tap("slow_logits", (B, 8192))[slot].copy(), prefill_hidden=b.tap("hidden", (B, 768))[slot].copy(), hidden=[])
+    extra = dict(prefill_logits=b.tap("slow_logits", (B, 8192))[slot].copy(), prefill_hidden=b.tap("hidden", (B, 768))[slot].copy(), hidden=[],
+                 decode_path=b.decode_path())
     _stream_vs_golden.last = extra
     b.begin()
     n = 2048 * chunk
@@ -199,6 +200,69 @@ def test_teacher_forced_logits(eng, weights0):
         for cb in range(8):
             gotf = fast[f][cb][g["fast_top_i"][f, cb]]
             assert np.abs(gotf - g["fast_top_v"][f, cb]).max() <= LOGIT_TOL, (f, cb)
+
+
+def _assert_forced_logits(g, slow, fast, tol, first=0):
+    """top-32 slow / fast logits of the decoded frames [first, first + len(slow)) against the fixture's (teacher-forced runs)."""
+    lf = int(g["logit_first"]) if "logit_first" in g.files else 0
+    worst = 0.0
+    for k in range(len(slow)):
+        f = first + k - lf
+        if f < 0 or f >= g["slow_top_i"].shape[0]:
+            continue
+        worst = max(worst, float(np.abs(slow[k][g["slow_top_i"][f]] - g["slow_top_v"][f]).max()))
+        assert int(np.argmax(slow[k])) == int(g["slow_top_i"][f][0]), f
+        for cb in range(8):
+            worst = max(worst, float(np.abs(fast[k][cb][g["fast_top_i"][f, cb]] - g["fast_top_v"][f, cb]).max()))
+    assert worst <= tol, worst
+    return worst
+
+
+@pytest.mark.parametrize("B,path", [(8, 2), (12, 2), (24, 2), (128, 0)])
+def test_batched_decode_teacher_forced_logits_vs_reference(eng, weights0, B, path, record_property):
+    """The hard AR gate THROUGH the kernels that serve batches: ar_batch.hip (one persistent launch per frame, the default decode at
+    5-24 synchronous fp32 streams; path 2) and the multi-launch decode at 128 streams (path 0).  Every slot carries the fixture
+    utterance; with the codes teacher-forced, the top-32 slow and fast logits of every frame are within 2e-3 of the REFERENCE's
+    (tests/golden/stream_s0.npz), taken from the last slot; a free run of the same batch reproduces the reference's codes."""
+    n_limit = 24 if B <= 24 else 10
+    g, outs, content, audio, slow, fast, _ = _stream_vs_golden(eng, weights0, "stream_s0", forced=True, n_streams=B, slot=B - 1, n_limit=n_limit)
+    assert _stream_vs_golden.last["decode_path"] == path, "the batch did not decode through the kernel this test is about"
+    assert len(slow) == n_limit - 2
+    worst = _assert_forced_logits(g, slow, fast, LOGIT_TOL)
+    record_property("batched_teacher_forced", dict(streams=B, path=path, frames=len(slow), worst_logit_abs_err=worst))
+    np.testing.assert_array_equal(content, g["content_codes"][:content.shape[0]])
+    ex = _stream_vs_golden.last
+    assert np.abs(ex["prefill_logits"][g["prefill_top_i"]] - g["prefill_top_v"]).max() <= LOGIT_TOL
+    # free run: codes identical to the reference's in the first and the last slot
+    for slot in (0, B - 1):
+        g2, outs2, content2, audio2, *_ = _stream_vs_golden(eng, weights0, "stream_s0", n_streams=B, slot=slot, n_limit=n_limit)
+        np.testing.assert_array_equal(audio2, g["audio_codes"][:, :audio2.shape[1]])
+        for k, idx in enumerate(g["pcm_full_idx"]):
+            if int(idx) < len(outs2):
+                np.testing.assert_allclose(outs2[int(idx)], g["pcm_full"][k], atol=PCM_TOL)
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_long_stream_default_max_seq_frames_reprefill_vs_reference(eng, weights0, forced):
+    """672 chunks at the reference's DEFAULT max_seq_frames = 768 / buffer_frames = 32 (evaluations/infer_arvc.py:443-460): the stream
+    runs into its first re-prefill (:547-564, pos // 2 >= 768) at chunk 646 and continues on the rebuilt cache.  Against the
+    reference-captured fixture (tools/make_golden.py stream_long): content codes and audio codes identical for all 670 frames, KV
+    position, pre-norm hidden state of every frame, PCM of the chunks around the re-prefill; teacher-forced: top-32 logits of the
+    frames [628, 670) -- before, at and after the re-prefill -- within 2e-3.  The engine takes its one-pass re-prefill form here
+    (the appended rows against the cached prompt prefix), so this is that form against the reference, not against itself."""
+    g, outs, content, audio, slow, fast, last_pos = _stream_vs_golden(eng, weights0, "stream_long_reprefill", forced=forced)
+    np.testing.assert_array_equal(content, g["content_codes"])
+    np.testing.assert_array_equal(audio, g["audio_codes"])
+    assert last_pos == int(g["final_pos"]) and last_pos < 768          # (the cache was rebuilt: far below 2 * 768)
+    for k, idx in enumerate(g["pcm_full_idx"]):
+        np.testing.assert_allclose(outs[int(idx)], g["pcm_full"][k], atol=PCM_TOL)
+    sums = np.array([float(o.astype(np.float64).sum()) for o in outs])
+    np.testing.assert_allclose(sums, g["pcm_sum"], atol=5e-2)
+    for f, h16 in _stream_vs_golden.last["hidden"]:
+        assert np.abs(h16 - g["hidden16"][f]).max() <= LOGIT_TOL, f
+    if forced:
+        lf = int(g["logit_first"])
+        _assert_forced_logits(g, slow[lf:lf + g["slow_top_i"].shape[0]], fast[lf:lf + g["slow_top_i"].shape[0]], LOGIT_TOL, first=lf)
 
 
 def test_device_rng_equals_host_noise(eng, weights0):
@@ -1983,43 +2047,6 @@ def test_f16w_stress_tool_is_clean():
     assert r.returncode == 0 and last, r.stdout[-2000:] + r.stderr[-2000:]
     n, bad = int(last[-1].split()[0]), int(last[-1].split()[2])
     assert n >= 1000 and bad == 0, r.stdout[-2000:]
-
-
-@pytest.mark.parametrize("B", [2, 3, 4])
-def test_group_form_of_the_persistent_decode_equals_the_default_path(eng, B):
-    """csrc/ar_group.hip (SVA_DEBUG ar_group=1: 2-4 streams share each phase's weight registers and hand-offs on one set of 96
-    workgroups; measured slower than the default policy and therefore off) computes per stream exactly what ar_decode.hip computes:
-    codes and PCM of a batch identical to the default path's, bit for bit."""
-    from streamvoiceanon_amd import engine as E
-    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
-
-    lib, n_chunks = E.load_library(), 8
-    src = np.stack([synth_utterance(1700 + s, 2048 * n_chunks) for s in range(B)])
-
-    def run(mode):
-        lib.sva_debug_configure(f"ar_group={mode}".encode())          # (read at batch creation)
-        try:
-            b = E.Batch(eng, n_streams=B)
-        finally:
-            lib.sva_debug_configure(b"ar_group=0")
-        for s in range(B):
-            ac, cc, style, timbre = synth_prompt(2300 + s, 50 + 9 * s)
-            b.prefill_prompt(s, cc, ac, style, timbre, noise_seed=1700 + s)
-        b.begin()
-        pcm = [b.step(src[:, i * 2048:(i + 1) * 2048]) for i in range(n_chunks)]
-        codes = np.stack([b.pred_codes(s) for s in range(B)])
-        path = b.decode_path()
-        b.close()
-        return np.concatenate(pcm, axis=1), codes, path
-
-    p1, c1, path1 = run(1)
-    p0, c0, _ = run(0)
-    assert path1 == 1 and c1.shape[-1] >= n_chunks - 2
-    np.testing.assert_array_equal(c1, c0)
-    if B == 2:          # the default path at 2 streams is ar_decode.hip itself: the same arithmetic, so the same bits
-        np.testing.assert_array_equal(p1, p0)
-    else:
-        assert np.abs(p1 - p0).max() <= PCM_TOL
 
 
 def test_fp16_planes_range_check_reports_an_operand_beyond_the_fp16_range():

@@ -118,6 +118,42 @@ def test_stream_matches_reference(name, weights0):
             np.testing.assert_allclose(fast[f][cb].numpy()[g["fast_top_i"][f, cb]], g["fast_top_v"][f, cb], atol=2e-4)
 
 
+def test_long_stream_default_reprefill_matches_reference(weights0):
+    """The 672-chunk fixture at the reference's default max_seq_frames = 768 (tools/make_golden.py stream_long): the oracle's AR state
+    machine -- prompt prefill, delay fill, 645 decoded frames, the re-prefill of evaluations/infer_arvc.py:547-564 when pos // 2 >= 768,
+    24 more frames on the rebuilt cache -- against the reference's codes, KV position, hidden state of every frame and the top-32
+    logits of the frames around the re-prefill.  To keep the CPU suite short the content codes come from the fixture (the encoder has
+    its own fixtures) and the vocoder runs for the stored chunks only."""
+    g = load_golden("stream_long_reprefill")
+    useed, pseed = int(g["audio_seed"]), int(g["prompt_seed"])
+    ac, cc, style, timbre = synth_prompt(pseed, int(g["prompt_frames"]))
+    n_chunks = int(g["n_chunks"])
+    sess = O.StreamSession(weights0, torch.from_numpy(cc), torch.from_numpy(ac), torch.from_numpy(style), torch.from_numpy(timbre),
+                           noise_fn=lambda f: tuple(torch.from_numpy(a) for a in frame_noise(useed, f)), delay=int(g["delay"]),
+                           max_seq_frames=int(g["max_seq_frames"]), buffer_frames=int(g["buffer_frames"]))
+    keep = {int(i): k for k, i in enumerate(g["pcm_full_idx"])}
+    zero = torch.zeros(1, 2048)
+    content = torch.from_numpy(g["content_codes"])
+    for i in range(n_chunks):
+        out = sess.process_one_chunk(zero, content_override=content[i:i + 1], vocode=i in keep)
+        if i in keep:
+            np.testing.assert_allclose(out[0].numpy(), g["pcm_full"][keep[i]], atol=1e-5)
+    assert sess.n_reprefill == 1
+    np.testing.assert_array_equal(sess.pred_codes.numpy(), g["audio_codes"])
+    assert sess.ar.last_pos == int(g["final_pos"])
+    hid = [h for r in sess.trace for h in r["hidden"]]
+    slow = [x for r in sess.trace for x in r["slow_logits"]]
+    fast = [x for r in sess.trace for x in r["fast_logits"]]
+    assert len(hid) == g["hidden16"].shape[0] == n_chunks - 2
+    lf = int(g["logit_first"])
+    for f in range(len(hid)):
+        np.testing.assert_allclose(hid[f][:16].numpy(), g["hidden16"][f], atol=2e-4)
+        if lf <= f < lf + g["slow_top_v"].shape[0]:
+            np.testing.assert_allclose(slow[f].numpy()[g["slow_top_i"][f - lf]], g["slow_top_v"][f - lf], atol=2e-4)
+            for cb in range(8):
+                np.testing.assert_allclose(fast[f][cb].numpy()[g["fast_top_i"][f - lf, cb]], g["fast_top_v"][f - lf, cb], atol=2e-4)
+
+
 def test_offline_generate_matches_reference(weights0):
     g = load_golden("offline_s0")
     useed = int(g["audio_seed"])

@@ -3,7 +3,7 @@ through tools/ref_harness.py) on CPU with the synthetic weights of
 streamvoiceanon_amd.synth_weights.  Runs only in the build container; the fixtures it writes
 are data (inputs are regenerated from seeds; outputs are the reference's tensors).
 
-    python tools/make_golden.py            # writes tests/golden/*.npz   (~3 min on 8 vCPU)
+    python tools/make_golden.py            # writes tests/golden/*.npz   (~10 min on 8 vCPU; idempotent: `git diff --stat tests/golden` stays empty)
 
 Fixture contents (SURVEY.md §8c "Golden vectors to capture"):
   encoder_s{0,1}.npz   BSQ indices [128] + pre-sign u [128,13] + sampled mel / backbone values
@@ -11,6 +11,7 @@ Fixture contents (SURVEY.md §8c "Golden vectors to capture"):
   stream_s0.npz        24-chunk stream (delay 2, chunk 1): content codes, audio codes, PCM of
                        3 frames + per-chunk checksums, per-frame top-32 slow/fast logits
   stream_reprefill.npz stream with max_seq_frames small enough to trigger a re-prefill
+  stream_long_reprefill.npz  672-chunk stream at the reference's default max_seq_frames = 768 (first re-prefill at chunk ~ 646)
   stream_chunk4.npz    chunk = 4 stream (config-5 shape), delay 2
   offline_s0.npz       offline ARVCWrapper.generate codes for a short source
   melfb.npz            mel filterbank checksums
@@ -125,12 +126,16 @@ def vocoder_fixture(w, wseed):
 
 
 def stream_fixture(w, feed, name, wseed, useed, pseed, n_chunks, chunk=1, delay=2, max_seq_frames=768,
-                   buffer_frames=32, prompt_frames=107, full_pcm_frames=(2, 3, -1)):
+                   buffer_frames=32, prompt_frames=107, full_pcm_frames=(2, 3, -1), logit_frames=None):
+    """logit_frames: (first, last) decoded-frame range whose top-32 logits are stored (default: every frame); the
+    long fixture keeps the frames around its re-prefill only, codes / hidden states / PCM checksums for all."""
     import modules.dual_ar_stream as das
 
     ac, cc, style, timbre = synth_prompt(pseed, prompt_frames)
     tup = (torch.from_numpy(ac)[None], torch.from_numpy(cc)[None], torch.from_numpy(style)[None],
            torch.from_numpy(timbre)[None], torch.zeros(1, prompt_frames * 2048))
+    had_cp = "calculate_prompt" in w.__dict__
+    saved_cp = w.__dict__.get("calculate_prompt")
     w.calculate_prompt = lambda ref, alpha=1.0, spk_emb_collate_type="concat_mel": tup
     ar = w.model.decoder.model
     rec = dict(slow_v=[], slow_i=[], fast_v=[], fast_i=[], hidden=[])
@@ -191,6 +196,8 @@ def stream_fixture(w, feed, name, wseed, useed, pseed, n_chunks, chunk=1, delay=
         pcm_full[i] = out[0].numpy().copy()
     keep = sorted({(f if f >= 0 else n_chunks + f) for f in full_pcm_frames})
     audio_codes = w.pred_codes[0].numpy().copy()          # [8, frames decoded]
+    lf0, lf1 = logit_frames if logit_frames else (0, len(rec["slow_v"]))
+    extra = dict(logit_first=lf0) if logit_frames else {}
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
         weight_seed=wseed, audio_seed=useed, prompt_seed=pseed, prompt_frames=prompt_frames,
@@ -198,15 +205,30 @@ def stream_fixture(w, feed, name, wseed, useed, pseed, n_chunks, chunk=1, delay=
         content_codes=np.concatenate(content), audio_codes=audio_codes,
         pcm_sum=np.array(pcm_sum), pcm_abs=np.array(pcm_abs),
         pcm_full_idx=np.array(keep), pcm_full=np.stack([pcm_full[k] for k in keep]),
-        slow_top_v=np.stack(rec["slow_v"]), slow_top_i=np.stack(rec["slow_i"]),
-        fast_top_v=np.stack(rec["fast_v"]).reshape(-1, 8, 32), fast_top_i=np.stack(rec["fast_i"]).reshape(-1, 8, 32),
+        slow_top_v=np.stack(rec["slow_v"])[lf0:lf1], slow_top_i=np.stack(rec["slow_i"])[lf0:lf1],
+        fast_top_v=np.stack(rec["fast_v"]).reshape(-1, 8, 32)[lf0:lf1], fast_top_i=np.stack(rec["fast_i"]).reshape(-1, 8, 32)[lf0:lf1],
         hidden16=np.stack(rec["hidden"]),
         prefill_top_v=pre["v"][0], prefill_top_i=pre["v"][1],
-        final_pos=int(w.model.decoder.cached_kv_pos[-1]),
+        final_pos=int(w.model.decoder.cached_kv_pos[-1]), **extra,
     )
     ar.forward_generate, ar.forward_generate_fast = orig_fg, orig_ff
     del w.model.decode_one
+    # every patch of this function is undone: the wrapper goes on to other fixtures (prompt_fixture calls the REAL
+    # calculate_prompt; round 4's recipe left the lambda in place and a full run wrote the synthetic prompt into prompt_s0.npz)
+    if had_cp:
+        w.calculate_prompt = saved_cp
+    else:
+        del w.calculate_prompt
     print(name, "frames", audio_codes.shape, "time %.1fs" % (time.time() - t0), "final pos", int(w.model.decoder.cached_kv_pos[-1]))
+
+
+def long_reprefill_fixture(w, feed):
+    """One stream at the reference's DEFAULT max_seq_frames = 768 / buffer_frames = 32 (evaluations/infer_arvc.py:443-460) run past
+    its first re-prefill (:547-564): prompt 107 frames -> 33 + 2 * 107 = 247 positions, +2 per source frame, re-prefill when
+    pos // 2 >= 768, i.e. in chunk ~ 646; 672 chunks = 31.2 s of audio.  Full PCM of the chunks around the re-prefill, top-32
+    logits of the frames [628, 670)."""
+    stream_fixture(w, feed, "stream_long_reprefill", 0, useed=1006, pseed=2006, n_chunks=672, max_seq_frames=768,
+                   buffer_frames=32, full_pcm_frames=(640, 644, 645, 646, 647, 648, 650, -1), logit_frames=(628, 670))
 
 
 def offline_fixture(w, feed, wseed, useed, pseed, src_frames=12, prompt_frames=40, delay=2):
@@ -340,6 +362,9 @@ def main():
     if only == "encoder_long":
         encoder_long_fixture(rh.build_wrapper(seed=0))
         return
+    if only == "stream_long":
+        long_reprefill_fixture(rh.build_wrapper(seed=0), feed)
+        return
     if only in (None, "prompt_encoders"):
         prompt_encoder_fixture(0)
         if only:
@@ -362,6 +387,7 @@ def main():
             offline_fixture(w, feed, 0, useed=1003, pseed=2003)
             encoder_long_fixture(w)
             prompt_fixture(w, 0, useed=1004)
+            long_reprefill_fixture(w, feed)
 
 
 if __name__ == "__main__":
