@@ -58,8 +58,9 @@ typedef struct sva_config {
     int mm_mode;           /* fp32-grade batch-scale GEMMs (>= 3072 rows) of the encoder / vocoder: 1 (default) = two pre-split fp16 planes per
                             * operand, three part products (csrc/gemm_planes.hip): half the matrix work of 0, for operands inside the fp16
                             * range -- which torch.autocast(fp16), infer_arvc.py:493, demands of the reference too; 0 = three bf16 parts split
-                            * inside the K loop, six products (csrc/gemm_split.hip, the round-3 kernel): any fp32 range; 2 = three pre-split
-                            * bf16 planes, six products (A/B: slower than 0, its planes are 6 bytes per element) */
+                            * inside the K loop, six products (csrc/gemm_split.hip, the round-3 kernel): any fp32 range.  (2 -- three pre-split
+                            * bf16 planes -- was an A/B arm of round 4, slower than 0, and is refused since round 5.)  NOTE: mode 1, the default,
+                            * has fp16's RANGE: an operand beyond +-65504 raises an error at the next sva_step* / sva_sync naming mm_mode = 0 */
     int voc_dtype;         /* 0: vocoder (firefly.decode) GEMMs in the mm_mode grade; 1: fp16 operands, fp32 accumulate -- the reference's
                             * own precision for this stage (torch.autocast(fp16) around code2wav_fn, infer_arvc.py:493, 571-590) */
 } sva_config;

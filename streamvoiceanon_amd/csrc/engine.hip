@@ -45,6 +45,7 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "ar_batch_wgs") o.ar_batch_wgs = atoi(v.c_str());
             else if (k == "planes_dbg") o.planes_dbg = atoi(v.c_str());
             else if (k == "reprefill") o.reprefill = atoi(v.c_str());
+            else if (k == "planes_dma") o.planes_dma = atoi(v.c_str());
             else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());

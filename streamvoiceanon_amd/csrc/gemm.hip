@@ -706,6 +706,14 @@ static const PlanesRow g_planes_table[] = {
 #include "planes_table.inc"
 };
 static int planes_variant(const ConvGemm& g, int group_n) {
+    // both operands as planes, whole 128-column tiles: the persistent LDS-DMA form (variants 8 / 9).  256 x 128 tiles move two thirds of
+    // the operand bytes per flop of 128 x 128; which one is a matter of how the tile count quantises over the CUs (one workgroup each)
+    if (group_n == 1 && planes_dma_gemm_supported(g) && debug_options().planes_dma != 0) {
+        // measured at 64 streams on the ten encoder shapes (profiles/r05_planes_dma_bench.txt): 128 x 128 tiles with TWO workgroups per CU
+        // (variant 10: one workgroup's epilogue runs under the other's K steps) win or tie everywhere; 256 x 128 (8) never wins
+        const long t9 = (long)((g.M + 127) / 128) * (g.N / 128);
+        if (t9 >= 64) return 10;
+    }
     // measured winners for the encoder's shapes (tools/planes_tune.py -> planes_table.inc; every variant computes the same bits, the K
     // loop is the same): the row with this (N, K) whose M is nearest, if within a quarter of it
     if (group_n == 1 && g.taps == 1) {
@@ -1045,7 +1053,7 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
     }
     t_planes_mode = -1;
     SVA_TRY_RC(launch_choice(g, st, ch));
-    t_last_kind = t_planes_mode >= 0 ? 6 + t_planes_mode : ch.kind;       // 6 / 7 / 8: planes kernel in S6 / H3 / H1
+    t_last_kind = t_planes_mode >= 0 ? 6 + t_planes_mode : ch.kind;       // 7 / 8: planes kernel in H3 / H1
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -1062,7 +1070,7 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
         return 0;
     }
     if (kind == 6) {                    // the planes kernel (gemm_planes.hip), a = its tile variant
-        SVA_CHECK(planes_gemm_supported(g) && a >= 0 && a <= 7 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the planes kernel needs weight planes, Cin % 32 == 0 and 16-byte aligned C rows");
+        SVA_CHECK(planes_gemm_supported(g) && a >= 0 && a <= 10 && (a < 8 || planes_dma_gemm_supported(g)) && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the planes kernel needs weight planes, Cin % 32 == 0 and 16-byte aligned C rows");
         SVA_TRY_RC(launch_choice(g, st, Choice{4, 8 + a, 0, 0}));
         SVA_HIP(hipGetLastError());
         return 0;

@@ -9,13 +9,17 @@
 //     firefly.py:421-440, and w1|w3 -> w2 of the window transformer, windowed_transformer.py:134-143, hand their hidden tensor
 //     over as planes and never store it as fp32) or by to_planes_kernel after a non-GEMM producer; an A operand that only exists
 //     as fp32 is split while it is staged, as before (APL = false).
-// Three precisions (ConvGemm::pmode), all accumulating in fp32 on v_mfma_f32_16x16x32_{bf16,f16}:
-//   S6: x = hi + mid + lo in bf16 (3 x 8 bits), six part products >= 2^-16 of the leading one -- fp32-grade for any fp32 range
-//       (the arithmetic of gemm_split.hip);
-//   H3: x = hi + lo in fp16 (2 x 11 bits, |x - hi - lo| <= 2^-23 |x|), three products hi.hi + hi.lo + lo.hi; the dropped lo.lo is
-//       <= 2^-24 of the leading one -- fp32-grade with HALF the matrix work and two planes instead of three, for operands inside the
-//       fp16 range (the reference runs this path under torch.autocast(fp16), evaluations/infer_arvc.py:493, so its own
-//       activations are);
+// Two precisions (ConvGemm::pmode), both accumulating in fp32 on v_mfma_f32_16x16x32_f16 (round 4's third format -- S6, three bf16
+// planes / six products -- was measured slower than the in-loop split of gemm_split.hip, 6 bytes per element against 4, and removed in
+// round 5: profiles/r04_mm_mode_ab.txt, git history; the range-safe fp32-grade path is sva_config.mm_mode = 0 = gemm_split.hip):
+//   H3: x = hi + lo in fp16 (2 x 11 bits), three products hi.hi + hi.lo + lo.hi; the dropped lo.lo is <= 2^-24 of the leading one --
+//       fp32-grade with HALF the matrix work of the six-product bf16 split, for operands inside the fp16 range (the reference runs this
+//       path under torch.autocast(fp16), evaluations/infer_arvc.py:493, so its own activations are).  Error of the split itself:
+//       |x - hi - lo| <= 2^-23 |x| while lo is a NORMAL fp16 number, i.e. for |x| >= 2^-3; below that lo is subnormal (or the residual
+//       falls under fp16's smallest subnormal 2^-24) and the error is ABSOLUTE, <= 2^-25: 3e-8 per element, i.e. 3e-5 relative at
+//       |x| = 1e-3.  Weights are pre-scaled into [2^7, 2^8) so theirs are relative; activation planes are NOT scaled (LayerNorm / GELU /
+//       SwiGLU outputs of O(1) magnitude): an output's error from its small activations is bounded by 2^-25 * sum_k |w_k|, far below
+//       the 2^-24-relative rounding of the O(1) terms of the same sum (tests: test_planes_gemm_small_activations_absolute_floor);
 //   H1: x = fp16(x), one product -- the reference's own precision (autocast), a sixth of the matrix work.
 //
 // LDS image (both operands, every path): a K tile is cut into 1 KiB PIECES = 16 rows x 32 k of one plane, stored chunk-major --
@@ -31,9 +35,11 @@
 #include <type_traits>
 #include <vector>
 
+#include "planes_split.h"
 #include "sva_common.h"
 
 namespace sva {
+bool planes_gemm_supported(const ConvGemm& g);
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -49,31 +55,21 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 template <int MODE> struct PM;
-template <> struct PM<PLANES_S6> { static constexpr int NPL = 3; };
 template <> struct PM<PLANES_H3> { static constexpr int NPL = 2; };
 template <> struct PM<PLANES_H1> { static constexpr int NPL = 1; };
 
 // two fp32 -> one packed pair per plane
 template <int MODE>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[PM<MODE>::NPL]) {
-    if constexpr (MODE == PLANES_S6) {
-        const f32x2 v = {a, b};
-        o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-        const f32x2 r1 = {a - __uint_as_float(o[0] << 16), b - __uint_as_float(o[0] & 0xffff0000u)};
-        o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-        const f32x2 r2 = {r1.x - __uint_as_float(o[1] << 16), r1.y - __uint_as_float(o[1] & 0xffff0000u)};
-        o[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-    } else {
-        const f32x2 v = {a, b};
-        f16x2 h = __builtin_convertvector(v, f16x2);
-        o[0] = __builtin_bit_cast(unsigned, h);
-        if constexpr (MODE == PLANES_H3) {
-            // (an opaque copy of hi: the residual must be taken from the ROUNDED value, whatever the optimiser makes of the casts -- gemm_f16w.hip: split8)
-            asm("" : "+v"(o[0]));
-            const f16x2 hq = __builtin_bit_cast(f16x2, o[0]);
-            const f32x2 r = {a - (float)hq.x, b - (float)hq.y};
-            o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-        }
+    const f32x2 v = {a, b};
+    f16x2 h = __builtin_convertvector(v, f16x2);
+    o[0] = __builtin_bit_cast(unsigned, h);
+    if constexpr (MODE == PLANES_H3) {
+        // (an opaque copy of hi: the residual must be taken from the ROUNDED value, whatever the optimiser makes of the casts -- gemm_f16w.hip: split8)
+        asm("" : "+v"(o[0]));
+        const f16x2 hq = __builtin_bit_cast(f16x2, o[0]);
+        const f32x2 r = {a - (float)hq.x, b - (float)hq.y};
+        o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
     }
 }
 // eight consecutive k of one row -> one 16-byte chunk per plane
@@ -91,14 +87,13 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4 (
 
 template <int MODE>
 __device__ __forceinline__ f32x4 mma1(const u32x4& a, const u32x4& b, const f32x4& c) {
-    if constexpr (MODE == PLANES_S6) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 // BM x BN tile, WM x WN waves of 64 x 64 (or smaller) wave tiles, BK = 32 KB k per tile.  APL: the A operand comes as planes (g.Ap),
 // otherwise as fp32 (g.A) and is split while it is staged
 template <int MODE, int BM, int BN, int KB, bool APL, int WM = 2, int WN = 2>
-__global__ __launch_bounds__(64 * WM * WN, ((WM * WN > 4 && BM > 128) || (MODE == PLANES_S6 && BM + BN > 192)) ? 1 : 2) void planes_gemm_kernel(const ConvGemmGroup gg) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 && BM > 128) ? 1 : 2) void planes_gemm_kernel(const ConvGemmGroup gg) {
     constexpr int NW = WM * WN, NTH = 64 * NW, BK = 32 * KB, NPL = PM<MODE>::NPL;
     constexpr int NS = KB == 1 ? 3 : 2;                         // register stages of global loads in flight
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -127,15 +122,15 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN > 4 && BM > 128) || (MODE =
         const int b = m / g.T, t = m - b * g.T;
         const long off = (long)b * g.a_bstride + g.a_off + (long)t * g.stride * g.lda + pchunk * 8;
         a_f32[i] = g.A + off;
-        a_pl[i] = g.Ap + off;
+        // planes are K-blocked over dense rows (planes_split.h): this lane's 16 bytes of k block 0
+        a_pl[i] = g.Ap + ((long)b * (g.a_bstride / g.lda) + g.a_off / g.lda + t) * 32 + pchunk * 8;
     }
-    const long Kt = (long)g.taps * g.Cin;
     const unsigned short* b_pl[IB];
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
         int n = bn0 + (wave + NW * i) * 16 + prow;
         if (n > g.N - 1) n = g.N - 1;
-        b_pl[i] = g.Wp + (long)n * Kt + pchunk * 8;
+        b_pl[i] = g.Wp + (long)n * 32 + pchunk * 8;
     }
 
     f32x4 acc[MI][NI];
@@ -149,6 +144,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN > 4 && BM > 128) || (MODE =
     const int dbg = gg.xcd_swz >> 8;            // TIMING EXPERIMENT (results are garbage): 1 no global loads in the K loop, 2 no LDS stores, 4 no MFMAs, 8 no epilogue
     // (kernel-argument fields the K loop needs, as values)
     const long g_tapstep = (long)g.dil * g.lda, g_ap_ps = g.ap_pstride, g_wp_ps = g.wp_pstride;
+    const long g_ablk = g.ap_rows * 32, g_wblk = (long)g.N * 32;          // elements between consecutive 32-k blocks of a plane
     const int g_cin = g.Cin, g_silu = g.a_silu;
 
     // NS register stages: the loads of tiles k + 2 .. k + NS are in flight while tile k multiplies and tile k + 1 is written to LDS
@@ -165,14 +161,14 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN > 4 && BM > 128) || (MODE =
         const int tap = kt / kc_tiles;
         const int kc = (kt - tap * kc_tiles) * BK;
         const long aoff = (long)tap * g_tapstep + kc;
-        const long boff = (long)tap * g_cin + kc;
+        const long bblk = ((long)tap * g_cin + kc) >> 5;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
                 if constexpr (APL) {
 #pragma unroll
-                    for (int p = 0; p < NPL; ++p) r.a[kb][i][p] = *reinterpret_cast<const u32x4*>(a_pl[i] + (long)p * g_ap_ps + aoff + kb * 32);
+                    for (int p = 0; p < NPL; ++p) r.a[kb][i][p] = *reinterpret_cast<const u32x4*>(a_pl[i] + (long)p * g_ap_ps + ((kc >> 5) + kb) * g_ablk);
                 } else {
                     r.a[kb][i][0] = *reinterpret_cast<const u32x4*>(a_f32[i] + aoff + kb * 32);
                     r.a[kb][i][1] = *reinterpret_cast<const u32x4*>(a_f32[i] + aoff + kb * 32 + 4);
@@ -181,7 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN > 4 && BM > 128) || (MODE =
 #pragma unroll
             for (int i = 0; i < IB; ++i)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) r.b[kb][i][p] = *reinterpret_cast<const u32x4*>(b_pl[i] + (long)p * g_wp_ps + boff + kb * 32);
+                for (int p = 0; p < NPL; ++p) r.b[kb][i][p] = *reinterpret_cast<const u32x4*>(b_pl[i] + (long)p * g_wp_ps + (bblk + kb) * g_wblk);
         }
     };
     auto lstore = [&](int buf, const Regs& r) {
@@ -229,14 +225,6 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN > 4 && BM > 128) || (MODE =
         // small products first
 #pragma unroll
         for (int j = j0; j < j1; ++j) {
-            if constexpr (MODE == PLANES_S6) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(f.a[i][2], f.b[j][0], acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(f.a[i][0], f.b[j][2], acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(f.a[i][1], f.b[j][1], acc[i][j]);
-            }
             if constexpr (MODE != PLANES_H1) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) acc[i][j] = mma1<MODE>(f.a[i][1], f.b[j][0], acc[i][j]);
@@ -293,8 +281,9 @@ k_done:
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cs[(wm * TM + i * 16 + rq + r) * CS + wn * TN + j * 16 + col] = acc[i][j][r] * winv;
     __syncthreads();
-    auto store4 = [&](const float4& v, long idx) {
-        if constexpr (MODE != PLANES_S6) {
+    const long c_rows_b = g.ldc ? g.c_bstride / g.ldc : 0, c_row0 = g.ldc ? g.c_off / g.ldc : 0;
+    auto store4 = [&](const float4& v, long idx, int b_, int t_, int n_) {
+        {
             // fp16 parts have fp16's range: an operand beyond +-65504 turns into inf and the output into inf / nan.  The reference
             // (torch.autocast(fp16)) has the same limit; here it is REPORTED (sva_sync fails, naming mm_mode = 0) instead of propagating
             if (g.ovf && !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < INFINITY)) *reinterpret_cast<volatile int*>(g.ovf) = 1;
@@ -304,8 +293,9 @@ k_done:
             unsigned p0[NPL], p1[NPL];
             split_pair<MODE>(v.x, v.y, p0);
             split_pair<MODE>(v.z, v.w, p1);
+            const long po = plane_off_blocked((long)b_ * c_rows_b + c_row0 + t_, n_, g.cp_rows);
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x2*>(g.Cp + (long)p * g.cp_pstride + idx) = (u32x2){p0[p], p1[p]};
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x2*>(g.Cp + (long)p * g.cp_pstride + po) = (u32x2){p0[p], p1[p]};
         }
     };
     if (g.w13) {
@@ -325,7 +315,7 @@ k_done:
             const float4 w = *reinterpret_cast<const float4*>(&Cs[row * CS + grp * 32 + 16 + c4]);
             float4 o;
             o.x = silu_f(a.x) * w.x; o.y = silu_f(a.y) * w.y; o.z = silu_f(a.z) * w.z; o.w = silu_f(a.w) * w.w;
-            store4(o, (long)b * g.c_bstride + g.c_off + (long)t * g.ldc + ((bn0 + grp * 32) >> 1) + c4);
+            store4(o, (long)b * g.c_bstride + g.c_off + (long)t * g.ldc + ((bn0 + grp * 32) >> 1) + c4, b, t, ((bn0 + grp * 32) >> 1) + c4);
         }
         return;
     }
@@ -359,7 +349,7 @@ k_done:
             const float4 cc = *reinterpret_cast<const float4*>(g.C + ci);
             v.x += cc.x; v.y += cc.y; v.z += cc.z; v.w += cc.w;
         }
-        store4(v, ci);
+        store4(v, ci, b, t, n);
     }
 }
 
@@ -391,9 +381,7 @@ int launch_planes_m(const ConvGemmGroup& gg, int variant, hipStream_t st) {
         case 2: return launch_planes_t<MODE, 64, 128, 1, APL>(gg, st);
         case 3: return launch_planes_t<MODE, 64, 64, 1, APL>(gg, st);
         // 64-deep K tiles (half the barriers; the tile's stage is twice as large)
-        case 4:             // (three planes x 2 stages x 64 k of a 128 x 128 tile would need 192 KiB of LDS)
-            if constexpr (MODE != PLANES_S6) { if (k64) return launch_planes_t<MODE, 128, 128, 2, APL>(gg, st); }
-            return launch_planes_t<MODE, 128, 128, 1, APL>(gg, st);
+        case 4: if (k64) return launch_planes_t<MODE, 128, 128, 2, APL>(gg, st); return launch_planes_t<MODE, 128, 128, 1, APL>(gg, st);
         case 5: if (k64) return launch_planes_t<MODE, 64, 64, 2, APL>(gg, st); return launch_planes_t<MODE, 64, 64, 1, APL>(gg, st);
         // 8 waves: 256 x 128 (each weight tile feeds twice the rows: two thirds of the operand traffic per flop of 128 x 128)
         case 6: return launch_planes_t<MODE, 256, 128, 1, APL, 4, 2>(gg, st);
@@ -405,12 +393,320 @@ int launch_planes_m(const ConvGemmGroup& gg, int variant, hipStream_t st) {
     return -1;
 }
 
-// fp32 rows -> planes (a non-GEMM producer's output that feeds a planes GEMM as its A operand): element index space of `src` kept
-template <int MODE>
-__global__ void to_planes_kernel(const float* __restrict__ src, long n8, unsigned short* __restrict__ dst, long pstride, float scale, int silu) {
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// planes_dma_kernel (round 5): the same GEMM as ONE CONTINUOUS, LDS-DMA-FED STREAM OF K STEPS per workgroup.
+//
+// Round 4's leave-one-out probe (profiles/r04_planes_probe.txt) showed planes_gemm_kernel to be the SUM of its phases: global loads
+// into registers, ds_write_b128 of the same bytes, fragment reads, MFMAs and an epilogue through LDS each took their turn -- hipcc
+// drains the load queue (vmcnt(0)) at the loop head whatever ring of register stages the source keeps, and with K = 384-2048 a tile's
+// fill / drain / epilogue are ~40 % of it.  This kernel changes the structure instead of the schedule:
+//   * both operands are planes (the producers split: weights at finalize, activations in the epilogue / output pass of whoever wrote
+//     them), so global -> LDS is a pure copy: `global_load_lds_dwordx4` (16 bytes per lane, one 1 KiB piece = 16 rows x 32 k of one
+//     plane per wave-instruction; the lane-linear LDS image IS the chunk-major piece layout of the header, the rows are picked by the
+//     per-lane SOURCE offsets).  No staging registers, no ds_write, no VALU in the K loop;
+//   * a ring of NST LDS stages, requests NST - 1 K steps ahead, COUNTED s_waitcnt vmcnt(N) (never 0 in steady state) + one raw
+//     s_barrier per K step: the DMA stays in flight across barriers (cdna_hip_programming.md, "Pipelining across barriers").  The
+//     loads are inline asm, invisible to hipcc's wait-count pass, and the K loop holds no other VMEM instruction;
+//   * PERSISTENT: a workgroup walks its tiles as one stream of (tile, k) steps -- the first K steps of the next tile are already in
+//     flight while the current tile's epilogue runs;
+//   * the epilogue never touches LDS (the ring keeps flowing): the products are taken TRANSPOSED -- weights as the MFMA's row
+//     operand -- so a lane holds FOUR CONSECUTIVE OUTPUT COLUMNS of one row (D[n][m]: n = 4 (lane >> 4) + r, m = lane & 15): bias /
+//     GELU / gamma / residual / SwiGLU (its w1 | w3 column groups are two accumulators of the same lane) and the split into output
+//     planes happen in registers, stores are 16 bytes (fp32) or 8 bytes per plane per lane.
+// Tile BM x 128 on 8 waves (two per SIMD): BM = 256 -> 4 x 2 waves of 64 x 64, three 48 KiB stages; BM = 128 -> 2 x 4 waves of
+// 64 x 32, four 32 KiB stages (the shapes with few column tiles).  One workgroup per CU; the grid is min(tiles, CUs of the stream);
+// XCD x owns a contiguous band of the (n-fastest) tile sequence, so the row panel a band shares is fetched into one L2.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const char* uni_ptr(const char* p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned long long r = ((unsigned long long)uni((unsigned)(u >> 32)) << 32) | uni((unsigned)u);
+    return reinterpret_cast<const char*>(r);
+}
+// one 1 KiB piece: lane l copies 16 bytes from base + voff(l) to LDS byte address lds_dst + 16 l (M0 = the wave-uniform destination;
+// saved and restored around the instruction: the register is the compiler's)
+__device__ __forceinline__ void glds16(const char* base, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(base) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int MODE, int BM, int NST, bool PROBE>
+__global__ __launch_bounds__(512, 2) void planes_dma_kernel(const ConvGemm g, const int n_tiles_n, const int n_tiles, const int dbg_arg) {
+    const int dbg = PROBE ? dbg_arg : 0;          // (the product instantiation carries none of the switches below)
+    // dbg: TIMING EXPERIMENTS (SVA_DEBUG planes_dbg; results are garbage): 1 no LDS-DMA requests, 4 no MFMAs, 8 no epilogue, 32 no fragment reads
+    constexpr int NPL = PM<MODE>::NPL, BN = 128, NW = 8;
+    constexpr int PD = NST - 1;                                           // NST LDS stages; K steps requested ahead
+    constexpr int WM = BM / 64, WN = NW / WM, TN = BN / WN, MI = 4, NI = TN / 16;
+    constexpr int RBA = BM / 16, RBB = BN / 16, PA = RBA / NW, PB = RBB / NW;
+    constexpr int A_BYTES = NPL * RBA * 1024, STAGE = A_BYTES + NPL * RBB * 1024;
+    constexpr int LPW = (PA + PB) * NPL;                                  // LDS-DMA instructions per wave and K step
+    static_assert(PD * LPW <= 48, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    const unsigned lds0 = uni((unsigned)(size_t)lds);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)uni((unsigned)(tid >> 6));
+    const int wm = wave / WN, wn = wave % WN;
+    const int prow = lane & 15, pchunk = lane >> 4;
+
+    // ---- this workgroup's tiles: XCD x (= workgroup id & 7, a speed assumption only) owns the x-th contiguous eighth of the sequence ----
+    const int G = gridDim.x, wg = blockIdx.x;
+    const int xcd = wg & 7, slot = wg >> 3, nslots = (G - xcd + 7) >> 3;
+    const int q = n_tiles >> 3, r8 = n_tiles & 7;
+    const int band_lo = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q, band_n = q + (xcd < r8 ? 1 : 0);
+    const int my_tiles = slot < band_n ? (band_n - slot + nslots - 1) / nslots : 0;
+    const int nk = g.Cin / 32;           // (taps == 1: blocked A planes are linear layers' operands)
+    const int total = my_tiles * nk;
+    if (total == 0) return;
+
+    // ---- load side: (tile, k) of the next step to request, per-lane source offsets relative to the tile's wave-uniform bases ----
+    int ld_it = 0, ld_k = 0, ld_stage = 0;
+    unsigned offA[PA], offW[PB];
+    const char *baseA = nullptr, *baseW = nullptr;
+    const long a_rows_b = g.a_bstride / g.lda, a_row0 = g.a_off / g.lda;       // dense row of (b, t) = b * a_rows_b + a_row0 + t
+    auto row_of = [&](int m) -> long {
+        if (m > g.M - 1) m = g.M - 1;
+        const int b = m / g.T, t = m - b * g.T;
+        return (long)b * a_rows_b + a_row0 + t;
+    };
+    auto ld_tile = [&]() {
+        const int tile = band_lo + slot + ld_it * nslots;
+        const int tm = tile / n_tiles_n, tn = tile - tm * n_tiles_n;
+        const int bm0 = tm * BM, bn0 = tn * BN;
+        // K-blocked planes: a row's 32 k of one block are 64 contiguous bytes, consecutive rows are adjacent -- the 16 rows of a piece are
+        // one contiguous KiB wherever the tile does not straddle a batch item
+        const long r0 = row_of(bm0);
+        baseA = uni_ptr(reinterpret_cast<const char*>(g.Ap + r0 * 32));
+        baseW = uni_ptr(reinterpret_cast<const char*>(g.Wp + (long)bn0 * 32));
+#pragma unroll
+        for (int i = 0; i < PA; ++i) offA[i] = (unsigned)(((row_of(bm0 + (wave + NW * i) * 16 + prow) - r0) * 32 + pchunk * 8) * 2);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            int n = bn0 + (wave + NW * i) * 16 + prow;
+            if (n > g.N - 1) n = g.N - 1;
+            offW[i] = (unsigned)(((long)(n - bn0) * 32 + pchunk * 8) * 2);
+        }
+    };
+    const long a_ps2 = g.ap_pstride * 2, w_ps2 = g.wp_pstride * 2, a_blk2 = g.ap_rows * 64, w_blk2 = (long)g.N * 64;      // bytes between planes / 32-k blocks
+    auto issue = [&]() {
+        if (ld_k == 0) ld_tile();
+        const char* const ba = baseA + (long)ld_k * a_blk2;
+        const char* const bw = baseW + (long)ld_k * w_blk2;
+        const unsigned dst = lds0 + (unsigned)ld_stage * STAGE;
+        if (!(dbg & 1)) {
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+                for (int i = 0; i < PA; ++i) glds16(ba + p * a_ps2, offA[i], dst + (unsigned)((p * RBA + wave + NW * i) * 1024));
+#pragma unroll
+                for (int i = 0; i < PB; ++i) glds16(bw + p * w_ps2, offW[i], dst + (unsigned)(A_BYTES + (p * RBB + wave + NW * i) * 1024));
+            }
+        }
+        if (++ld_k == nk) { ld_k = 0; ++ld_it; }
+        if (++ld_stage == NST) ld_stage = 0;
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- epilogue of the tile the compute side has finished: registers -> global, no LDS ----
+    const float winv = g.wp_inv;
+    const long c_rows_b = g.ldc ? g.c_bstride / g.ldc : 0, c_row0 = g.ldc ? g.c_off / g.ldc : 0;
+    auto store4 = [&](const f32x4& v, long idx, int b_, int t_, int n_) {
+        // fp16 parts have fp16's range: an operand beyond +-65504 is REPORTED (host-mapped flag; sva_sync / the next step fails naming mm_mode = 0)
+        if (g.ovf && !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < INFINITY)) *reinterpret_cast<volatile int*>(g.ovf) = 1;
+        if (g.C) *reinterpret_cast<f32x4*>(g.C + idx) = v;
+        if (g.Cp) {
+            unsigned p0[NPL], p1[NPL];
+            split_pair<MODE>(v.x, v.y, p0);
+            split_pair<MODE>(v.z, v.w, p1);
+            const long po = plane_off_blocked((long)b_ * c_rows_b + c_row0 + t_, n_, g.cp_rows);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x2*>(g.Cp + (long)p * g.cp_pstride + po) = (u32x2){p0[p], p1[p]};
+        }
+    };
+    auto epilogue = [&](int tile) {
+        const int tm = tile / n_tiles_n, tn = tile - tm * n_tiles_n;
+        const int bm0 = tm * BM, bn0 = tn * BN;
+        const int nq = 4 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = bm0 + wm * 64 + i * 16 + (lane & 15);
+            const int b = m / g.T, t = m - b * g.T;
+            const bool row_ok = m < g.M && !(t >= g.skip_lo && t < g.skip_hi);
+            if (g.w13) {
+                // SwiGLU: the tile's columns alternate 16 x w1 | 16 x w3 -- accumulators j (w1) and j + 1 (w3) of this lane; output column (n0 >> 1) + c
+#pragma unroll
+                for (int j = 0; j + 1 < NI; j += 2) {
+                    const int n = bn0 + wn * TN + j * 16;              // w1 column block
+                    if (!row_ok || n >= g.N) continue;
+                    const f32x4 a = acc[i][j] * winv, w = acc[i][j + 1] * winv;
+                    f32x4 o;
+                    o.x = silu_f(a.x) * w.x; o.y = silu_f(a.y) * w.y; o.z = silu_f(a.z) * w.z; o.w = silu_f(a.w) * w.w;
+                    store4(o, (long)b * g.c_bstride + g.c_off + (long)t * g.ldc + (n >> 1) + nq, b, t, (n >> 1) + nq);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = bn0 + wn * TN + j * 16 + nq;
+                if (!row_ok || n >= g.N) continue;
+                f32x4 v = acc[i][j] * winv;
+                if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+                if (g.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+                else if (g.act == ACT_LOGCLAMP) { v.x = __logf(fmaxf(v.x, 1e-5f)); v.y = __logf(fmaxf(v.y, 1e-5f)); v.z = __logf(fmaxf(v.z, 1e-5f)); v.w = __logf(fmaxf(v.w, 1e-5f)); }
+                if (g.gamma) v *= *reinterpret_cast<const f32x4*>(g.gamma + n);
+                if (g.res) v += *reinterpret_cast<const f32x4*>(g.res + (long)b * g.r_bstride + g.r_off + (long)t * g.ldr + n);
+                v *= g.scale;
+                const long ci = (long)b * g.c_bstride + g.c_off + (long)t * g.ldc + n;
+                if (g.accumulate) v += *reinterpret_cast<const f32x4*>(g.C + ci);
+                store4(v, ci, b, t, n);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- the stream: steps 0 .. PD - 1 requested up front; iteration s waits for step s (its own pieces), meets the other waves (all
+    // pieces of step s landed, everybody is done reading the stage of step s - 1), requests step s + PD into that stage, multiplies ----
+#pragma unroll
+    for (int s_ = 0; s_ < PD; ++s_)
+        if (s_ < total) issue();
+    int cs = 0, ck = 0, cit = 0;
+    bool prewaited = false;
+    auto wait_step = [&](int allow) {         // at most `allow` requested steps may still be in flight (LPW instructions each)
+        if (allow <= 0) wait_vm<0>();
+        else if (allow == 1) wait_vm<LPW>();
+        else if (PD < 3 || allow == 2) wait_vm<2 * LPW>();
+        else wait_vm<3 * LPW>();
+    };
+    for (int s_ = 0; s_ < total; ++s_) {
+        if (!prewaited) wait_step(min(PD - 1, total - 1 - s_));
+        prewaited = false;
+        __builtin_amdgcn_s_barrier();
+        if (s_ + PD < total) issue();
+        {
+            const char* const sa = lds + cs * STAGE + lane * 16 + (wm * MI) * 1024;
+            const char* const sb = lds + cs * STAGE + A_BYTES + lane * 16 + (wn * NI) * 1024;
+            u32x4 fa[MI][NPL], fb[NI][NPL];
+            if (dbg & 32) {
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) fb[j][p] = (u32x4){(unsigned)s_, 1u, 2u, 3u};
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) fa[i][p] = (u32x4){(unsigned)s_, 5u, 6u, 7u};
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) fb[j][p] = *reinterpret_cast<const u32x4*>(sb + (p * RBB + j) * 1024);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) fa[i][p] = *reinterpret_cast<const u32x4*>(sa + (p * RBA + i) * 1024);
+                }
+            }
+            if (dbg & 4) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) { acc[i][j][0] += __uint_as_float(fa[i][0][0] ^ fb[j][NPL - 1][1]); acc[i][j][1] += __uint_as_float(fa[i][NPL - 1][2] ^ fb[j][0][3]); }
+            } else {
+            // D[n][m] = sum_k W[n][k] X[m][k]: weights first.  Small products first; 16 (8) independent accumulators between dependent ones
+            if constexpr (MODE == PLANES_H3) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mma1<MODE>(fb[j][0], fa[i][1], acc[i][j]);        // w_hi . x_lo
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mma1<MODE>(fb[j][1], fa[i][0], acc[i][j]);        // w_lo . x_hi
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mma1<MODE>(fb[j][0], fa[i][0], acc[i][j]);
+            }
+        }
+        if (++cs == NST) cs = 0;
+        if (++ck == nk) {
+            ck = 0;
+            // the next step's pieces are waited for BEFORE the epilogue's stores join the queue (vmcnt counts them too: waiting behind them
+            // would park the first K step of every tile for a store round trip); the barrier of the next iteration makes it workgroup-wide
+            if (s_ + 1 < total) { wait_step(min(PD - 1, total - 2 - s_)); prewaited = true; }
+            if (dbg & 8) { if (acc[0][0][0] == 123.456f) epilogue(0); }
+            else
+            epilogue(band_lo + slot + cit * nslots);
+            ++cit;
+        }
+    }
+}
+
+static int g_dma_cu_limit = 0;          // CUs a planes-DMA launch may count on (0: the device's); the engine lowers it for CU-masked streams
+
+template <int MODE, int BM, int NST>
+int launch_planes_dma_t(const ConvGemm& g, hipStream_t st) {
     constexpr int NPL = PM<MODE>::NPL;
+    constexpr size_t smem = (size_t)NST * NPL * (BM + 128) / 16 * 1024;
+    constexpr int WG_PER_CU = smem * 2 <= 160 * 1024 ? 2 : 1;            // two resident workgroups: one's epilogue runs under the other's K steps
+    static_assert(smem <= 160 * 1024, "LDS of one CU");
+    static DeviceOnce attr_set;
+    if (attr_set.needed()) {
+        SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<MODE, BM, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (MODE == PLANES_H3) SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<PLANES_H3, BM, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set.done();
+    }
+    int cus = g_dma_cu_limit;
+    if (cus <= 0) {
+        static int dev_cus = 0;
+        if (dev_cus == 0) {
+            int dev = 0;
+            SVA_HIP(hipGetDevice(&dev));
+            SVA_HIP(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        cus = dev_cus;
+    }
+    const int tn = g.N / 128, tm = (g.M + BM - 1) / BM, tiles = tn * tm;
+    const int grid = std::min(tiles, cus * WG_PER_CU);
+    const int dbg = debug_options().planes_dbg;
+    if (dbg && MODE == PLANES_H3) hipLaunchKernelGGL((planes_dma_kernel<PLANES_H3, BM, NST, true>), dim3(grid), dim3(512), smem, st, g, tn, tiles, dbg);
+    else hipLaunchKernelGGL((planes_dma_kernel<MODE, BM, NST, false>), dim3(grid), dim3(512), smem, st, g, tn, tiles, 0);
+    return 0;
+}
+
+// variants 8 .. 10 of launch_planes_gemm
+bool planes_dma_supported(const ConvGemm& g) {
+    return planes_gemm_supported(g) && g.Ap && !g.a_silu && g.N % 128 == 0 && g.ksplit <= 1 && (!g.w13 || g.N % 32 == 0) &&
+           (!g.C || (g.ldc % 4 == 0 && g.c_off % 4 == 0 && g.c_bstride % 4 == 0)) && (!g.res || (g.ldr % 4 == 0 && g.r_off % 4 == 0 && g.r_bstride % 4 == 0));
+}
+int launch_planes_dma(const ConvGemm& g, int variant, hipStream_t st) {
+    SVA_CHECK(planes_dma_supported(g) && variant >= 8 && variant <= 10, "planes_dma: unsupported problem (A as planes, N % 128 == 0)");
+    // 8: 256 x 128, three stages; 9: 128 x 128, four stages, one workgroup per CU; 10: 128 x 128, two stages, TWO workgroups per CU
+    if (g.pmode == PLANES_H3)
+        return variant == 8 ? launch_planes_dma_t<PLANES_H3, 256, 3>(g, st) : variant == 9 ? launch_planes_dma_t<PLANES_H3, 128, 4>(g, st) : launch_planes_dma_t<PLANES_H3, 128, 2>(g, st);
+    return variant == 8 ? launch_planes_dma_t<PLANES_H1, 256, 3>(g, st) : variant == 9 ? launch_planes_dma_t<PLANES_H1, 128, 4>(g, st) : launch_planes_dma_t<PLANES_H1, 128, 2>(g, st);
+}
+
+// fp32 [rows][K] (row stride ld) -> K-blocked planes (planes_split.h): one thread per 8 consecutive k of a row
+template <int MODE>
+__global__ void to_planes_kernel(const float* __restrict__ src, long rows, int K, long ld, unsigned short* __restrict__ dst, long pstride, float scale, int silu) {
+    constexpr int NPL = PM<MODE>::NPL;
+    const int k8 = K / 8;
+    const long n8 = rows * k8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(src + i * 8), v1 = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+        const long row = i / k8;
+        const int k = (int)(i - row * k8) * 8;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(src + row * ld + k), v1 = *reinterpret_cast<const f32x4*>(src + row * ld + k + 4);
         v0 *= scale; v1 *= scale;
         if (silu) {
             v0.x = silu_f(v0.x); v0.y = silu_f(v0.y); v0.z = silu_f(v0.z); v0.w = silu_f(v0.w);
@@ -418,20 +714,25 @@ __global__ void to_planes_kernel(const float* __restrict__ src, long n8, unsigne
         }
         u32x4 o[NPL];
         split8<MODE>(v0, v1, o);
+        const long po = plane_off_blocked(row, k, rows);
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dst + (long)p * pstride + i * 8) = o[p];
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dst + (long)p * pstride + po) = o[p];
     }
 }
 
 }  // namespace
 
-int planes_count(int mode) { return mode == PLANES_S6 ? 3 : mode == PLANES_H3 ? 2 : 1; }
+void planes_dma_set_cu_limit(int cus) { g_dma_cu_limit = cus; }
+bool planes_dma_gemm_supported(const ConvGemm& g) { return planes_dma_supported(g); }
+
+int planes_count(int mode) { return mode == PLANES_H3 ? 2 : 1; }
 
 // channels in whole 32-wide K tiles, planes of the weights present; the tiled epilogue's conditions (16-byte aligned C rows) are the caller's
 bool planes_gemm_supported(const ConvGemm& g) {
-    return g.Wp && g.pmode >= 0 && g.pmode <= 2 && g.Cin % 32 == 0 && g.stride >= 1 && !g.rms_w && !g.dw_wT && (g.C || g.Cp) && !(g.accumulate && !g.C) &&
-           (g.A || g.Ap) && (!g.Ap || (g.lda % 8 == 0 && g.a_off % 8 == 0 && g.a_bstride % 8 == 0 && g.ap_pstride % 8 == 0)) &&
-           (!g.Cp || (g.ldc % 4 == 0 && g.c_off % 4 == 0 && g.c_bstride % 4 == 0 && g.cp_pstride % 4 == 0));
+    return g.Wp && (g.pmode == PLANES_H3 || g.pmode == PLANES_H1) && g.Cin % 32 == 0 && g.stride >= 1 && !g.rms_w && !g.dw_wT && (g.C || g.Cp) && !(g.accumulate && !g.C) &&
+           (g.A || g.Ap) &&
+           (!g.Ap || (g.taps == 1 && g.stride == 1 && g.lda > 0 && g.a_off % g.lda == 0 && g.a_bstride % g.lda == 0 && g.ap_pstride % 8 == 0 && g.ap_rows > 0)) &&
+           (!g.Cp || (g.ldc > 0 && g.ldc % 4 == 0 && g.c_off % g.ldc == 0 && g.c_bstride % g.ldc == 0 && g.cp_pstride % 4 == 0 && g.cp_rows > 0 && (g.w13 ? g.N / 2 : g.N) % 32 == 0));
 }
 
 int launch_planes_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st) {
@@ -441,42 +742,35 @@ int launch_planes_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st) {
         SVA_CHECK(planes_gemm_supported(gg.g[i]) && gg.g[i].pmode == g.pmode && !gg.g[i].Ap == !g.Ap, "planes_gemm: group members differ");
     if (g.Ap) {
         SVA_CHECK(!g.a_silu, "planes_gemm: SiLU belongs to the producer of the planes");
-        switch (g.pmode) {
-            case PLANES_S6: return launch_planes_m<PLANES_S6, true>(gg, variant, st);
-            case PLANES_H3: return launch_planes_m<PLANES_H3, true>(gg, variant, st);
-            default: return launch_planes_m<PLANES_H1, true>(gg, variant, st);
-        }
+        if (variant >= 8) return launch_planes_dma(g, variant, st);
+        return g.pmode == PLANES_H3 ? launch_planes_m<PLANES_H3, true>(gg, variant, st) : launch_planes_m<PLANES_H1, true>(gg, variant, st);
     }
-    switch (g.pmode) {
-        case PLANES_S6: return launch_planes_m<PLANES_S6, false>(gg, variant, st);
-        case PLANES_H3: return launch_planes_m<PLANES_H3, false>(gg, variant, st);
-        default: return launch_planes_m<PLANES_H1, false>(gg, variant, st);
-    }
+    SVA_CHECK(variant < 8, "planes_gemm: the LDS-DMA variants take the A operand as planes");
+    return g.pmode == PLANES_H3 ? launch_planes_m<PLANES_H3, false>(gg, variant, st) : launch_planes_m<PLANES_H1, false>(gg, variant, st);
 }
 
-int launch_to_planes(const float* src, long n, unsigned short* dst, long pstride, int mode, float scale, int silu, hipStream_t st) {
-    SVA_CHECK(n % 8 == 0 && mode >= 0 && mode <= 2, "to_planes: whole 8-element chunks");
-    const long n8 = n / 8;
+int launch_to_planes(const float* src, long rows, int K, long ld, unsigned short* dst, long pstride, int mode, float scale, int silu, hipStream_t st) {
+    SVA_CHECK(K % 32 == 0 && ld % 4 == 0 && (mode == PLANES_H3 || mode == PLANES_H1), "to_planes: whole 32-k blocks, an fp16 planes format");
+    const long n8 = rows * (K / 8);
     const int blocks = (int)std::min<long>((n8 + 255) / 256, 2048);
-    if (mode == PLANES_S6) hipLaunchKernelGGL(to_planes_kernel<PLANES_S6>, dim3(blocks), dim3(256), 0, st, src, n8, dst, pstride, scale, silu);
-    else if (mode == PLANES_H3) hipLaunchKernelGGL(to_planes_kernel<PLANES_H3>, dim3(blocks), dim3(256), 0, st, src, n8, dst, pstride, scale, silu);
-    else hipLaunchKernelGGL(to_planes_kernel<PLANES_H1>, dim3(blocks), dim3(256), 0, st, src, n8, dst, pstride, scale, silu);
+    if (mode == PLANES_H3) hipLaunchKernelGGL(to_planes_kernel<PLANES_H3>, dim3(blocks), dim3(256), 0, st, src, rows, K, ld, dst, pstride, scale, silu);
+    else hipLaunchKernelGGL(to_planes_kernel<PLANES_H1>, dim3(blocks), dim3(256), 0, st, src, rows, K, ld, dst, pstride, scale, silu);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 
-// Planes of a weight matrix W [n elements] already on the device: dst = [NPL][n] 16-bit, element = part of W * 2^e with e chosen so
+// Planes of a weight matrix W [N][K] already on the device: dst = [NPL] K-blocked planes of N rows, element = part of W * 2^e with e chosen so
 // that max |W| 2^e lies in [2^7, 2^8) in the fp16 modes (the low part of a weight 2^-9 of the largest is still a normal fp16; far
 // from the fp16 overflow threshold) and e = 0 for bf16 (fp32's exponent range).  *inv = 2^-e for the accumulator.
-int make_weight_planes(const float* dW, long n, float max_abs, int mode, unsigned short* dst, float* inv, hipStream_t st) {
+int make_weight_planes(const float* dW, int N, int K, float max_abs, int mode, unsigned short* dst, float* inv, hipStream_t st) {
     int e = 0;
-    if (mode != PLANES_S6 && max_abs > 0.f && std::isfinite(max_abs)) {
+    if (max_abs > 0.f && std::isfinite(max_abs)) {
         int ex;
         (void)frexpf(max_abs, &ex);            // max_abs = f * 2^ex, f in [0.5, 1)
         e = 8 - ex;
     }
     *inv = ldexpf(1.f, -e);
-    return launch_to_planes(dW, n, dst, n, mode, ldexpf(1.f, e), 0, st);
+    return launch_to_planes(dW, N, K, K, dst, (long)N * K, mode, ldexpf(1.f, e), 0, st);
 }
 
 }  // namespace sva

@@ -18,16 +18,19 @@ int launch_stft_mag_ring2(const float* ring, const int* step, int n_chunk, int a
 // depthwise causal k=7 conv + LayerNorm(eps) over channels (ConvNeXtBlock prologue).
 //   x element (b, r, c): x[b*x_bstride + x_off + r*C + c]; output row t reads rows t..t+6.
 //   wT [7][C] (tap-major), out element (b, t, c) at out[b*o_bstride + t*C + c].
+//   outp != null: the consumer is a planes GEMM (gemm_planes.hip) -- fp16 hi (+ lo when op_planes == 2) parts instead of the fp32 rows, plane
+//   p at outp + p * op_pstride, element (b, t, c) at the fp32 tensor's index (op_rows == 0) or K-blocked over op_rows = B * T rows (planes_split.h)
 int launch_dwconv7_ln(const float* x, long x_bstride, long x_off, int B, int T, int C, const float* wT,
                       const float* bias, const float* ln_w, const float* ln_b, float eps, float* out, long o_bstride,
-                      hipStream_t st);
+                      hipStream_t st, unsigned short* outp = nullptr, long op_pstride = 0, int op_planes = 0, long op_rows = 0);
 
 // row LayerNorm / RMSNorm with strided in/out (rows = B*T).
 int launch_layernorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C,
                           const float* w, const float* b, float eps, float* out, long o_bstride, long o_off,
                           int ldo, hipStream_t st, int skip_lo = 0, int skip_hi = 0);      // rows t in [skip_lo, skip_hi) of each item are left alone
 int launch_rmsnorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
-                        float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st);
+                        float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st,
+                        unsigned short* outp = nullptr, long op_pstride = 0, int op_planes = 0, long op_rows = 0);     // planes output as launch_dwconv7_ln
 
 // causal self-attention of the BSQ pre-transformer: qkv [B, T, 3*D] -> out [B, T, D]; RoPE
 // (adjacent pairs, bf16-rounded table rope[T][hd/2][2]) applied to q and k on load.

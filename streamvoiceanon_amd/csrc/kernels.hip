@@ -4,6 +4,7 @@
 // StreamVoiceAnon repository); the CPU oracle (oracle/sva_oracle.py) is the checker.
 #include "kernels.h"
 #include "device_util.h"
+#include "planes_split.h"
 
 namespace sva {
 
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
                                                          int C, int rows, const float* __restrict__ wT,
                                                          const float* __restrict__ bias, const float* __restrict__ lw,
                                                          const float* __restrict__ lb, float eps, float* __restrict__ out,
-                                                         long o_bstride) {
+                                                         long o_bstride, unsigned short* __restrict__ outp, long op_pstride, int op_planes,
+                                                         long op_rows) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * (blockDim.x >> 6) + wave;
     if (row >= rows) return;
@@ -179,21 +181,29 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
         r.y = (v[i].y - mean) * inv * g.y + h.y;
         r.z = (v[i].z - mean) * inv * g.z + h.z;
         r.w = (v[i].w - mean) * inv * g.w + h.w;
-        *reinterpret_cast<float4*>(o + c) = r;
+        if (outp) {          // the consumer is a planes GEMM (gemm_planes.hip): fp16 hi (+ lo) parts instead of the fp32 row
+            unsigned short hi[4], lo[4];
+            h3_split(r.x, hi[0], lo[0]); h3_split(r.y, hi[1], lo[1]); h3_split(r.z, hi[2], lo[2]); h3_split(r.w, hi[3], lo[3]);
+            const long po = op_rows > 0 ? plane_off_blocked((long)b * T + t, c, op_rows) : (long)b * o_bstride + (long)t * C + c;
+            *reinterpret_cast<uint2*>(outp + po) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+            if (op_planes > 1) *reinterpret_cast<uint2*>(outp + op_pstride + po) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+        } else {
+            *reinterpret_cast<float4*>(o + c) = r;
+        }
     }
 }
 int launch_dwconv7_ln(const float* x, long x_bstride, long x_off, int B, int T, int C, const float* wT,
                       const float* bias, const float* ln_w, const float* ln_b, float eps, float* out, long o_bstride,
-                      hipStream_t st) {
+                      hipStream_t st, unsigned short* outp, long op_pstride, int op_planes, long op_rows) {
     SVA_CHECK(C % 4 == 0 && C <= 512 && x_bstride % 4 == 0 && x_off % 4 == 0 && o_bstride % 4 == 0,
               "dwconv7_ln: C must be a multiple of 4, <= 512, float4-aligned rows");
     const int rows = B * T;
     const int wpb = rows >= 4096 ? 4 : 1;       // few rows: one wave per workgroup so the rows spread over the CUs
     dim3 grid((rows + wpb - 1) / wpb);
     if (C <= 256)
-        hipLaunchKernelGGL((dwconv7_ln_kernel<1>), grid, dim3(64 * wpb), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out, o_bstride);
+        hipLaunchKernelGGL((dwconv7_ln_kernel<1>), grid, dim3(64 * wpb), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out, o_bstride, outp, op_pstride, op_planes, op_rows);
     else
-        hipLaunchKernelGGL((dwconv7_ln_kernel<2>), grid, dim3(64 * wpb), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out, o_bstride);
+        hipLaunchKernelGGL((dwconv7_ln_kernel<2>), grid, dim3(64 * wpb), 0, st, x, x_bstride, x_off, T, C, rows, wT, bias, ln_w, ln_b, eps, out, o_bstride, outp, op_pstride, op_planes, op_rows);
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -206,7 +216,8 @@ template <int NPL, bool RMS>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ x, long x_bstride, long x_off, int ldx,
                                                         int T, int C, int rows, const float* __restrict__ w,
                                                         const float* __restrict__ bvec, float eps,
-                                                        float* __restrict__ out, long o_bstride, long o_off, int ldo, int skip_lo, int skip_hi) {
+                                                        float* __restrict__ out, long o_bstride, long o_off, int ldo, int skip_lo, int skip_hi,
+                                                        unsigned short* __restrict__ outp, long op_pstride, int op_planes, long op_rows) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
@@ -214,6 +225,18 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
     if (t >= skip_lo && t < skip_hi) return;          // rows the caller keeps (streaming history of the merged encoder pass)
     const float* xr = x + (long)b * x_bstride + x_off + (long)t * ldx;
     float* o = out + (long)b * o_bstride + o_off + (long)t * ldo;
+    // planes output (the consumer is a planes GEMM): fp16 hi (+ lo) parts at the fp32 element's index, or K-blocked (planes_split.h)
+    auto put = [&](int c, float val) {
+        if (outp) {
+            unsigned short hi, lo;
+            h3_split(val, hi, lo);
+            const long po = op_rows > 0 ? plane_off_blocked((long)b * (o_bstride / ldo) + o_off / ldo + t, c, op_rows) : (long)b * o_bstride + o_off + (long)t * ldo + c;
+            outp[po] = hi;
+            if (op_planes > 1) outp[op_pstride + po] = lo;
+        } else {
+            o[c] = val;
+        }
+    };
     float v[NPL];
     float s = 0.f;
 #pragma unroll
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
     if (RMS) {
         const float inv = 1.f / sqrtf(wave_sum(s) / (float)C + eps);
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) o[lane + 64 * i] = v[i] * inv * w[lane + 64 * i];
+        for (int i = 0; i < NPL; ++i) put(lane + 64 * i, v[i] * inv * w[lane + 64 * i]);
     } else {
         const float mean = wave_sum(s) / (float)C;
         float q = 0.f;
@@ -237,17 +260,19 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const int c = lane + 64 * i;
-            o[c] = (v[i] - mean) * inv * w[c] + bvec[c];
+            put(c, (v[i] - mean) * inv * w[c] + bvec[c]);
         }
     }
 }
 template <bool RMS>
 static int launch_norm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
-                            const float* b, float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st, int skip_lo = 0, int skip_hi = 0) {
+                            const float* b, float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st, int skip_lo = 0, int skip_hi = 0,
+                            unsigned short* outp = nullptr, long op_pstride = 0, int op_planes = 0, long op_rows = 0) {
     SVA_CHECK(C % 64 == 0 && C <= 1024, "norm_rows: C must be a multiple of 64, <= 1024");
+    SVA_CHECK(!outp || op_rows == 0 || (o_bstride % ldo == 0 && o_off % ldo == 0), "norm_rows: K-blocked planes need whole rows");
     const int rows = B * T;
     dim3 grid((rows + 3) / 4);
-#define SVA_NR(N_) hipLaunchKernelGGL((norm_rows_kernel<N_, RMS>), grid, dim3(256), 0, st, x, x_bstride, x_off, ldx, T, C, rows, w, b, eps, out, o_bstride, o_off, ldo, skip_lo, skip_hi)
+#define SVA_NR(N_) hipLaunchKernelGGL((norm_rows_kernel<N_, RMS>), grid, dim3(256), 0, st, x, x_bstride, x_off, ldx, T, C, rows, w, b, eps, out, o_bstride, o_off, ldo, skip_lo, skip_hi, outp, op_pstride, op_planes, op_rows)
     switch (C / 64) {
         case 1: SVA_NR(1); break;
         case 2: SVA_NR(2); break;
@@ -268,8 +293,8 @@ int launch_layernorm_rows(const float* x, long x_bstride, long x_off, int ldx, i
     return launch_norm_rows<false>(x, x_bstride, x_off, ldx, B, T, C, w, b, eps, out, o_bstride, o_off, ldo, st, skip_lo, skip_hi);
 }
 int launch_rmsnorm_rows(const float* x, long x_bstride, long x_off, int ldx, int B, int T, int C, const float* w,
-                        float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st) {
-    return launch_norm_rows<true>(x, x_bstride, x_off, ldx, B, T, C, w, nullptr, eps, out, o_bstride, o_off, ldo, st);
+                        float eps, float* out, long o_bstride, long o_off, int ldo, hipStream_t st, unsigned short* outp, long op_pstride, int op_planes, long op_rows) {
+    return launch_norm_rows<true>(x, x_bstride, x_off, ldx, B, T, C, w, nullptr, eps, out, o_bstride, o_off, ldo, st, 0, 0, outp, op_pstride, op_planes, op_rows);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -445,9 +445,10 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
     }
     // ---- pre-split operand planes of the encoder / vocoder weights (gemm_planes.hip) ----
     {
-        const int enc_mode = c.mm_mode == 1 ? PLANES_H3 : c.mm_mode == 2 ? PLANES_S6 : -1;
+        const int enc_mode = c.mm_mode == 1 ? PLANES_H3 : -1;
         const int voc_mode = c.voc_dtype == 1 ? PLANES_H1 : enc_mode;
-        SVA_CHECK(c.mm_mode >= 0 && c.mm_mode <= 2 && (c.voc_dtype == 0 || c.voc_dtype == 1), "bad mm_mode / voc_dtype");
+        SVA_CHECK((c.mm_mode == 0 || c.mm_mode == 1) && (c.voc_dtype == 0 || c.voc_dtype == 1),
+                  "bad mm_mode / voc_dtype (mm_mode = 2, pre-split bf16 planes, was measured slower than mm_mode = 0 and removed in round 5)");
         std::vector<float> host;
         auto planes = [&](Lin& l, int mode) -> int {
             if (mode < 0 || !l.W || l.N < (mode == PLANES_H1 ? 32 : 64) || l.K % 32 != 0) return 0;
@@ -457,7 +458,7 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
             float mx = 0.f;
             for (long i = 0; i < n; ++i) mx = std::max(mx, fabsf(host[i]));
             SVA_TRY(dev_alloc(e->allocs, &l.Wp, (size_t)planes_count(mode) * n, false));
-            SVA_TRY(make_weight_planes(l.W, n, mx, mode, l.Wp, &l.wp_inv, 0));
+            SVA_TRY(make_weight_planes(l.W, l.N, l.K, mx, mode, l.Wp, &l.wp_inv, 0));
             l.pmode = mode;
             return 0;
         };

@@ -129,7 +129,12 @@ __global__ void mean3_kernel(const float* __restrict__ y0, const float* __restri
 // they live in its buffer -- and the problem is at the scale where the planes kernel is the dispatcher's choice anyway.
 bool planes_edge(const Lin& producer, const Lin& consumer, long rows) {
     return rows >= 3072 && producer.Wp && consumer.Wp && producer.pmode == consumer.pmode && (producer.pmode == PLANES_H3 || producer.pmode == PLANES_H1) &&
-           producer.N % 8 == 0;
+           consumer.K % 32 == 0;
+}
+// A non-GEMM producer (dwconv7 + LayerNorm, RMSNorm rows) can write its output as the planes its consumer GEMM takes -- same scale rule;
+// with BOTH operands as planes the GEMM runs in its persistent LDS-DMA form (gemm_planes.hip, planes_dma_kernel)
+bool planes_input(const Lin& consumer, long rows) {
+    return rows >= 3072 && consumer.Wp && (consumer.pmode == PLANES_H3 || consumer.pmode == PLANES_H1) && consumer.K % 32 == 0 && debug_options().planes_dma != 0;
 }
 
 // ConvNeXtBlock (firefly.py:421-440) on x rows [x.H, x.H+T); result into `out` rows [out.H, out.H+T)
@@ -145,9 +150,11 @@ int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs
     p1.act = ACT_GELU;
     ConvGemm p2;
     // batch scale: the hidden tensor goes from pwconv1's GELU epilogue to pwconv2 as operand planes, in the scratch buffer's own memory
-    if (planes_edge(c.pw1, c.pw2, b->B * T)) {
-        p1.Cp = reinterpret_cast<unsigned short*>(h2); p1.cp_pstride = h2_bs * b->B;
-        p2.Ap = p1.Cp; p2.ap_pstride = p1.cp_pstride;
+    const long rows = (long)b->B * T;
+    if (planes_edge(c.pw1, c.pw2, rows)) {
+        SVA_CHECK(h2_bs == (long)T * 4 * C, "cnx_block: planes hand-over needs dense hidden rows");
+        p1.Cp = reinterpret_cast<unsigned short*>(h2); p1.cp_pstride = h2_bs * b->B; p1.cp_rows = rows;
+        p2.Ap = p1.Cp; p2.ap_pstride = p1.cp_pstride; p2.ap_rows = rows;
     }
     if (b->B * T <= 16 && C <= 512) {
         // a handful of rows (streaming pass, upsampler at small B): depthwise conv + LayerNorm happen in the prologue of the
@@ -155,7 +162,13 @@ int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs
         p1.dw_wT = c.dwT; p1.dw_b = c.dwb; p1.ln_w = c.lnw; p1.ln_b = c.lnb; p1.ln_eps = 1e-6f;
         SVA_TRY(gemm_call(b, x.p, x.bstride, (long)(x.H - 6) * C, C, b->B, T, 1, 1, 1, C, c.pw1, h2, h2_bs, 0, 4 * C, p1));
     } else {
-        SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, h1_bs, b->stream));
+        if (planes_input(c.pw1, rows) && h1_bs == (long)T * C) {        // LayerNorm output straight into operand planes, in h1's own memory
+            p1.Ap = reinterpret_cast<unsigned short*>(h1); p1.ap_pstride = h1_bs * b->B; p1.ap_rows = rows;
+            SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, h1_bs, b->stream,
+                                      reinterpret_cast<unsigned short*>(h1), p1.ap_pstride, planes_count(c.pw1.pmode), rows));
+        } else {
+            SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, h1_bs, b->stream));
+        }
         SVA_TRY(gemm_call(b, h1, h1_bs, 0, C, b->B, T, 1, 1, 1, C, c.pw1, h2, h2_bs, 0, 4 * C, p1));
     }
     p2.gamma = c.gamma;
@@ -405,6 +418,12 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows, int part) {
             ConvGemm pn;
             pn.rms_w = L.attn_norm; pn.rms_eps = 1e-5f;
             SVA_TRY(gemm_call(b, xr, xr_bs, xr_off, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D, pn));
+        } else if (planes_input(L.wqkv, (long)B * T2)) {        // RMSNorm output as operand planes (in tr_hn's own memory)
+            ConvGemm pn;
+            pn.Ap = reinterpret_cast<unsigned short*>(b->tr_hn); pn.ap_pstride = (long)B * T2 * D; pn.ap_rows = (long)B * T2;
+            SVA_TRY(launch_rmsnorm_rows(xr, xr_bs, xr_off, D, B, T2, D, L.attn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st,
+                                        reinterpret_cast<unsigned short*>(b->tr_hn), pn.ap_pstride, planes_count(L.wqkv.pmode), pn.ap_rows));
+            SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D, pn));
         } else {
             SVA_TRY(launch_rmsnorm_rows(xr, xr_bs, xr_off, D, B, T2, D, L.attn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
             SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D));
@@ -420,14 +439,20 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows, int part) {
         pg.w13 = 1;
         ConvGemm pd;
         if (planes_edge(L.w13, L.w2, (long)B * Tr)) {          // SwiGLU output -> w2 as operand planes, in tr_g's memory
-            pg.Cp = reinterpret_cast<unsigned short*>(b->tr_g); pg.cp_pstride = (long)B * T2 * I;
-            pd.Ap = pg.Cp; pd.ap_pstride = pg.cp_pstride;
+            pg.Cp = reinterpret_cast<unsigned short*>(b->tr_g); pg.cp_pstride = (long)B * T2 * I; pg.cp_rows = (long)B * T2;
+            pd.Ap = pg.Cp; pd.ap_pstride = pg.cp_pstride; pd.ap_rows = pg.cp_rows;
         }
         if (conv_gemm_can_fuse_rms(B * Tr, 2 * I)) {
             pg.rms_w = L.ffn_norm; pg.rms_eps = 1e-5f;
             SVA_TRY(gemm_call(b, xw, xw_bs, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, (long)r0 * I, I, pg));
         } else {
-            SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, (long)r0 * D, D, B, Tr, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, (long)r0 * D, D, st));
+            if (planes_input(L.w13, (long)B * Tr)) {
+                pg.Ap = reinterpret_cast<unsigned short*>(b->tr_hn); pg.ap_pstride = (long)B * T2 * D; pg.ap_rows = (long)B * T2;
+                SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, (long)r0 * D, D, B, Tr, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, (long)r0 * D, D, st,
+                                            reinterpret_cast<unsigned short*>(b->tr_hn), pg.ap_pstride, planes_count(L.w13.pmode), pg.ap_rows));
+            } else {
+                SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, (long)r0 * D, D, B, Tr, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, (long)r0 * D, D, st));
+            }
             SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, (long)r0 * I, I, pg));
         }
         pd.gamma = L.ls_ffn;

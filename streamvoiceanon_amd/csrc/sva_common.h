@@ -28,12 +28,13 @@ void set_error(const std::string& msg);
 //                     (downsampler + transformer + BSQ), 4 AR, 8 vocoder (tools/pipe_skip.sh)
 //   planes_dbg=mask   TIMING DIAGNOSTIC (results are garbage): leave parts of the planes GEMM out -- 1 global loads of its K loop, 2 LDS stores, 4 MFMAs,
 //                     8 epilogue (tools/planes_probe.py)
+//   planes_dma=0      the planes GEMM never takes its persistent LDS-DMA form (variants 8 / 9): round 4's register-staged tiles (A/B)
 //   reprefill=0       re-prefill as one whole-prompt prefill per slot behind a host synchronisation (round 3) instead of one pass over the
 //                     appended rows of all due slots against the cached prompt prefix (A/B, parity)
 //   f16_weights=0|2   ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B) / on gemm_f16w.hip even when
 //                     the library was built with a compiler the kernel was not validated with
 struct DebugOptions {
-    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1;
+    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1, planes_dma = 1;
     std::string tune_dump;
 };
 const DebugOptions& debug_options();
@@ -82,8 +83,8 @@ struct DeviceOnce {
 // is the same GEMM with N = stride*Cout and 2 (or 1) taps -- see DESIGN.md.
 // ---------------------------------------------------------------------------------------
 enum ActKind : int { ACT_NONE = 0, ACT_GELU = 1, ACT_LOGCLAMP = 2 };
-// operand-plane formats of gemm_planes.hip (sva_config::mm_mode): S6 = 3 bf16 planes / six products (fp32-grade, any range),
-// H3 = 2 fp16 planes / three products (fp32-grade inside the fp16 range), H1 = 1 fp16 plane / one product (torch.autocast(fp16))
+// operand-plane formats of gemm_planes.hip: H3 = 2 fp16 planes / three products (fp32-grade inside the fp16 range; sva_config::mm_mode = 1),
+// H1 = 1 fp16 plane / one product (torch.autocast(fp16); voc_dtype = 1).  (0 was S6, three bf16 planes / six products: removed in round 5)
 enum PlanesMode : int { PLANES_S6 = 0, PLANES_H3 = 1, PLANES_H1 = 2 };
 
 struct ConvGemm {
@@ -126,16 +127,20 @@ struct ConvGemm {
     float ln_eps = 1e-6f;
     const float* rms_w = nullptr;   // [Cin] fused RMSNorm of the A rows (taps == 1): A' = A * rms_w * rsqrt(mean(A^2) + rms_eps);
     float rms_eps = 1e-5f;          //       only on the small-M path -- ask conv_gemm_can_fuse_rms() first
-    // pre-split 16-bit operand planes (gemm_planes.hip).  Wp: [planes][N][taps*Cin] parts of W * 2^e, wp_inv = 2^-e; Ap / Cp: planes
-    // of the A / C tensor in the SAME element index space as A / C (plane p at + p * pstride elements).  C may be null when Cp is set.
+    // pre-split 16-bit operand planes (gemm_planes.hip), ALL K-BLOCKED (planes_split.h: [k / 32][rows][32] per plane, so that the 16 rows x
+    // 32 k of an MFMA operand piece are one contiguous KiB).  Wp: parts of W * 2^e over N rows, wp_inv = 2^-e.  Ap / Cp: planes of the A / C
+    // tensor over ap_rows / cp_rows DENSE rows (row of (b, t) = b * (bstride / ld) + off / ld + t: whole rows only; taps = stride = 1), plane
+    // p at + p * pstride elements.  A / C may be null when Ap / Cp is set.
     const unsigned short* Wp = nullptr;
     long wp_pstride = 0;
     float wp_inv = 1.f;
     int pmode = -1;                 // PlanesMode of Wp (and of Ap / Cp)
     const unsigned short* Ap = nullptr;
     long ap_pstride = 0;
+    long ap_rows = 0;
     unsigned short* Cp = nullptr;
     long cp_pstride = 0;
+    long cp_rows = 0;
     int* ovf = nullptr;             // fp16 planes only: set to 1 when an output is not finite (an operand outside the fp16 range); host-mapped
 };
 
@@ -175,12 +180,17 @@ bool split_gemm_supported(const ConvGemm& g);
 int launch_split_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 bool pipe_gemm_supported(const ConvGemm& g);
 int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
-// gemm_planes.hip: 16-bit matrix pipes fed from pre-split operand planes (variant 0..3 = 128x128, 128x64, 64x128, 64x64; 4 / 5 = 128x128 / 64x64 with 64-deep K tiles)
+// gemm_planes.hip: 16-bit matrix pipes fed from pre-split operand planes (variant 0..3 = 128x128, 128x64, 64x128, 64x64; 4 / 5 = 128x128 / 64x64 with 64-deep K
+// tiles; 6 = 256x128 and 7 = 128x128 on 8 waves)
 int planes_count(int mode);
 bool planes_gemm_supported(const ConvGemm& g);
 int launch_planes_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
-int launch_to_planes(const float* src, long n, unsigned short* dst, long pstride, int mode, float scale, int silu, hipStream_t st);
-int make_weight_planes(const float* dW, long n, float max_abs, int mode, unsigned short* dst, float* inv, hipStream_t st);
+// variants 8 / 9 of it: the persistent LDS-DMA-fed form (256 x 128 / 128 x 128 tiles; A as planes, N % 128 == 0, one problem per launch)
+bool planes_dma_gemm_supported(const ConvGemm& g);
+void planes_dma_set_cu_limit(int cus);        // CUs its grid may count on (0 = the device's); the engine sets it around launches on CU-masked streams
+// fp32 [rows][K] (row stride ld) -> K-blocked planes
+int launch_to_planes(const float* src, long rows, int K, long ld, unsigned short* dst, long pstride, int mode, float scale, int silu, hipStream_t st);
+int make_weight_planes(const float* dW, int N, int K, float max_abs, int mode, unsigned short* dst, float* inv, hipStream_t st);
 // gemm_f16w.hip: fp16 weights on the f16 matrix pipes (fp32 activations split hi + lo), plain linear layers of the AR chain
 bool f16w_gemm_supported(const ConvGemm& g);
 bool f16w_gemm_validated_compiler();      // built with the compiler the kernel's workarounds were validated with

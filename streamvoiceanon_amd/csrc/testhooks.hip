@@ -283,7 +283,7 @@ extern "C" int sva_host_launch_cost(int device, int iters, float* us_per_launch)
 extern "C" int sva_test_gemm_planes(int device, int M, int N, int K, const float* A, const float* W, const float* bias, float* C, int mode,
                                     int variant, int flags, int iters, float* out_us) {
     SVA_HIP(hipSetDevice(device));
-    SVA_CHECK(mode >= 0 && mode <= 2 && K % 32 == 0 && N % 4 == 0, "test_gemm_planes: bad arguments");
+    SVA_CHECK((mode == PLANES_H3 || mode == PLANES_H1) && K % 32 == 0 && N % 4 == 0, "test_gemm_planes: bad arguments");
     const int npl = planes_count(mode);
     float *dA, *dW, *dB = nullptr, *dC;
     unsigned short *dWp, *dAp = nullptr, *dCp = nullptr;
@@ -303,18 +303,42 @@ extern "C" int sva_test_gemm_planes(int device, int M, int N, int K, const float
     g.A = dA; g.a_bstride = (long)M * K; g.lda = K; g.T = M; g.M = M; g.Cin = K; g.taps = 1;
     g.W = dW; g.N = N; g.bias = dB; g.C = dC; g.c_bstride = (long)M * N; g.ldc = N;
     g.Wp = dWp; g.wp_pstride = (long)N * K; g.pmode = mode;
-    SVA_TRY(make_weight_planes(dW, (long)N * K, mx, mode, dWp, &g.wp_inv, 0));
+    SVA_TRY(make_weight_planes(dW, N, K, mx, mode, dWp, &g.wp_inv, 0));
     if (flags & 1) {
         SVA_HIP(hipMalloc(&dAp, 2 * (size_t)npl * M * K));
-        SVA_TRY(launch_to_planes(dA, (long)M * K, dAp, (long)M * K, mode, 1.f, 0, 0));
-        g.Ap = dAp; g.ap_pstride = (long)M * K; g.A = nullptr;
+        SVA_TRY(launch_to_planes(dA, M, K, K, dAp, (long)M * K, mode, 1.f, 0, 0));
+        g.Ap = dAp; g.ap_pstride = (long)M * K; g.ap_rows = M; g.A = nullptr;
     }
     if (flags & 2) {
         SVA_HIP(hipMalloc(&dCp, 2 * (size_t)npl * M * N));
-        g.Cp = dCp; g.cp_pstride = (long)M * N; g.C = nullptr;
+        g.Cp = dCp; g.cp_pstride = (long)M * N; g.cp_rows = M; g.C = nullptr;
     }
     if (flags & 4) g.act = ACT_GELU;
     if ((flags & 8) && !(flags & 1)) g.a_silu = 1;
+    // flags 32: SwiGLU (W rows interleave w1 | w3 in groups of 16; C is [M][N / 2]); 64: gamma (= bias vector reversed) and a residual (= a
+    // deterministic pattern) in front of the store; 128: rows t in [T / 3, T / 3 + 6) of every batch item of T = 170 rows are not stored
+    // (M % 170 == 0), C is pre-filled with a marker there
+    const int Nout = (flags & 32) ? N / 2 : N;
+    float *dG = nullptr, *dR = nullptr;
+    if (flags & 32) {
+        g.w13 = 1; g.ldc = Nout; g.c_bstride = (long)M * Nout; g.cp_pstride = (long)M * Nout;
+    }
+    if (flags & 64) {
+        std::vector<float> hg(N), hr((size_t)M * N);
+        for (int i = 0; i < N; ++i) hg[i] = 0.5f + 0.001f * (float)((i * 37) % 101);
+        for (size_t i = 0; i < hr.size(); ++i) hr[i] = 0.01f * (float)((i * 13) % 257) - 1.f;
+        SVA_HIP(hipMalloc(&dG, sizeof(float) * N));
+        SVA_HIP(hipMalloc(&dR, sizeof(float) * (size_t)M * N));
+        SVA_HIP(hipMemcpy(dG, hg.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+        SVA_HIP(hipMemcpy(dR, hr.data(), sizeof(float) * hr.size(), hipMemcpyHostToDevice));
+        g.gamma = dG; g.res = dR; g.r_bstride = (long)M * N; g.ldr = N;
+    }
+    if (flags & 128) {
+        SVA_CHECK(M % 170 == 0 && !(flags & 2), "test_gemm_planes: the skip-rows case takes M = 170 b and an fp32 C");
+        g.T = 170; g.a_bstride = (long)170 * K; g.c_bstride = (long)170 * Nout; g.r_bstride = (long)170 * N; g.skip_lo = 56; g.skip_hi = 62;
+        std::vector<float> mark((size_t)M * Nout, -77.f);
+        SVA_HIP(hipMemcpy(dC, mark.data(), sizeof(float) * mark.size(), hipMemcpyHostToDevice));
+    }
     int* h_ovf = nullptr;
     if (flags & 16) {       // the range check of the fp16 formats: a non-finite output is an error of the call
         SVA_HIP(hipHostMalloc((void**)&h_ovf, sizeof(int), hipHostMallocMapped));
@@ -332,17 +356,18 @@ extern "C" int sva_test_gemm_planes(int device, int M, int N, int K, const float
     if (flags & 2) {
         std::vector<uint16_t> hp((size_t)npl * M * N);
         SVA_HIP(hipMemcpy(hp.data(), dCp, hp.size() * 2, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < (size_t)M * N; ++i) {
+        for (size_t i = 0; i < (size_t)M * Nout; ++i) {
             float s = 0.f;
+            const size_t row = i / Nout, col = i % Nout;
+            const size_t bo = ((col >> 5) * (size_t)M + row) * 32 + (col & 31);          // K-blocked (planes_split.h)
             for (int p = npl - 1; p >= 0; --p) {
-                const uint16_t bits = hp[(size_t)p * M * N + i];
-                if (mode == PLANES_S6) { const uint32_t u = (uint32_t)bits << 16; float f; memcpy(&f, &u, 4); s += f; }
-                else { _Float16 h; memcpy(&h, &bits, 2); s += (float)h; }
+                const uint16_t bits = hp[(size_t)p * M * Nout + bo];
+                _Float16 h; memcpy(&h, &bits, 2); s += (float)h;
             }
             C[i] = s;
         }
     } else {
-        SVA_HIP(hipMemcpy(C, dC, sizeof(float) * (size_t)M * N, hipMemcpyDeviceToHost));
+        SVA_HIP(hipMemcpy(C, dC, sizeof(float) * (size_t)M * Nout, hipMemcpyDeviceToHost));
     }
     if (iters > 0 && out_us) {
         hipEvent_t e0, e1;
@@ -361,5 +386,7 @@ extern "C" int sva_test_gemm_planes(int device, int M, int N, int K, const float
     if (dB) (void)hipFree(dB);
     if (dAp) (void)hipFree(dAp);
     if (dCp) (void)hipFree(dCp);
+    if (dG) (void)hipFree(dG);
+    if (dR) (void)hipFree(dR);
     return 0;
 }

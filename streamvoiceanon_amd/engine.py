@@ -500,17 +500,21 @@ def test_gemm_f16w(A, W, bias=None, rms_w=None, res=None, swiglu=False, iters=0,
     return out, float(us[0])
 
 
-def test_gemm_planes(A, W, bias=None, mode=1, variant=0, a_planes=False, c_planes=False, gelu=False, silu=False, iters=0, device=0, range_check=False):
-    """The planes GEMM (csrc/gemm_planes.hip): epi(A @ W.T) with both operands as pre-split 16-bit planes.  Returns (C, us_per_launch)."""
+def test_gemm_planes(A, W, bias=None, mode=1, variant=0, a_planes=False, c_planes=False, gelu=False, silu=False, iters=0, device=0, range_check=False,
+                     swiglu=False, gamma_res=False, skip_rows=False):
+    """The planes GEMM (csrc/gemm_planes.hip): epi(A @ W.T) with both operands as pre-split 16-bit planes.  Returns (C, us_per_launch).
+    swiglu: W rows interleave w1 | w3 in groups of 16, C is [M, N / 2]; gamma_res: C = gamma * (.) + residual with gamma[i] = 0.5 + 0.001 ((37 i) % 101),
+    residual.flat[i] = 0.01 ((13 i) % 257) - 1; skip_rows (M = 170 b): rows 56..61 of every 170-row item are left at the marker -77."""
     lib = load_library()
     A = np.ascontiguousarray(A, dtype=np.float32)
     W = np.ascontiguousarray(W, dtype=np.float32)
     M, K = A.shape
     N = W.shape[0]
-    out = np.empty((M, N), dtype=np.float32)
+    out = np.empty((M, N // 2 if swiglu else N), dtype=np.float32)
     b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
     us = np.zeros(1, dtype=np.float32)
-    flags = (1 if a_planes else 0) | (2 if c_planes else 0) | (4 if gelu else 0) | (8 if silu else 0) | (16 if range_check else 0)
+    flags = ((1 if a_planes else 0) | (2 if c_planes else 0) | (4 if gelu else 0) | (8 if silu else 0) | (16 if range_check else 0) | (32 if swiglu else 0) |
+             (64 if gamma_res else 0) | (128 if skip_rows else 0))
     _check(lib.sva_test_gemm_planes(device, M, N, K, _ptr(A), _ptr(W), _ptr(b), _ptr(out), int(mode), int(variant), flags, int(iters), _ptr(us)),
            "sva_test_gemm_planes")
     return out, float(us[0])

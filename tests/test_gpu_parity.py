@@ -1816,23 +1816,29 @@ def test_batched_persistent_decode_equals_multi_launch(eng, eng_fp16, B, fp16):
 
 def test_planes_gemm_every_mode_vs_fp64():
     """csrc/gemm_planes.hip: every precision format x tile variant x operand form (A as fp32 or as planes, C as fp32 or as planes
-    only) against an fp64 product on ragged shapes.  S6 (three bf16 planes, six products) and H3 (two fp16 planes, three products)
-    are fp32-grade; H1 (one fp16 plane) is the reference's torch.autocast(fp16) precision."""
+    only) against an fp64 product on ragged shapes.  H3 (two fp16 planes, three products) is fp32-grade; H1 (one fp16 plane) is the
+    reference's torch.autocast(fp16) precision.  Variants 8 / 9 are the persistent LDS-DMA form (A as planes, N % 128 == 0)."""
     from streamvoiceanon_amd import engine as E
 
     rng = np.random.default_rng(11)
-    for (M, N, K) in ((200, 192, 256), (515, 288, 128), (160, 320, 384), (1030, 132, 96)):
+    for (M, N, K) in ((200, 192, 256), (515, 288, 128), (160, 320, 384), (1030, 132, 96), (700, 256, 160), (300, 128, 64)):
         A = rng.standard_normal((M, K)).astype(np.float32)
         W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
         bias = rng.standard_normal(N).astype(np.float32)
         ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
         scale = np.abs(ref).max()
-        for mode in (0, 1, 2):
-            for variant in range(8):
+        for mode in (1, 2):
+            for variant in range(11):
                 if (variant in (0, 1, 4, 7) and M < 128) or (variant in (0, 2, 4, 6, 7) and N < 128) or (variant == 6 and M < 256):
                     continue
+                if variant >= 8 and N % 128:
+                    continue
                 for ap in (False, True):
+                    if variant >= 8 and not ap:
+                        continue
                     for cp in (False, True):
+                        if cp and N % 32:          # (output planes are K-blocked for the consumer GEMM: whole 32-column blocks)
+                            continue
                         out, _ = E.test_gemm_planes(A, W, bias=bias, mode=mode, variant=variant, a_planes=ap, c_planes=cp)
                         err = np.abs(out - ref).max() / scale
                         # fp32-grade: a few fp32 roundings of the largest output; planes-only output adds its own 2^-23 / 2^-24 split error.
@@ -1846,18 +1852,92 @@ def test_planes_gemm_every_mode_vs_fp64():
     g64 = a64 @ w64.T
     gel = 0.5 * g64 * (1.0 + torch.erf(torch.from_numpy(g64) / np.sqrt(2.0)).numpy())
     sil = (a64 / (1.0 + np.exp(-a64))) @ w64.T
-    for mode in (0, 1):
-        out, _ = E.test_gemm_planes(A, W, mode=mode, variant=3, gelu=True, c_planes=True)
-        assert np.abs(out - gel).max() / np.abs(gel).max() <= 3e-6, mode
-        out, _ = E.test_gemm_planes(A, W, mode=mode, variant=3, silu=True)
-        assert np.abs(out - sil).max() / np.abs(sil).max() <= 3e-6, mode
+    out, _ = E.test_gemm_planes(A, W, mode=1, variant=3, gelu=True, c_planes=True)
+    assert np.abs(out - gel).max() / np.abs(gel).max() <= 3e-6
+    out, _ = E.test_gemm_planes(A, W, mode=1, variant=3, silu=True)
+    assert np.abs(out - sil).max() / np.abs(sil).max() <= 3e-6
 
 
-@pytest.mark.parametrize("mm_mode", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 6, 8, 9, 10])
+def test_planes_gemm_epilogues_vs_fp64(variant):
+    """The epilogues the encoder hands to the planes GEMM at batch scale, per kernel form (0 / 6: register-staged tiles with the epilogue
+    through LDS; 8 / 9: the persistent LDS-DMA form whose epilogue works on TRANSPOSED accumulators in registers): GELU into output planes
+    (pwconv1, firefly.py:421-440), gamma * (.) + residual with unstored history rows (pwconv2 of the merged encoder pass), SwiGLU of
+    interleaved w1 | w3 column groups into output planes (windowed_transformer.py:134-143), a tile sequence longer than the grid
+    (several tiles per workgroup: the stream crosses tile boundaries), K = one step and K = 48 steps."""
+    from streamvoiceanon_amd import engine as E
+
+    rng = np.random.default_rng(100 + variant)
+
+    def gelu64(x):
+        return 0.5 * x * (1.0 + torch.erf(torch.from_numpy(x) / np.sqrt(2.0)).numpy())
+
+    for (M, N, K) in ((170 * 4, 384, 96), (170 * 2, 256, 32), (170 * 6, 128, 1536)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) * (1.0 / np.sqrt(K))).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        a64, w64 = A.astype(np.float64), W.astype(np.float64)
+        g64 = a64 @ w64.T + bias
+        out, _ = E.test_gemm_planes(A, W, bias=bias, mode=1, variant=variant, a_planes=True, c_planes=True, gelu=True)
+        assert np.abs(out - gelu64(g64)).max() / np.abs(g64).max() <= 3e-6, ("gelu", M, N, K)
+        gamma = 0.5 + 0.001 * ((np.arange(N) * 37) % 101)
+        res = (0.01 * ((np.arange(M * N) * 13) % 257) - 1.0).reshape(M, N)
+        want = gamma * g64 + res
+        out, _ = E.test_gemm_planes(A, W, bias=bias, mode=1, variant=variant, a_planes=True, gamma_res=True, skip_rows=True)
+        t = np.arange(M) % 170
+        skipped = (t >= 56) & (t < 62)
+        assert np.all(out[skipped] == -77.0), "history rows must not be stored"
+        assert np.abs(out[~skipped] - want[~skipped]).max() / np.abs(want).max() <= 3e-6, ("gamma_res", M, N, K)
+        # SwiGLU: W rows interleave 16 x w1 | 16 x w3
+        nn = np.arange(N)
+        w1r, w3r = nn[(nn // 16) % 2 == 0], nn[(nn // 16) % 2 == 1]
+        g0 = a64 @ w64.T
+        want = (g0[:, w1r] / (1.0 + np.exp(-g0[:, w1r]))) * g0[:, w3r]
+        for cp in (False, True):
+            out, _ = E.test_gemm_planes(A, W, mode=1, variant=variant, a_planes=True, c_planes=cp, swiglu=True)
+            assert out.shape == (M, N // 2)
+            assert np.abs(out - want).max() / np.abs(want).max() <= 4e-6, ("swiglu", M, N, K, cp)
+    # many tiles per workgroup: 85 x 12 = 1020 (128-row) / 43 x 12 = 516 (256-row) tiles on 256 CUs, ragged last row tile
+    M, N, K = 10880, 1536, 384
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    out, _ = E.test_gemm_planes(A, W, mode=1, variant=variant, a_planes=True)
+    assert np.abs(out - ref).max() / np.abs(ref).max() <= 3e-6
+    for _ in range(3):          # launch-to-launch bit equality (a pipeline hazard shows up as a rare wrong tile)
+        out2, _ = E.test_gemm_planes(A, W, mode=1, variant=variant, a_planes=True)
+        np.testing.assert_array_equal(out, out2)
+
+
+def test_planes_gemm_small_activations_absolute_floor():
+    """H3's split x = hi + lo is relative (2^-23 |x|) only while lo is a normal fp16; activation planes carry no scale, so activations of
+    1e-3 .. 1e-4 keep an ABSOLUTE error floor of ~2^-25 per element (header of gemm_planes.hip).  Stated as a test: with every
+    activation that small the GEMM's error is bounded by 2^-24 * sum_k |w_k| (absolute), NOT by 3e-6 of the output -- and with O(1)
+    activations mixed in (what LayerNorm / GELU / SwiGLU outputs look like) the small ones do not show."""
+    from streamvoiceanon_amd import engine as E
+
+    rng = np.random.default_rng(5)
+    M, N, K = 512, 256, 512
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    wabs = np.abs(W.astype(np.float64)).sum(1)
+    small = (rng.standard_normal((M, K)) * 3e-4).astype(np.float32)
+    for variant, ap in ((0, False), (0, True), (8, True), (10, True)):
+        out, _ = E.test_gemm_planes(small, W, mode=1, variant=variant, a_planes=ap)
+        ref = small.astype(np.float64) @ W.astype(np.float64).T
+        err = np.abs(out - ref)
+        assert (err <= 2.0 ** -24 * wabs[None, :] + 3e-6 * np.abs(ref)).all(), (variant, ap, err.max())
+        mixed = small.copy()
+        mixed[:, ::7] = rng.standard_normal((M, (K + 6) // 7)).astype(np.float32)
+        out, _ = E.test_gemm_planes(mixed, W, mode=1, variant=variant, a_planes=ap)
+        ref = mixed.astype(np.float64) @ W.astype(np.float64).T
+        assert np.abs(out - ref).max() / np.abs(ref).max() <= 3e-6, (variant, ap)
+
+
+@pytest.mark.parametrize("mm_mode", [0, 1])
 def test_mm_modes_batch64_vs_reference_golden(weights0, mm_mode):
     """The fp32-grade batch-scale GEMM formats of sva_config.mm_mode (0: bf16 parts split in the K loop, six products -- round 3's
-    kernel; 1: pre-split fp16 planes, three products, the ConvNeXt and FFN hidden tensors handed over as planes -- the default;
-    2: pre-split bf16 planes, six products): 64 copies of the fixture utterance in one batch (10880-row encoder passes, 8192-row
+    kernel; 1: pre-split fp16 planes, three products, every big GEMM's operands handed over as planes, the persistent LDS-DMA kernel --
+    the default): 64 copies of the fixture utterance in one batch (10880-row encoder passes, 8192-row
     transformer passes: the sizes the planes kernel serves) reproduce the reference fixture -- content codes and audio codes
     identical, PCM within the fp32 tolerance."""
     from streamvoiceanon_amd import engine as E
@@ -2052,7 +2132,7 @@ def test_f16w_stress_tool_is_clean():
 def test_fp16_planes_range_check_reports_an_operand_beyond_the_fp16_range():
     """The default batch-scale GEMM format (sva_config.mm_mode = 1: fp16 operand planes) has fp16's range, like the reference under
     torch.autocast(fp16).  An operand beyond +-65504 must not propagate silently: the kernel raises a host-visible flag on a non-finite
-    output (sva_sync of a batch fails and names mm_mode = 0; here through the unit hook).  The bf16 format takes the same operand."""
+    output (sva_sync / the next step of a batch fails and names mm_mode = 0; here through the unit hook), in every kernel form."""
     from streamvoiceanon_amd import engine as E
 
     rng = np.random.default_rng(3)
@@ -2061,9 +2141,6 @@ def test_fp16_planes_range_check_reports_an_operand_beyond_the_fp16_range():
     out, _ = E.test_gemm_planes(A, W, mode=1, variant=3, range_check=True)          # in range: fine
     assert np.isfinite(out).all()
     A[17, 5] = 1.0e5
-    for mode in (1, 2):
+    for mode, variant, ap in ((1, 3, False), (2, 3, False), (1, 8, True), (1, 9, True), (1, 10, True)):
         with pytest.raises(RuntimeError, match="non-finite"):
-            E.test_gemm_planes(A, W, mode=mode, variant=3, range_check=True)
-    ref = A.astype(np.float64) @ W.astype(np.float64).T
-    out, _ = E.test_gemm_planes(A, W, mode=0, variant=3, range_check=True)          # bf16 x 3: fp32's range
-    assert np.abs(out - ref).max() <= 3e-6 * np.abs(ref).max()
+            E.test_gemm_planes(A, W, mode=mode, variant=variant, a_planes=ap, range_check=True)

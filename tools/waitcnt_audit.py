@@ -19,7 +19,7 @@ def h(a):
 W = sw.generate_all(0, specs.all_specs(prompt_path=True))
 for ar_dtype in (0, 1):
     eng = E.Engine(W, ar_dtype=ar_dtype)
-    for B, chunk, steps, R in ((1, 1, 14, 107), (2, 1, 8, 60), (8, 1, 6, 60), (16, 4, 3, 80), (64, 1, 4, 107)):
+    for B, chunk, steps, R in ((1, 1, 14, 107), (2, 1, 8, 60), (8, 1, 6, 60), (12, 1, 6, 60), (16, 1, 5, 60), (24, 1, 4, 60), (16, 4, 3, 80), (64, 1, 4, 107)):
         b = E.Batch(eng, n_streams=B, chunk_frames=chunk)
         for s in range(B):
             ac, cc, style, timbre = synth_prompt(2000 + s % 3, R)
@@ -31,7 +31,7 @@ for ar_dtype in (0, 1):
         for i in range(steps):
             pcm.append(b.step(np.stack([x[i * n:(i + 1) * n] for x in srcs])))
         codes = np.stack([b.pred_codes(s) for s in range(B)])
-        print(f"ar_dtype={ar_dtype} B={B} chunk={chunk}: codes {h(codes)} pcm {h(np.stack(pcm))} content {h(b.tap('content_codes', (B, chunk), np.int32))}", flush=True)
+        print(f"ar_dtype={ar_dtype} B={B} chunk={chunk} decode_path={b.decode_path()}: codes {h(codes)} pcm {h(np.stack(pcm))} content {h(b.tap('content_codes', (B, chunk), np.int32))}", flush=True)
         b.close()
     # offline path + whole-utterance seams + re-prefill inside a stream
     ac, cc, style, timbre = synth_prompt(2100, 168)
@@ -55,19 +55,13 @@ for ar_dtype in (0, 1):
     eng.close()
 
 # round 4: the fp16-operand vocoder (gemm_planes.hip, one plane), the range-safe bf16 kernels at batch scale, a whole batch re-prefilling
-# in one pass, the group form of the persistent kernel
+# in one pass
 lib = E.load_library()
-cases = [("voc_dtype=1", dict(voc_dtype=1), ""), ("mm_mode=0", dict(mm_mode=0), ""), ("mm_mode=2", dict(mm_mode=2), "")]
-if not os.environ.get("AUDIT_SKIP_GROUP"):      # (ar_group.hip, like ar_batch.hip, raises an illegal-instruction fault when built with forcezero)
-    cases.append(("ar_group=1", {}, "ar_group=1"))
-for tag, kw, dbg in cases:
+cases = [("voc_dtype=1", dict(voc_dtype=1)), ("mm_mode=0", dict(mm_mode=0))]
+for tag, kw in cases:
     eng = E.Engine(W, **kw)
-    for B, steps, msf in ((64, 4, 768), (3, 6, 768), (16, 40, 100)) if not dbg else ((2, 6, 768), (3, 6, 768), (4, 6, 768)):
-        if dbg:
-            lib.sva_debug_configure(dbg.encode())
+    for B, steps, msf in ((64, 4, 768), (3, 6, 768), (16, 40, 100)):
         b = E.Batch(eng, n_streams=B, max_seq_frames=msf, buffer_frames=32)
-        if dbg:
-            lib.sva_debug_configure(b"ar_group=0")
         for s in range(B):
             ac, cc, style, timbre = synth_prompt(2000 + s % 3, 60)
             b.prefill_prompt(s, cc, ac, style, timbre, noise_seed=1000 + s)
