@@ -52,7 +52,12 @@ def parse():
     ap.add_argument("--ar-dtype", type=int, default=0, choices=(0, 1),
                     help="0: fp32 AR weights + fp32 KV (parity mode, the headline); 1: fp16 AR weights + fp16 slow KV cache, as the "
                          "reference decodes under torch.autocast(fp16) (evaluations/infer_arvc.py:55-59, 483)")
-    ap.add_argument("--mm-mode", type=int, default=None, choices=(0, 1, 2),
+    ap.add_argument("--config", type=int, default=None, choices=(4, 5),
+                    help="build BASELINE.json configs[3] / configs[4] exactly (1-based 4 / 5), per GPU: 4 = 64 concurrent 10 s utterances, chunk 1 "
+                         "(512 over 8 GPUs); 5 = the anonymisation path, 32 utterances, chunk 4, alpha = 0.7 noise-mixed speaker embeddings of a prompt "
+                         "made of three concatenated references (256 over 8 GPUs).  Sets --streams / --chunk / the prompt; --steps defaults to the "
+                         "whole utterance (216 / 54 chunk-steps); combine with --gpus N")
+    ap.add_argument("--mm-mode", type=int, default=None, choices=(0, 1),
                     help="sva_config.mm_mode (default: the library's): batch-scale encoder / vocoder GEMM format, csrc/gemm_planes.hip")
     ap.add_argument("--voc-dtype", type=int, default=None, choices=(0, 1),
                     help="sva_config.voc_dtype: 1 = fp16-operand vocoder GEMMs, the reference's autocast precision (infer_arvc.py:493)")
@@ -132,6 +137,36 @@ def cpu_baseline(args, W):
     }
 
 
+def offline_cpu_baseline(W, threads):
+    """BASELINE.json configs[0]'s own leg: OFFLINE infer (evaluations/infer_arvc.py:261-380) on the host cores through the oracle -- whole-utterance
+    content encode, DualARWrapper.generate (prompt prefill + S decode steps), whole-utterance vocode -- for the shape the GPU `offline` block runs
+    (prompt R = 168, source S = 153 frames).  A bounded sample by construction (one 7.1 s utterance, ~15-25 s of CPU work)."""
+    import torch
+
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(threads)
+    R, S = 168, 153
+    ac, cc, style, timbre = synth_prompt(2100, R)
+    src = torch.from_numpy(synth_utterance(1100, 2048 * S))[None]
+    t0 = time.perf_counter()
+    src_codes = O.encode_window(src, W)[0, 0]
+    t1 = time.perf_counter()
+    ar = O.DualAR(W)
+    codes = ar.generate(torch.from_numpy(cc), torch.from_numpy(ac), src_codes, torch.from_numpy(style), torch.from_numpy(timbre), 2,
+                        noise_fn=lambda s_: tuple(torch.from_numpy(a) for a in frame_noise(7, s_)))
+    t2 = time.perf_counter()
+    wav = O.vocode_window(codes.long(), W)
+    t3 = time.perf_counter()
+    tot = t3 - t0
+    return {"value": round(S / tot, 3), "unit": "frames/s", "cores": threads, "kind": "port", "total_ms": round(tot * 1e3, 1),
+            "encode_ms": round((t1 - t0) * 1e3, 1), "generate_ms": round((t2 - t1) * 1e3, 1), "vocode_ms": round((t3 - t2) * 1e3, 1),
+            "rtf": round(tot / (S * FRAME_S), 4), "pcm_samples": int(wav.numel()),
+            "sample": f"one offline utterance, R = {R} / S = {S} frames ({S * FRAME_S:.2f} s of audio), oracle restatement on {threads} intra-op threads, fp32"}
+
+
 def torch_gpu_baseline(args, W, steps=20):
     """Second baseline: the reference's FORMULATION run by PyTorch-ROCm eager on the same MI355X -- the oracle
     (the reference itself cannot travel to the GPU box) with its tensors on cuda:0, i.e. sliding-window recompute of encoder
@@ -141,6 +176,8 @@ def torch_gpu_baseline(args, W, steps=20):
     from oracle import sva_oracle as O
     from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
 
+    os.environ.setdefault("MIOPEN_LOG_LEVEL", "1")          # (its workspace warnings on every conv of the eager leg bury the JSON line in a log tail)
+    os.environ.setdefault("MIOPEN_ENABLE_LOGGING", "0")
     dev = torch.device("cuda")
     Wd = {k: v.to(dev) for k, v in W.items()}
     useed = 1000
@@ -541,6 +578,12 @@ def main():
     from streamvoiceanon_amd.sharding import gather_results, shard_utterances
     from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
 
+    if args.config == 4:
+        args.streams, args.chunk = 64, 1
+    elif args.config == 5:
+        args.streams, args.chunk = 32, 4
+    if args.config and "--steps" not in sys.argv:
+        args.steps = (216 if args.config == 4 else 54) - args.warmup - 4          # 10 s = 215.3 frames; delay fill and warm-up come out of the utterance
     B, c = args.streams, args.chunk
     n = 2048 * c
     W = synth_weights.generate_all(0, specs.all_specs())
@@ -555,7 +598,20 @@ def main():
         # utterances are global ids sharded over ranks (weak scaling: B per rank)
         my_utts = shard_utterances(list(range(world * B)), world)[rank]
         for s_, u in enumerate(my_utts):
-            ac, cc, style, timbre = synth_prompt(2000 + u, args.prompt_frames)
+            if args.config == 5:
+                # three references concatenated (concat_mel semantics, evaluations/infer_arvc.py:413-424), speaker embeddings of the first one
+                # noise-mixed with alpha = 0.7 (:228-232: alpha x + (1 - alpha)(randn std + mean)); the Gaussian is keyed by the utterance id
+                parts = [synth_prompt(2000 + 10 * u + j, args.prompt_frames // 3) for j in range(3)]
+                ac = np.concatenate([p_[0] for p_ in parts], axis=1)
+                cc = np.concatenate([p_[1] for p_ in parts])
+                gen = torch.Generator().manual_seed(500 + u)
+
+                def mix(x, alpha=0.7):
+                    t = torch.from_numpy(x)
+                    return (alpha * t + (1 - alpha) * (torch.randn(t.shape, generator=gen) * t.std() + t.mean())).numpy()
+                style, timbre = mix(parts[0][2]), mix(parts[0][3])
+            else:
+                ac, cc, style, timbre = synth_prompt(2000 + u, args.prompt_frames)
             batch.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=1000 + u)
         batch.begin()
         n_delay = (2 + c - 1) // c              # chunks that only fill the delay (return zeros)
@@ -744,7 +800,8 @@ def main():
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if not args.ar_dtype else "f32 (encoder, vocoder) / f16 weights + f16 KV, f32 accumulate (AR)", "data": "synthetic",
-        "config": {"workload": f"infer_arvc --simulate_streaming --decode_chunk_frames {c}, delay=2, {B} stream(s) per GPU, "
+        "config": {"workload": ("" if not args.config else f"BASELINE.json configs[{args.config - 1}] per-GPU shape" + (", alpha = 0.7, three concatenated references" if args.config == 5 else "") + ": ") +
+                               f"infer_arvc --simulate_streaming --decode_chunk_frames {c}, delay=2, {B} stream(s) per GPU, "
                                f"encode window 128 / vocoder window 64 frames, synthetic 44.1 kHz speech-like audio, "
                                f"synthetic prompt R={args.prompt_frames}, random-init weights of the reference architecture",
                    "streams_per_gpu": B, "chunk_frames": c, "parallelism": f"utterance-parallel x{world}",
@@ -753,6 +810,8 @@ def main():
                    "stage_pipelining": bool(args.pipeline) and not args.graph, "mm_mode": int(eng.cfg.mm_mode), "voc_dtype": int(eng.cfg.voc_dtype), "skip_semantic_head": bool(args.skip_semantic),
                    "enqueue_thread": pin_info or None},
         "rtf": round(ms * 1e-3 / (c * FRAME_S), 5), "x_realtime": round(fps * FRAME_S, 2),
+        # what a caller that waits for every chunk sees (the reference's process_one_chunk contract): median synchronous latency / chunk duration
+        "rtf_live": round(extra["sync_latency_ms"]["p50"] * 1e-3 / (c * FRAME_S), 5), "sync_latency_p50_ms": extra["sync_latency_ms"]["p50"],
         "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm.items()},
         "gathered_utterances": n_gathered,
     }
@@ -818,7 +877,14 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         os.sched_setaffinity(0, cpus_at_start)      # the CPU leg uses all host cores again
         import torch as _t
-        out["cpu_baseline"] = cpu_baseline(args, {k: _t.from_numpy(v) for k, v in W.items()})
+        Wt = {k: _t.from_numpy(v) for k, v in W.items()}
+        out["cpu_baseline"] = cpu_baseline(args, Wt)
+        if args.offline and isinstance(out.get("offline"), dict) and "error" not in out["offline"]:
+            try:
+                out["offline"]["cpu_baseline"] = offline_cpu_baseline(Wt, out["cpu_baseline"]["cores"])
+                out["offline_vs_cpu"] = round(out["offline"]["cpu_baseline"]["total_ms"] / out["offline"]["total_ms"], 1)
+            except Exception as ex:
+                out["offline"]["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if world == 1 and args.torch_gpu_baseline:
         import torch as _t
         eng.close()
@@ -838,6 +904,10 @@ def main():
         r64 = b64.get("roofline") or {}
         out["b64"] = {"ms_per_step": b64["ms_per_step"], "value": b64["value"], "unit": "frames/s", "frac_of_own_pipes": r64.get("frac_of_own_pipes"),
                       "stage_ms": b64["stage_ms_last_step"]}
+        # ... and flat scalar keys (a parser that keeps top-level scalars keeps these)
+        out["b64_frames_per_s"], out["b64_ms_per_step"], out["b64_frac_of_own_pipes"] = b64["value"], b64["ms_per_step"], r64.get("frac_of_own_pipes")
+        for k_, v_ in b64["stage_ms_last_step"].items():
+            out[f"b64_{k_}_ms"] = v_
     print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()

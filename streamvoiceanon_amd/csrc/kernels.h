@@ -34,8 +34,10 @@ int launch_rmsnorm_rows(const float* x, long x_bstride, long x_off, int ldx, int
 
 // causal self-attention of the BSQ pre-transformer: qkv [B, T, 3*D] -> out [B, T, D]; RoPE
 // (adjacent pairs, bf16-rounded table rope[T][hd/2][2]) applied to q and k on load.
+//   outp != null (T <= 128 only, enc_attention_can_write_planes): planes output as launch_dwconv7_ln
+bool enc_attention_can_write_planes(int T);
 int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out, int row0,
-                         hipStream_t st);
+                         hipStream_t st, unsigned short* outp = nullptr, long op_pstride = 0, int op_planes = 0, long op_rows = 0);
 
 // BSQ: u = W z + b (nbits x C), index = sum_d (u_d > 0) << (nbits-1-d); optional L2-normalised u out.
 int launch_bsq(const float* z, long z_bstride, long z_off, int ldz, int B, int T, int C, const float* norm_w /*fused RMSNorm or null*/,

@@ -387,7 +387,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 __global__ __launch_bounds__(256) void enc_attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rope,
-                                                                 int T, int H, float* __restrict__ out, int row0) {
+                                                                 int T, int H, float* __restrict__ out, int row0,
+                                                                 unsigned short* __restrict__ outp, long op_pstride, int op_planes, long op_rows) {
     constexpr int HD = 64, LK = HD + 4, NTM = 8;          // up to 8 key tiles (T <= 128)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LV = T + 4;
@@ -487,6 +488,17 @@ __global__ __launch_bounds__(256) void enc_attention_mfma_kernel(const float* __
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float inv = 1.f / sum[r];
+            if (outp) {          // the output projection takes its A operand as K-blocked planes (planes_split.h)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    unsigned short hi, lo;
+                    h3_split(o[dt][r] * inv, hi, lo);
+                    const long po = plane_off_blocked((long)b * T + r0 + 4 * fk + r, h * HD + dt * 16 + fr, op_rows);
+                    outp[po] = hi;
+                    if (op_planes > 1) outp[op_pstride + po] = lo;
+                }
+                continue;
+            }
             float* orow = out + ((long)b * T + r0 + 4 * fk + r) * D + h * HD + fr;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) orow[dt * 16] = o[dt][r] * inv;
@@ -560,8 +572,11 @@ __global__ __launch_bounds__(256) void enc_attention_flash_kernel(const float* _
     if (r0 + wave < T) out[((long)b * T + r) * D + h * HD + lane] = o / l;
 }
 
-int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out, int row0, hipStream_t st) {
+bool enc_attention_can_write_planes(int T) { return T % 16 == 0 && T <= 128; }
+int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int H, int hd, float* out, int row0, hipStream_t st,
+                         unsigned short* outp, long op_pstride, int op_planes, long op_rows) {
     SVA_CHECK(hd == 64 && T % 4 == 0, "enc_attention: head_dim must be 64 and T a multiple of 4");
+    SVA_CHECK(!outp || enc_attention_can_write_planes(T), "enc_attention: planes output only from the <= 128-token MFMA kernel");
     if (T % 16 == 0 && T <= 128) {
         const size_t sm = ((size_t)T * 68 + 64 * (size_t)(T + 4) + 4 * 16 * (size_t)(T + 4)) * sizeof(float);
         static DeviceOnce attr_m;
@@ -572,7 +587,7 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
         const int tiles = T / 16 - row0 / 16;
         int qsplit = 1;                                    // more workgroups per (head, stream) while the chip is under-filled
         while (qsplit * 4 < tiles && (long)H * B * qsplit < 128) qsplit *= 2;
-        hipLaunchKernelGGL(enc_attention_mfma_kernel, dim3(H, B, qsplit), dim3(256), sm, st, qkv, rope, T, H, out, row0);
+        hipLaunchKernelGGL(enc_attention_mfma_kernel, dim3(H, B, qsplit), dim3(256), sm, st, qkv, rope, T, H, out, row0, outp, op_pstride, op_planes, op_rows);
         SVA_HIP(hipGetLastError());
         return 0;
     }

@@ -428,8 +428,14 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows, int part) {
             SVA_TRY(launch_rmsnorm_rows(xr, xr_bs, xr_off, D, B, T2, D, L.attn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st));
             SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D));
         }
-        SVA_TRY(launch_enc_attention(b->tr_qkv, e->rope_enc, B, T2, c.tr_heads, 64, b->tr_att, r0, st));
         ConvGemm po;
+        if (planes_input(L.wo, (long)B * Tr) && enc_attention_can_write_planes(T2)) {          // attention output as operand planes (in tr_att's own memory)
+            po.Ap = reinterpret_cast<unsigned short*>(b->tr_att); po.ap_pstride = (long)B * T2 * D; po.ap_rows = (long)B * T2;
+            SVA_TRY(launch_enc_attention(b->tr_qkv, e->rope_enc, B, T2, c.tr_heads, 64, b->tr_att, r0, st,
+                                         reinterpret_cast<unsigned short*>(b->tr_att), po.ap_pstride, planes_count(L.wo.pmode), po.ap_rows));
+        } else {
+            SVA_TRY(launch_enc_attention(b->tr_qkv, e->rope_enc, B, T2, c.tr_heads, 64, b->tr_att, r0, st));
+        }
         po.gamma = L.ls_attn;
         po.res = xr; po.r_bstride = xr_bs; po.r_off = xr_off + (long)r0 * D; po.ldr = D;
         SVA_TRY(gemm_call(b, b->tr_att, (long)T2 * D, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.wo, xw, xw_bs, (long)r0 * D, D, po));

@@ -46,6 +46,47 @@ def gather_results(local, world: int, rank: int, dst: int = 0, force: bool = Fal
     return torch.cat(bufs, dim=0)
 
 
+def gather_ragged(items, world: int, rank: int, dst: int = 0, force: bool = False, pad_value=0):
+    """Gather per-utterance results of UNEQUAL length -- `items`: this rank's list of tensors [..., T_i] (same leading dims and dtype,
+    time last; e.g. int16 / int32 codes [8, T_i] of utterances of different durations, which is what LPT sharding by length produces,
+    and ranks may hold different NUMBERS of utterances) -- to `dst`.  Two fixed-shape collectives instead of a gather_object (device
+    tensors stay on the device, RCCL-friendly): all ranks agree on (max count, max T) with one all_reduce(MAX), every rank sends
+    [n_max, ..., T_max] padded with `pad_value` plus its lengths [n_max] (-1 = no utterance); `dst` cuts the padding off again.
+    Returns the list of tensors in rank-major order on `dst` (sharding.unshard maps it back to utterance order), None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    if (world == 1 and not force) or not dist.is_initialized():
+        return list(items)
+    assert len(items) > 0 or world > 1
+    dev = items[0].device if items else torch.device("cpu")
+    dims = torch.tensor([len(items), max((int(t.shape[-1]) for t in items), default=0)], dtype=torch.int64, device=dev)
+    dist.all_reduce(dims, op=dist.ReduceOp.MAX)
+    n_max, t_max = int(dims[0]), int(dims[1])
+    lead = tuple(items[0].shape[:-1]) if items else None
+    if lead is None:          # a rank without utterances still takes part: learn the leading dims from the root's view (all ranks share them)
+        raise ValueError("gather_ragged: every rank must hold at least one utterance (shard_utterances gives each rank one when n >= world)")
+    dtype = items[0].dtype
+    pad = torch.full((n_max,) + lead + (t_max,), pad_value, dtype=dtype, device=dev)
+    lens = torch.full((n_max,), -1, dtype=torch.int64, device=dev)
+    for i, t in enumerate(items):
+        pad[i, ..., : t.shape[-1]] = t
+        lens[i] = t.shape[-1]
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    lbufs = [torch.empty_like(lens) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    dist.gather(lens, lbufs, dst=dst)
+    if rank != dst:
+        return None
+    out = []
+    for r in range(world):
+        for i in range(n_max):
+            n = int(lbufs[r][i])
+            if n >= 0:
+                out.append(bufs[r][i, ..., :n])
+    return out
+
+
 def unshard(gathered_ids: List[List[int]]):
     """Permutation that maps the rank-major gather order back to global utterance order."""
     flat = [u for part in gathered_ids for u in part]

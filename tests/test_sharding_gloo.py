@@ -52,6 +52,54 @@ def _rank_main(rank, world, port, n_utts, q):
     dist.destroy_process_group()
 
 
+def _ragged_work(utt, length):
+    """[8, length] int32 result keyed by the utterance id only"""
+    rng = np.random.RandomState(100 + utt)
+    return torch.from_numpy(rng.randint(0, 1000, size=(8, length)).astype(np.int32))
+
+
+def _ragged_main(rank, world, port, lengths, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from streamvoiceanon_amd.sharding import gather_ragged, shard_utterances, unshard
+
+    ids = list(range(len(lengths)))
+    shards = shard_utterances(ids, world, lengths=lengths)          # LPT by length: ranks get different counts AND different lengths
+    mine = [_ragged_work(u, lengths[u]) for u in shards[rank]]
+    got = gather_ragged(mine, world, rank)
+    if rank == 0:
+        perm = unshard(shards)
+        q.put(([got[i].numpy() for i in perm], [len(s) for s in shards]))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ragged_gather_equals_single_process():
+    """Utterances of unequal length (what LPT sharding is for): per-rank counts differ (1 vs 4 here) and every utterance keeps its own
+    length through the gather -- the path configs[3] / configs[4] take when their utterances are not all 10 s long."""
+    lengths = [400, 90, 110, 95, 101]
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_main, args=(r, world, port, lengths, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, counts = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(counts) == [1, 4]
+    assert len(got) == len(lengths)
+    for u, n in enumerate(lengths):
+        assert got[u].shape == (8, n)
+        np.testing.assert_array_equal(got[u], _ragged_work(u, n).numpy())
+
+
 def test_shard_utterances_lpt():
     sys.path.insert(0, ROOT)
     from streamvoiceanon_amd.sharding import shard_utterances
