@@ -205,7 +205,8 @@ long sva_get_gemm_profile_table(sva_batch* b, double* out, long max_rows);
  * modules/bicodec_speaker_encoder/speaker_encoder.py:136-144) run once per utterance; the host mirror
  * (streamvoiceanon_amd/prompt_encoders.py) owns the activation buffers and the topology, these entry points do the arithmetic
  * on device arrays (channel-last rows [T][C], row strides in floats; every pointer below is a DEVICE pointer from sva_dev_alloc
- * unless it says host).  All of them run on the device's default stream, in call order. */
+ * unless it says host).  All of them run on ONE engine-owned stream, in call order (sva_dev_upload / _download are ordered with them and
+ * return when their copy is done). */
 int sva_dev_alloc(sva_engine* e, long n_floats, float** out);            /* zero-initialised */
 int sva_dev_free(sva_engine* e, float* p);
 int sva_dev_upload(sva_engine* e, float* dst, const float* host_src, long n_floats);
@@ -217,7 +218,7 @@ int sva_op_conv(sva_engine* e, const float* x, long ldx, int T, int stride, int 
 /* y = post(scale[c] * pre(x) + shift[c]); relu_mode 0 none, 1 ReLU after (batchnorm-relu), 2 ReLU before (Conv1dReluBn); eval-mode
  * BatchNorm arrives folded into scale / shift (either may be NULL) */
 int sva_op_affine(sva_engine* e, const float* x, long ldx, int T, int C, const float* scale, const float* shift, int relu_mode, float* y, long ldy);
-int sva_op_unary(sva_engine* e, float* x, long n, int op /* 1 log(max(x, p0)), 2 FSQ level-4 quantise, 3 sigmoid */, float p0);
+int sva_op_unary(sva_engine* e, float* x, long n, int op /* 1 log(max(x, p0)), 2 FSQ level-4 quantise, 3 sigmoid, 4 negate */, float p0);
 int sva_op_colstats(sva_engine* e, const float* x, long ldx, int T, int C, float* mean, float* std_or_null, int unbiased);
 int sva_op_cam_context(sva_engine* e, const float* y, long ldy, int T, int C, int seg_len, const float* mean, float* ctx, long ldc);   /* layers.py:103-119 */
 int sva_op_mul(sva_engine* e, float* y, long ldy, const float* m, long ldm /* 0 = broadcast one row */, int T, int C, int sigmoid);
@@ -231,6 +232,14 @@ int sva_op_stft_mag(sva_engine* e, const float* wave, long n, int n_fft, int win
 int sva_op_attention(sva_engine* e, const float* q, const float* kv, int Lq, int Lk, int n_valid, int H, float* out, float* scratch /* [Lq][H][Lk] */);
 int sva_op_geglu(sva_engine* e, const float* h, long ldh, int T, int Dh, float* out, long ldo);
 int sva_op_l2norm(sva_engine* e, const float* x, int T, int C, const float* gamma, float scale, float* y);
+/* The op sequence of one speaker-encoder call as a hipGraph: between _begin and _end the sva_op_* calls are recorded, not run (no
+ * sva_dev_alloc / _upload / _download in between); _end returns an executable graph that sva_ops_graph_launch replays on the ops stream.
+ * The reference computes these encoders once per utterance (evaluations/infer_arvc.py:179-223); the host mirror keeps one graph per
+ * reference length (prompt_encoders.py), ~600 launches -> 1. */
+int sva_ops_capture_begin(sva_engine* e);
+int sva_ops_capture_end(sva_engine* e, void** graph_exec);
+int sva_ops_graph_launch(sva_engine* e, void* graph_exec);
+int sva_ops_graph_free(sva_engine* e, void* graph_exec);
 
 /* Which decode the batch runs per frame: 1 = the persistent kernel of ar_decode.hip (two streams per launch: <= 6 streams, <= 4 with
  * ar_dtype = 1), 2 = the batched persistent kernel of ar_batch.hip (every stream of the batch in one launch: the larger batches), 0 = the

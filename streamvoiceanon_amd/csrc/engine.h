@@ -136,6 +136,7 @@ struct sva_engine {
     int device = 0;
     // persistent AR decode launches of DIFFERENT batches of this engine are chained (event): two half-resident persistent grids
     // waiting for each other's CUs would only end at their spin timeouts
+    hipStream_t ops_stream = nullptr;      // stream of the prompt-path primitives (prompt_ops.hip: created on first use), capturable
     hipEvent_t mega_ev = nullptr;          // created by sva_engine_finalize, destroyed with the engine
     bool mega_ev_valid = false;
     const void* mega_last = nullptr;       // (cleared when that batch is destroyed)
@@ -224,6 +225,7 @@ struct sva_batch {
     long long* d_ar_dbg = nullptr;         // SVA_AR_TIMING=1: phase timestamps of workgroup 0
     float* kv_fast_mega = nullptr;         // [4][8][2][768] fast-AR K/V scratch of the persistent kernel
     // batched persistent decode kernel (ar_batch.hip): every stream of the batch in ONE launch per frame
+    int enc_cus = 0;                       // CUs of the encoder / vocoder streams' mask when the batch is CU-partitioned (0: the whole device)
     bool use_abatch = false;
     int abatch_G = 0;                      // workgroups of its launch (all co-resident: checked at batch creation)
     unsigned long long* d_ab_gran = nullptr;      // hand-off granules, arrays at ab_offs (ar_batch_granule_words)

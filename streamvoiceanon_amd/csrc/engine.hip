@@ -165,7 +165,10 @@ static bool abatch_serves(int B, int ar_dtype, bool pipelined, int chunk) {
     const int mode = debug_options().ar_batch;
     if (mode == 0 || B > AR_BATCH_MAX_STREAMS) return false;
     if (mode == 2) return true;
-    const int hi = chunk > 1 ? 32 : (ar_dtype == 1 ? 11 : 24);
+    // (round 5, after the planes-DMA kernel shortened the encoder stage: at 32 fp32 streams the one-launch kernel unpartitioned gives 6416 frames/s / sync p50
+    // 9.5 ms against 5773 / 11.5 for the multi-launch chain on its 64-CU partition and 5638 / 9.2 unpartitioned; at 48 it loses, 5915 vs 7220 --
+    // profiles/r05_partition_sweep.txt)
+    const int hi = chunk > 1 ? 32 : (ar_dtype == 1 ? 11 : 32);
     return B >= abatch_lo(ar_dtype, pipelined) && B <= hi;
 }
 
@@ -240,6 +243,11 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         SVA_TRY(get_streams(e->device, !b->voc_grouped, part_streams, &ss, ar_cus));
         b->ar_cus = part_streams >= 1 ? ar_cus : 0;
         b->ar_partitioned = part_streams >= 1;
+        if (b->ar_partitioned) {
+            int cus = 0;
+            SVA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+            b->enc_cus = std::max(8, cus - ar_cus);
+        }
         b->stream = b->main_stream = ss.main;
         b->aux[0] = ss.aux0;
         b->aux[1] = b->voc_grouped ? nullptr : ss.aux1;

@@ -666,7 +666,7 @@ int launch_planes_dma_t(const ConvGemm& g, hipStream_t st) {
         if (MODE == PLANES_H3) SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<PLANES_H3, BM, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set.done();
     }
-    int cus = g_dma_cu_limit;
+    int cus = g.cu_limit > 0 ? g.cu_limit : g_dma_cu_limit;
     if (cus <= 0) {
         static int dev_cus = 0;
         if (dev_cus == 0) {

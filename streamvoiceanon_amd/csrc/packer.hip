@@ -61,6 +61,7 @@ extern "C" void sva_engine_destroy(sva_engine* e) {
     hipSetDevice(e->device);
     for (void* p : e->allocs.chunks) hipFree(p);
     if (e->mega_ev) (void)hipEventDestroy(e->mega_ev);
+    if (e->ops_stream) (void)hipStreamDestroy(e->ops_stream);
     delete e;
 }
 

@@ -36,33 +36,75 @@ __global__ void unary_kernel(float* __restrict__ x, long n, int op, float p0) {
         const float shift = atanhf(0.5f / half_l);
         v = rintf(tanhf(v + shift) * half_l - 0.5f) / 2.f;       // torch.round = round half to even = rintf
     } else if (op == 3) v = 1.f / (1.f + expf(-v));
+    else if (op == 4) v = -v;
     x[i] = v;
 }
 
 // column statistics over the T rows: mean[c], std[c] (unbiased or not)
-__global__ void colstats_kernel(const float* __restrict__ x, long ldx, int T, int C, float* __restrict__ mean, float* __restrict__ stdv, int unbiased) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int t = 0; t < T; ++t) s += (double)x[t * ldx + c];
-    const double m = s / T;
-    mean[c] = (float)m;
-    if (stdv) {
+// Block = 64 columns x CS_R row lanes: lane (c, r) sums rows r, r + CS_R, ... (two independent chains), the CS_R partials of a column are
+// added in lane order through LDS -- a fixed summation order, in double.  (Round 4's one-thread-per-column loop was a chain of T dependent
+// loads: 52 us per call, 54 calls per CAM++ pass -- 2.8 of the style encoder's 7 ms: profiles/r05_style_encoder_kernel_stats.csv)
+constexpr int CS_R = 8;
+__global__ __launch_bounds__(64 * CS_R) void colstats_kernel(const float* __restrict__ x, long ldx, int T, int C, float* __restrict__ mean, float* __restrict__ stdv, int unbiased) {
+    __shared__ double part[CS_R][64];
+    __shared__ double mu[64];
+    const int cx = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const bool on = c < C;
+    double s0 = 0.0, s1 = 0.0;
+    if (on) {
+        int t = r;
+        for (; t + CS_R < T; t += 2 * CS_R) { s0 += (double)x[t * ldx + c]; s1 += (double)x[(t + CS_R) * ldx + c]; }
+        if (t < T) s0 += (double)x[t * ldx + c];
+    }
+    part[r][cx] = s0 + s1;
+    __syncthreads();
+    if (r == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < CS_R; ++i) s += part[i][cx];
+        mu[cx] = s / T;
+        if (on) mean[c] = (float)mu[cx];
+    }
+    if (!stdv) return;
+    __syncthreads();
+    const double m = mu[cx];
+    double q0 = 0.0, q1 = 0.0;
+    if (on) {
+        int t = r;
+        for (; t + CS_R < T; t += 2 * CS_R) {
+            const double d0 = (double)x[t * ldx + c] - m, d1 = (double)x[(t + CS_R) * ldx + c] - m;
+            q0 += d0 * d0; q1 += d1 * d1;
+        }
+        if (t < T) { const double d0 = (double)x[t * ldx + c] - m; q0 += d0 * d0; }
+    }
+    __syncthreads();
+    part[r][cx] = q0 + q1;
+    __syncthreads();
+    if (r == 0 && on) {
         double q = 0.0;
-        for (int t = 0; t < T; ++t) { const double d = (double)x[t * ldx + c] - m; q += d * d; }
+#pragma unroll
+        for (int i = 0; i < CS_R; ++i) q += part[i][cx];
         stdv[c] = (float)sqrt(q / (unbiased ? (T - 1) : T));
     }
 }
 
 // CAMLayer context (modules/campplus/layers.py:103-119): ctx[t][c] = mean_t(y)[c] + mean over the 100-frame segment of t
-__global__ void cam_context_kernel(const float* __restrict__ y, long ldy, int T, int C, int seg, const float* __restrict__ mean, float* __restrict__ ctx, long ldc) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (c >= C) return;
+// (block = 64 columns x 4 row lanes; the four partial sums of a column are added in lane order)
+__global__ __launch_bounds__(256) void cam_context_kernel(const float* __restrict__ y, long ldy, int T, int C, int seg, const float* __restrict__ mean, float* __restrict__ ctx, long ldc) {
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx, s = blockIdx.y;
+    const bool on = c < C;
     const int lo = s * seg, hi = min(T, lo + seg);
     float a = 0.f;
-    for (int t = lo; t < hi; ++t) a += y[t * ldy + c];
-    a = a / (float)(hi - lo) + mean[c];                    // avg_pool1d(ceil_mode=True): the last window divides by its valid length
-    for (int t = lo; t < hi; ++t) ctx[t * ldc + c] = a;
+    if (on)
+        for (int t = lo + r; t < hi; t += 4) a += y[t * ldy + c];
+    part[r][cx] = a;
+    __syncthreads();
+    if (!on) return;
+    a = ((part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx])) / (float)(hi - lo) + mean[c];      // avg_pool1d(ceil_mode=True): the last window divides by its valid length
+    for (int t = lo + r; t < hi; t += 4) ctx[t * ldc + c] = a;
 }
 
 // y[t][c] *= (sig ? sigmoid(m) : m)[t * ldm + c]   (ldm = 0: one row broadcast over time -- SE connection)
@@ -234,16 +276,29 @@ inline unsigned nblk(long n, int th = 256) { return (unsigned)((n + th - 1) / th
 
 }  // namespace
 
+#define SVA_TRY_OPS(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+// Every op runs on the ENGINE'S ops stream (created on first use, non-blocking), in call order: a real stream can be captured into a
+// hipGraph (sva_ops_capture_*), the legacy default stream cannot.
+static int ops_stream(sva_engine* e, hipStream_t* out) {
+    if (!e->ops_stream) {
+        SVA_HIP(hipStreamCreateWithFlags(&e->ops_stream, hipStreamNonBlocking));
+        SVA_TRY_OPS(conv_gemm_prepare_stream(e->ops_stream));          // (split-K scratch up front: a launch inside a capture must not allocate)
+    }
+    *out = e->ops_stream;
+    return 0;
+}
 #define OPS_ENTER(e)                                   \
     SVA_CHECK((e) != nullptr, "null engine");          \
     SVA_HIP(hipSetDevice((e)->device));                \
-    (void)hipGetLastError();
+    (void)hipGetLastError();                           \
+    hipStream_t os_ = nullptr;                         \
+    { int rc_ = ops_stream((e), &os_); if (rc_) return rc_; }
 
 extern "C" int sva_dev_alloc(sva_engine* e, long n, float** out) {
     OPS_ENTER(e);
     SVA_CHECK(out && n > 0, "bad argument");
     SVA_HIP(hipMalloc((void**)out, sizeof(float) * (size_t)n));
-    SVA_HIP(hipMemset(*out, 0, sizeof(float) * (size_t)n));
+    SVA_HIP(hipMemsetAsync(*out, 0, sizeof(float) * (size_t)n, os_));
     return 0;
 }
 extern "C" int sva_dev_free(sva_engine* e, float* p) {
@@ -254,13 +309,14 @@ extern "C" int sva_dev_free(sva_engine* e, float* p) {
 }
 extern "C" int sva_dev_upload(sva_engine* e, float* dst, const float* src, long n) {
     OPS_ENTER(e);
-    SVA_HIP(hipMemcpy(dst, src, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpyAsync(dst, src, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, os_));
+    SVA_HIP(hipStreamSynchronize(os_));          // (src is the caller's pageable buffer)
     return 0;
 }
 extern "C" int sva_dev_download(sva_engine* e, float* dst, const float* src, long n) {
     OPS_ENTER(e);
-    SVA_HIP(hipDeviceSynchronize());
-    SVA_HIP(hipMemcpy(dst, src, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    SVA_HIP(hipMemcpyAsync(dst, src, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, os_));
+    SVA_HIP(hipStreamSynchronize(os_));
     return 0;
 }
 
@@ -274,45 +330,45 @@ extern "C" int sva_op_conv(sva_engine* e, const float* x, long ldx, int T, int s
         ConvGemm g;
         g.A = x; g.a_bstride = 0; g.a_off = 0; g.lda = (int)ldx; g.T = T; g.M = T; g.stride = stride; g.dil = dil; g.taps = taps; g.Cin = Cin;
         g.W = W; g.N = N; g.bias = bias; g.C = y; g.c_bstride = 0; g.c_off = 0; g.ldc = (int)ldy;
-        return launch_conv_gemm(g, 0);
+        return launch_conv_gemm(g, os_);
     }
-    hipLaunchKernelGGL(conv_naive_kernel, dim3(nblk((long)T * N)), dim3(256), 0, 0, x, ldx, T, stride, dil, taps, Cin, W, bias, N, y, ldy);
+    hipLaunchKernelGGL(conv_naive_kernel, dim3(nblk((long)T * N)), dim3(256), 0, os_, x, ldx, T, stride, dil, taps, Cin, W, bias, N, y, ldy);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int sva_op_affine(sva_engine* e, const float* x, long ldx, int T, int C, const float* scale, const float* shift, int relu_mode, float* y, long ldy) {
     OPS_ENTER(e);
-    hipLaunchKernelGGL(affine_kernel, dim3(nblk((long)T * C)), dim3(256), 0, 0, x, ldx, T, C, scale, shift, relu_mode, y, ldy);
+    hipLaunchKernelGGL(affine_kernel, dim3(nblk((long)T * C)), dim3(256), 0, os_, x, ldx, T, C, scale, shift, relu_mode, y, ldy);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int sva_op_unary(sva_engine* e, float* x, long n, int op, float p0) {
     OPS_ENTER(e);
-    hipLaunchKernelGGL(unary_kernel, dim3(nblk(n)), dim3(256), 0, 0, x, n, op, p0);
+    hipLaunchKernelGGL(unary_kernel, dim3(nblk(n)), dim3(256), 0, os_, x, n, op, p0);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int sva_op_colstats(sva_engine* e, const float* x, long ldx, int T, int C, float* mean, float* stdv, int unbiased) {
     OPS_ENTER(e);
-    hipLaunchKernelGGL(colstats_kernel, dim3(nblk(C, 64)), dim3(64), 0, 0, x, ldx, T, C, mean, stdv, unbiased);
+    hipLaunchKernelGGL(colstats_kernel, dim3(nblk(C, 64)), dim3(64 * CS_R), 0, os_, x, ldx, T, C, mean, stdv, unbiased);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int sva_op_cam_context(sva_engine* e, const float* y, long ldy, int T, int C, int seg, const float* mean, float* ctx, long ldc) {
     OPS_ENTER(e);
-    hipLaunchKernelGGL(cam_context_kernel, dim3(nblk(C, 64), (T + seg - 1) / seg), dim3(64), 0, 0, y, ldy, T, C, seg, mean, ctx, ldc);
+    hipLaunchKernelGGL(cam_context_kernel, dim3(nblk(C, 64), (T + seg - 1) / seg), dim3(256), 0, os_, y, ldy, T, C, seg, mean, ctx, ldc);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int sva_op_mul(sva_engine* e, float* y, long ldy, const float* m, long ldm, int T, int C, int sigmoid) {
     OPS_ENTER(e);
-    hipLaunchKernelGGL(mul_kernel, dim3(nblk((long)T * C)), dim3(256), 0, 0, y, ldy, m, ldm, T, C, sigmoid);
+    hipLaunchKernelGGL(mul_kernel, dim3(nblk((long)T * C)), dim3(256), 0, os_, y, ldy, m, ldm, T, C, sigmoid);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int sva_op_add(sva_engine* e, float* y, long ldy, const float* x, long ldx, int T, int C) {
     OPS_ENTER(e);
-    hipLaunchKernelGGL(add_kernel, dim3(nblk((long)T * C)), dim3(256), 0, 0, y, ldy, x, ldx, T, C);
+    hipLaunchKernelGGL(add_kernel, dim3(nblk((long)T * C)), dim3(256), 0, os_, y, ldy, x, ldx, T, C);
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -321,13 +377,13 @@ extern "C" int sva_op_conv2d(sva_engine* e, const float* x, int Cin, int F, int 
     OPS_ENTER(e);
     SVA_CHECK(k == 1 || k == 3, "conv2d: k must be 1 or 3");
     const int Fo = (F + 2 * (k / 2) - k) / stride_f + 1;
-    hipLaunchKernelGGL(conv2d_kernel, dim3(nblk((long)Cout * Fo * T)), dim3(256), 0, 0, x, Cin, F, T, W, Cout, k, stride_f, scale, shift, res, relu, y, Fo);
+    hipLaunchKernelGGL(conv2d_kernel, dim3(nblk((long)Cout * Fo * T)), dim3(256), 0, os_, x, Cin, F, T, W, Cout, k, stride_f, scale, shift, res, relu, y, Fo);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int sva_op_cf_to_rows(sva_engine* e, const float* x, int CF, int T, float* y, long ldy) {
     OPS_ENTER(e);
-    hipLaunchKernelGGL(cf_to_rows_kernel, dim3(nblk((long)CF * T)), dim3(256), 0, 0, x, CF, T, y, ldy);
+    hipLaunchKernelGGL(cf_to_rows_kernel, dim3(nblk((long)CF * T)), dim3(256), 0, os_, x, CF, T, y, ldy);
     SVA_HIP(hipGetLastError());
     return 0;
 }
@@ -337,8 +393,8 @@ extern "C" int sva_op_fbank_power(sva_engine* e, const float* wave, long n, floa
     const int ws = 400, sh = 160, npad = 512;
     SVA_CHECK(n >= ws && ldo >= npad / 2 + 1, "fbank: input shorter than one 25 ms frame");
     const int m = 1 + (int)((n - ws) / sh);
-    hipLaunchKernelGGL(fbank_frames_kernel, dim3(m), dim3(64), 0, 0, wave, ws, sh, npad, frames_scratch);
-    hipLaunchKernelGGL(dft_kernel, dim3(m), dim3(256), npad * sizeof(float), 0, frames_scratch, npad, 1, out, ldo);
+    hipLaunchKernelGGL(fbank_frames_kernel, dim3(m), dim3(64), 0, os_, wave, ws, sh, npad, frames_scratch);
+    hipLaunchKernelGGL(dft_kernel, dim3(m), dim3(256), npad * sizeof(float), os_, frames_scratch, npad, 1, out, ldo);
     SVA_HIP(hipGetLastError());
     if (frames_out) *frames_out = m;
     return 0;
@@ -348,8 +404,8 @@ extern "C" int sva_op_stft_mag(sva_engine* e, const float* wave, long n, int n_f
     OPS_ENTER(e);
     SVA_CHECK(n > n_fft / 2 && ldo >= n_fft / 2 + 1, "stft: input too short for reflect padding");
     const int m = 1 + (int)(n / hop);
-    hipLaunchKernelGGL(stft_frames_kernel, dim3(m), dim3(256), 0, 0, wave, (int)n, n_fft, win, hop, frames_scratch);
-    hipLaunchKernelGGL(dft_kernel, dim3(m), dim3(256), n_fft * sizeof(float), 0, frames_scratch, n_fft, 0, out, ldo);
+    hipLaunchKernelGGL(stft_frames_kernel, dim3(m), dim3(256), 0, os_, wave, (int)n, n_fft, win, hop, frames_scratch);
+    hipLaunchKernelGGL(dft_kernel, dim3(m), dim3(256), n_fft * sizeof(float), os_, frames_scratch, n_fft, 0, out, ldo);
     SVA_HIP(hipGetLastError());
     if (frames_out) *frames_out = m;
     return 0;
@@ -357,19 +413,53 @@ extern "C" int sva_op_stft_mag(sva_engine* e, const float* wave, long n, int n_f
 extern "C" int sva_op_attention(sva_engine* e, const float* q, const float* kv, int Lq, int Lk, int n_valid, int H, float* out, float* scratch) {
     OPS_ENTER(e);
     SVA_CHECK(n_valid >= 1 && n_valid <= Lk, "attention: bad key count");
-    hipLaunchKernelGGL(attention_kernel, dim3(Lq, H), dim3(64), 0, 0, q, kv, Lk, n_valid, H, out, scratch);
+    hipLaunchKernelGGL(attention_kernel, dim3(Lq, H), dim3(64), 0, os_, q, kv, Lk, n_valid, H, out, scratch);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int sva_op_geglu(sva_engine* e, const float* h, long ldh, int T, int Dh, float* out, long ldo) {
     OPS_ENTER(e);
-    hipLaunchKernelGGL(geglu_kernel, dim3(nblk((long)T * ldo)), dim3(256), 0, 0, h, ldh, T, Dh, out, ldo);
+    hipLaunchKernelGGL(geglu_kernel, dim3(nblk((long)T * ldo)), dim3(256), 0, os_, h, ldh, T, Dh, out, ldo);
     SVA_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int sva_op_l2norm(sva_engine* e, const float* x, int T, int C, const float* gamma, float scale, float* y) {
     OPS_ENTER(e);
-    hipLaunchKernelGGL(l2norm_kernel, dim3(T), dim3(64), 0, 0, x, C, gamma, scale, y);
+    hipLaunchKernelGGL(l2norm_kernel, dim3(T), dim3(64), 0, os_, x, C, gamma, scale, y);
     SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- the op sequence of one encoder call as a hipGraph: the host mirror issues ~600 launches per calculate_prompt;
+// between sva_ops_capture_begin and _end they are RECORDED on the ops stream instead of executed (no allocation, upload or download in
+// between: prompt_encoders.py replays its allocations from the recording run), and the instantiated graph replays them in one launch ----
+extern "C" int sva_ops_capture_begin(sva_engine* e) {
+    OPS_ENTER(e);
+    SVA_HIP(hipStreamSynchronize(os_));
+    SVA_HIP(hipStreamBeginCapture(os_, hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+extern "C" int sva_ops_capture_end(sva_engine* e, void** graph_exec) {
+    OPS_ENTER(e);
+    SVA_CHECK(graph_exec, "null output");
+    hipGraph_t graph = nullptr;
+    SVA_HIP(hipStreamEndCapture(os_, &graph));
+    hipGraphExec_t ex = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    SVA_HIP(ie);
+    *graph_exec = ex;
+    return 0;
+}
+extern "C" int sva_ops_graph_launch(sva_engine* e, void* graph_exec) {
+    OPS_ENTER(e);
+    SVA_CHECK(graph_exec, "null graph");
+    SVA_HIP(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), os_));
+    return 0;
+}
+extern "C" int sva_ops_graph_free(sva_engine* e, void* graph_exec) {
+    OPS_ENTER(e);
+    SVA_HIP(hipStreamSynchronize(os_));
+    if (graph_exec) SVA_HIP(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)));
     return 0;
 }

@@ -21,6 +21,7 @@ int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda,
     g.T = T; g.M = nb * T; g.stride = stride; g.dil = dil; g.taps = taps; g.Cin = Cin;
     g.W = w.W; g.Wh = w.Wh; g.N = w.N; g.bias = w.b;
     g.Wp = w.Wp; g.wp_pstride = (long)w.N * w.K; g.wp_inv = w.wp_inv; g.pmode = w.pmode; g.ovf = b->d_mm_ovf;
+    g.cu_limit = b->enc_cus;        // (the encoder / vocoder streams' CU mask when the batch runs its AR chain on a partition of its own)
     g.C = C; g.c_bstride = c_bstride; g.c_off = c_off; g.ldc = ldc;
     if (g.Ap) g.A = nullptr;        // operand planes replace the fp32 tensor (cnx_block_t / enc_transformer hand-overs)
     if (g.Cp) g.C = nullptr;

@@ -141,6 +141,7 @@ struct ConvGemm {
     unsigned short* Cp = nullptr;
     long cp_pstride = 0;
     long cp_rows = 0;
+    int cu_limit = 0;               // CUs the launch's stream may use (0 = the whole device): sizes the persistent grid of the planes-DMA kernel on CU-masked streams
     int* ovf = nullptr;             // fp16 planes only: set to 1 when an output is not finite (an operand outside the fp16 range); host-mapped
 };
 

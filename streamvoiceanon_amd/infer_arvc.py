@@ -272,14 +272,29 @@ class InferenceWrapper:
             from . import audio_io
 
             ref16 = audio_io.resample(ref, self.sr, self.RESAMPLE_FREQ)                    # :415-417
-            if style_vectors is None:
-                style_vectors = self.calculate_style_vec(ref16)
-            if timbre_latents is None:
-                timbre_latents = self.calculate_timbre_latent(ref16)
+            # the device encoders replay one captured graph each on the engine's ops stream (prompt_encoders._Plan): enqueue both, compute the
+            # two code streams on the batch streams meanwhile, fetch the embeddings last -- four independent functions of the same audio
+            se, te = self.style_encoder, self.timbre_encoder
+            split = style_vectors is None and timbre_latents is None and all(hasattr(x, "prepare") for x in (se, te))
+            if split:
+                hs, ht = se.prepare(ref16), te.prepare(ref16)
+                se.launch(hs); te.launch(ht)
+                ref_audio_codes = self.wav2target_fn(ref)
+                ref_content_codes = self.encode_content(ref)
+                style_vectors = np.asarray(se.finish(hs), np.float32).reshape(1, -1)
+                timbre_latents = np.asarray(te.finish(ht), np.float32).reshape(1, 32, -1)
+            else:
+                if style_vectors is None:
+                    style_vectors = self.calculate_style_vec(ref16)
+                if timbre_latents is None:
+                    timbre_latents = self.calculate_timbre_latent(ref16)
+        else:
+            split = False
         style_vectors = self.apply_noise_mixing(torch.as_tensor(np.asarray(style_vectors), dtype=torch.float32), alpha)
         timbre_latents = self.apply_noise_mixing(torch.as_tensor(np.asarray(timbre_latents), dtype=torch.float32), alpha)
-        ref_audio_codes = self.wav2target_fn(ref)                       # :431-434
-        ref_content_codes = self.encode_content(ref)                    # :436-439
+        if not split:
+            ref_audio_codes = self.wav2target_fn(ref)                       # :431-434
+            ref_content_codes = self.encode_content(ref)                    # :436-439
         return ref_audio_codes, ref_content_codes, style_vectors, timbre_latents, ref
 
     def apply_noise_mixing(self, tensor, alpha, gauss=None):

@@ -29,25 +29,46 @@ def _np(x):
     return np.ascontiguousarray(np.asarray(x), dtype=np.float32)
 
 
-class _Dev:
-    """Device arrays of one encoder call (freed together) + the persistent weight arrays of an encoder."""
+class _Plan:
+    """The device arrays of one encoder call for ONE input length, kept between calls, and the hipGraph of the call's op sequence.
+    Call 1 of a length records the allocations (and runs eagerly), call 2 replays them under stream capture (sva_ops_capture_*),
+    later calls are: upload the wav, one graph launch, download the result."""
 
-    def __init__(self, engine: E.Engine):
+    def __init__(self):
+        self.addrs, self.graph, self.out = [], None, None
+
+
+class _Dev:
+    """Device arrays of one encoder call (freed together) + the persistent weight arrays of an encoder.
+    plan + mode "record": allocations are real and remembered in the plan (not freed with the call); "replay": the i-th allocation returns
+    the plan's i-th array and constants are NOT uploaded again (they are functions of the input LENGTH only and still there)."""
+
+    def __init__(self, engine: E.Engine, plan: _Plan = None, mode: str = "eager"):
         self.engine, self.lib, self.h = engine, engine.lib, engine.h
         self.ptrs = []
+        self.plan, self.mode, self.cursor = plan, mode, 0
 
     def alloc(self, n: int) -> int:
+        if self.mode == "replay":
+            addr = self.plan.addrs[self.cursor]
+            self.cursor += 1
+            return addr
         p = C.POINTER(C.c_float)()
         E._check(self.lib.sva_dev_alloc(self.h, int(n), C.byref(p)), "sva_dev_alloc")
         addr = C.cast(p, C.c_void_p).value
-        self.ptrs.append(addr)
+        (self.plan.addrs if self.mode == "record" else self.ptrs).append(addr)
         return addr
 
     def put(self, arr) -> int:
         a = _np(arr).reshape(-1)
         addr = self.alloc(a.size)
-        E._check(self.lib.sva_dev_upload(self.h, C.c_void_p(addr), E._ptr(a), a.size), "sva_dev_upload")
+        if self.mode != "replay":
+            E._check(self.lib.sva_dev_upload(self.h, C.c_void_p(addr), E._ptr(a), a.size), "sva_dev_upload")
         return addr
+
+    def upload(self, addr: int, arr):
+        a = _np(arr).reshape(-1)
+        E._check(self.lib.sva_dev_upload(self.h, C.c_void_p(addr), E._ptr(a), a.size), "sva_dev_upload")
 
     def get(self, addr: int, shape) -> np.ndarray:
         out = np.empty(shape, np.float32)
@@ -82,12 +103,17 @@ def _declare(lib):
     lib.sva_op_attention.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.sva_op_geglu.argtypes = [vp, vp, lng, i32, i32, vp, lng]
     lib.sva_op_l2norm.argtypes = [vp, vp, i32, i32, vp, f32, vp]
+    lib.sva_ops_capture_begin.argtypes = [vp]
+    lib.sva_ops_capture_end.argtypes = [vp, C.POINTER(vp)]
+    lib.sva_ops_graph_launch.argtypes = [vp, vp]
+    lib.sva_ops_graph_free.argtypes = [vp, vp]
     lib._prompt_ops_declared = True
 
 
 PROMPT_OP_SYMBOLS = ["sva_dev_alloc", "sva_dev_free", "sva_dev_upload", "sva_dev_download", "sva_op_conv", "sva_op_affine", "sva_op_unary",
                      "sva_op_colstats", "sva_op_cam_context", "sva_op_mul", "sva_op_add", "sva_op_conv2d", "sva_op_cf_to_rows", "sva_op_fbank_power",
-                     "sva_op_stft_mag", "sva_op_attention", "sva_op_geglu", "sva_op_l2norm"]
+                     "sva_op_stft_mag", "sva_op_attention", "sva_op_geglu", "sva_op_l2norm", "sva_ops_capture_begin", "sva_ops_capture_end",
+                     "sva_ops_graph_launch", "sva_ops_graph_free"]
 
 
 def kaldi_mel_banks(num_bins=80, padded=512, sr=16000.0, low=20.0, high=0.0) -> np.ndarray:
@@ -115,6 +141,78 @@ class _Net:
         self.wd = _Dev(engine)                       # persistent: weights
         self.W = {k[len(prefix):]: _np(v) for k, v in weights.items() if k.startswith(prefix)}
         self.dev = {}
+        self.plans = {}                              # input length -> _Plan (insertion-ordered: the oldest is evicted)
+        self.use_graphs = True                       # False: every call allocates, runs op by op and frees (the round-3 behaviour; tests A/B)
+        self.max_plans = 4
+
+    # ---- one call: eager / recording / captured / replayed (see _Plan) ---------------------------------------------
+    def _call(self, wav) -> np.ndarray:
+        n = wav.shape[0]
+        if not self.use_graphs:
+            d = _Dev(self.engine)
+            try:
+                addr, shape = self._run(d, wav)
+                return d.get(addr, shape)
+            finally:
+                d.free()
+        plan = self.plans.get(n)
+        if plan is None:
+            while len(self.plans) >= self.max_plans:
+                self._drop(next(iter(self.plans)))
+            plan = _Plan()
+            d = _Dev(self.engine, plan, "record")
+            try:
+                addr, shape = self._run(d, wav)
+                out = d.get(addr, shape)
+            except Exception:
+                self._free_plan(plan)
+                raise
+            self.plans[n] = plan
+            return out
+        d = _Dev(self.engine, plan, "replay")
+        d.upload(plan.addrs[0], wav)                 # (the input is the call's first array)
+        if plan.graph is None:
+            E._check(self.lib.sva_ops_capture_begin(self.h), "sva_ops_capture_begin")
+            g = C.c_void_p()
+            try:
+                plan.out = self._run(d, wav)
+            finally:
+                rc = self.lib.sva_ops_capture_end(self.h, C.byref(g))
+            E._check(rc, "sva_ops_capture_end")
+            plan.graph = g
+        E._check(self.lib.sva_ops_graph_launch(self.h, plan.graph), "sva_ops_graph_launch")
+        return d.get(*plan.out)
+
+    # ---- split call for overlap with other device work (InferenceWrapper.calculate_prompt): prepare() uploads the input (synchronises the
+    # ops stream, so do it for EVERY encoder before the first launch()), launch() enqueues the graph and returns at once, finish() downloads.
+    # Lengths without a captured graph yet (the first two calls) compute synchronously in prepare().
+    def prepare(self, wave16k):
+        wav = _np(wave16k).reshape(-1)
+        plan = self.plans.get(wav.shape[0]) if self.use_graphs else None
+        if plan is None or plan.graph is None:
+            return ("done", self._call(wav))
+        _Dev(self.engine, plan, "replay").upload(plan.addrs[0], wav)
+        return ("ready", plan)
+
+    def launch(self, handle):
+        if handle[0] == "ready":
+            E._check(self.lib.sva_ops_graph_launch(self.h, handle[1].graph), "sva_ops_graph_launch")
+        return handle
+
+    def finish(self, handle) -> np.ndarray:
+        if handle[0] == "done":
+            return handle[1]
+        return _Dev(self.engine, handle[1], "replay").get(*handle[1].out)
+
+    def _free_plan(self, plan):
+        if plan.graph is not None:
+            self.lib.sva_ops_graph_free(self.h, plan.graph)
+        for a in plan.addrs:
+            self.lib.sva_dev_free(self.h, C.c_void_p(a))
+        plan.addrs, plan.graph = [], None
+
+    def _drop(self, n):
+        self._free_plan(self.plans.pop(n))
 
     # ---- weight preparation -----------------------------------------------------------------------------------
     def w_conv(self, key, pad_k_to=None):
@@ -155,6 +253,8 @@ class _Net:
         E._check(self.lib.sva_op_affine(self.h, x, ldx, T, Cc, scale, shift, relu_mode, y, ldy), "sva_op_affine")
 
     def close(self):
+        for n in list(self.plans):
+            self._drop(n)
         self.wd.free()
 
 
@@ -171,11 +271,7 @@ class StyleEncoder(_Net):
         self.banks = self.wd.put(banks)
 
     def __call__(self, wave16k) -> np.ndarray:
-        d = _Dev(self.engine)
-        try:
-            return self._run(d, _np(wave16k).reshape(-1))
-        finally:
-            d.free()
+        return self._call(_np(wave16k).reshape(-1))
 
     def _run(self, d, wav):
         lib, h = self.lib, self.h
@@ -191,8 +287,8 @@ class StyleEncoder(_Net):
         E._check(lib.sva_op_unary(h, feat, m * 80, 1, float(np.finfo(np.float32).eps)), "log")
         mean = d.alloc(80)
         E._check(lib.sva_op_colstats(h, feat, 80, m, 80, mean, None, 0), "colstats")
-        neg = d.put(-d.get(mean, (80,)))                          # feat - feat.mean(0)   (evaluations/infer_arvc.py:192)
-        self.affine(feat, 80, m, 80, None, neg, 0, feat, 80)
+        E._check(lib.sva_op_unary(h, mean, 80, 4, 0.0), "negate")                       # feat - feat.mean(0)   (evaluations/infer_arvc.py:192), on the device:
+        self.affine(feat, 80, m, 80, None, mean, 0, feat, 80)                             # no host round trip inside the op sequence (it is captured as a graph)
         # ---- FCM head (DTDNN.py:14-48), channel-first [C][F][T]; input x[0][f][t] = feat[t][f]
         T = m
         x0 = d.alloc(80 * T)
@@ -266,7 +362,7 @@ class StyleEncoder(_Net):
         self.conv(stats, 2 * ch, 1, 1, 1, 1, 2 * ch, self.w_conv("dense.linear.weight"), None, 192, emb, 192)
         sc, sh = self.bn("dense.nonlinear.batchnorm.", affine=False)
         self.affine(emb, 192, 1, 192, sc, sh, 0, emb, 192)
-        return d.get(emb, (1, 192))
+        return emb, (1, 192)
 
 
 class TimbreEncoder(_Net):
@@ -280,11 +376,7 @@ class TimbreEncoder(_Net):
         self.fb = self.wd.put(w)
 
     def __call__(self, wave16k) -> np.ndarray:
-        d = _Dev(self.engine)
-        try:
-            return self._run(d, _np(wave16k).reshape(-1))
-        finally:
-            d.free()
+        return self._call(_np(wave16k).reshape(-1))
 
     def _crb(self, d, x, ldx, T, taps, dil, Cin, p, N, y, ldy):
         """Conv1dReluBn (ecapa_tdnn.py:68-85): bn(relu(conv(x)))"""
@@ -345,7 +437,9 @@ class TimbreEncoder(_Net):
         kvin = d.alloc(Lk * 128)
         ctx = kvin + 32 * 128 * F4
         self.conv(lat, 1536, T, 1, 1, 1, 1536, self.w_conv(ps + "proj_context.weight"), self.w_raw(ps + "proj_context.bias"), 128, ctx, 128)
-        latents = d.put(self.W[ps + "latents"])
+        lat0 = d.put(self.W[ps + "latents"])                      # the learned latents are updated in place below: work on a per-call copy
+        latents = d.alloc(32 * 128)
+        self.affine(lat0, 128, 32, 128, None, None, 0, latents, 128)
         qb, kv, att, tmp = d.alloc(32 * 512), d.alloc(Lk * 1024), d.alloc(32 * 512), d.alloc(32 * 128)
         scr = d.alloc(32 * 8 * Lk)
         hbuf, gbuf = d.alloc(32 * 688), d.alloc(32 * 352)
@@ -369,4 +463,4 @@ class TimbreEncoder(_Net):
         self.conv(xq, 128, 32, 1, 1, 1, 128, self.w_conv("quantizer.project_in.weight"), self.w_raw("quantizer.project_in.bias"), 6, z6, 6)
         E._check(lib.sva_op_unary(h, z6, 32 * 6, 2, 0.0), "fsq")
         self.conv(z6, 6, 32, 1, 1, 1, 6, self.w_conv("quantizer.project_out.weight"), self.w_raw("quantizer.project_out.bias"), 128, zq, 128)
-        return d.get(zq, (1, 32, 128))
+        return zq, (1, 32, 128)

@@ -1051,6 +1051,32 @@ def test_prompt_speaker_encoders_vs_reference_golden(eng, record_property):
     se.close(); te.close()
 
 
+def test_prompt_speaker_encoders_graph_replay_equals_op_by_op(eng):
+    """The two speaker encoders as captured hipGraphs (sva_ops_capture_*; one graph per reference length, prompt_encoders._Plan): the first
+    call of a length runs op by op and records its allocations, the second is captured, later ones are one graph launch.  Every call --
+    recorded, captured, replayed, with DIFFERENT audio of the same length, with another length in between, after an eviction -- gives
+    bit for bit what the op-by-op path (use_graphs = False: allocate, run, free) gives; the in-place updated Perceiver latents are
+    re-initialised inside the graph."""
+    from streamvoiceanon_amd import specs, synth_weights as sw
+    from streamvoiceanon_amd.prompt_encoders import StyleEncoder, TimbreEncoder
+    from streamvoiceanon_amd.synth_audio import synth_utterance
+
+    Wn = sw.generate_all(0, specs.prompt_encoder_specs())
+    se, te = StyleEncoder(eng, Wn), TimbreEncoder(eng, Wn)
+    se.max_plans = te.max_plans = 2
+    ref_s, ref_t = StyleEncoder(eng, Wn), TimbreEncoder(eng, Wn)
+    ref_s.use_graphs = ref_t.use_graphs = False
+    n1, n2, n3 = 16000 * 2 + 123, 16000 * 3, 16000 + 4000
+    seq = [(n1, 1), (n1, 2), (n1, 3), (n2, 4), (n1, 5), (n2, 6), (n2, 7), (n3, 8), (n3, 9), (n1, 10), (n1, 11), (n1, 12)]     # n3 evicts n1 (two plans kept)
+    for n, seed in seq:
+        wav = synth_utterance(8000 + seed, n)
+        np.testing.assert_array_equal(se(wav), ref_s(wav))
+        np.testing.assert_array_equal(te(wav), ref_t(wav))
+    assert len(se.plans) == 2 and len(te.plans) == 2 and all(p_.graph is not None for p_ in te.plans.values())
+    for x in (se, te, ref_s, ref_t):
+        x.close()
+
+
 def test_stream_infer_from_wav_files_without_injected_embeddings(weights0, tmp_path):
     """The reference's call shape end to end (evaluations/infer_arvc.py:724-743): stream_infer(src.wav, ref.wav, out_dir) with NO
     injected tensors -- style vector and timbre latents come from the device encoders, audio codes and content codes from the

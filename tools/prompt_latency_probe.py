@@ -14,7 +14,7 @@ from streamvoiceanon_amd.synth_audio import synth_utterance  # noqa: E402
 w = bench._wrapper_with_prompt_path()
 
 
-def best(fn, n=3):
+def best(fn, n=5):
     v = []
     for _ in range(n):
         t0 = time.perf_counter()
