@@ -63,7 +63,7 @@ int stream_fork(sva_batch* b, hipStream_t from, hipStream_t to);
 int conv_act(sva_batch* b, const Act& in, int T_out, int stride, int dil, int taps, const Lin& w, Act& out, ConvGemm proto = ConvGemm());
 int conv_desc(sva_batch* b, const Act& in, int T_out, int dil, int taps, const Lin& w, Act& out, ConvGemm& g);
 int gemm_group_call(sva_batch* b, const ConvGemm* gs, int n);
-bool planes_edge(const Lin& producer, const Lin& consumer, long rows);
+bool planes_edge(const Lin& producer, const Lin& consumer, long rows, int streams);
 int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs, float* h2, long h2_bs, Act* out = nullptr, int skip_lo = 0, int skip_hi = 0);
 int cnx_block(sva_batch* b, const CNX& c, Act& x, int T, float* h1, float* h2, Act* out = nullptr);
 int enc_frontend_window(sva_batch* b, const int* step_ptr, int n_chunk, int add, int Tm, const EncFront* front = nullptr, Act* tokens_out = nullptr);

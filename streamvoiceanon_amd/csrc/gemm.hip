@@ -706,22 +706,22 @@ static const PlanesRow g_planes_table[] = {
 #include "planes_table.inc"
 };
 static int planes_variant(const ConvGemm& g, int group_n) {
-    // both operands as planes, whole 128-column tiles: the persistent LDS-DMA form (variants 8 / 9).  256 x 128 tiles move two thirds of
-    // the operand bytes per flop of 128 x 128; which one is a matter of how the tile count quantises over the CUs (one workgroup each)
-    if (group_n == 1 && planes_dma_gemm_supported(g) && debug_options().planes_dma != 0) {
-        // measured at 64 streams on the ten encoder shapes (profiles/r05_planes_dma_bench.txt): 128 x 128 tiles with TWO workgroups per CU
-        // (variant 10: one workgroup's epilogue runs under the other's K steps) win or tie everywhere; 256 x 128 (8) never wins
-        const long t9 = (long)((g.M + 127) / 128) * (g.N / 128);
-        if (t9 >= 64) return 10;
-    }
-    // measured winners for the encoder's shapes (tools/planes_tune.py -> planes_table.inc; every variant computes the same bits, the K
-    // loop is the same): the row with this (N, K) whose M is nearest, if within a quarter of it
+    const bool dma_ok = group_n == 1 && planes_dma_gemm_supported(g) && debug_options().planes_dma != 0;
+    // measured winners for the encoder's shapes (tools/planes_tune.py -> planes_table.inc; every variant computes the same accumulation per
+    // output, so the table is a speed choice only): the row with this (N, K) whose M is nearest, if within a quarter of it
     if (group_n == 1 && g.taps == 1) {
         const PlanesRow* best = nullptr;
         for (const PlanesRow& r : g_planes_table)
-            if (r.N == g.N && r.K == g.Cin && (!best || std::abs(r.M - g.M) < std::abs(best->M - g.M))) best = &r;
-        if (best && std::abs(best->M - g.M) * 4 <= g.M && (best->variant != 6 || g.M >= 256) && (g.M >= 128 || best->variant == 2 || best->variant == 3)) return best->variant;
+            if (r.N == g.N && r.K == g.Cin && (r.variant < 8 || dma_ok) &&
+                (!best || std::abs(r.M - g.M) < std::abs(best->M - g.M))) best = &r;
+        if (best && std::abs(best->M - g.M) * 4 <= g.M && (best->variant != 6 || g.M >= 256) &&
+            (g.M >= 128 || best->variant == 2 || best->variant == 3 || best->variant >= 9)) return best->variant;
     }
+    // both operands as planes, whole 128-column tiles, a shape outside the table: the persistent LDS-DMA form with 128 x 128 tiles and TWO
+    // workgroups per CU (variant 10: one workgroup's epilogue runs under the other's K steps) -- it wins or ties on every encoder shape at 64
+    // streams with the real epilogues (profiles/r05_planes_dma_bench.txt); 256 x 128 (8) never wins.  (Table vs this rule for the shapes
+    // the table holds: encoder stage 4.41 / 5.13 / 8.50 ms against 4.67 / 5.28 / 8.68 at 48 / 64 / 128 streams, pipelined frames/s equal.)
+    if (dma_ok && (long)((g.M + 127) / 128) * (g.N / 128) >= 64) return 10;
     if (g.N < 128) return g.M >= 128 ? 1 : 3;
     if (g.M < 128) return 2;
     const long wg0 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * group_n, wg6 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * group_n;

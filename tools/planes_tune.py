@@ -8,12 +8,15 @@ from streamvoiceanon_amd import engine as E
 
 rng = np.random.default_rng(5)
 # (rows per stream, N, K, A handed over as planes)
-SHAPES = ((170, 512, 128, False), (170, 128, 512, True), (170, 1024, 256, False), (170, 256, 1024, True), (170, 1536, 384, False), (170, 384, 1536, True),
-          (170, 2048, 512, False), (170, 512, 2048, True), (88, 2048, 512, False), (88, 512, 2048, True), (128, 1536, 512, False), (128, 512, 512, False),
-          (128, 3072, 512, False), (128, 512, 1536, True), (170, 256, 128, False), (170, 384, 256, False), (170, 512, 384, False))
+# round 5: every batch-scale GEMM of the encoder takes its A operand as planes now (the producers write them), so the candidates include the
+# persistent LDS-DMA forms 8 / 9 / 10; the three transition convs (LayerNorm rows -> conv k1) still arrive as fp32
+SHAPES = ((170, 512, 128, True), (170, 128, 512, True), (170, 1024, 256, True), (170, 256, 1024, True), (170, 1536, 384, True), (170, 384, 1536, True),
+          (170, 2048, 512, True), (170, 512, 2048, True), (88, 2048, 512, True), (88, 512, 2048, True), (47, 2048, 512, True), (47, 512, 2048, True),
+          (128, 1536, 512, True), (128, 512, 512, True),
+          (128, 3072, 512, True), (128, 512, 1536, True), (170, 256, 128, False), (170, 384, 256, False), (170, 512, 384, False))
 print("// {M, N, K, variant}: measured winner of tools/planes_tune.py (MI355X, H3 format), sorted by (N, K, M)")
 rows = []
-for B in (12, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128):
+for B in (16, 24, 32, 40, 48, 64, 96, 128):
     for (T, N, K, ap) in SHAPES:
         M = B * T
         if M < 1024:
@@ -21,8 +24,8 @@ for B in (12, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128):
         A = rng.standard_normal((M, K)).astype(np.float32)
         W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
         best = None
-        for v in (0, 1, 2, 3, 6, 7):
-            if (v == 6 and M < 256) or (v in (0, 2, 6, 7) and N < 128):
+        for v in (0, 1, 2, 3, 6, 7, 8, 9, 10):
+            if (v == 6 and M < 256) or (v in (0, 2, 6, 7) and N < 128) or (v >= 8 and (not ap or N % 128)):
                 continue
             us = min(E.test_gemm_planes(A, W, mode=1, variant=v, a_planes=ap, iters=15)[1] for _ in range(2))
             if best is None or us < best[0]:
