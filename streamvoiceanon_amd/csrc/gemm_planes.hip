@@ -433,11 +433,11 @@ __device__ __forceinline__ void glds16(const char* base, unsigned voff, unsigned
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int MODE, int BM, int NST, bool PROBE>
-__global__ __launch_bounds__(512, 2) void planes_dma_kernel(const ConvGemm g, const int n_tiles_n, const int n_tiles, const int dbg_arg) {
+template <int MODE, int BM, int NST, bool PROBE, int BN = 128, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW / 4) void planes_dma_kernel(const ConvGemm g, const int n_tiles_n, const int n_tiles, const int dbg_arg) {
     const int dbg = PROBE ? dbg_arg : 0;          // (the product instantiation carries none of the switches below)
     // dbg: TIMING EXPERIMENTS (SVA_DEBUG planes_dbg; results are garbage): 1 no LDS-DMA requests, 4 no MFMAs, 8 no epilogue, 32 no fragment reads
-    constexpr int NPL = PM<MODE>::NPL, BN = 128, NW = 8;
+    constexpr int NPL = PM<MODE>::NPL;
     constexpr int PD = NST - 1;                                           // NST LDS stages; K steps requested ahead
     constexpr int WM = BM / 64, WN = NW / WM, TN = BN / WN, MI = 4, NI = TN / 16;
     constexpr int RBA = BM / 16, RBB = BN / 16, PA = RBA / NW, PB = RBB / NW;
@@ -654,16 +654,16 @@ __global__ __launch_bounds__(512, 2) void planes_dma_kernel(const ConvGemm g, co
 
 static int g_dma_cu_limit = 0;          // CUs a planes-DMA launch may count on (0: the device's); the engine lowers it for CU-masked streams
 
-template <int MODE, int BM, int NST>
+template <int MODE, int BM, int NST, int BN = 128, int NW = 8>
 int launch_planes_dma_t(const ConvGemm& g, hipStream_t st) {
     constexpr int NPL = PM<MODE>::NPL;
-    constexpr size_t smem = (size_t)NST * NPL * (BM + 128) / 16 * 1024;
+    constexpr size_t smem = (size_t)NST * NPL * (BM + BN) / 16 * 1024;
     constexpr int WG_PER_CU = smem * 2 <= 160 * 1024 ? 2 : 1;            // two resident workgroups: one's epilogue runs under the other's K steps
     static_assert(smem <= 160 * 1024, "LDS of one CU");
     static DeviceOnce attr_set;
     if (attr_set.needed()) {
-        SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<MODE, BM, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        if (MODE == PLANES_H3) SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<PLANES_H3, BM, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<MODE, BM, NST, false, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (MODE == PLANES_H3) SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set.done();
     }
     int cus = g.cu_limit > 0 ? g.cu_limit : g_dma_cu_limit;
@@ -676,11 +676,11 @@ int launch_planes_dma_t(const ConvGemm& g, hipStream_t st) {
         }
         cus = dev_cus;
     }
-    const int tn = g.N / 128, tm = (g.M + BM - 1) / BM, tiles = tn * tm;
+    const int tn = g.N / BN, tm = (g.M + BM - 1) / BM, tiles = tn * tm;
     const int grid = std::min(tiles, cus * WG_PER_CU);
     const int dbg = debug_options().planes_dbg;
-    if (dbg && MODE == PLANES_H3) hipLaunchKernelGGL((planes_dma_kernel<PLANES_H3, BM, NST, true>), dim3(grid), dim3(512), smem, st, g, tn, tiles, dbg);
-    else hipLaunchKernelGGL((planes_dma_kernel<MODE, BM, NST, false>), dim3(grid), dim3(512), smem, st, g, tn, tiles, 0);
+    if (dbg && MODE == PLANES_H3) hipLaunchKernelGGL((planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW>), dim3(grid), dim3(64 * NW), smem, st, g, tn, tiles, dbg);
+    else hipLaunchKernelGGL((planes_dma_kernel<MODE, BM, NST, false, BN, NW>), dim3(grid), dim3(64 * NW), smem, st, g, tn, tiles, 0);
     return 0;
 }
 
@@ -690,11 +690,14 @@ bool planes_dma_supported(const ConvGemm& g) {
            (!g.C || (g.ldc % 4 == 0 && g.c_off % 4 == 0 && g.c_bstride % 4 == 0)) && (!g.res || (g.ldr % 4 == 0 && g.r_off % 4 == 0 && g.r_bstride % 4 == 0));
 }
 int launch_planes_dma(const ConvGemm& g, int variant, hipStream_t st) {
-    SVA_CHECK(planes_dma_supported(g) && variant >= 8 && variant <= 10, "planes_dma: unsupported problem (A as planes, N % 128 == 0)");
-    // 8: 256 x 128, three stages; 9: 128 x 128, four stages, one workgroup per CU; 10: 128 x 128, two stages, TWO workgroups per CU
-    if (g.pmode == PLANES_H3)
-        return variant == 8 ? launch_planes_dma_t<PLANES_H3, 256, 3>(g, st) : variant == 9 ? launch_planes_dma_t<PLANES_H3, 128, 4>(g, st) : launch_planes_dma_t<PLANES_H3, 128, 2>(g, st);
-    return variant == 8 ? launch_planes_dma_t<PLANES_H1, 256, 3>(g, st) : variant == 9 ? launch_planes_dma_t<PLANES_H1, 128, 4>(g, st) : launch_planes_dma_t<PLANES_H1, 128, 2>(g, st);
+    SVA_CHECK(planes_dma_supported(g) && (variant == 9 || variant == 10), "planes_dma: unsupported problem (A as planes, N % 128 == 0)");
+    // 9: 128 x 128, four stages, one workgroup per CU; 10: 128 x 128, two stages, TWO workgroups per CU (one's epilogue under the other's K steps).
+    // Measured and NOT instantiated (profiles/r05_planes_dma_bench_all_variants.txt; the template still takes them): 256 x 128 on 8 waves /
+    // three stages (was 8), 256 x 256 on 16 waves / two stages (11: half the operand bytes per flop, 56 % MFMA use inside its K loop, but
+    // one workgroup per CU leaves its epilogue and the 1.5-round tile counts of these shapes exposed), 128 x 256 on 8 waves (12) -- none
+    // wins on any encoder shape
+    if (g.pmode == PLANES_H3) return variant == 9 ? launch_planes_dma_t<PLANES_H3, 128, 4>(g, st) : launch_planes_dma_t<PLANES_H3, 128, 2>(g, st);
+    return variant == 9 ? launch_planes_dma_t<PLANES_H1, 128, 4>(g, st) : launch_planes_dma_t<PLANES_H1, 128, 2>(g, st);
 }
 
 // fp32 [rows][K] (row stride ld) -> K-blocked planes (planes_split.h): one thread per 8 consecutive k of a row

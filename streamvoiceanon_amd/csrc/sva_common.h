@@ -186,7 +186,7 @@ int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 int planes_count(int mode);
 bool planes_gemm_supported(const ConvGemm& g);
 int launch_planes_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
-// variants 8 / 9 of it: the persistent LDS-DMA-fed form (256 x 128 / 128 x 128 tiles; A as planes, N % 128 == 0, one problem per launch)
+// variants 9 / 10 of it: the persistent LDS-DMA-fed form (128 x 128 tiles, one / two workgroups per CU; A as planes, N % 128 == 0, one problem per launch)
 bool planes_dma_gemm_supported(const ConvGemm& g);
 void planes_dma_set_cu_limit(int cus);        // CUs its grid may count on (0 = the device's); the engine sets it around launches on CU-masked streams
 // fp32 [rows][K] (row stride ld) -> K-blocked planes

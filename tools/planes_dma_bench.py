@@ -1,6 +1,6 @@
 """The batch-scale GEMM shapes of the encoder (64 streams unless given) through the planes GEMM's tile variants: round 4's register-staged
-forms (0: 128 x 128 / 4 waves, 6: 256 x 128 / 8 waves, 7: 128 x 128 / 8 waves) against the persistent LDS-DMA forms (8: 256 x 128, 9:
-128 x 128), both operands as planes.  Prints us per launch and algorithmic TF/s (2 M N K; the matrix pipe does three times that in H3).
+forms (0: 128 x 128 / 4 waves, 6: 256 x 128 / 8 waves, 7: 128 x 128 / 8 waves) against the persistent LDS-DMA forms (9: 128 x 128 with one workgroup per CU and four stages,
+10: two workgroups per CU and two stages), both operands as planes.  Prints us per launch and algorithmic TF/s (2 M N K; the matrix pipe does three times that in H3).
     python tools/planes_dma_bench.py [streams ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,7 @@ for B in streams:
         W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
         kw = dict(gelu="gelu" in epi, c_planes="cp" in epi, swiglu="swiglu" in epi, gamma_res="gamma_res" in epi)
         row = []
-        for v in (0, 6, 7, 8, 9, 10):
+        for v in (0, 6, 7, 9, 10):
             us = min(E.test_gemm_planes(A, W, mode=1, variant=v, a_planes=True, iters=20, **kw)[1] for _ in range(2))
             row.append((v, us))
         best_old = min(u for v, u in row if v < 8)
