@@ -434,7 +434,7 @@ __device__ __forceinline__ void glds16(const char* base, unsigned voff, unsigned
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 template <int MODE, int BM, int NST, bool PROBE, int BN = 128, int NW = 8>
-__global__ __launch_bounds__(64 * NW, NW / 4) void planes_dma_kernel(const ConvGemm g, const int n_tiles_n, const int n_tiles, const int dbg_arg, const int tile_map) {
+__global__ __launch_bounds__(64 * NW, NW / 4) void planes_dma_kernel(const ConvGemm g, const int n_tiles_n, const int n_tiles, const int dbg_arg) {
     const int dbg = PROBE ? dbg_arg : 0;          // (the product instantiation carries none of the switches below)
     // dbg: TIMING EXPERIMENTS (SVA_DEBUG planes_dbg; results are garbage): 1 no LDS-DMA requests, 4 no MFMAs, 8 no epilogue, 32 no fragment reads
     constexpr int NPL = PM<MODE>::NPL;
@@ -455,11 +455,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void planes_dma_kernel(const ConvG
 
     // ---- this workgroup's tiles: XCD x (= workgroup id & 7, a speed assumption only) owns the x-th contiguous eighth of the sequence ----
     const int G = gridDim.x, wg = blockIdx.x;
-    const int xcd = wg & 7, nslots = (G - xcd + 7) >> 3;
-    // tile_map 1 (two workgroups per CU): the XCD's workgroups s and s + nslots / 2 -- dispatched half a grid apart, the likely co-residents of
-    // a CU -- take NEIGHBOURING tiles (same row panel, adjacent column tiles): the second one's A pieces can hit the CU's vector L1
-    int slot = wg >> 3;
-    if (tile_map == 1 && (nslots & 1) == 0) slot = (slot % (nslots >> 1)) * 2 + slot / (nslots >> 1);
+    const int xcd = wg & 7, slot = wg >> 3, nslots = (G - xcd + 7) >> 3;
     const int q = n_tiles >> 3, r8 = n_tiles & 7;
     const int band_lo = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q, band_n = q + (xcd < r8 ? 1 : 0);
     const int my_tiles = slot < band_n ? (band_n - slot + nslots - 1) / nslots : 0;
@@ -683,8 +679,8 @@ int launch_planes_dma_t(const ConvGemm& g, hipStream_t st) {
     const int tn = g.N / BN, tm = (g.M + BM - 1) / BM, tiles = tn * tm;
     const int grid = std::min(tiles, cus * WG_PER_CU);
     const int dbg = debug_options().planes_dbg;
-    if ((dbg & 63) && MODE == PLANES_H3) hipLaunchKernelGGL((planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW>), dim3(grid), dim3(64 * NW), smem, st, g, tn, tiles, dbg, (dbg >> 6) & 1);
-    else hipLaunchKernelGGL((planes_dma_kernel<MODE, BM, NST, false, BN, NW>), dim3(grid), dim3(64 * NW), smem, st, g, tn, tiles, 0, (debug_options().planes_dbg >> 6) & 1);
+    if (dbg && MODE == PLANES_H3) hipLaunchKernelGGL((planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW>), dim3(grid), dim3(64 * NW), smem, st, g, tn, tiles, dbg);
+    else hipLaunchKernelGGL((planes_dma_kernel<MODE, BM, NST, false, BN, NW>), dim3(grid), dim3(64 * NW), smem, st, g, tn, tiles, 0);
     return 0;
 }
 
