@@ -718,11 +718,12 @@ def main():
             tm_prof = batch.timings()          # stage times of this serial, event-bracketed step
             tab = batch.gemm_profile_table()
             pipes = {"f32_mfma": [0.0, 0.0, 0], "bf16_split": [0.0, 0.0, 0], "f16_weights": [0.0, 0.0, 0], "planes_bf16x3": [0.0, 0.0, 0],
-                     "planes_f16x2": [0.0, 0.0, 0], "planes_f16x1": [0.0, 0.0, 0]}       # flops, us, launches
-            KIND_PIPE = {4: "bf16_split", 5: "f16_weights", 6: "planes_bf16x3", 7: "planes_f16x2", 8: "planes_f16x1"}
+                     "planes_f16x2": [0.0, 0.0, 0], "planes_f16x1": [0.0, 0.0, 0], "planes_dma_f16x2": [0.0, 0.0, 0], "planes_dma_f16x1": [0.0, 0.0, 0]}       # flops, us, launches
+            KIND_PIPE = {4: "bf16_split", 5: "f16_weights", 6: "planes_bf16x3", 7: "planes_f16x2", 8: "planes_f16x1", 9: "planes_dma_f16x2", 10: "planes_dma_f16x1"}
             for M_, N_, K_, taps_, mode_, us in tab:
                 # 0 small-M, 1 tiled, 2 pipelined: v_mfma_f32_16x16x4_f32; 4: six bf16 part products split in the K loop; 5: fp16 weights x (hi + lo)
-                # fp16 activations; 6 / 7 / 8: pre-split operand planes (gemm_planes.hip): bf16 x 3 (six products), fp16 x 2 (three), fp16 x 1 (one)
+                # fp16 activations; 7 / 8: pre-split operand planes (gemm_planes.hip), register-staged tiles: fp16 x 2 (three products), fp16 x 1 (one);
+                # 9 / 10: the same formats through the persistent LDS-DMA kernel (both operands as planes: the encoder's big GEMMs)
                 kind = (int(mode_) >> 8) - 1
                 pp = pipes[KIND_PIPE.get(kind, "f32_mfma")]
                 pp[0] += 2.0 * M_ * N_ * K_; pp[1] += us; pp[2] += 1
@@ -758,16 +759,17 @@ def main():
             for name, (fl, us, cnt) in pipes.items():
                 if cnt:
                     pk = {"f32_mfma": PEAK_F32_MFMA_TFLOPS, "bf16_split": PEAK_SPLIT, "planes_bf16x3": PEAK_SPLIT, "planes_f16x2": 2500.0 / 3.0,
-                          "planes_f16x1": 2500.0, "f16_weights": PEAK_F16W}[name]
+                          "planes_f16x1": 2500.0, "planes_dma_f16x2": 2500.0 / 3.0, "planes_dma_f16x1": 2500.0, "f16_weights": PEAK_F16W}[name]
                     by_pipe[name] = {"launches": cnt, "ms": round(us * 1e-3, 4), "gflop": round(fl / 1e9, 3), "achieved": round(fl / us / 1e6, 3),
                                      "peak": round(pk, 1), "frac": round(fl / us / 1e6 / pk, 5)}
             # the fraction of what the launches COULD have done in their own time on the pipes they ran on
             cap = sum(v["ms"] * v["peak"] for v in by_pipe.values())
             frac_own = (flops / 1e9) / cap if cap > 0 else 0.0
             roof = {"bound": "mfma", "kernel": "conv-GEMM family: pipe_gemm_kernel / conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32) and split_gemm_kernel / "
-                              "planes_gemm_kernel (the same fp32 problems on the 16-bit pipes from pre-split operand planes: six bf16 part products, or three "
-                              "fp16 part products with sva_config.mm_mode = 1 -- fp32-grade results either way; one fp16 product for a voc_dtype = 1 vocoder; "
-                              "the per-shape table picks)",
+                              "planes_gemm_kernel / planes_dma_kernel (the same fp32 problems on the 16-bit pipes: six bf16 part products split in the K loop, or "
+                              "three fp16 part products from pre-split operand planes with sva_config.mm_mode = 1 -- fp32-grade results either way; one fp16 "
+                              "product for a voc_dtype = 1 vocoder; planes_dma = the persistent LDS-DMA form the encoder's batch-scale GEMMs run in; the "
+                              "per-shape table picks)",
                     "peak_note": "peak = 157.3 TF/s, the dense f32-MFMA peak (the arithmetic the path is specified in) -- `frac` = achieved / 157.3 as the contract "
                                  "defines it; launches of the split-bf16 kernel run on the bf16 pipes, whose ceiling for this work is 2500 / 6 = 416.7 TF/s: `by_pipe` "
                                  "prices each kernel family against its own pipe and `frac_of_own_pipes` is the time-weighted combination (the honest figure when "
@@ -909,6 +911,9 @@ def main():
         out["b64_frames_per_s"], out["b64_ms_per_step"], out["b64_frac_of_own_pipes"] = b64["value"], b64["ms_per_step"], r64.get("frac_of_own_pipes")
         for k_, v_ in b64["stage_ms_last_step"].items():
             out[f"b64_{k_}_ms"] = v_
+        dma = (r64.get("by_pipe") or {}).get("planes_dma_f16x2")
+        if dma:          # the encoder's batch-scale GEMMs (persistent LDS-DMA planes kernel): algorithmic TF/s and fraction of the 833 TF/s three-product ceiling
+            out["b64_planes_dma_tflops"], out["b64_planes_dma_frac"] = dma["achieved"], dma["frac"]
     print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()

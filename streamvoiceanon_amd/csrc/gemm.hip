@@ -739,7 +739,7 @@ static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
         ConvGemmGroup gg;
         if (t_group) gg = *t_group; else gg.g[0] = g;
         if (ch.a >= 8) {                // the kernel fed from pre-split operand planes (gemm_planes.hip), its tile variant a - 8
-            t_planes_mode = g.pmode;
+            t_planes_mode = g.pmode + (ch.a - 8 >= 8 ? 2 : 0);          // (+ 2: its persistent LDS-DMA form)
             return launch_planes_gemm(gg, ch.a - 8, st);
         }
         SVA_CHECK(!g.Ap && !g.Cp, "conv_gemm: operand planes need the planes kernel");
@@ -1053,7 +1053,7 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
     }
     t_planes_mode = -1;
     SVA_TRY_RC(launch_choice(g, st, ch));
-    t_last_kind = t_planes_mode >= 0 ? 6 + t_planes_mode : ch.kind;       // 7 / 8: planes kernel in H3 / H1
+    t_last_kind = t_planes_mode >= 0 ? 6 + t_planes_mode : ch.kind;       // 7 / 8: planes kernel in H3 / H1, 9 / 10: its LDS-DMA form
     SVA_HIP(hipGetLastError());
     return 0;
 }

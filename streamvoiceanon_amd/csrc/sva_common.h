@@ -197,7 +197,7 @@ bool f16w_gemm_supported(const ConvGemm& g);
 bool f16w_gemm_validated_compiler();      // built with the compiler the kernel's workarounds were validated with
 int launch_f16w_gemm(const ConvGemm& g, hipStream_t st);
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
-int conv_gemm_last_kind();          // kernel family the calling thread's latest launch_conv_gemm[_group] picked: 0 small-M, 1 tiled, 2 pipelined (f32 MFMA), 4 split-bf16, 5 fp16 weights (f16 MFMA)
+int conv_gemm_last_kind();          // kernel family the calling thread's latest launch_conv_gemm[_group] picked: 0 small-M, 1 tiled, 2 pipelined (f32 MFMA), 4 split-bf16, 5 fp16 weights (f16 MFMA), 7 / 8 planes H3 / H1, 9 / 10 their LDS-DMA form
 int launch_conv_gemm_group(const ConvGemm* gs, int n, hipStream_t st);
 // true when launch_conv_gemm would route this (M, N) problem to the K-split small-M kernel, which can normalise its A rows
 bool conv_gemm_can_fuse_rms(int M, int N);
