@@ -328,6 +328,13 @@ struct sva_batch {
     sva::Act tb[5][3][3];                  // c1 outputs
     sva::Act yb[5][3][2];                  // y_{b,1}, y_{b,2}
     sva::Act y3[5][3];                     // y_{b,3}: branch outputs before the ParallelBlock mean (no history)
+    // wide levels on the LDS-DMA planes kernel (stages.hip, vocode): the conv inputs silu(X), silu(tb), silu(yb) live as K-blocked operand
+    // planes over the same dense rows as the fp32 tensors above (history rows included: they are the streaming state of such a level)
+    bool voc_dma[5] = {false, false, false, false, false};
+    int voc_pmode = -1;
+    unsigned short* XP[5] = {};
+    unsigned short* tbP[5][3][3] = {};
+    unsigned short* ybP[5][3][2] = {};
     bool voc_grouped = true;               // the three ResBlock branches of a level share one launch per conv stage
     float* d_pcm = nullptr;                // [B][2048*Tv]
     // per-step redirections of the device-buffer step (no staging copies): chunk source, PCM destination, codes source

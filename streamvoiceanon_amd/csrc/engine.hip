@@ -46,6 +46,8 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "planes_dbg") o.planes_dbg = atoi(v.c_str());
             else if (k == "reprefill") o.reprefill = atoi(v.c_str());
             else if (k == "planes_dma") o.planes_dma = atoi(v.c_str());
+            else if (k == "voc_dma") o.voc_dma = atoi(v.c_str());
+            else if (k == "voc_dma_variant") o.voc_dma_variant = atoi(v.c_str());
             else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());
@@ -536,16 +538,47 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         ch /= 2;
         b->voc_rpf[i] = rpf;
         const bool fused_level = voc_level_is_fused(b, ch);
+        // Levels with C % 32 == 0 of a batch with enough rows per step: the 18 ResBlock convs on the LDS-DMA planes kernel, three branches per launch,
+        // the activations between them as operand planes (history included).  A static choice per batch -- the history lives in one form.  From 16
+        // code frames per step over the batch (streams x voc_max_frames): measured +4.7 / +5.7 / +6.7 / +5.2 / +3.9 % frames/s at 16 / 24 / 32 / 48 /
+        // 128 streams, even at 8 (profiles/r05_voc_dma_sweep.txt)
+        bool dma_level = !fused_level && ch % 32 == 0 && debug_options().planes_dma != 0 && debug_options().voc_dma != 0 &&
+                         (debug_options().voc_dma == 1 || (long)B * Tv >= 16);
+        for (int br = 0; br < 3 && dma_level; ++br)
+            for (int j = 0; j < 3; ++j) {
+                const ResConv& rcv = e->res[i][br][j];
+                const int pm = rcv.c1.pmode;
+                dma_level = dma_level && rcv.c1.Wp && rcv.c2.Wp && (pm == PLANES_H3 || pm == PLANES_H1) && rcv.c2.pmode == pm && (b->voc_pmode < 0 || b->voc_pmode == pm);
+                if (dma_level) b->voc_pmode = pm;
+            }
+        b->voc_dma[i] = dma_level;
+        auto alloc_planes = [&](const Act& a, unsigned short** P) -> int {
+            const size_t n = (size_t)planes_count(b->voc_pmode) * B * a.bstride;
+            SVA_TRY(dev_alloc(A, P, n));
+            if (a.H == 0) return 0;
+            // the history rows of every (plane, 32-channel block) shift like a [B][rows][16 floats] tensor of its own
+            for (int p = 0; p < planes_count(b->voc_pmode); ++p)
+                for (int kb = 0; kb < a.C / 32; ++kb) {
+                    ShiftDesc d;
+                    d.ptr = reinterpret_cast<float*>(*P + (size_t)p * B * a.bstride + (size_t)kb * B * a.rows * 32);
+                    d.bstride = a.rows * 16; d.H = a.H; d.T = 0; d.C = 16; d.pad = rpf;
+                    b->shift_host.push_back(d);
+                }
+            return 0;
+        };
         // fused levels keep the receptive field of the whole six-conv chain as input history (their only streaming state)
         SVA_TRY(alloc_act(A, b->X[i], B, fused_level ? (kResK[2] - 1) * 2 * (kResD[0] + kResD[1] + kResD[2]) : (kResK[2] - 1) * kResD[0], rows, ch));
-        SVA_TRY(register_shift(b, b->X[i], rpf));
+        if (dma_level) SVA_TRY(alloc_planes(b->X[i], &b->XP[i]));        // (the fp32 tensors of such a level are read as residuals only: current rows)
+        else SVA_TRY(register_shift(b, b->X[i], rpf));
         for (int br = 0; br < 3; ++br)
             for (int j = 0; j < 3; ++j) {
                 SVA_TRY(alloc_act(A, b->tb[i][br][j], B, (kResK[br] - 1) * kResD[j], rows, ch));
-                SVA_TRY(register_shift(b, b->tb[i][br][j], rpf));
+                if (dma_level) SVA_TRY(alloc_planes(b->tb[i][br][j], &b->tbP[i][br][j]));
+                else SVA_TRY(register_shift(b, b->tb[i][br][j], rpf));
                 if (j < 2) {
                     SVA_TRY(alloc_act(A, b->yb[i][br][j], B, (kResK[br] - 1) * kResD[j + 1], rows, ch));
-                    SVA_TRY(register_shift(b, b->yb[i][br][j], rpf));
+                    if (dma_level) SVA_TRY(alloc_planes(b->yb[i][br][j], &b->ybP[i][br][j]));
+                    else SVA_TRY(register_shift(b, b->yb[i][br][j], rpf));
                 }
             }
         for (int br = 0; br < 3; ++br) SVA_TRY(alloc_act(A, b->y3[i][br], B, 0, rows, ch));
@@ -676,12 +709,21 @@ extern "C" int sva_vocode_reset(sva_batch* b) {
     SVA_TRY(zero(b->u0)); SVA_TRY(zero(b->u1)); SVA_TRY(zero(b->pin));
     SVA_HIP(hipMemsetAsync(b->d_voc_frames, 0, sizeof(int), b->stream));
     for (int i = 0; i < 6; ++i) SVA_TRY(zero(b->S[i]));
+    auto zero_planes = [&](const Act& a, unsigned short* P) -> int {
+        if (P) SVA_HIP(hipMemsetAsync(P, 0, sizeof(unsigned short) * (size_t)planes_count(b->voc_pmode) * b->B * a.bstride, b->stream));
+        return 0;
+    };
     for (int i = 0; i < 5; ++i) {
         SVA_TRY(zero(b->X[i]));
+        SVA_TRY(zero_planes(b->X[i], b->XP[i]));
         for (int br = 0; br < 3; ++br)
             for (int j = 0; j < 3; ++j) {
                 SVA_TRY(zero(b->tb[i][br][j]));
-                if (j < 2) SVA_TRY(zero(b->yb[i][br][j]));
+                SVA_TRY(zero_planes(b->tb[i][br][j], b->tbP[i][br][j]));
+                if (j < 2) {
+                    SVA_TRY(zero(b->yb[i][br][j]));
+                    SVA_TRY(zero_planes(b->yb[i][br][j], b->ybP[i][br][j]));
+                }
             }
     }
     SVA_HIP(hipStreamSynchronize(b->stream));

@@ -706,7 +706,20 @@ static const PlanesRow g_planes_table[] = {
 #include "planes_table.inc"
 };
 static int planes_variant(const ConvGemm& g, int group_n) {
-    const bool dma_ok = group_n == 1 && planes_dma_gemm_supported(g) && debug_options().planes_dma != 0;
+    // conv taps over A planes (the HiFiGAN levels' ResBlock convs, three branches per launch): only the LDS-DMA form reads them; its tile by
+    // the output width and by whether 128 x 128 tiles would fill the chip
+    if (g.Ap && (g.taps > 1 || group_n > 1 || g.cp_silu) && debug_options().planes_dma != 0) {
+        bool ok = planes_dma_conv_supported(g);
+        if (t_group) for (int i = 0; i < t_group->n; ++i) ok = ok && planes_dma_conv_supported(t_group->g[i]);
+        if (ok) {
+            const int dv = debug_options().voc_dma_variant;
+            if (g.N % 128 == 0 && (long)((g.M + 127) / 128) * (g.N / 128) * group_n >= 192) return dv >= 9 && dv <= 14 && dv != 11 && dv != 12 ? dv : 9;
+            if (g.N % 64 == 0) return g.N == 64 && g.M * (long)group_n >= 3 * 8192 ? 13 : 14;
+            return 15;
+        }
+    }
+    bool dma_ok = planes_dma_gemm_supported(g) && debug_options().planes_dma != 0;
+    if (group_n > 1) dma_ok = false;
     // measured winners for the encoder's shapes (tools/planes_tune.py -> planes_table.inc; every variant computes the same accumulation per
     // output, so the table is a speed choice only): the row with this (N, K) whose M is nearest, if within a quarter of it
     if (group_n == 1 && g.taps == 1) {
@@ -1047,7 +1060,7 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
         // grouped convs -- 5.6 GFLOP per launch at ~60 TF/s there)
         const double gflop = 2e-9 * g.M * (double)g.N * g.taps * g.Cin * group_n;
         const bool want = g.Ap || g.Cp ||
-                          (g.pmode == PLANES_H1 ? g.M >= 1024 : ((ch.kind == 4 && g.M >= 3072) || (ch.kind != 4 && g.M >= 2048 && g.N >= 128 && gflop >= 2.0)));
+                          (g.pmode == PLANES_H1 ? g.M >= 1024 && g.N >= 32 : g.N < 64 ? false : ((ch.kind == 4 && g.M >= 3072) || (ch.kind != 4 && g.M >= 2048 && g.N >= 128 && gflop >= 2.0)));
         if (planes && want) ch = Choice{4, 8 + planes_variant(g, group_n), 0, 0};
         else SVA_CHECK(!g.Ap && !g.Cp, "conv_gemm: operand planes handed to a problem the planes kernel does not take");
     }

@@ -433,8 +433,21 @@ __device__ __forceinline__ void glds16(const char* base, unsigned voff, unsigned
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int MODE, int BM, int NST, bool PROBE, int BN = 128, int NW = 8>
-__global__ __launch_bounds__(64 * NW, NW / 4) void planes_dma_kernel(const ConvGemm g, const int n_tiles_n, const int n_tiles, const int dbg_arg) {
+// resident workgroups per CU of a tile configuration: eight-wave workgroups two when the LDS allows (one's epilogue runs under the other's K
+// steps); the narrow-tile configurations of the HiFiGAN levels (four / two waves) as many as LDS and 16 waves per CU allow
+template <int MODE, int BM, int BN, int NST, int NW> struct DmaCfg {
+    static constexpr size_t smem = (size_t)NST * PM<MODE>::NPL * (BM + BN) / 16 * 1024;
+    static constexpr int by_lds = (int)((160 * 1024) / smem), by_waves = 16 / NW;
+    static constexpr int WG_PER_CU = NW == 8 ? (by_lds >= 2 ? 2 : 1) : (by_lds < by_waves ? by_lds : by_waves);
+    static constexpr int WAVES_PER_SIMD = NW == 8 ? 2 : (WG_PER_CU * NW + 3) / 4;
+};
+
+template <int MODE, int BM, int NST, bool PROBE, int BN = 128, int NW = 8, bool CONV = false>
+__global__ __launch_bounds__(64 * NW, (DmaCfg<MODE, BM, BN, NST, NW>::WAVES_PER_SIMD)) void planes_dma_kernel(const ConvGemmGroup gg, const int n_tiles_n, const int n_tiles, const int dbg_arg) {
+    // CONV: conv taps and / or a group of problems (the generic tile deal and per-tile problem lookup); !CONV: one taps == 1 problem, every
+    // per-problem quantity a launch constant (the encoder's GEMMs: the K loop carries no trace of the generality)
+    // gg.n problems of ONE shape (M, N, Cin, T) that may differ in taps / dilation / pointers (the three ResBlock branches of a HiFiGAN level, k = 3 / 7 / 11):
+    // tile ids [p * n_tiles, (p + 1) * n_tiles) belong to problem p; a workgroup's stream of K steps simply runs on across problems
     const int dbg = PROBE ? dbg_arg : 0;          // (the product instantiation carries none of the switches below)
     // dbg: TIMING EXPERIMENTS (SVA_DEBUG planes_dbg; results are garbage): 1 no LDS-DMA requests, 4 no MFMAs, 8 no epilogue, 32 no fragment reads
     constexpr int NPL = PM<MODE>::NPL;
@@ -453,49 +466,75 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void planes_dma_kernel(const ConvG
     const int wm = wave / WN, wn = wave % WN;
     const int prow = lane & 15, pchunk = lane >> 4;
 
-    // ---- this workgroup's tiles: XCD x (= workgroup id & 7, a speed assumption only) owns the x-th contiguous eighth of the sequence ----
+    // ---- this workgroup's tiles (XCD x = workgroup id & 7, a speed assumption only).  One problem: XCD x owns the x-th contiguous eighth of the
+    // tile sequence (a band of M tiles with all their N tiles: the A panel is fetched into one L2).  A group (members sorted by the host, longest K
+    // first): XCD x owns the M tiles with tm % 8 == x of every member, and its workgroups deal them out boustrophedon (slot s: s, 2 S - 1 - s,
+    // 2 S + s, ...), so that the workgroup that drew a long-K tile first draws a short one next -- the members' K differ 11 : 7 : 3 ----
     const int G = gridDim.x, wg = blockIdx.x;
+    const int all_tiles = n_tiles * gg.n;
     const int xcd = wg & 7, slot = wg >> 3, nslots = (G - xcd + 7) >> 3;
-    const int q = n_tiles >> 3, r8 = n_tiles & 7;
-    const int band_lo = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q, band_n = q + (xcd < r8 ? 1 : 0);
-    const int my_tiles = slot < band_n ? (band_n - slot + nslots - 1) / nslots : 0;
-    const int nk = g.Cin / 32;           // (taps == 1: blocked A planes are linear layers' operands)
-    const int total = my_tiles * nk;
+    const bool grouped = CONV && gg.n > 1;
+    const int n_tiles_m = n_tiles / n_tiles_n;
+    const int q = all_tiles >> 3, r8 = all_tiles & 7;
+    const int band_lo = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const int per_member = ((n_tiles_m - xcd + 7) >> 3) * n_tiles_n;          // grouped: this XCD's tiles of one member
+    const int band_n = grouped ? per_member * gg.n : q + (xcd < r8 ? 1 : 0);
+    auto seq_of = [&](int it) { return (grouped && (it & 1)) ? it * nslots + (nslots - 1 - slot) : it * nslots + slot; };
+    int my_tiles = slot < band_n ? (band_n - slot + nslots - 1) / nslots : 0;
+    if (grouped) { my_tiles = 0; while (seq_of(my_tiles) < band_n) ++my_tiles; }
+    auto tau_of = [&](int it) -> int {       // tile id = member * n_tiles + tm * n_tiles_n + tn
+        const int j = seq_of(it);
+        if (!grouped) return band_lo + j;
+        const int pi = j / per_member, r = j - pi * per_member;
+        const int tmx = r / n_tiles_n;
+        return pi * n_tiles + (xcd + 8 * tmx) * n_tiles_n + (r - tmx * n_tiles_n);
+    };
+    const int kcb = gg.g[0].Cin / 32;                                     // 32-wide K blocks per tap
+    // (!CONV: the row geometry of the one problem, divided once)
+    const long a_rows_b0 = gg.g[0].a_bstride / gg.g[0].lda, a_row00 = gg.g[0].a_off / gg.g[0].lda;
+    const long c_rows_b0 = gg.g[0].ldc ? gg.g[0].c_bstride / gg.g[0].ldc : 0, c_row00 = gg.g[0].ldc ? gg.g[0].c_off / gg.g[0].ldc : 0;
+    auto nk_of = [&](int it) { return CONV ? gg.g[tau_of(it) / n_tiles].taps * kcb : kcb; };
+    int total = my_tiles * kcb;
+    if (CONV) { total = 0; for (int it = 0; it < my_tiles; ++it) total += nk_of(it); }
     if (total == 0) return;
 
     // ---- load side: (tile, k) of the next step to request, per-lane source offsets relative to the tile's wave-uniform bases ----
-    int ld_it = 0, ld_k = 0, ld_stage = 0;
+    int ld_it = 0, ld_k = 0, ld_kb = 0, ld_tap = 0, ld_nk = 0, ld_stage = 0;
     unsigned offA[PA], offW[PB];
     const char *baseA = nullptr, *baseW = nullptr;
-    const long a_rows_b = g.a_bstride / g.lda, a_row0 = g.a_off / g.lda;       // dense row of (b, t) = b * a_rows_b + a_row0 + t
-    auto row_of = [&](int m) -> long {
-        if (m > g.M - 1) m = g.M - 1;
-        const int b = m / g.T, t = m - b * g.T;
-        return (long)b * a_rows_b + a_row0 + t;
-    };
+    long a_blk2 = 0, a_ps2 = 0, w_ps2 = 0, tap2 = 0;          // bytes between 32-k blocks of an A plane / between planes / per tap (dil rows of 64 bytes)
+    const long w_blk2 = (long)gg.g[0].N * 64;
     auto ld_tile = [&]() {
-        const int tile = band_lo + slot + ld_it * nslots;
+        const int tau = tau_of(ld_it);
+        const int pi = CONV ? tau / n_tiles : 0, tile = tau - pi * n_tiles;
+        const ConvGemm& gl = gg.g[pi];
         const int tm = tile / n_tiles_n, tn = tile - tm * n_tiles_n;
         const int bm0 = tm * BM, bn0 = tn * BN;
-        // K-blocked planes: a row's 32 k of one block are 64 contiguous bytes, consecutive rows are adjacent -- the 16 rows of a piece are
-        // one contiguous KiB wherever the tile does not straddle a batch item
+        // K-blocked planes over dense rows (planes_split.h): dense row of (b, t) = b * (a_bstride / lda) + a_off / lda + t, + tap * dil for a conv tap
+        const long a_rows_b = CONV ? gl.a_bstride / gl.lda : a_rows_b0, a_row0 = CONV ? gl.a_off / gl.lda : a_row00;
+        auto row_of = [&](int m) -> long {
+            if (m > gl.M - 1) m = gl.M - 1;
+            const int b = m / gl.T, t = m - b * gl.T;
+            return (long)b * a_rows_b + a_row0 + t;
+        };
         const long r0 = row_of(bm0);
-        baseA = uni_ptr(reinterpret_cast<const char*>(g.Ap + r0 * 32));
-        baseW = uni_ptr(reinterpret_cast<const char*>(g.Wp + (long)bn0 * 32));
+        baseA = uni_ptr(reinterpret_cast<const char*>(gl.Ap + r0 * 32));
+        baseW = uni_ptr(reinterpret_cast<const char*>(gl.Wp + (long)bn0 * 32));
 #pragma unroll
         for (int i = 0; i < PA; ++i) offA[i] = (unsigned)(((row_of(bm0 + (wave + NW * i) * 16 + prow) - r0) * 32 + pchunk * 8) * 2);
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             int n = bn0 + (wave + NW * i) * 16 + prow;
-            if (n > g.N - 1) n = g.N - 1;
+            if (n > gl.N - 1) n = gl.N - 1;
             offW[i] = (unsigned)(((long)(n - bn0) * 32 + pchunk * 8) * 2);
         }
+        a_blk2 = gl.ap_rows * 64; a_ps2 = gl.ap_pstride * 2; w_ps2 = gl.wp_pstride * 2; tap2 = (long)gl.dil * 64;
+        ld_nk = CONV ? gl.taps * kcb : kcb;
     };
-    const long a_ps2 = g.ap_pstride * 2, w_ps2 = g.wp_pstride * 2, a_blk2 = g.ap_rows * 64, w_blk2 = (long)g.N * 64;      // bytes between planes / 32-k blocks
     auto issue = [&]() {
         if (ld_k == 0) ld_tile();
-        const char* const ba = baseA + (long)ld_k * a_blk2;
-        const char* const bw = baseW + (long)ld_k * w_blk2;
+        const char* const ba = CONV ? uni_ptr(baseA + (long)ld_kb * a_blk2 + (long)ld_tap * tap2) : baseA + (long)ld_k * a_blk2;
+        const char* const bw = CONV ? uni_ptr(baseW + (long)ld_k * w_blk2) : baseW + (long)ld_k * w_blk2;             // (W is K-blocked over taps * Cin: block = tap * kcb + kb = the step)
         const unsigned dst = lds0 + (unsigned)ld_stage * STAGE;
         if (!(dbg & 1)) {
 #pragma unroll
@@ -506,7 +545,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void planes_dma_kernel(const ConvG
                 for (int i = 0; i < PB; ++i) glds16(bw + p * w_ps2, offW[i], dst + (unsigned)(A_BYTES + (p * RBB + wave + NW * i) * 1024));
             }
         }
-        if (++ld_k == nk) { ld_k = 0; ++ld_it; }
+        if (CONV) { if (++ld_kb == kcb) { ld_kb = 0; ++ld_tap; } }
+        if (++ld_k == ld_nk) { ld_k = 0; ld_tap = 0; ++ld_it; }
         if (++ld_stage == NST) ld_stage = 0;
     };
 
@@ -517,22 +557,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void planes_dma_kernel(const ConvG
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- epilogue of the tile the compute side has finished: registers -> global, no LDS ----
-    const float winv = g.wp_inv;
-    const long c_rows_b = g.ldc ? g.c_bstride / g.ldc : 0, c_row0 = g.ldc ? g.c_off / g.ldc : 0;
-    auto store4 = [&](const f32x4& v, long idx, int b_, int t_, int n_) {
-        // fp16 parts have fp16's range: an operand beyond +-65504 is REPORTED (host-mapped flag; sva_sync / the next step fails naming mm_mode = 0)
-        if (g.ovf && !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < INFINITY)) *reinterpret_cast<volatile int*>(g.ovf) = 1;
-        if (g.C) *reinterpret_cast<f32x4*>(g.C + idx) = v;
-        if (g.Cp) {
-            unsigned p0[NPL], p1[NPL];
-            split_pair<MODE>(v.x, v.y, p0);
-            split_pair<MODE>(v.z, v.w, p1);
-            const long po = plane_off_blocked((long)b_ * c_rows_b + c_row0 + t_, n_, g.cp_rows);
+    auto epilogue = [&](int tau) {
+        const int pi = CONV ? tau / n_tiles : 0, tile = tau - pi * n_tiles;
+        const ConvGemm& g = gg.g[pi];
+        const float winv = g.wp_inv;
+        const long c_rows_b = CONV ? (g.ldc ? g.c_bstride / g.ldc : 0) : c_rows_b0, c_row0 = CONV ? (g.ldc ? g.c_off / g.ldc : 0) : c_row00;
+        auto store4 = [&](const f32x4& v, long idx, int b_, int t_, int n_) {
+            // fp16 parts have fp16's range: an operand beyond +-65504 is REPORTED (host-mapped flag; sva_sync / the next step fails naming mm_mode = 0)
+            if (g.ovf && !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < INFINITY)) *reinterpret_cast<volatile int*>(g.ovf) = 1;
+            if (g.C) *reinterpret_cast<f32x4*>(g.C + idx) = v;
+            if (g.Cp) {
+                f32x4 w = v;
+                if (CONV && g.cp_silu) { w.x = silu_f(v.x); w.y = silu_f(v.y); w.z = silu_f(v.z); w.w = silu_f(v.w); }      // the consumer conv reads silu(.) (HiFiGAN)
+                unsigned p0[NPL], p1[NPL];
+                split_pair<MODE>(w.x, w.y, p0);
+                split_pair<MODE>(w.z, w.w, p1);
+                const long po = plane_off_blocked((long)b_ * c_rows_b + c_row0 + t_, n_, g.cp_rows);
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x2*>(g.Cp + (long)p * g.cp_pstride + po) = (u32x2){p0[p], p1[p]};
-        }
-    };
-    auto epilogue = [&](int tile) {
+                for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x2*>(g.Cp + (long)p * g.cp_pstride + po) = (u32x2){p0[p], p1[p]};
+            }
+        };
         const int tm = tile / n_tiles_n, tn = tile - tm * n_tiles_n;
         const int bm0 = tm * BM, bn0 = tn * BN;
         const int nq = 4 * (lane >> 4);
@@ -581,7 +625,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void planes_dma_kernel(const ConvG
 #pragma unroll
     for (int s_ = 0; s_ < PD; ++s_)
         if (s_ < total) issue();
-    int cs = 0, ck = 0, cit = 0;
+    int cs = 0, ck = 0, cit = 0, cnk = nk_of(0);
     bool prewaited = false;
     auto wait_step = [&](int allow) {         // at most `allow` requested steps may still be in flight (LPW instructions each)
         if (allow <= 0) wait_vm<0>();
@@ -639,31 +683,32 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void planes_dma_kernel(const ConvG
             }
         }
         if (++cs == NST) cs = 0;
-        if (++ck == nk) {
+        if (++ck == cnk) {
             ck = 0;
             // the next step's pieces are waited for BEFORE the epilogue's stores join the queue (vmcnt counts them too: waiting behind them
             // would park the first K step of every tile for a store round trip); the barrier of the next iteration makes it workgroup-wide
             if (s_ + 1 < total) { wait_step(min(PD - 1, total - 2 - s_)); prewaited = true; }
             if (dbg & 8) { if (acc[0][0][0] == 123.456f) epilogue(0); }
             else
-            epilogue(band_lo + slot + cit * nslots);
+            epilogue(tau_of(cit));
             ++cit;
+            if (cit < my_tiles) cnk = nk_of(cit);
         }
     }
 }
 
 static int g_dma_cu_limit = 0;          // CUs a planes-DMA launch may count on (0: the device's); the engine lowers it for CU-masked streams
 
-template <int MODE, int BM, int NST, int BN = 128, int NW = 8>
-int launch_planes_dma_t(const ConvGemm& g, hipStream_t st) {
-    constexpr int NPL = PM<MODE>::NPL;
-    constexpr size_t smem = (size_t)NST * NPL * (BM + BN) / 16 * 1024;
-    constexpr int WG_PER_CU = smem * 2 <= 160 * 1024 ? 2 : 1;            // two resident workgroups: one's epilogue runs under the other's K steps
-    static_assert(smem <= 160 * 1024, "LDS of one CU");
+template <int MODE, int BM, int NST, bool CONV, int BN = 128, int NW = 8>
+int launch_planes_dma_t(const ConvGemmGroup& gg, hipStream_t st) {
+    const ConvGemm& g = gg.g[0];
+    constexpr size_t smem = DmaCfg<MODE, BM, BN, NST, NW>::smem;
+    constexpr int WG_PER_CU = DmaCfg<MODE, BM, BN, NST, NW>::WG_PER_CU;
+    static_assert(smem <= 160 * 1024 && WG_PER_CU >= 1, "LDS of one CU");
     static DeviceOnce attr_set;
     if (attr_set.needed()) {
-        SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<MODE, BM, NST, false, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        if (MODE == PLANES_H3) SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<MODE, BM, NST, false, BN, NW, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (MODE == PLANES_H3) SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set.done();
     }
     int cus = g.cu_limit > 0 ? g.cu_limit : g_dma_cu_limit;
@@ -677,27 +722,56 @@ int launch_planes_dma_t(const ConvGemm& g, hipStream_t st) {
         cus = dev_cus;
     }
     const int tn = g.N / BN, tm = (g.M + BM - 1) / BM, tiles = tn * tm;
-    const int grid = std::min(tiles, cus * WG_PER_CU);
+    const int grid = std::min(tiles * gg.n, cus * WG_PER_CU);
+    ConvGemmGroup sorted = gg;                      // (longest K first: the kernel's tile deal relies on it)
+    std::stable_sort(sorted.g, sorted.g + sorted.n, [](const ConvGemm& a, const ConvGemm& b_) { return a.taps > b_.taps; });
     const int dbg = debug_options().planes_dbg;
-    if (dbg && MODE == PLANES_H3) hipLaunchKernelGGL((planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW>), dim3(grid), dim3(64 * NW), smem, st, g, tn, tiles, dbg);
-    else hipLaunchKernelGGL((planes_dma_kernel<MODE, BM, NST, false, BN, NW>), dim3(grid), dim3(64 * NW), smem, st, g, tn, tiles, 0);
+    if (dbg && MODE == PLANES_H3) hipLaunchKernelGGL((planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW, CONV>), dim3(grid), dim3(64 * NW), smem, st, sorted, tn, tiles, dbg);
+    else hipLaunchKernelGGL((planes_dma_kernel<MODE, BM, NST, false, BN, NW, CONV>), dim3(grid), dim3(64 * NW), smem, st, sorted, tn, tiles, 0);
     return 0;
 }
 
 // variants 8 .. 10 of launch_planes_gemm
-bool planes_dma_supported(const ConvGemm& g) {
-    return planes_gemm_supported(g) && g.Ap && !g.a_silu && g.N % 128 == 0 && g.ksplit <= 1 && (!g.w13 || g.N % 32 == 0) &&
+bool planes_dma_supported(const ConvGemm& g, bool conv = false) {
+    return planes_gemm_supported(g) && g.Ap && !g.a_silu && g.N % (conv ? 32 : 128) == 0 && (!conv || !g.w13) && g.ksplit <= 1 && (!g.w13 || g.N % 32 == 0) &&
            (!g.C || (g.ldc % 4 == 0 && g.c_off % 4 == 0 && g.c_bstride % 4 == 0)) && (!g.res || (g.ldr % 4 == 0 && g.r_off % 4 == 0 && g.r_bstride % 4 == 0));
 }
-int launch_planes_dma(const ConvGemm& g, int variant, hipStream_t st) {
-    SVA_CHECK(planes_dma_supported(g) && (variant == 9 || variant == 10), "planes_dma: unsupported problem (A as planes, N % 128 == 0)");
+int launch_planes_dma(const ConvGemmGroup& gg, int variant, hipStream_t st) {
+    const ConvGemm& g = gg.g[0];
+    bool conv = gg.n > 1;
+    for (int i = 0; i < gg.n; ++i) conv = conv || gg.g[i].taps > 1 || gg.g[i].cp_silu;
+    const int bn = variant == 13 || variant == 14 ? 64 : variant == 15 ? 32 : 128;
+    SVA_CHECK(variant == 9 || variant == 10 || (conv && variant >= 13 && variant <= 15 && g.N % bn == 0), "planes_dma: variant");
+    for (int i = 0; i < gg.n; ++i)
+        SVA_CHECK(planes_dma_supported(gg.g[i], conv) && g.N % bn == 0 && gg.g[i].M == g.M && gg.g[i].N == g.N && gg.g[i].Cin == g.Cin && gg.g[i].T == g.T && gg.g[i].pmode == g.pmode,
+                  "planes_dma: unsupported problem (A as planes, N % 128 == 0, group members of one shape)");
     // 9: 128 x 128, four stages, one workgroup per CU; 10: 128 x 128, two stages, TWO workgroups per CU (one's epilogue under the other's K steps).
     // Measured and NOT instantiated (profiles/r05_planes_dma_bench_all_variants.txt; the template still takes them): 256 x 128 on 8 waves /
     // three stages (was 8), 256 x 256 on 16 waves / two stages (11: half the operand bytes per flop, 56 % MFMA use inside its K loop, but
     // one workgroup per CU leaves its epilogue and the 1.5-round tile counts of these shapes exposed), 128 x 256 on 8 waves (12) -- none
     // wins on any encoder shape
-    if (g.pmode == PLANES_H3) return variant == 9 ? launch_planes_dma_t<PLANES_H3, 128, 4>(g, st) : launch_planes_dma_t<PLANES_H3, 128, 2>(g, st);
-    return variant == 9 ? launch_planes_dma_t<PLANES_H1, 128, 4>(g, st) : launch_planes_dma_t<PLANES_H1, 128, 2>(g, st);
+    if (conv) {
+        // conv taps / a group / SiLU'd output planes: the HiFiGAN levels' ResBlock convs.  Their narrow outputs take narrow tiles -- 13: 128 x 64
+        // and 14: 64 x 64 on four waves (C = 64; C >= 128 with too few rows for 128 x 128 tiles to fill the chip), 15: 128 x 32 on two waves (C = 32)
+        if (g.pmode == PLANES_H3) {
+            switch (variant) {
+                case 9: return launch_planes_dma_t<PLANES_H3, 128, 4, true>(gg, st);
+                case 10: return launch_planes_dma_t<PLANES_H3, 128, 2, true>(gg, st);
+                case 13: return launch_planes_dma_t<PLANES_H3, 128, 2, true, 64, 4>(gg, st);
+                case 14: return launch_planes_dma_t<PLANES_H3, 64, 4, true, 64, 4>(gg, st);
+                default: return launch_planes_dma_t<PLANES_H3, 128, 2, true, 32, 2>(gg, st);
+            }
+        }
+        switch (variant) {
+            case 9: return launch_planes_dma_t<PLANES_H1, 128, 4, true>(gg, st);
+            case 10: return launch_planes_dma_t<PLANES_H1, 128, 2, true>(gg, st);
+            case 13: return launch_planes_dma_t<PLANES_H1, 128, 2, true, 64, 4>(gg, st);
+            case 14: return launch_planes_dma_t<PLANES_H1, 64, 4, true, 64, 4>(gg, st);
+            default: return launch_planes_dma_t<PLANES_H1, 128, 2, true, 32, 2>(gg, st);
+        }
+    }
+    if (g.pmode == PLANES_H3) return variant == 9 ? launch_planes_dma_t<PLANES_H3, 128, 4, false>(gg, st) : launch_planes_dma_t<PLANES_H3, 128, 2, false>(gg, st);
+    return variant == 9 ? launch_planes_dma_t<PLANES_H1, 128, 4, false>(gg, st) : launch_planes_dma_t<PLANES_H1, 128, 2, false>(gg, st);
 }
 
 // fp32 [rows][K] (row stride ld) -> K-blocked planes (planes_split.h): one thread per 8 consecutive k of a row
@@ -723,10 +797,34 @@ __global__ void to_planes_kernel(const float* __restrict__ src, long rows, int K
     }
 }
 
+// rows [row0, row0 + T) of every stream of an activation tensor [nb][rows_b][K] -> the same dense rows of its planes mirror (nb * rows_b rows)
+template <int MODE>
+__global__ void to_planes_act_kernel(const float* __restrict__ src, int nb, long rows_b, long row0, int T, int K, unsigned short* __restrict__ dst, long pstride, int silu) {
+    constexpr int NPL = PM<MODE>::NPL;
+    const int k8 = K / 8;
+    const long n8 = (long)nb * T * k8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / k8;
+        const int k = (int)(i - m * k8) * 8;
+        const long b = m / T, row = b * rows_b + row0 + (m - b * T);
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(src + row * K + k), v1 = *reinterpret_cast<const f32x4*>(src + row * K + k + 4);
+        if (silu) {
+            v0.x = silu_f(v0.x); v0.y = silu_f(v0.y); v0.z = silu_f(v0.z); v0.w = silu_f(v0.w);
+            v1.x = silu_f(v1.x); v1.y = silu_f(v1.y); v1.z = silu_f(v1.z); v1.w = silu_f(v1.w);
+        }
+        u32x4 o[NPL];
+        split8<MODE>(v0, v1, o);
+        const long po = plane_off_blocked(row, k, (long)nb * rows_b);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dst + (long)p * pstride + po) = o[p];
+    }
+}
+
 }  // namespace
 
 void planes_dma_set_cu_limit(int cus) { g_dma_cu_limit = cus; }
 bool planes_dma_gemm_supported(const ConvGemm& g) { return planes_dma_supported(g); }
+bool planes_dma_conv_supported(const ConvGemm& g) { return planes_dma_supported(g, true); }
 
 int planes_count(int mode) { return mode == PLANES_H3 ? 2 : 1; }
 
@@ -734,7 +832,7 @@ int planes_count(int mode) { return mode == PLANES_H3 ? 2 : 1; }
 bool planes_gemm_supported(const ConvGemm& g) {
     return g.Wp && (g.pmode == PLANES_H3 || g.pmode == PLANES_H1) && g.Cin % 32 == 0 && g.stride >= 1 && !g.rms_w && !g.dw_wT && (g.C || g.Cp) && !(g.accumulate && !g.C) &&
            (g.A || g.Ap) &&
-           (!g.Ap || (g.taps == 1 && g.stride == 1 && g.lda > 0 && g.a_off % g.lda == 0 && g.a_bstride % g.lda == 0 && g.ap_pstride % 8 == 0 && g.ap_rows > 0)) &&
+           (!g.Ap || (g.taps >= 1 && g.stride == 1 && g.lda > 0 && g.a_off % g.lda == 0 && g.a_bstride % g.lda == 0 && g.ap_pstride % 8 == 0 && g.ap_rows > 0)) &&
            (!g.Cp || (g.ldc > 0 && g.ldc % 4 == 0 && g.c_off % g.ldc == 0 && g.c_bstride % g.ldc == 0 && g.cp_pstride % 4 == 0 && g.cp_rows > 0 && (g.w13 ? g.N / 2 : g.N) % 32 == 0));
 }
 
@@ -745,10 +843,12 @@ int launch_planes_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st) {
         SVA_CHECK(planes_gemm_supported(gg.g[i]) && gg.g[i].pmode == g.pmode && !gg.g[i].Ap == !g.Ap, "planes_gemm: group members differ");
     if (g.Ap) {
         SVA_CHECK(!g.a_silu, "planes_gemm: SiLU belongs to the producer of the planes");
-        if (variant >= 8) return launch_planes_dma(g, variant, st);
+        if (variant >= 8) return launch_planes_dma(gg, variant, st);
+        for (int i = 0; i < gg.n; ++i) SVA_CHECK(gg.g[i].taps == 1 && !gg.g[i].cp_silu, "planes_gemm: conv taps over A planes / SiLU'd output planes need the LDS-DMA form");
         return g.pmode == PLANES_H3 ? launch_planes_m<PLANES_H3, true>(gg, variant, st) : launch_planes_m<PLANES_H1, true>(gg, variant, st);
     }
     SVA_CHECK(variant < 8, "planes_gemm: the LDS-DMA variants take the A operand as planes");
+    for (int i = 0; i < gg.n; ++i) SVA_CHECK(!gg.g[i].cp_silu, "planes_gemm: SiLU'd output planes need the LDS-DMA form");
     return g.pmode == PLANES_H3 ? launch_planes_m<PLANES_H3, false>(gg, variant, st) : launch_planes_m<PLANES_H1, false>(gg, variant, st);
 }
 
@@ -758,6 +858,16 @@ int launch_to_planes(const float* src, long rows, int K, long ld, unsigned short
     const int blocks = (int)std::min<long>((n8 + 255) / 256, 2048);
     if (mode == PLANES_H3) hipLaunchKernelGGL(to_planes_kernel<PLANES_H3>, dim3(blocks), dim3(256), 0, st, src, rows, K, ld, dst, pstride, scale, silu);
     else hipLaunchKernelGGL(to_planes_kernel<PLANES_H1>, dim3(blocks), dim3(256), 0, st, src, rows, K, ld, dst, pstride, scale, silu);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_to_planes_act(const float* src, int nb, long rows_b, long row0, int T, int K, unsigned short* dst, long pstride, int mode, int silu, hipStream_t st) {
+    SVA_CHECK(K % 32 == 0 && (mode == PLANES_H3 || mode == PLANES_H1), "to_planes_act: whole 32-k blocks, an fp16 planes format");
+    const long n8 = (long)nb * T * (K / 8);
+    const int blocks = (int)std::min<long>((n8 + 255) / 256, 4096);
+    if (mode == PLANES_H3) hipLaunchKernelGGL(to_planes_act_kernel<PLANES_H3>, dim3(blocks), dim3(256), 0, st, src, nb, rows_b, row0, T, K, dst, pstride, silu);
+    else hipLaunchKernelGGL(to_planes_act_kernel<PLANES_H1>, dim3(blocks), dim3(256), 0, st, src, nb, rows_b, row0, T, K, dst, pstride, silu);
     SVA_HIP(hipGetLastError());
     return 0;
 }

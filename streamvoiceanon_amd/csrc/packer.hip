@@ -451,8 +451,8 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
         SVA_CHECK((c.mm_mode == 0 || c.mm_mode == 1) && (c.voc_dtype == 0 || c.voc_dtype == 1),
                   "bad mm_mode / voc_dtype (mm_mode = 2, pre-split bf16 planes, was measured slower than mm_mode = 0 and removed in round 5)");
         std::vector<float> host;
-        auto planes = [&](Lin& l, int mode) -> int {
-            if (mode < 0 || !l.W || l.N < (mode == PLANES_H1 ? 32 : 64) || l.K % 32 != 0) return 0;
+        auto planes = [&](Lin& l, int mode, int min_n = 64) -> int {
+            if (mode < 0 || !l.W || l.N < (mode == PLANES_H1 ? 32 : min_n) || l.K % 32 != 0) return 0;
             const long n = (long)l.N * l.K;
             host.resize(n);
             SVA_HIP(hipMemcpy(host.data(), l.W, sizeof(float) * n, hipMemcpyDeviceToHost));
@@ -481,7 +481,10 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
         for (int i = 0; i < 5; ++i) {
             SVA_TRY(planes(e->ups[i], voc_mode));
             for (int bb = 0; bb < 3; ++bb)
-                for (int j = 0; j < 3; ++j) { SVA_TRY(planes(e->res[i][bb][j].c1, voc_mode)); SVA_TRY(planes(e->res[i][bb][j].c2, voc_mode)); }
+                for (int j = 0; j < 3; ++j) {        // (down to the C = 32 level: the ResBlock convs' LDS-DMA form takes 32-column tiles)
+                    SVA_TRY(planes(e->res[i][bb][j].c1, voc_mode, 32));
+                    SVA_TRY(planes(e->res[i][bb][j].c2, voc_mode, 32));
+                }
         }
     }
     SVA_HIP(hipEventCreateWithFlags(&e->mega_ev, hipEventDisableTiming));      // chains persistent decode launches of different batches (stages.hip)

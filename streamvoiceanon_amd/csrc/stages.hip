@@ -969,6 +969,47 @@ int vocode(sva_batch* b, int T, bool shift, int part) {
             SVA_HIP(hipGetLastError());
             continue;
         }
+        if (b->voc_dma[i]) {
+            // wide level of a large batch: every conv on the LDS-DMA planes kernel, the three branches' tiles as one sequence per conv stage.
+            // Operands are planes throughout: silu(X) from a split pass over the new rows, then each conv's epilogue writes the parts of
+            // silu(output) for its consumer (c1: only those; c2: also the fp32 sum the next residual / the mean reads)
+            const int pm = b->voc_pmode;
+            auto planes_in = [&](ConvGemm& g, const Act& a, const unsigned short* P) {
+                g.A = nullptr; g.a_silu = 0;
+                g.Ap = P; g.ap_pstride = (long)B * a.bstride; g.ap_rows = (long)B * a.rows;
+            };
+            auto planes_out = [&](ConvGemm& g, const Act& a, unsigned short* P) {
+                g.Cp = P; g.cp_pstride = (long)B * a.bstride; g.cp_rows = (long)B * a.rows; g.cp_silu = 1;
+            };
+            SVA_TRY(launch_to_planes_act(b->X[i].p, B, b->X[i].rows, b->X[i].H, (int)Tl, Cout, b->XP[i], (long)B * b->X[i].bstride, pm, 1, st));
+            Act* y[3] = {&b->X[i], &b->X[i], &b->X[i]};
+            const unsigned short* yp[3] = {b->XP[i], b->XP[i], b->XP[i]};
+            for (int j = 0; j < 3; ++j) {
+                ConvGemm g1[3], g2[3];
+                for (int br = 0; br < 3; ++br) {
+                    const ResConv& rcv = e->res[i][br][j];
+                    Act& t = b->tb[i][br][j];
+                    SVA_TRY(conv_desc(b, *y[br], (int)Tl, rcv.dil, rcv.k, rcv.c1, t, g1[br]));
+                    planes_in(g1[br], *y[br], yp[br]);
+                    planes_out(g1[br], t, b->tbP[i][br][j]);
+                    g1[br].C = nullptr;
+                    Act& dst = j < 2 ? b->yb[i][br][j] : b->y3[i][br];
+                    g2[br].res = y[br]->p; g2[br].r_bstride = y[br]->bstride; g2[br].r_off = (long)y[br]->H * Cout; g2[br].ldr = Cout;
+                    SVA_TRY(conv_desc(b, t, (int)Tl, rcv.dil, rcv.k, rcv.c2, dst, g2[br]));
+                    planes_in(g2[br], t, b->tbP[i][br][j]);
+                    if (j < 2) planes_out(g2[br], dst, b->ybP[i][br][j]);
+                    g1[br].cu_limit = g2[br].cu_limit = b->enc_cus;
+                }
+                SVA_TRY(gemm_group_call(b, g1, 3));
+                SVA_TRY(gemm_group_call(b, g2, 3));
+                for (int br = 0; br < 3 && j < 2; ++br) { y[br] = &b->yb[i][br][j]; yp[br] = b->ybP[i][br][j]; }
+            }
+            const long n4 = Tl * Cout / 4;
+            hipLaunchKernelGGL(mean3_kernel, dim3((unsigned)((n4 + 255) / 256), B), dim3(256), 0, st, b->y3[i][0].p, b->y3[i][1].p, b->y3[i][2].p,
+                               b->y3[i][0].bstride, out.p, out.bstride, (long)out.H * Cout, n4);
+            SVA_HIP(hipGetLastError());
+            continue;
+        }
         if (b->voc_grouped) {
             // one launch per conv stage for the three branches (same M, N, Cin; k = 3 / 7 / 11 taps): 12 launches + the
             // mean per level instead of 18 on three streams -- at small B the step is bound by the number of kernels

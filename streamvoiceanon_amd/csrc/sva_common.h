@@ -29,12 +29,15 @@ void set_error(const std::string& msg);
 //   planes_dbg=mask   TIMING DIAGNOSTIC (results are garbage): leave parts of the planes GEMM out -- 1 global loads of its K loop, 2 LDS stores, 4 MFMAs,
 //                     8 epilogue (tools/planes_probe.py)
 //   planes_dma=0      the planes GEMM never takes its persistent LDS-DMA form (variants 8 / 9): round 4's register-staged tiles (A/B)
+//   voc_dma=0|1       the C % 32 == 0 HiFiGAN levels' ResBlock convs on the LDS-DMA planes kernel (activations between them as planes): never /
+//                     at every batch size (default: from 16 code frames per step over the batch; parity tests force it at small batches)
+//   voc_dma_variant=9|10|13|14  tile configuration of those convs where 128 x 128 tiles fill the chip (A/B)
 //   reprefill=0       re-prefill as one whole-prompt prefill per slot behind a host synchronisation (round 3) instead of one pass over the
 //                     appended rows of all due slots against the cached prompt prefix (A/B, parity)
 //   f16_weights=0|2   ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B) / on gemm_f16w.hip even when
 //                     the library was built with a compiler the kernel was not validated with
 struct DebugOptions {
-    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1, planes_dma = 1;
+    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1, planes_dma = 1, voc_dma = -1, voc_dma_variant = 9;
     std::string tune_dump;
 };
 const DebugOptions& debug_options();
@@ -129,8 +132,8 @@ struct ConvGemm {
     float rms_eps = 1e-5f;          //       only on the small-M path -- ask conv_gemm_can_fuse_rms() first
     // pre-split 16-bit operand planes (gemm_planes.hip), ALL K-BLOCKED (planes_split.h: [k / 32][rows][32] per plane, so that the 16 rows x
     // 32 k of an MFMA operand piece are one contiguous KiB).  Wp: parts of W * 2^e over N rows, wp_inv = 2^-e.  Ap / Cp: planes of the A / C
-    // tensor over ap_rows / cp_rows DENSE rows (row of (b, t) = b * (bstride / ld) + off / ld + t: whole rows only; taps = stride = 1), plane
-    // p at + p * pstride elements.  A / C may be null when Ap / Cp is set.
+    // tensor over ap_rows / cp_rows DENSE rows (row of (b, t) = b * (bstride / ld) + off / ld + t (+ tap * dil): whole rows only; stride = 1;
+    // several taps only in the LDS-DMA form), plane p at + p * pstride elements.  A / C may be null when Ap / Cp is set.
     const unsigned short* Wp = nullptr;
     long wp_pstride = 0;
     float wp_inv = 1.f;
@@ -141,6 +144,7 @@ struct ConvGemm {
     unsigned short* Cp = nullptr;
     long cp_pstride = 0;
     long cp_rows = 0;
+    int cp_silu = 0;                // LDS-DMA form: Cp receives the parts of silu(v) while C receives v (HiFiGAN: the next conv reads silu of this output)
     int cu_limit = 0;               // CUs the launch's stream may use (0 = the whole device): sizes the persistent grid of the planes-DMA kernel on CU-masked streams
     int* ovf = nullptr;             // fp16 planes only: set to 1 when an output is not finite (an operand outside the fp16 range); host-mapped
 };
@@ -186,11 +190,15 @@ int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 int planes_count(int mode);
 bool planes_gemm_supported(const ConvGemm& g);
 int launch_planes_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
-// variants 9 / 10 of it: the persistent LDS-DMA-fed form (128 x 128 tiles, one / two workgroups per CU; A as planes, N % 128 == 0, one problem per launch)
+// variants 9 / 10 of it: the persistent LDS-DMA-fed form (128 x 128 tiles, one / two workgroups per CU; A as planes, N % 128 == 0; a group's tiles form one sequence)
 bool planes_dma_gemm_supported(const ConvGemm& g);
+// its conv form (taps over A planes, a group's tiles as one sequence, SiLU'd output planes; variants 9 / 10 and the narrow tiles 13 .. 15): N % 32 == 0
+bool planes_dma_conv_supported(const ConvGemm& g);
 void planes_dma_set_cu_limit(int cus);        // CUs its grid may count on (0 = the device's); the engine sets it around launches on CU-masked streams
 // fp32 [rows][K] (row stride ld) -> K-blocked planes
 int launch_to_planes(const float* src, long rows, int K, long ld, unsigned short* dst, long pstride, int mode, float scale, int silu, hipStream_t st);
+// rows [row0, row0 + T) of each of nb streams of an activation tensor ([nb][rows_b][K] fp32) -> the same dense rows of its planes mirror
+int launch_to_planes_act(const float* src, int nb, long rows_b, long row0, int T, int K, unsigned short* dst, long pstride, int mode, int silu, hipStream_t st);
 int make_weight_planes(const float* dW, int N, int K, float max_abs, int mode, unsigned short* dst, float* inv, hipStream_t st);
 // gemm_f16w.hip: fp16 weights on the f16 matrix pipes (fp32 activations split hi + lo), plain linear layers of the AR chain
 bool f16w_gemm_supported(const ConvGemm& g);

@@ -117,6 +117,43 @@ def test_vocoder_window_and_stream(eng, weights0, fused_mask):
     b.close()
 
 
+@pytest.mark.parametrize("voc_dtype", [0, 1])
+def test_vocoder_wide_levels_on_planes_dma_window_and_stream(weights0, voc_dtype):
+    """The C = 256 / C = 128 HiFiGAN levels with every ResBlock conv on the LDS-DMA planes kernel (three branches per launch, conv taps over
+    K-blocked operand planes, the activations between the convs -- and their streaming history -- as planes): forced at a small batch
+    (SVA_DEBUG voc_dma=1; the default policy takes it from 32 streams), window and ragged streaming pieces against the oracle
+    (firefly.py:183-215, 243-293).  Two streams with different codes, so a row mapped to the wrong stream shows."""
+    from oracle import sva_oracle as O
+    from streamvoiceanon_amd import engine as E
+
+    eng = E.Engine(weights0, voc_dtype=voc_dtype)
+    lib = E.load_library()
+    g = load_golden("vocoder_s0")
+    codes0 = g["codes"].astype(np.int32)
+    rng = np.random.default_rng(77)
+    codes = np.concatenate([codes0, rng.permuted(codes0, axis=2)], axis=0)
+    lib.sva_debug_configure(b"voc_dma=1")
+    try:
+        b = E.Batch(eng, n_streams=2, voc_max_frames=24)
+    finally:
+        lib.sva_debug_configure(b"voc_dma=-1")
+    T = 24
+    tol = PCM_TOL if voc_dtype == 0 else VOC_FP16_TOL
+    ref = O.vocode_window(torch.from_numpy(codes[:, :, :T].astype(np.int64)), weights0)[:, 0].numpy()
+    pcm = b.vocode_window(codes[:, :, :T])
+    assert np.abs(pcm - ref).max() <= tol, np.abs(pcm - ref).max()
+    b.vocode_reset()
+    outs, i = [], 0
+    for n in (1, 1, 3, 1, 8, 2, 8):
+        outs.append(b.vocode_stream(codes[:, :, i:i + n]))
+        i += n
+    assert i == T
+    got = np.concatenate(outs, axis=1)
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+    b.close()
+    eng.close()
+
+
 def _stream_vs_golden(eng, W, name, forced=False, device_rng=False, n_limit=None, use_graph=False, n_streams=1, slot=0):
     """n_streams > 1: the fixture's utterance in every slot of a batch (the batched kernels); taps are taken from `slot`."""
     from oracle import sva_oracle as O
