@@ -127,6 +127,10 @@ struct EncFront {
 struct ResConv {
     Lin c1, c2;
     int k = 0, dil = 1;
+    // narrow levels (C = 16 / 32): weight planes for voc_conv_kernel, K-blocked with K = k * C padded to whole 32-k blocks (C = 32: c1.Wp / c2.Wp themselves)
+    unsigned short *q1 = nullptr, *q2 = nullptr;
+    float q1_inv = 1.f, q2_inv = 1.f;
+    int Kq = 0;
 };
 
 }  // namespace sva
@@ -330,7 +334,7 @@ struct sva_batch {
     sva::Act y3[5][3];                     // y_{b,3}: branch outputs before the ParallelBlock mean (no history)
     // wide levels on the LDS-DMA planes kernel (stages.hip, vocode): the conv inputs silu(X), silu(tb), silu(yb) live as K-blocked operand
     // planes over the same dense rows as the fp32 tensors above (history rows included: they are the streaming state of such a level)
-    bool voc_dma[5] = {false, false, false, false, false};
+    int voc_dma[5] = {0, 0, 0, 0, 0};        // 1: K-blocked planes + the LDS-DMA GEMM's conv form (C >= 64); 2: row-major planes + voc_conv_kernel (C = 16 / 32)
     int voc_pmode = -1;
     unsigned short* XP[5] = {};
     unsigned short* tbP[5][3][3] = {};

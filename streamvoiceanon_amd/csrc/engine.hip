@@ -538,32 +538,45 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         ch /= 2;
         b->voc_rpf[i] = rpf;
         const bool fused_level = voc_level_is_fused(b, ch);
-        // Levels with C % 32 == 0 of a batch with enough rows per step: the 18 ResBlock convs on the LDS-DMA planes kernel, three branches per launch,
-        // the activations between them as operand planes (history included).  A static choice per batch -- the history lives in one form.  From 16
+        // Every level of a batch with enough rows per step: the 18 ResBlock convs on operand planes, three branches per launch (C >= 64: the LDS-DMA
+        // planes kernel's conv form; C = 16 / 32: voc_conv_kernel), the activations between them as planes (history included).  A static choice per batch -- the history lives in one form.  From 16
         // code frames per step over the batch (streams x voc_max_frames): measured +4.7 / +5.7 / +6.7 / +5.2 / +3.9 % frames/s at 16 / 24 / 32 / 48 /
         // 128 streams, even at 8 (profiles/r05_voc_dma_sweep.txt)
-        bool dma_level = !fused_level && ch % 32 == 0 && debug_options().planes_dma != 0 && debug_options().voc_dma != 0 &&
+        const int voc_pm = c.voc_dtype == 1 ? PLANES_H1 : (c.mm_mode == 1 ? PLANES_H3 : -1);
+        bool dma_level = !fused_level && ch % 16 == 0 && voc_pm >= 0 && debug_options().planes_dma != 0 && debug_options().voc_dma != 0 &&
                          (debug_options().voc_dma == 1 || (long)B * Tv >= 16);
+        // C = 16 / 32: row-major planes + voc_conv_kernel (the input rows of a tile and the branch's whole weight resident in LDS); wider: K-blocked planes +
+        // the LDS-DMA GEMM's conv form
+        const bool halo_level = dma_level && ch <= 32 && voc_conv_supported(ch, rpf, voc_pm);
         for (int br = 0; br < 3 && dma_level; ++br)
             for (int j = 0; j < 3; ++j) {
                 const ResConv& rcv = e->res[i][br][j];
-                const int pm = rcv.c1.pmode;
-                dma_level = dma_level && rcv.c1.Wp && rcv.c2.Wp && (pm == PLANES_H3 || pm == PLANES_H1) && rcv.c2.pmode == pm && (b->voc_pmode < 0 || b->voc_pmode == pm);
-                if (dma_level) b->voc_pmode = pm;
+                if (halo_level) dma_level = dma_level && rcv.q1 && rcv.q2;
+                else dma_level = dma_level && ch % 64 == 0 && rcv.c1.Wp && rcv.c2.Wp && rcv.c1.pmode == voc_pm && rcv.c2.pmode == voc_pm;
             }
-        b->voc_dma[i] = dma_level;
+        if (dma_level) b->voc_pmode = voc_pm;
+        b->voc_dma[i] = dma_level ? (halo_level ? 2 : 1) : 0;
         auto alloc_planes = [&](const Act& a, unsigned short** P) -> int {
-            const size_t n = (size_t)planes_count(b->voc_pmode) * B * a.bstride;
+            const int npl = planes_count(b->voc_pmode);
+            const size_t n = (size_t)npl * B * a.bstride;
             SVA_TRY(dev_alloc(A, P, n));
             if (a.H == 0) return 0;
-            // the history rows of every (plane, 32-channel block) shift like a [B][rows][16 floats] tensor of its own
-            for (int p = 0; p < planes_count(b->voc_pmode); ++p)
+            for (int p = 0; p < npl; ++p) {
+                if (halo_level) {       // row-major plane: a [B][rows][C / 2 floats] tensor
+                    ShiftDesc d;
+                    d.ptr = reinterpret_cast<float*>(*P + (size_t)p * B * a.bstride);
+                    d.bstride = a.rows * (a.C / 2); d.H = a.H; d.T = 0; d.C = a.C / 2; d.pad = rpf;
+                    b->shift_host.push_back(d);
+                    continue;
+                }
+                // K-blocked: the history rows of every (plane, 32-channel block) shift like a [B][rows][16 floats] tensor of its own
                 for (int kb = 0; kb < a.C / 32; ++kb) {
                     ShiftDesc d;
                     d.ptr = reinterpret_cast<float*>(*P + (size_t)p * B * a.bstride + (size_t)kb * B * a.rows * 32);
                     d.bstride = a.rows * 16; d.H = a.H; d.T = 0; d.C = 16; d.pad = rpf;
                     b->shift_host.push_back(d);
                 }
+            }
             return 0;
         };
         // fused levels keep the receptive field of the whole six-conv chain as input history (their only streaming state)

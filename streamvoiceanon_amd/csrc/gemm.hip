@@ -714,8 +714,7 @@ static int planes_variant(const ConvGemm& g, int group_n) {
         if (ok) {
             const int dv = debug_options().voc_dma_variant;
             if (g.N % 128 == 0 && (long)((g.M + 127) / 128) * (g.N / 128) * group_n >= 192) return dv >= 9 && dv <= 14 && dv != 11 && dv != 12 ? dv : 9;
-            if (g.N % 64 == 0) return g.N == 64 && g.M * (long)group_n >= 3 * 8192 ? 13 : 14;
-            return 15;
+            return g.N == 64 && g.M * (long)group_n >= 3 * 8192 ? 13 : 14;
         }
     }
     bool dma_ok = planes_dma_gemm_supported(g) && debug_options().planes_dma != 0;

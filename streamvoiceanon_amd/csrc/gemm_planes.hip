@@ -733,15 +733,15 @@ int launch_planes_dma_t(const ConvGemmGroup& gg, hipStream_t st) {
 
 // variants 8 .. 10 of launch_planes_gemm
 bool planes_dma_supported(const ConvGemm& g, bool conv = false) {
-    return planes_gemm_supported(g) && g.Ap && !g.a_silu && g.N % (conv ? 32 : 128) == 0 && (!conv || !g.w13) && g.ksplit <= 1 && (!g.w13 || g.N % 32 == 0) &&
+    return planes_gemm_supported(g) && g.Ap && !g.a_silu && g.N % (conv ? 64 : 128) == 0 && (!conv || !g.w13) && g.ksplit <= 1 && (!g.w13 || g.N % 32 == 0) &&
            (!g.C || (g.ldc % 4 == 0 && g.c_off % 4 == 0 && g.c_bstride % 4 == 0)) && (!g.res || (g.ldr % 4 == 0 && g.r_off % 4 == 0 && g.r_bstride % 4 == 0));
 }
 int launch_planes_dma(const ConvGemmGroup& gg, int variant, hipStream_t st) {
     const ConvGemm& g = gg.g[0];
     bool conv = gg.n > 1;
     for (int i = 0; i < gg.n; ++i) conv = conv || gg.g[i].taps > 1 || gg.g[i].cp_silu;
-    const int bn = variant == 13 || variant == 14 ? 64 : variant == 15 ? 32 : 128;
-    SVA_CHECK(variant == 9 || variant == 10 || (conv && variant >= 13 && variant <= 15 && g.N % bn == 0), "planes_dma: variant");
+    const int bn = variant == 13 || variant == 14 ? 64 : 128;
+    SVA_CHECK(variant == 9 || variant == 10 || (conv && (variant == 13 || variant == 14) && g.N % bn == 0), "planes_dma: variant");
     for (int i = 0; i < gg.n; ++i)
         SVA_CHECK(planes_dma_supported(gg.g[i], conv) && g.N % bn == 0 && gg.g[i].M == g.M && gg.g[i].N == g.N && gg.g[i].Cin == g.Cin && gg.g[i].T == g.T && gg.g[i].pmode == g.pmode,
                   "planes_dma: unsupported problem (A as planes, N % 128 == 0, group members of one shape)");
@@ -751,23 +751,23 @@ int launch_planes_dma(const ConvGemmGroup& gg, int variant, hipStream_t st) {
     // one workgroup per CU leaves its epilogue and the 1.5-round tile counts of these shapes exposed), 128 x 256 on 8 waves (12) -- none
     // wins on any encoder shape
     if (conv) {
-        // conv taps / a group / SiLU'd output planes: the HiFiGAN levels' ResBlock convs.  Their narrow outputs take narrow tiles -- 13: 128 x 64
-        // and 14: 64 x 64 on four waves (C = 64; C >= 128 with too few rows for 128 x 128 tiles to fill the chip), 15: 128 x 32 on two waves (C = 32)
+        // conv taps / a group / SiLU'd output planes: the HiFiGAN levels' ResBlock convs.  Narrow outputs take narrow tiles on four waves -- 13: 128 x 64,
+        // two stages (C = 64); 14: 64 x 64, four stages (C >= 128 with too few rows for 128 x 128 tiles to fill the chip: a workgroup there holds one
+        // tile, so only the ring depth hides the fill latency -- two stages 77 us, four 54).  (128 x 32 on two waves, C = 32: measured equal to
+        // voc_conv_kernel, which also takes C = 16 -- not instantiated.)
         if (g.pmode == PLANES_H3) {
             switch (variant) {
                 case 9: return launch_planes_dma_t<PLANES_H3, 128, 4, true>(gg, st);
                 case 10: return launch_planes_dma_t<PLANES_H3, 128, 2, true>(gg, st);
                 case 13: return launch_planes_dma_t<PLANES_H3, 128, 2, true, 64, 4>(gg, st);
-                case 14: return launch_planes_dma_t<PLANES_H3, 64, 4, true, 64, 4>(gg, st);
-                default: return launch_planes_dma_t<PLANES_H3, 128, 2, true, 32, 2>(gg, st);
+                default: return launch_planes_dma_t<PLANES_H3, 64, 4, true, 64, 4>(gg, st);
             }
         }
         switch (variant) {
             case 9: return launch_planes_dma_t<PLANES_H1, 128, 4, true>(gg, st);
             case 10: return launch_planes_dma_t<PLANES_H1, 128, 2, true>(gg, st);
             case 13: return launch_planes_dma_t<PLANES_H1, 128, 2, true, 64, 4>(gg, st);
-            case 14: return launch_planes_dma_t<PLANES_H1, 64, 4, true, 64, 4>(gg, st);
-            default: return launch_planes_dma_t<PLANES_H1, 128, 2, true, 32, 2>(gg, st);
+            default: return launch_planes_dma_t<PLANES_H1, 64, 4, true, 64, 4>(gg, st);
         }
     }
     if (g.pmode == PLANES_H3) return variant == 9 ? launch_planes_dma_t<PLANES_H3, 128, 4, false>(gg, st) : launch_planes_dma_t<PLANES_H3, 128, 2, false>(gg, st);
@@ -799,7 +799,7 @@ __global__ void to_planes_kernel(const float* __restrict__ src, long rows, int K
 
 // rows [row0, row0 + T) of every stream of an activation tensor [nb][rows_b][K] -> the same dense rows of its planes mirror (nb * rows_b rows)
 template <int MODE>
-__global__ void to_planes_act_kernel(const float* __restrict__ src, int nb, long rows_b, long row0, int T, int K, unsigned short* __restrict__ dst, long pstride, int silu) {
+__global__ void to_planes_act_kernel(const float* __restrict__ src, int nb, long rows_b, long row0, int T, int K, unsigned short* __restrict__ dst, long pstride, int silu, int blocked) {
     constexpr int NPL = PM<MODE>::NPL;
     const int k8 = K / 8;
     const long n8 = (long)nb * T * k8;
@@ -814,10 +814,155 @@ __global__ void to_planes_act_kernel(const float* __restrict__ src, int nb, long
         }
         u32x4 o[NPL];
         split8<MODE>(v0, v1, o);
-        const long po = plane_off_blocked(row, k, (long)nb * rows_b);
+        const long po = blocked ? plane_off_blocked(row, k, (long)nb * rows_b) : row * K + k;
 #pragma unroll
         for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dst + (long)p * pstride + po) = o[p];
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// voc_conv_kernel: one conv stage (c1 or c2) of the three ResBlock branches of a NARROW HiFiGAN level (C = 16 / 32 channels; sva_common.h:
+// VocConv).  The LDS-DMA GEMM above re-fetches the input rows once per tap (K = taps * C in 32-wide steps: at C = 32 every step is a whole
+// new A piece for 32 output columns) and is bound by that fill; here a workgroup (four waves) keeps
+//   * its branch's WHOLE weight as MFMA fragments in LDS (C = 32, k = 11: 44 KiB; loaded once, the workgroup walks tiles of one branch),
+//   * per tile of BM output rows the input rows WITH their halo, (BM + (taps - 1) dil) x C fp16 parts per plane, as the row-major image
+//     the global tensor has (one contiguous run per plane -> 1 KiB LDS-DMA pieces),
+// and every K step's A operand is a SHIFTED ds_read_b128 of that image: rows + tap * dil (C = 32: one tap per 32-k step; C = 16: two taps
+// per step, lanes' k chunks 0-1 / 2-3 read tap 2s / 2s + 1, the odd last tap meets zero weights).  Products transposed as above (weights as
+// the row operand): a lane ends with four consecutive channels of one row -- bias, residual, fp32 store and the parts of silu(.) for the
+// next conv from registers.  Workgroups are split over the branches in proportion to their taps (11 : 7 : 3).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int MODE, int C, int BM>
+__global__ __launch_bounds__(256, C == 16 ? 4 : 2) void voc_conv_kernel(const VocConvGroup gg) {
+    constexpr int NPL = PM<MODE>::NPL, NI = C / 16, MI = BM / 64;
+    constexpr int KS_MAX = C == 32 ? 11 : 6;
+    constexpr int ROWB = C * 2, RPP = 1024 / ROWB;          // bytes per row of a plane; rows per 1 KiB piece
+    constexpr int R_MAX = BM + 64, A_PLANE = R_MAX * ROWB;  // image rows (tile + halo <= 50, whole pieces)
+    constexpr int W_BYTES = NPL * KS_MAX * NI * 1024;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    const unsigned lds0 = uni((unsigned)(size_t)lds);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)uni((unsigned)(tid >> 6));
+
+    int pi = 0;
+    while (pi + 1 < gg.n && (int)blockIdx.x >= gg.wg0[pi + 1]) ++pi;
+    const VocConv& g = gg.g[pi];
+    const int nw = gg.wg0[pi + 1] - gg.wg0[pi], wi = (int)blockIdx.x - gg.wg0[pi];
+    const int tiles_b = gg.T / BM, n_tiles = gg.B * tiles_b;
+    const int taps = g.taps, dil = g.dil;
+    const int KS = C == 32 ? taps : (taps + 1) / 2;
+    if (wi >= n_tiles) return;
+
+    // ---- the branch's weight fragments: K-blocked planes [plane][ks][C rows][32] -> fragment (plane, ks, 16-row block j) lane-linear ----
+    for (int f = wave; f < NPL * KS * NI; f += 4) {
+        const int pl = f / (KS * NI), r = f - pl * (KS * NI);             // r = ks * NI + j: 16 rows x 32 k = the r-th KiB of the plane
+        const char* src = reinterpret_cast<const char*>(g.Wp + (long)pl * g.wp_pstride) + (long)r * 1024;
+        glds16(uni_ptr(src), (unsigned)(((lane & 15) * 32 + (lane >> 4) * 8) * 2), uni(lds0 + (unsigned)f * 1024));
+    }
+    const float winv = g.wp_inv;
+    const int padL = (taps - 1) * dil;
+    const int npieces = (BM + padL + RPP - 1) / RPP;
+    const int rl = wave * (BM / 4) + (lane & 15), c = lane >> 4;
+
+    for (int tile = wi; tile < n_tiles; tile += nw) {
+        const int b = tile / tiles_b, t0 = (tile - b * tiles_b) * BM;
+        const long row_in0 = (long)b * g.a_rows_b + g.a_row0 + t0;
+        __builtin_amdgcn_s_barrier();              // (every wave has read the previous tile's image)
+        for (int q = wave; q < npieces * NPL; q += 4) {
+            const int pl = q / npieces, pc = q - pl * npieces;
+            long r = row_in0 + (long)pc * RPP + (lane * 16) / ROWB;
+            if (r > g.a_rows_total - 1) r = g.a_rows_total - 1;        // (the whole pieces' tail rows past the tile's halo: never used)
+            const char* base = reinterpret_cast<const char*>(g.Ap + (long)pl * g.ap_pstride + row_in0 * C);
+            glds16(uni_ptr(base), (unsigned)((r - row_in0) * ROWB + (lane * 16) % ROWB), uni(lds0 + (unsigned)(W_BYTES + pl * A_PLANE + pc * 1024)));
+        }
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const char* const aimg = lds + W_BYTES;
+        for (int ks = 0; ks < KS; ++ks) {
+            int tap, coff;
+            if (C == 32) { tap = ks; coff = c * 16; }
+            else { tap = 2 * ks + (c >> 1); if (tap > taps - 1) tap = taps - 1; coff = (c & 1) * 16; }
+            const int roff = (rl + tap * dil) * ROWB + coff;
+            u32x4 fa[MI][NPL], fb[NI][NPL];
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fb[j][p] = *reinterpret_cast<const u32x4*>(lds + ((p * KS + ks) * NI + j) * 1024 + lane * 16);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i][p] = *reinterpret_cast<const u32x4*>(aimg + p * A_PLANE + roff + i * 16 * ROWB);
+            }
+            if constexpr (MODE == PLANES_H3) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mma1<MODE>(fb[j][0], fa[i][1], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mma1<MODE>(fb[j][1], fa[i][0], acc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mma1<MODE>(fb[j][0], fa[i][0], acc[i][j]);
+        }
+        // ---- epilogue: registers -> global ----
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int t = t0 + rl + i * 16;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = j * 16 + 4 * c;
+                f32x4 v = acc[i][j] * winv;
+                if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+                if (g.res) v += *reinterpret_cast<const f32x4*>(g.res + (long)b * g.r_bstride + g.r_off + (long)t * C + n);
+                if (gg.ovf && !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < INFINITY)) *reinterpret_cast<volatile int*>(gg.ovf) = 1;
+                if (g.Cf) *reinterpret_cast<f32x4*>(g.Cf + (long)b * g.c_bstride + g.c_off + (long)t * C + n) = v;
+                if (g.Cp) {
+                    unsigned p0[NPL], p1[NPL];
+                    split_pair<MODE>(silu_f(v.x), silu_f(v.y), p0);
+                    split_pair<MODE>(silu_f(v.z), silu_f(v.w), p1);
+                    const long po = ((long)b * g.c_rows_b + g.c_row0 + t) * C + n;
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x2*>(g.Cp + (long)p * g.cp_pstride + po) = (u32x2){p0[p], p1[p]};
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, int C, int BM>
+int launch_voc_conv_t(VocConvGroup& gg, int cus, hipStream_t st) {
+    constexpr int NPL = PM<MODE>::NPL;
+    constexpr size_t smem = (size_t)NPL * (C == 32 ? 11 : 6) * (C / 16) * 1024 + (size_t)NPL * (BM + 64) * C * 2;
+    constexpr int WG_PER_CU = C == 16 ? 4 : 2;
+    static_assert(smem * WG_PER_CU <= 160 * 1024, "LDS of one CU");
+    static DeviceOnce attr_set;
+    if (attr_set.needed()) {
+        SVA_HIP(hipFuncSetAttribute((const void*)voc_conv_kernel<MODE, C, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set.done();
+    }
+    const int n_tiles = gg.B * (gg.T / BM);
+    // longest K first; workgroups in proportion to the members' taps (each member's tiles are equally many), at most one per tile
+    std::stable_sort(gg.g, gg.g + gg.n, [](const VocConv& a, const VocConv& b_) { return a.taps > b_.taps; });
+    int sum_taps = 0;
+    for (int i = 0; i < gg.n; ++i) sum_taps += gg.g[i].taps;
+    const int G = std::min(n_tiles * gg.n, cus * WG_PER_CU);
+    gg.wg0[0] = 0;
+    for (int i = 0; i < gg.n; ++i) {
+        int w = std::max(1, (int)((long)G * gg.g[i].taps / sum_taps));
+        w = std::min(w, n_tiles);
+        gg.wg0[i + 1] = gg.wg0[i] + w;
+    }
+    hipLaunchKernelGGL((voc_conv_kernel<MODE, C, BM>), dim3(gg.wg0[gg.n]), dim3(256), smem, st, gg);
+    return 0;
 }
 
 }  // namespace
@@ -862,12 +1007,33 @@ int launch_to_planes(const float* src, long rows, int K, long ld, unsigned short
     return 0;
 }
 
-int launch_to_planes_act(const float* src, int nb, long rows_b, long row0, int T, int K, unsigned short* dst, long pstride, int mode, int silu, hipStream_t st) {
-    SVA_CHECK(K % 32 == 0 && (mode == PLANES_H3 || mode == PLANES_H1), "to_planes_act: whole 32-k blocks, an fp16 planes format");
+bool voc_conv_supported(int C, int T, int mode) {
+    return (mode == PLANES_H3 || mode == PLANES_H1) && ((C == 32 && T % 128 == 0) || (C == 16 && T % 256 == 0));
+}
+int launch_voc_conv(VocConvGroup gg, int C, int mode, int cu_limit, hipStream_t st) {
+    SVA_CHECK(voc_conv_supported(C, gg.T, mode) && gg.n >= 1 && gg.n <= 3 && gg.B >= 1, "voc_conv: C = 16 / 32, whole tiles per stream");
+    for (int i = 0; i < gg.n; ++i)
+        SVA_CHECK(gg.g[i].Ap && gg.g[i].Wp && (gg.g[i].Cf || gg.g[i].Cp) && gg.g[i].taps >= 1 && gg.g[i].taps <= 11 && (gg.g[i].taps - 1) * gg.g[i].dil <= 50,
+                  "voc_conv: operands as planes, at most 11 taps and 50 halo rows");
+    int cus = cu_limit > 0 ? cu_limit : g_dma_cu_limit;
+    if (cus <= 0) {
+        int dev = 0;
+        SVA_HIP(hipGetDevice(&dev));
+        SVA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    int rc;
+    if (mode == PLANES_H3) rc = C == 32 ? launch_voc_conv_t<PLANES_H3, 32, 128>(gg, cus, st) : launch_voc_conv_t<PLANES_H3, 16, 256>(gg, cus, st);
+    else rc = C == 32 ? launch_voc_conv_t<PLANES_H1, 32, 128>(gg, cus, st) : launch_voc_conv_t<PLANES_H1, 16, 256>(gg, cus, st);
+    SVA_HIP(hipGetLastError());
+    return rc;
+}
+
+int launch_to_planes_act(const float* src, int nb, long rows_b, long row0, int T, int K, unsigned short* dst, long pstride, int mode, int silu, hipStream_t st, int blocked) {
+    SVA_CHECK((blocked ? K % 32 == 0 : K % 8 == 0) && (mode == PLANES_H3 || mode == PLANES_H1), "to_planes_act: whole 32-k blocks, an fp16 planes format");
     const long n8 = (long)nb * T * (K / 8);
     const int blocks = (int)std::min<long>((n8 + 255) / 256, 4096);
-    if (mode == PLANES_H3) hipLaunchKernelGGL(to_planes_act_kernel<PLANES_H3>, dim3(blocks), dim3(256), 0, st, src, nb, rows_b, row0, T, K, dst, pstride, silu);
-    else hipLaunchKernelGGL(to_planes_act_kernel<PLANES_H1>, dim3(blocks), dim3(256), 0, st, src, nb, rows_b, row0, T, K, dst, pstride, silu);
+    if (mode == PLANES_H3) hipLaunchKernelGGL(to_planes_act_kernel<PLANES_H3>, dim3(blocks), dim3(256), 0, st, src, nb, rows_b, row0, T, K, dst, pstride, silu, blocked);
+    else hipLaunchKernelGGL(to_planes_act_kernel<PLANES_H1>, dim3(blocks), dim3(256), 0, st, src, nb, rows_b, row0, T, K, dst, pstride, silu, blocked);
     SVA_HIP(hipGetLastError());
     return 0;
 }

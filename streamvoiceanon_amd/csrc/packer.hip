@@ -473,6 +473,27 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
             for (int i = 0; i < 2; ++i) { SVA_TRY(planes(F.ds_conv[i], mode)); SVA_TRY(planes(F.ds_cnx[i].pw1, mode)); SVA_TRY(planes(F.ds_cnx[i].pw2, mode)); }
             return 0;
         };
+        // (narrow levels: K = k * C padded with zero columns to whole 32-k blocks)
+        auto planes_padded = [&](const Lin& l, int mode, unsigned short** out, float* inv, int* Kq) -> int {
+            if (mode < 0 || !l.W) return 0;
+            const int Kp = (l.K + 31) / 32 * 32;
+            *Kq = Kp;
+            const long n = (long)l.N * l.K;
+            host.resize(n);
+            SVA_HIP(hipMemcpy(host.data(), l.W, sizeof(float) * n, hipMemcpyDeviceToHost));
+            std::vector<float> pad((size_t)l.N * Kp, 0.f);
+            float mx = 0.f;
+            for (int r = 0; r < l.N; ++r)
+                for (int k = 0; k < l.K; ++k) { const float v = host[(long)r * l.K + k]; pad[(size_t)r * Kp + k] = v; mx = std::max(mx, fabsf(v)); }
+            float* tmp = nullptr;
+            SVA_HIP(hipMalloc((void**)&tmp, sizeof(float) * pad.size()));
+            SVA_HIP(hipMemcpy(tmp, pad.data(), sizeof(float) * pad.size(), hipMemcpyHostToDevice));
+            SVA_TRY(dev_alloc(e->allocs, out, (size_t)planes_count(mode) * pad.size(), false));
+            int rc = make_weight_planes(tmp, l.N, Kp, mx, mode, *out, inv, 0);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(tmp);
+            return rc;
+        };
         SVA_TRY(front(e->tokf, enc_mode));
         SVA_TRY(front(e->vocf, enc_mode));           // firefly.encode of the prompt produces FSQ indices: encoder grade
         for (auto& L : e->tr) { SVA_TRY(planes(L.wqkv, enc_mode)); SVA_TRY(planes(L.wo, enc_mode)); SVA_TRY(planes(L.w13, enc_mode)); SVA_TRY(planes(L.w2, enc_mode)); }
@@ -484,6 +505,12 @@ extern "C" int sva_engine_finalize(sva_engine* e) {
                 for (int j = 0; j < 3; ++j) {        // (down to the C = 32 level: the ResBlock convs' LDS-DMA form takes 32-column tiles)
                     SVA_TRY(planes(e->res[i][bb][j].c1, voc_mode, 32));
                     SVA_TRY(planes(e->res[i][bb][j].c2, voc_mode, 32));
+                    ResConv& rc = e->res[i][bb][j];
+                    if (rc.c1.N == 32 && rc.c1.Wp && rc.c2.Wp) { rc.q1 = rc.c1.Wp; rc.q2 = rc.c2.Wp; rc.q1_inv = rc.c1.wp_inv; rc.q2_inv = rc.c2.wp_inv; rc.Kq = rc.c1.K; }
+                    if (rc.c1.N == 16) {
+                        SVA_TRY(planes_padded(rc.c1, voc_mode, &rc.q1, &rc.q1_inv, &rc.Kq));
+                        SVA_TRY(planes_padded(rc.c2, voc_mode, &rc.q2, &rc.q2_inv, &rc.Kq));
+                    }
                 }
         }
     }

@@ -111,6 +111,35 @@ int gemm_group_call(sva_batch* b, const ConvGemm* gs, int n) {
     return launch_conv_gemm_group(gs, n, b->stream);
 }
 
+// one voc_conv_kernel launch (three branches of one conv stage of a narrow level), bookkeeping as gemm_group_call
+int voc_conv_call(sva_batch* b, const VocConvGroup& gg, int C, int pmode) {
+    double fl = 0, by = 0;
+    int ksum = 0;
+    for (int i = 0; i < gg.n; ++i) {
+        const VocConv& g = gg.g[i];
+        fl += 2.0 * gg.B * (double)gg.T * C * g.taps * C;
+        by += 4.0 * ((double)gg.B * ((double)gg.T + (g.taps - 1) * g.dil) * C + (double)C * g.taps * C + (double)gg.B * gg.T * C * (g.res ? 2 : 1));
+        ksum += g.taps * C;
+    }
+    b->gemm_flops += fl;
+    b->gemm_launches += 1;
+    b->gemm_bytes += by;
+    if (b->prof_on) {
+        if (b->prof_n + 2 > (int)b->prof_ev.size()) {
+            const size_t old = b->prof_ev.size();
+            b->prof_ev.resize(old + 512);
+            for (size_t i = old; i < b->prof_ev.size(); ++i) SVA_HIP(hipEventCreate(&b->prof_ev[i]));
+        }
+        b->prof_shapes.push_back({gg.B * gg.T, C, ksum, 11, 16 + (gg.g[0].res ? 2 : 0) + 256 * ((pmode == PLANES_H3 ? 9 : 10) + 1)});
+        SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n], b->stream));
+        int rc = launch_voc_conv(gg, C, pmode, b->enc_cus, b->stream);
+        SVA_HIP(hipEventRecord(b->prof_ev[b->prof_n + 1], b->stream));
+        b->prof_n += 2;
+        return rc;
+    }
+    return launch_voc_conv(gg, C, pmode, b->enc_cus, b->stream);
+}
+
 __global__ void mean3_kernel(const float* __restrict__ y0, const float* __restrict__ y1, const float* __restrict__ y2, long y_bstride,
                              float* __restrict__ out, long o_bstride, long o_off, long n4) {
     // ParallelBlock: torch.stack([...]).mean(0) (firefly.py:214-215) of the three branch outputs, float4 lanes
@@ -962,6 +991,43 @@ int vocode(sva_batch* b, int T, bool shift, int part) {
                 b->gemm_flops += 2.0 * B * (double)Tl * Cout * Cout * kk;
                 b->gemm_launches += 1;
                 b->gemm_bytes += 4.0 * ((double)B * (Tl + b->X[i].H) * Cout + kk * Cout * Cout + 3.0 * B * (double)Tl * Cout);
+            }
+            const long n4 = Tl * Cout / 4;
+            hipLaunchKernelGGL(mean3_kernel, dim3((unsigned)((n4 + 255) / 256), B), dim3(256), 0, st, b->y3[i][0].p, b->y3[i][1].p, b->y3[i][2].p,
+                               b->y3[i][0].bstride, out.p, out.bstride, (long)out.H * Cout, n4);
+            SVA_HIP(hipGetLastError());
+            continue;
+        }
+        if (b->voc_dma[i] == 2) {
+            // narrow level (C = 16 / 32) of a large batch: every conv stage of the three branches as ONE voc_conv_kernel launch (gemm_planes.hip: the
+            // tile's input rows + halo and the branch's whole weight resident in LDS), activations between the convs as ROW-MAJOR operand planes
+            const int pm = b->voc_pmode;
+            SVA_TRY(launch_to_planes_act(b->X[i].p, B, b->X[i].rows, b->X[i].H, (int)Tl, Cout, b->XP[i], (long)B * b->X[i].bstride, pm, 1, st, 0));
+            Act* y[3] = {&b->X[i], &b->X[i], &b->X[i]};
+            const unsigned short* yp[3] = {b->XP[i], b->XP[i], b->XP[i]};
+            for (int j = 0; j < 3; ++j) {
+                VocConvGroup g1, g2;
+                g1.B = g2.B = B; g1.T = g2.T = (int)Tl; g1.ovf = g2.ovf = b->d_mm_ovf; g1.n = g2.n = 3;
+                for (int br = 0; br < 3; ++br) {
+                    const ResConv& rcv = e->res[i][br][j];
+                    const int padL = (rcv.k - 1) * rcv.dil;
+                    Act& t = b->tb[i][br][j];
+                    SVA_CHECK(y[br]->H >= padL && t.H >= padL, "voc_conv: not enough history rows");
+                    VocConv& a = g1.g[br];
+                    a.Ap = yp[br]; a.ap_pstride = (long)B * y[br]->bstride; a.a_rows_b = y[br]->rows; a.a_row0 = y[br]->H - padL; a.a_rows_total = (long)B * y[br]->rows;
+                    a.Wp = rcv.q1; a.wp_pstride = (long)Cout * rcv.Kq; a.wp_inv = rcv.q1_inv; a.bias = rcv.c1.b; a.taps = rcv.k; a.dil = rcv.dil;
+                    a.Cp = b->tbP[i][br][j]; a.cp_pstride = (long)B * t.bstride; a.c_rows_b = t.rows; a.c_row0 = t.H;
+                    Act& dst = j < 2 ? b->yb[i][br][j] : b->y3[i][br];
+                    VocConv& c2 = g2.g[br];
+                    c2.Ap = b->tbP[i][br][j]; c2.ap_pstride = (long)B * t.bstride; c2.a_rows_b = t.rows; c2.a_row0 = t.H - padL; c2.a_rows_total = (long)B * t.rows;
+                    c2.Wp = rcv.q2; c2.wp_pstride = (long)Cout * rcv.Kq; c2.wp_inv = rcv.q2_inv; c2.bias = rcv.c2.b; c2.taps = rcv.k; c2.dil = rcv.dil;
+                    c2.res = y[br]->p; c2.r_bstride = y[br]->bstride; c2.r_off = (long)y[br]->H * Cout;
+                    c2.Cf = dst.p; c2.c_bstride = dst.bstride; c2.c_off = (long)dst.H * Cout;
+                    if (j < 2) { c2.Cp = b->ybP[i][br][j]; c2.cp_pstride = (long)B * dst.bstride; c2.c_rows_b = dst.rows; c2.c_row0 = dst.H; }
+                }
+                SVA_TRY(voc_conv_call(b, g1, Cout, pm));
+                SVA_TRY(voc_conv_call(b, g2, Cout, pm));
+                for (int br = 0; br < 3 && j < 2; ++br) { y[br] = &b->yb[i][br][j]; yp[br] = b->ybP[i][br][j]; }
             }
             const long n4 = Tl * Cout / 4;
             hipLaunchKernelGGL(mean3_kernel, dim3((unsigned)((n4 + 255) / 256), B), dim3(256), 0, st, b->y3[i][0].p, b->y3[i][1].p, b->y3[i][2].p,

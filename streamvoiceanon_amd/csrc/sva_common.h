@@ -29,8 +29,8 @@ void set_error(const std::string& msg);
 //   planes_dbg=mask   TIMING DIAGNOSTIC (results are garbage): leave parts of the planes GEMM out -- 1 global loads of its K loop, 2 LDS stores, 4 MFMAs,
 //                     8 epilogue (tools/planes_probe.py)
 //   planes_dma=0      the planes GEMM never takes its persistent LDS-DMA form (variants 8 / 9): round 4's register-staged tiles (A/B)
-//   voc_dma=0|1       the C % 32 == 0 HiFiGAN levels' ResBlock convs on the LDS-DMA planes kernel (activations between them as planes): never /
-//                     at every batch size (default: from 16 code frames per step over the batch; parity tests force it at small batches)
+//   voc_dma=0|1       the HiFiGAN levels' ResBlock convs on operand planes (C >= 64: the LDS-DMA planes kernel's conv form, C = 16 / 32: voc_conv_kernel;
+//                     activations between them as planes): never / at every batch size (default: from 16 code frames per step over the batch; parity tests force it at small batches)
 //   voc_dma_variant=9|10|13|14  tile configuration of those convs where 128 x 128 tiles fill the chip (A/B)
 //   reprefill=0       re-prefill as one whole-prompt prefill per slot behind a host synchronisation (round 3) instead of one pass over the
 //                     appended rows of all due slots against the cached prompt prefix (A/B, parity)
@@ -192,13 +192,42 @@ bool planes_gemm_supported(const ConvGemm& g);
 int launch_planes_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 // variants 9 / 10 of it: the persistent LDS-DMA-fed form (128 x 128 tiles, one / two workgroups per CU; A as planes, N % 128 == 0; a group's tiles form one sequence)
 bool planes_dma_gemm_supported(const ConvGemm& g);
-// its conv form (taps over A planes, a group's tiles as one sequence, SiLU'd output planes; variants 9 / 10 and the narrow tiles 13 .. 15): N % 32 == 0
+// its conv form (taps over A planes, a group's tiles as one sequence, SiLU'd output planes; variants 9 / 10 and the narrow tiles 13 / 14): N % 64 == 0
 bool planes_dma_conv_supported(const ConvGemm& g);
 void planes_dma_set_cu_limit(int cus);        // CUs its grid may count on (0 = the device's); the engine sets it around launches on CU-masked streams
+// Narrow HiFiGAN levels (C = 16 / 32): one ResBlock conv stage of the three branches as a halo-resident conv over ROW-MAJOR operand planes
+// ([plane][dense rows][C] fp16 parts): a workgroup keeps its branch's whole weight in LDS and, per 128- / 256-row tile, the input rows with
+// their (taps - 1) * dil halo -- every tap's MFMA operand is a shifted read of that one image (gemm_planes.hip: voc_conv_kernel)
+struct VocConv {
+    const unsigned short* Ap = nullptr;     // input planes, plane p at + p * ap_pstride
+    long ap_pstride = 0, a_rows_b = 0, a_row0 = 0;      // dense rows per stream; row of (t = 0, tap 0) inside a stream = H - (taps - 1) * dil
+    long a_rows_total = 0;                  // dense rows of the input planes tensor (reads are clamped to it)
+    const unsigned short* Wp = nullptr;     // K-blocked weight planes [plane][KS][C][32], K = taps * C padded to whole 32-k blocks
+    long wp_pstride = 0;
+    float wp_inv = 1.f;
+    const float* bias = nullptr;
+    const float* res = nullptr;             // fp32 residual rows [B][.][C] (or null)
+    long r_bstride = 0, r_off = 0;
+    float* Cf = nullptr;                    // fp32 output rows (or null)
+    long c_bstride = 0, c_off = 0;
+    unsigned short* Cp = nullptr;           // planes of silu(output) (or null), same row geometry as an input: rows per stream, first row
+    long cp_pstride = 0, c_rows_b = 0, c_row0 = 0;
+    int taps = 1, dil = 1;
+};
+struct VocConvGroup {
+    VocConv g[3];
+    int n = 3;
+    int B = 0, T = 0;                       // streams, output rows per stream (a multiple of the tile rows)
+    int wg0[4] = {0, 0, 0, 0};              // workgroups [wg0[p], wg0[p + 1]) work on member p
+    int* ovf = nullptr;
+};
+bool voc_conv_supported(int C, int T, int mode);
+int launch_voc_conv(VocConvGroup gg, int C, int mode, int cu_limit, hipStream_t st);
 // fp32 [rows][K] (row stride ld) -> K-blocked planes
 int launch_to_planes(const float* src, long rows, int K, long ld, unsigned short* dst, long pstride, int mode, float scale, int silu, hipStream_t st);
 // rows [row0, row0 + T) of each of nb streams of an activation tensor ([nb][rows_b][K] fp32) -> the same dense rows of its planes mirror
-int launch_to_planes_act(const float* src, int nb, long rows_b, long row0, int T, int K, unsigned short* dst, long pstride, int mode, int silu, hipStream_t st);
+// (blocked = 0: row-major planes [plane][rows][K], the layout of voc_conv_kernel)
+int launch_to_planes_act(const float* src, int nb, long rows_b, long row0, int T, int K, unsigned short* dst, long pstride, int mode, int silu, hipStream_t st, int blocked = 1);
 int make_weight_planes(const float* dW, int N, int K, float max_abs, int mode, unsigned short* dst, float* inv, hipStream_t st);
 // gemm_f16w.hip: fp16 weights on the f16 matrix pipes (fp32 activations split hi + lo), plain linear layers of the AR chain
 bool f16w_gemm_supported(const ConvGemm& g);

@@ -117,12 +117,14 @@ def test_vocoder_window_and_stream(eng, weights0, fused_mask):
     b.close()
 
 
-@pytest.mark.parametrize("voc_dtype", [0, 1])
-def test_vocoder_wide_levels_on_planes_dma_window_and_stream(weights0, voc_dtype):
-    """The C = 256 / C = 128 HiFiGAN levels with every ResBlock conv on the LDS-DMA planes kernel (three branches per launch, conv taps over
-    K-blocked operand planes, the activations between the convs -- and their streaming history -- as planes): forced at a small batch
-    (SVA_DEBUG voc_dma=1; the default policy takes it from 32 streams), window and ragged streaming pieces against the oracle
-    (firefly.py:183-215, 243-293).  Two streams with different codes, so a row mapped to the wrong stream shows."""
+@pytest.mark.parametrize("voc_dtype,fused_mask", [(0, -1), (0, 0), (1, 0)])
+def test_vocoder_resblock_convs_on_operand_planes_window_and_stream(weights0, voc_dtype, fused_mask):
+    """The HiFiGAN levels' ResBlock convs with operand planes end to end (stages.hip, vocode; the default from 16 code frames per step over the
+    batch, forced here at two streams with SVA_DEBUG voc_dma=1): C = 256 / 128 / 64 on the LDS-DMA planes kernel's conv form (three branches per
+    launch, conv taps over K-blocked planes, the tiles 64 x 64 / 128 x 128 / 128 x 64), C = 32 -- and C = 16 when the fused level kernel is off
+    (voc_fused_mask = 0) -- on voc_conv_kernel (row-major planes, the tile's rows + halo and the branch's weight resident in LDS).  The activations
+    between the convs and their streaming history live as planes: window AND ragged streaming pieces against the oracle (firefly.py:183-215,
+    243-293).  Two streams with different codes, so a row mapped to the wrong stream shows."""
     from oracle import sva_oracle as O
     from streamvoiceanon_amd import engine as E
 
@@ -132,11 +134,11 @@ def test_vocoder_wide_levels_on_planes_dma_window_and_stream(weights0, voc_dtype
     codes0 = g["codes"].astype(np.int32)
     rng = np.random.default_rng(77)
     codes = np.concatenate([codes0, rng.permuted(codes0, axis=2)], axis=0)
-    lib.sva_debug_configure(b"voc_dma=1")
+    lib.sva_debug_configure(f"voc_dma=1,voc_fused_mask={fused_mask}".encode())
     try:
         b = E.Batch(eng, n_streams=2, voc_max_frames=24)
     finally:
-        lib.sva_debug_configure(b"voc_dma=-1")
+        lib.sva_debug_configure(b"voc_dma=-1,voc_fused_mask=-1")
     T = 24
     tol = PCM_TOL if voc_dtype == 0 else VOC_FP16_TOL
     ref = O.vocode_window(torch.from_numpy(codes[:, :, :T].astype(np.int64)), weights0)[:, 0].numpy()
