@@ -48,6 +48,7 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "planes_dma") o.planes_dma = atoi(v.c_str());
             else if (k == "voc_dma") o.voc_dma = atoi(v.c_str());
             else if (k == "voc_dma_variant") o.voc_dma_variant = atoi(v.c_str());
+            else if (k == "planes_lw") o.planes_lw = atoi(v.c_str());
             else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());

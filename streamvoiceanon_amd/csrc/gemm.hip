@@ -713,7 +713,7 @@ static int planes_variant(const ConvGemm& g, int group_n) {
         if (t_group) for (int i = 0; i < t_group->n; ++i) ok = ok && planes_dma_conv_supported(t_group->g[i]);
         if (ok) {
             const int dv = debug_options().voc_dma_variant;
-            if (g.N % 128 == 0 && (long)((g.M + 127) / 128) * (g.N / 128) * group_n >= 192) return dv >= 9 && dv <= 14 && dv != 11 && dv != 12 ? dv : 9;
+            if (g.N % 128 == 0 && (long)((g.M + 127) / 128) * (g.N / 128) * group_n >= 192) return dv >= 9 && dv <= 14 && dv != 12 ? dv : 11;       // (its loader-wave form: 66 / 61 -> 60 / 55 us per launch at C = 128, 64 streams)
             return g.N == 64 && g.M * (long)group_n >= 3 * 8192 ? 13 : 14;
         }
     }
@@ -727,7 +727,8 @@ static int planes_variant(const ConvGemm& g, int group_n) {
             if (r.N == g.N && r.K == g.Cin && (r.variant < 8 || dma_ok) &&
                 (!best || std::abs(r.M - g.M) < std::abs(best->M - g.M))) best = &r;
         if (best && std::abs(best->M - g.M) * 4 <= g.M && (best->variant != 6 || g.M >= 256) &&
-            (g.M >= 128 || best->variant == 2 || best->variant == 3 || best->variant >= 9)) return best->variant;
+            (g.M >= 128 || best->variant == 2 || best->variant == 3 || best->variant >= 9))
+            return best->variant >= 11 && debug_options().planes_lw == 0 ? 10 : best->variant;       // (A/B: the loader-wave forms off)
     }
     // both operands as planes, whole 128-column tiles, a shape outside the table: the persistent LDS-DMA form with 128 x 128 tiles and TWO
     // workgroups per CU (variant 10: one workgroup's epilogue runs under the other's K steps) -- it wins or ties on every encoder shape at 64
@@ -1082,7 +1083,7 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
         return 0;
     }
     if (kind == 6) {                    // the planes kernel (gemm_planes.hip), a = its tile variant
-        SVA_CHECK(planes_gemm_supported(g) && a >= 0 && a <= 10 && a != 8 && (a < 8 || planes_dma_gemm_supported(g)) && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the planes kernel needs weight planes, Cin % 32 == 0 and 16-byte aligned C rows");
+        SVA_CHECK(planes_gemm_supported(g) && a >= 0 && a <= 12 && a != 8 && (a < 8 || planes_dma_gemm_supported(g)) && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the planes kernel needs weight planes, Cin % 32 == 0 and 16-byte aligned C rows");
         SVA_TRY_RC(launch_choice(g, st, Choice{4, 8 + a, 0, 0}));
         SVA_HIP(hipGetLastError());
         return 0;

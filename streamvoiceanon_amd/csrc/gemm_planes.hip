@@ -442,8 +442,8 @@ template <int MODE, int BM, int BN, int NST, int NW> struct DmaCfg {
     static constexpr int WAVES_PER_SIMD = NW == 8 ? 2 : (WG_PER_CU * NW + 3) / 4;
 };
 
-template <int MODE, int BM, int NST, bool PROBE, int BN = 128, int NW = 8, bool CONV = false>
-__global__ __launch_bounds__(64 * NW, (DmaCfg<MODE, BM, BN, NST, NW>::WAVES_PER_SIMD)) void planes_dma_kernel(const ConvGemmGroup gg, const int n_tiles_n, const int n_tiles, const int dbg_arg) {
+template <int MODE, int BM, int NST, bool PROBE, int BN = 128, int NW = 8, bool CONV = false, int LW = 0>
+__global__ __launch_bounds__(64 * (NW + LW), (LW > 0 ? 3 : DmaCfg<MODE, BM, BN, NST, NW>::WAVES_PER_SIMD)) void planes_dma_kernel(const ConvGemmGroup gg, const int n_tiles_n, const int n_tiles, const int dbg_arg) {
     // CONV: conv taps and / or a group of problems (the generic tile deal and per-tile problem lookup); !CONV: one taps == 1 problem, every
     // per-problem quantity a launch constant (the encoder's GEMMs: the K loop carries no trace of the generality)
     // gg.n problems of ONE shape (M, N, Cin, T) that may differ in taps / dilation / pointers (the three ResBlock branches of a HiFiGAN level, k = 3 / 7 / 11):
@@ -453,10 +453,16 @@ __global__ __launch_bounds__(64 * NW, (DmaCfg<MODE, BM, BN, NST, NW>::WAVES_PER_
     constexpr int NPL = PM<MODE>::NPL;
     constexpr int PD = NST - 1;                                           // NST LDS stages; K steps requested ahead
     constexpr int WM = BM / 64, WN = NW / WM, TN = BN / WN, MI = 4, NI = TN / 16;
-    constexpr int RBA = BM / 16, RBB = BN / 16, PA = RBA / NW, PB = RBB / NW;
+    // LW > 0: LOADER WAVES.  Waves NW .. NW + LW - 1 issue every LDS-DMA request of the workgroup, waves 0 .. NW - 1 only read fragments, multiply and
+    // run the epilogue.  With every wave doing both, the 8 waves' 32 requests of a step queue at the CU's address unit for ~680 cycles right behind the
+    // barrier and no wave reaches its MFMAs before its own are accepted; then the matrix pipe runs ~770 cycles during which nobody requests anything:
+    // request phase and multiply phase alternate (tools/probes/fill_probe.hip: the request pattern alone 0.41 us per step, with the reads and MFMAs
+    // of the step 0.78, with two loader waves 0.55)
+    constexpr int NL = LW > 0 ? LW : NW;                                  // loading waves
+    constexpr int RBA = BM / 16, RBB = BN / 16, PA = RBA / NL, PB = RBB / NL;
     constexpr int A_BYTES = NPL * RBA * 1024, STAGE = A_BYTES + NPL * RBB * 1024;
-    constexpr int LPW = (PA + PB) * NPL;                                  // LDS-DMA instructions per wave and K step
-    static_assert(PD * LPW <= 48, "vmcnt is a 6-bit counter");
+    constexpr int LPW = (PA + PB) * NPL;                                  // LDS-DMA instructions per loading wave and K step
+    static_assert(PD * LPW <= 48 && RBA % NL == 0 && RBB % NL == 0, "vmcnt is a 6-bit counter; whole pieces per loading wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
     const unsigned lds0 = uni((unsigned)(size_t)lds);
@@ -464,7 +470,14 @@ __global__ __launch_bounds__(64 * NW, (DmaCfg<MODE, BM, BN, NST, NW>::WAVES_PER_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)uni((unsigned)(tid >> 6));
     const int wm = wave / WN, wn = wave % WN;
-    const int prow = lane & 15, pchunk = lane >> 4;
+    const int lwave = LW > 0 ? wave - NW : wave;          // index among the loading waves (negative: a consumer wave of the LW > 0 form)
+    // Lane order inside a 1 KiB piece (16 rows x 64 bytes, contiguous in the K-blocked planes): lane QUADS take a row's four 16-byte chunks, so the
+    // wave reads the KiB front to back -- with (row = lane & 15, chunk = lane >> 4), the MFMA operand order, every quad touches four rows and the
+    // fill runs at 76 instead of 105 GB/s per CU (tools/probes/fill_probe.hip).  The LDS image is therefore ROW-MAJOR; the chunk a quad lane takes is
+    // XOR-swizzled per row group (f = 0, 2, 3, 1 for rows 0-3, 4-7, 8-11, 12-15) so that the fragment reads (lane -> row lane & 15, chunk lane >> 4) of
+    // every ds_read_b128 lane group fall on sixteen different 16-byte slots (SQ_LDS_BANK_CONFLICT = 0)
+    const int prow = lane >> 2, pchunk = (lane & 3) ^ ((0x78 >> (2 * (lane >> 4))) & 3);
+    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((0x78 >> (2 * ((lane & 15) >> 2))) & 3)) * 16);
 
     // ---- this workgroup's tiles (XCD x = workgroup id & 7, a speed assumption only).  One problem: XCD x owns the x-th contiguous eighth of the
     // tile sequence (a band of M tiles with all their N tiles: the A panel is fetched into one L2).  A group (members sorted by the host, longest K
@@ -521,10 +534,10 @@ __global__ __launch_bounds__(64 * NW, (DmaCfg<MODE, BM, BN, NST, NW>::WAVES_PER_
         baseA = uni_ptr(reinterpret_cast<const char*>(gl.Ap + r0 * 32));
         baseW = uni_ptr(reinterpret_cast<const char*>(gl.Wp + (long)bn0 * 32));
 #pragma unroll
-        for (int i = 0; i < PA; ++i) offA[i] = (unsigned)(((row_of(bm0 + (wave + NW * i) * 16 + prow) - r0) * 32 + pchunk * 8) * 2);
+        for (int i = 0; i < PA; ++i) offA[i] = (unsigned)(((row_of(bm0 + (lwave + NL * i) * 16 + prow) - r0) * 32 + pchunk * 8) * 2);
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            int n = bn0 + (wave + NW * i) * 16 + prow;
+            int n = bn0 + (lwave + NL * i) * 16 + prow;
             if (n > gl.N - 1) n = gl.N - 1;
             offW[i] = (unsigned)(((long)(n - bn0) * 32 + pchunk * 8) * 2);
         }
@@ -540,9 +553,9 @@ __global__ __launch_bounds__(64 * NW, (DmaCfg<MODE, BM, BN, NST, NW>::WAVES_PER_
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-                for (int i = 0; i < PA; ++i) glds16(ba + p * a_ps2, offA[i], dst + (unsigned)((p * RBA + wave + NW * i) * 1024));
+                for (int i = 0; i < PA; ++i) glds16(ba + p * a_ps2, offA[i], dst + (unsigned)((p * RBA + lwave + NL * i) * 1024));
 #pragma unroll
-                for (int i = 0; i < PB; ++i) glds16(bw + p * w_ps2, offW[i], dst + (unsigned)(A_BYTES + (p * RBB + wave + NW * i) * 1024));
+                for (int i = 0; i < PB; ++i) glds16(bw + p * w_ps2, offW[i], dst + (unsigned)(A_BYTES + (p * RBB + lwave + NL * i) * 1024));
             }
         }
         if (CONV) { if (++ld_kb == kcb) { ld_kb = 0; ++ld_tap; } }
@@ -622,25 +635,75 @@ __global__ __launch_bounds__(64 * NW, (DmaCfg<MODE, BM, BN, NST, NW>::WAVES_PER_
 
     // ---- the stream: steps 0 .. PD - 1 requested up front; iteration s waits for step s (its own pieces), meets the other waves (all
     // pieces of step s landed, everybody is done reading the stage of step s - 1), requests step s + PD into that stage, multiplies ----
-#pragma unroll
-    for (int s_ = 0; s_ < PD; ++s_)
-        if (s_ < total) issue();
-    int cs = 0, ck = 0, cit = 0, cnk = nk_of(0);
-    bool prewaited = false;
     auto wait_step = [&](int allow) {         // at most `allow` requested steps may still be in flight (LPW instructions each)
         if (allow <= 0) wait_vm<0>();
         else if (allow == 1) wait_vm<LPW>();
         else if (PD < 3 || allow == 2) wait_vm<2 * LPW>();
         else wait_vm<3 * LPW>();
     };
+    int cs = 0, ck = 0, cit = 0, cnk = nk_of(0);
+    if constexpr (LW > 0) {
+        // one barrier per K step for everybody.  Loader at barrier s: its pieces of step s have landed; behind it it requests step s + PD into the stage
+        // of step s - 1.  Consumer at barrier s: its MFMAs of step s - 1 are issued (their fragments long read); behind it it reads step s.
+        if (wave >= NW) {
+#pragma unroll
+            for (int s_ = 0; s_ < PD; ++s_)
+                if (s_ < total) issue();
+            for (int s_ = 0; s_ < total; ++s_) {
+                wait_step(min(PD - 1, total - 1 - s_));
+                __builtin_amdgcn_s_barrier();
+                if (s_ + PD < total) issue();
+            }
+            return;
+        }
+        for (int s_ = 0; s_ < total; ++s_) {
+            __builtin_amdgcn_s_barrier();
+            const char* const sa = lds + cs * STAGE + frag_off + (wm * MI) * 1024;
+            const char* const sb = lds + cs * STAGE + A_BYTES + frag_off + (wn * NI) * 1024;
+            u32x4 fa[MI][NPL], fb[NI][NPL];
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fb[j][p] = *reinterpret_cast<const u32x4*>(sb + (p * RBB + j) * 1024);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i][p] = *reinterpret_cast<const u32x4*>(sa + (p * RBA + i) * 1024);
+            }
+            if constexpr (MODE == PLANES_H3) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mma1<MODE>(fb[j][0], fa[i][1], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mma1<MODE>(fb[j][1], fa[i][0], acc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mma1<MODE>(fb[j][0], fa[i][0], acc[i][j]);
+            if (++cs == NST) cs = 0;
+            if (++ck == cnk) {
+                ck = 0;
+                epilogue(tau_of(cit));
+                ++cit;
+                if (cit < my_tiles) cnk = nk_of(cit);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < PD; ++s_)
+        if (s_ < total) issue();
+    bool prewaited = false;
     for (int s_ = 0; s_ < total; ++s_) {
         if (!prewaited) wait_step(min(PD - 1, total - 1 - s_));
         prewaited = false;
         __builtin_amdgcn_s_barrier();
         if (s_ + PD < total) issue();
         {
-            const char* const sa = lds + cs * STAGE + lane * 16 + (wm * MI) * 1024;
-            const char* const sb = lds + cs * STAGE + A_BYTES + lane * 16 + (wn * NI) * 1024;
+            const char* const sa = lds + cs * STAGE + frag_off + (wm * MI) * 1024;
+            const char* const sb = lds + cs * STAGE + A_BYTES + frag_off + (wn * NI) * 1024;
             u32x4 fa[MI][NPL], fb[NI][NPL];
             if (dbg & 32) {
 #pragma unroll
@@ -699,16 +762,16 @@ __global__ __launch_bounds__(64 * NW, (DmaCfg<MODE, BM, BN, NST, NW>::WAVES_PER_
 
 static int g_dma_cu_limit = 0;          // CUs a planes-DMA launch may count on (0: the device's); the engine lowers it for CU-masked streams
 
-template <int MODE, int BM, int NST, bool CONV, int BN = 128, int NW = 8>
+template <int MODE, int BM, int NST, bool CONV, int BN = 128, int NW = 8, int LW = 0>
 int launch_planes_dma_t(const ConvGemmGroup& gg, hipStream_t st) {
     const ConvGemm& g = gg.g[0];
     constexpr size_t smem = DmaCfg<MODE, BM, BN, NST, NW>::smem;
-    constexpr int WG_PER_CU = DmaCfg<MODE, BM, BN, NST, NW>::WG_PER_CU;
+    constexpr int WG_PER_CU = LW > 0 ? 1 : DmaCfg<MODE, BM, BN, NST, NW>::WG_PER_CU;
     static_assert(smem <= 160 * 1024 && WG_PER_CU >= 1, "LDS of one CU");
     static DeviceOnce attr_set;
     if (attr_set.needed()) {
-        SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<MODE, BM, NST, false, BN, NW, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        if (MODE == PLANES_H3) SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<MODE, BM, NST, false, BN, NW, CONV, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (MODE == PLANES_H3) SVA_HIP(hipFuncSetAttribute((const void*)planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW, CONV, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set.done();
     }
     int cus = g.cu_limit > 0 ? g.cu_limit : g_dma_cu_limit;
@@ -726,8 +789,8 @@ int launch_planes_dma_t(const ConvGemmGroup& gg, hipStream_t st) {
     ConvGemmGroup sorted = gg;                      // (longest K first: the kernel's tile deal relies on it)
     std::stable_sort(sorted.g, sorted.g + sorted.n, [](const ConvGemm& a, const ConvGemm& b_) { return a.taps > b_.taps; });
     const int dbg = debug_options().planes_dbg;
-    if (dbg && MODE == PLANES_H3) hipLaunchKernelGGL((planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW, CONV>), dim3(grid), dim3(64 * NW), smem, st, sorted, tn, tiles, dbg);
-    else hipLaunchKernelGGL((planes_dma_kernel<MODE, BM, NST, false, BN, NW, CONV>), dim3(grid), dim3(64 * NW), smem, st, sorted, tn, tiles, 0);
+    if (dbg && MODE == PLANES_H3) hipLaunchKernelGGL((planes_dma_kernel<PLANES_H3, BM, NST, true, BN, NW, CONV, LW>), dim3(grid), dim3(64 * (NW + LW)), smem, st, sorted, tn, tiles, dbg);
+    else hipLaunchKernelGGL((planes_dma_kernel<MODE, BM, NST, false, BN, NW, CONV, LW>), dim3(grid), dim3(64 * (NW + LW)), smem, st, sorted, tn, tiles, 0);
     return 0;
 }
 
@@ -741,7 +804,7 @@ int launch_planes_dma(const ConvGemmGroup& gg, int variant, hipStream_t st) {
     bool conv = gg.n > 1;
     for (int i = 0; i < gg.n; ++i) conv = conv || gg.g[i].taps > 1 || gg.g[i].cp_silu;
     const int bn = variant == 13 || variant == 14 ? 64 : 128;
-    SVA_CHECK(variant == 9 || variant == 10 || (conv && (variant == 13 || variant == 14) && g.N % bn == 0), "planes_dma: variant");
+    SVA_CHECK(variant == 9 || variant == 10 || variant == 11 || (!conv && variant == 12) || (conv && (variant == 13 || variant == 14) && g.N % bn == 0), "planes_dma: variant");
     for (int i = 0; i < gg.n; ++i)
         SVA_CHECK(planes_dma_supported(gg.g[i], conv) && g.N % bn == 0 && gg.g[i].M == g.M && gg.g[i].N == g.N && gg.g[i].Cin == g.Cin && gg.g[i].T == g.T && gg.g[i].pmode == g.pmode,
                   "planes_dma: unsupported problem (A as planes, N % 128 == 0, group members of one shape)");
@@ -757,6 +820,7 @@ int launch_planes_dma(const ConvGemmGroup& gg, int variant, hipStream_t st) {
         // voc_conv_kernel, which also takes C = 16 -- not instantiated.)
         if (g.pmode == PLANES_H3) {
             switch (variant) {
+                case 11: return launch_planes_dma_t<PLANES_H3, 128, 4, true, 128, 8, 2>(gg, st);
                 case 9: return launch_planes_dma_t<PLANES_H3, 128, 4, true>(gg, st);
                 case 10: return launch_planes_dma_t<PLANES_H3, 128, 2, true>(gg, st);
                 case 13: return launch_planes_dma_t<PLANES_H3, 128, 2, true, 64, 4>(gg, st);
@@ -764,12 +828,18 @@ int launch_planes_dma(const ConvGemmGroup& gg, int variant, hipStream_t st) {
             }
         }
         switch (variant) {
+            case 11: return launch_planes_dma_t<PLANES_H1, 128, 4, true, 128, 8, 2>(gg, st);
             case 9: return launch_planes_dma_t<PLANES_H1, 128, 4, true>(gg, st);
             case 10: return launch_planes_dma_t<PLANES_H1, 128, 2, true>(gg, st);
             case 13: return launch_planes_dma_t<PLANES_H1, 128, 2, true, 64, 4>(gg, st);
             default: return launch_planes_dma_t<PLANES_H1, 64, 4, true, 64, 4>(gg, st);
         }
     }
+    // 11: variant 9's tile and ring with TWO LOADER WAVES beside the eight multiplying ones; 12: variant 10's (two stages, two workgroups per CU) with them
+    if (variant == 12)
+        return g.pmode == PLANES_H3 ? launch_planes_dma_t<PLANES_H3, 256, 3, false, 128, 8, 2>(gg, st) : launch_planes_dma_t<PLANES_H1, 256, 3, false, 128, 8, 2>(gg, st);
+    if (variant == 11)
+        return g.pmode == PLANES_H3 ? launch_planes_dma_t<PLANES_H3, 128, 4, false, 128, 8, 2>(gg, st) : launch_planes_dma_t<PLANES_H1, 128, 4, false, 128, 8, 2>(gg, st);
     if (g.pmode == PLANES_H3) return variant == 9 ? launch_planes_dma_t<PLANES_H3, 128, 4, false>(gg, st) : launch_planes_dma_t<PLANES_H3, 128, 2, false>(gg, st);
     return variant == 9 ? launch_planes_dma_t<PLANES_H1, 128, 4, false>(gg, st) : launch_planes_dma_t<PLANES_H1, 128, 2, false>(gg, st);
 }

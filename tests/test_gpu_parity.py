@@ -1893,7 +1893,7 @@ def test_planes_gemm_every_mode_vs_fp64():
         ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
         scale = np.abs(ref).max()
         for mode in (1, 2):
-            for variant in range(11):
+            for variant in range(13):
                 if variant == 8 or (variant in (0, 1, 4, 7) and M < 128) or (variant in (0, 2, 4, 6, 7) and N < 128) or (variant == 6 and M < 256):
                     continue
                 if variant >= 8 and N % 128:
@@ -1923,7 +1923,7 @@ def test_planes_gemm_every_mode_vs_fp64():
     assert np.abs(out - sil).max() / np.abs(sil).max() <= 3e-6
 
 
-@pytest.mark.parametrize("variant", [0, 6, 9, 10])
+@pytest.mark.parametrize("variant", [0, 6, 9, 10, 11, 12])
 def test_planes_gemm_epilogues_vs_fp64(variant):
     """The epilogues the encoder hands to the planes GEMM at batch scale, per kernel form (0 / 6: register-staged tiles with the epilogue
     through LDS; 9 / 10: the persistent LDS-DMA form whose epilogue works on TRANSPOSED accumulators in registers): GELU into output planes
@@ -1986,7 +1986,7 @@ def test_planes_gemm_small_activations_absolute_floor():
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     wabs = np.abs(W.astype(np.float64)).sum(1)
     small = (rng.standard_normal((M, K)) * 3e-4).astype(np.float32)
-    for variant, ap in ((0, False), (0, True), (9, True), (10, True)):
+    for variant, ap in ((0, False), (0, True), (9, True), (10, True), (11, True)):
         out, _ = E.test_gemm_planes(small, W, mode=1, variant=variant, a_planes=ap)
         ref = small.astype(np.float64) @ W.astype(np.float64).T
         err = np.abs(out - ref)

@@ -291,5 +291,5 @@ def test_planes_variant_table_is_well_formed():
     assert len(rows) >= 100
     assert len({r[:3] for r in rows}) == len(rows)
     for M, N, K, v in rows:
-        assert v in (0, 1, 2, 3, 6, 7, 9, 10) and K % 32 == 0 and N % 4 == 0 and M >= 1024          # (9 / 10: the persistent LDS-DMA forms, whole 128-column tiles)
+        assert v in (0, 1, 2, 3, 6, 7, 9, 10, 11, 12) and K % 32 == 0 and N % 4 == 0 and M >= 1024          # (9 .. 12: the persistent LDS-DMA forms, whole 128-column tiles; 11 / 12 with loader waves)
         assert not (v in (0, 2, 6, 7) and N < 128) and not (v == 6 and M < 256) and not (v >= 9 and N % 128)

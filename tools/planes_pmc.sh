@@ -28,7 +28,7 @@ import csv, glob, collections
 per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in glob.glob("$OUT/P*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "planes_gemm" not in r["Kernel_Name"]: continue
+        if "planes_gemm" not in r["Kernel_Name"] and "planes_dma" not in r["Kernel_Name"]: continue
         a = per[r["Kernel_Name"]][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
 for k, cs in per.items():
     print(k[:120])

@@ -9,7 +9,7 @@ from streamvoiceanon_amd import engine as E
 rng = np.random.default_rng(5)
 # (rows per stream, N, K, A handed over as planes)
 # round 5: every batch-scale GEMM of the encoder takes its A operand as planes now (the producers write them), so the candidates include the
-# persistent LDS-DMA forms 8 / 9 / 10; the three transition convs (LayerNorm rows -> conv k1) still arrive as fp32
+# persistent LDS-DMA forms 9 / 10 and their loader-wave forms 11 (128 x 128) / 12 (256 x 128); the three transition convs (LayerNorm rows -> conv k1) still arrive as fp32
 SHAPES = ((170, 512, 128, True), (170, 128, 512, True), (170, 1024, 256, True), (170, 256, 1024, True), (170, 1536, 384, True), (170, 384, 1536, True),
           (170, 2048, 512, True), (170, 512, 2048, True), (88, 2048, 512, True), (88, 512, 2048, True), (47, 2048, 512, True), (47, 512, 2048, True),
           (128, 1536, 512, True), (128, 512, 512, True),
@@ -24,7 +24,7 @@ for B in (16, 24, 32, 40, 48, 64, 96, 128):
         A = rng.standard_normal((M, K)).astype(np.float32)
         W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
         best = None
-        for v in (0, 1, 2, 3, 6, 7, 9, 10):
+        for v in (0, 1, 2, 3, 6, 7, 9, 10, 11, 12):
             if (v == 6 and M < 256) or (v in (0, 2, 6, 7) and N < 128) or (v >= 8 and (not ap or N % 128)):
                 continue
             us = min(E.test_gemm_planes(A, W, mode=1, variant=v, a_planes=ap, iters=15)[1] for _ in range(2))
