@@ -768,8 +768,8 @@ def main():
             roof = {"bound": "mfma", "kernel": "conv-GEMM family: pipe_gemm_kernel / conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32) and split_gemm_kernel / "
                               "planes_gemm_kernel / planes_dma_kernel (the same fp32 problems on the 16-bit pipes: six bf16 part products split in the K loop, or "
                               "three fp16 part products from pre-split operand planes with sva_config.mm_mode = 1 -- fp32-grade results either way; one fp16 "
-                              "product for a voc_dtype = 1 vocoder; planes_dma = the persistent LDS-DMA form the encoder's batch-scale GEMMs run in; the "
-                              "per-shape table picks)",
+                              "product for a voc_dtype = 1 vocoder; planes_dma = the persistent LDS-DMA form the encoder's batch-scale GEMMs and, from 16 code "
+                              "frames per step, the HiFiGAN ResBlock convs run in (incl. voc_conv_kernel for the C = 16 / 32 levels); the per-shape table picks)",
                     "peak_note": "peak = 157.3 TF/s, the dense f32-MFMA peak (the arithmetic the path is specified in) -- `frac` = achieved / 157.3 as the contract "
                                  "defines it; launches of the split-bf16 kernel run on the bf16 pipes, whose ceiling for this work is 2500 / 6 = 416.7 TF/s: `by_pipe` "
                                  "prices each kernel family against its own pipe and `frac_of_own_pipes` is the time-weighted combination (the honest figure when "
