@@ -1083,7 +1083,7 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
         return 0;
     }
     if (kind == 6) {                    // the planes kernel (gemm_planes.hip), a = its tile variant
-        SVA_CHECK(planes_gemm_supported(g) && a >= 0 && a <= 15 && a != 8 && a != 13 && a != 14 && (a < 8 || planes_dma_gemm_supported(g)) && (a != 15 || g.N % 256 == 0) && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the planes kernel needs weight planes, Cin % 32 == 0 and 16-byte aligned C rows");
+        SVA_CHECK(planes_gemm_supported(g) && a >= 0 && a <= 12 && a != 8 && (a < 8 || planes_dma_gemm_supported(g)) && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the planes kernel needs weight planes, Cin % 32 == 0 and 16-byte aligned C rows");
         SVA_TRY_RC(launch_choice(g, st, Choice{4, 8 + a, 0, 0}));
         SVA_HIP(hipGetLastError());
         return 0;

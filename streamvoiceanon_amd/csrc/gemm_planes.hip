@@ -804,7 +804,7 @@ int launch_planes_dma(const ConvGemmGroup& gg, int variant, hipStream_t st) {
     bool conv = gg.n > 1;
     for (int i = 0; i < gg.n; ++i) conv = conv || gg.g[i].taps > 1 || gg.g[i].cp_silu;
     const int bn = variant == 13 || variant == 14 ? 64 : 128;
-    SVA_CHECK(variant == 9 || variant == 10 || variant == 11 || (!conv && variant == 12) || (!conv && variant == 15 && g.N % 256 == 0) || (conv && (variant == 13 || variant == 14) && g.N % bn == 0), "planes_dma: variant");
+    SVA_CHECK(variant == 9 || variant == 10 || variant == 11 || (!conv && variant == 12) || (conv && (variant == 13 || variant == 14) && g.N % bn == 0), "planes_dma: variant");
     for (int i = 0; i < gg.n; ++i)
         SVA_CHECK(planes_dma_supported(gg.g[i], conv) && g.N % bn == 0 && gg.g[i].M == g.M && gg.g[i].N == g.N && gg.g[i].Cin == g.Cin && gg.g[i].T == g.T && gg.g[i].pmode == g.pmode,
                   "planes_dma: unsupported problem (A as planes, N % 128 == 0, group members of one shape)");
@@ -836,8 +836,6 @@ int launch_planes_dma(const ConvGemmGroup& gg, int variant, hipStream_t st) {
         }
     }
     // 11: variant 9's tile and ring with TWO LOADER WAVES beside the eight multiplying ones; 12: variant 10's (two stages, two workgroups per CU) with them
-    if (variant == 15)       // 128 x 256 tiles (the 256-wide form whose tile count suits M = 85 row tiles x N / 256)
-        return g.pmode == PLANES_H3 ? launch_planes_dma_t<PLANES_H3, 128, 3, false, 256, 8, 2>(gg, st) : launch_planes_dma_t<PLANES_H1, 128, 3, false, 256, 8, 2>(gg, st);
     if (variant == 12)
         return g.pmode == PLANES_H3 ? launch_planes_dma_t<PLANES_H3, 256, 3, false, 128, 8, 2>(gg, st) : launch_planes_dma_t<PLANES_H1, 256, 3, false, 128, 8, 2>(gg, st);
     if (variant == 11)
