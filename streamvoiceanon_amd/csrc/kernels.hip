@@ -386,7 +386,10 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void enc_attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rope,
+// NWV waves per workgroup: 8 when the window has more than four query tiles -- one wave per SIMD (the four-wave form with its 102 KiB of LDS per
+// workgroup) leaves the matrix pipe waiting on every LDS read; eight waves take one tile each instead of two and load K / V twice as fast
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void enc_attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rope,
                                                                  int T, int H, float* __restrict__ out, int row0,
                                                                  unsigned short* __restrict__ outp, long op_pstride, int op_planes, long op_rows) {
     constexpr int HD = 64, LK = HD + 4, NTM = 8;          // up to 8 key tiles (T <= 128)
@@ -394,12 +397,12 @@ __global__ __launch_bounds__(256) void enc_attention_mfma_kernel(const float* __
     const int LV = T + 4;
     float* Ks = smem;                                     // [T][68]    K with RoPE
     float* Vt = Ks + (long)T * LK;                        // [64][T+4]  V transposed
-    float* Ps = Vt + (long)HD * LV;                       // [4 waves][16][T+4]
+    float* Ps = Vt + (long)HD * LV;                       // [NWV waves][16][T+4]
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
     const int D = H * HD;
     const float* base = qkv + (long)b * T * 3 * D;
-    for (int idx = tid; idx < T * (HD / 2); idx += 256) {
+    for (int idx = tid; idx < T * (HD / 2); idx += 64 * NWV) {
         const int t = idx / (HD / 2), p = idx - t * (HD / 2);
         const float* row = base + (long)t * 3 * D + h * HD + 2 * p;
         const float2 kk = *reinterpret_cast<const float2*>(row + D);
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256) void enc_attention_mfma_kernel(const float* __
     const int n_tiles = T / 16;
     const int first_tile = row0 / 16;
     // query tiles first_tile .. n_tiles-1, dealt to (query split, wave) round-robin from the heaviest (last) tile down
-    for (int u = blockIdx.z * 4 + wave; u < n_tiles - first_tile; u += 4 * gridDim.z) {
+    for (int u = blockIdx.z * NWV + wave; u < n_tiles - first_tile; u += NWV * gridDim.z) {
         const int rt = n_tiles - 1 - u;
         const int r0 = rt * 16;
         // Q fragments with RoPE: lane (fr, fk) holds dims 16*blk + 4*fk .. +3 of row r0 + fr
@@ -578,16 +581,19 @@ int launch_enc_attention(const float* qkv, const float* rope, int B, int T, int 
     SVA_CHECK(hd == 64 && T % 4 == 0, "enc_attention: head_dim must be 64 and T a multiple of 4");
     SVA_CHECK(!outp || enc_attention_can_write_planes(T), "enc_attention: planes output only from the <= 128-token MFMA kernel");
     if (T % 16 == 0 && T <= 128) {
-        const size_t sm = ((size_t)T * 68 + 64 * (size_t)(T + 4) + 4 * 16 * (size_t)(T + 4)) * sizeof(float);
+        const int tiles = T / 16 - row0 / 16;
+        const int nwv = tiles > 4 ? 8 : 4;
+        const size_t sm = ((size_t)T * 68 + 64 * (size_t)(T + 4) + (size_t)nwv * 16 * (size_t)(T + 4)) * sizeof(float);
         static DeviceOnce attr_m;
         if (attr_m.needed()) {
-            SVA_HIP(hipFuncSetAttribute((const void*)enc_attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            SVA_HIP(hipFuncSetAttribute((const void*)enc_attention_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            SVA_HIP(hipFuncSetAttribute((const void*)enc_attention_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_m.done();
         }
-        const int tiles = T / 16 - row0 / 16;
         int qsplit = 1;                                    // more workgroups per (head, stream) while the chip is under-filled
-        while (qsplit * 4 < tiles && (long)H * B * qsplit < 128) qsplit *= 2;
-        hipLaunchKernelGGL(enc_attention_mfma_kernel, dim3(H, B, qsplit), dim3(256), sm, st, qkv, rope, T, H, out, row0, outp, op_pstride, op_planes, op_rows);
+        while (qsplit * nwv < tiles && (long)H * B * qsplit < 128) qsplit *= 2;
+        if (nwv == 8) hipLaunchKernelGGL(enc_attention_mfma_kernel<8>, dim3(H, B, qsplit), dim3(512), sm, st, qkv, rope, T, H, out, row0, outp, op_pstride, op_planes, op_rows);
+        else hipLaunchKernelGGL(enc_attention_mfma_kernel<4>, dim3(H, B, qsplit), dim3(256), sm, st, qkv, rope, T, H, out, row0, outp, op_pstride, op_planes, op_rows);
         SVA_HIP(hipGetLastError());
         return 0;
     }
