@@ -55,7 +55,7 @@ typedef struct sva_config {
     int ar_dtype;          /* 0: fp32 AR weights + fp32 KV (parity mode); 1: fp16 AR weights (streamed as fp16 by the batch-1 decode kernel;
                             * the batched / prefill GEMMs use the same fp16-rounded values) + fp16 slow KV cache, as the reference
                             * decodes under torch.autocast(fp16) with fp16 caches (evaluations/infer_arvc.py:55-59, 483, 493) */
-    int mm_mode;           /* fp32-grade batch-scale GEMMs (>= 3072 rows) of the encoder / vocoder: 1 (default) = two pre-split fp16 planes per
+    int mm_mode;           /* fp32-grade batch-scale GEMMs (batches of 10+ streams) of the encoder / vocoder: 1 (default) = two pre-split fp16 planes per
                             * operand, three part products (csrc/gemm_planes.hip): half the matrix work of 0, for operands inside the fp16
                             * range -- which torch.autocast(fp16), infer_arvc.py:493, demands of the reference too; 0 = three bf16 parts split
                             * inside the K loop, six products (csrc/gemm_split.hip, the round-3 kernel): any fp32 range.  (2 -- three pre-split

@@ -49,6 +49,7 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "voc_dma") o.voc_dma = atoi(v.c_str());
             else if (k == "voc_dma_variant") o.voc_dma_variant = atoi(v.c_str());
             else if (k == "planes_lw") o.planes_lw = atoi(v.c_str());
+            else if (k == "planes_min_streams") o.planes_min_streams = atoi(v.c_str());
             else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());
@@ -540,12 +541,12 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         b->voc_rpf[i] = rpf;
         const bool fused_level = voc_level_is_fused(b, ch);
         // Every level of a batch with enough rows per step: the 18 ResBlock convs on operand planes, three branches per launch (C >= 64: the LDS-DMA
-        // planes kernel's conv form; C = 16 / 32: voc_conv_kernel), the activations between them as planes (history included).  A static choice per batch -- the history lives in one form.  From 16
-        // code frames per step over the batch (streams x voc_max_frames): measured +4.7 / +5.7 / +6.7 / +5.2 / +3.9 % frames/s at 16 / 24 / 32 / 48 /
-        // 128 streams, even at 8 (profiles/r05_voc_dma_sweep.txt)
+        // planes kernel's conv form; C = 16 / 32: voc_conv_kernel), the activations between them as planes (history included).  A static choice per
+        // batch -- the history lives in one form.  From 10 code frames per step over the batch (streams x voc_max_frames): +4.7 / +5.7 / +6.7 / +5.2 /
+        // +3.9 % frames/s at 16 / 24 / 32 / 48 / 128 streams, +2 % and a 6 % shorter synchronous step at 10 / 12, even at 8 (profiles/r05_voc_dma_sweep.txt)
         const int voc_pm = c.voc_dtype == 1 ? PLANES_H1 : (c.mm_mode == 1 ? PLANES_H3 : -1);
         bool dma_level = !fused_level && ch % 16 == 0 && voc_pm >= 0 && debug_options().planes_dma != 0 && debug_options().voc_dma != 0 &&
-                         (debug_options().voc_dma == 1 || (long)B * Tv >= 16);
+                         (debug_options().voc_dma == 1 || (long)B * Tv >= 10);
         // C = 16 / 32: row-major planes + voc_conv_kernel (the input rows of a tile and the branch's whole weight resident in LDS); wider: K-blocked planes +
         // the LDS-DMA GEMM's conv form
         const bool halo_level = dma_level && ch <= 32 && voc_conv_supported(ch, rpf, voc_pm);

@@ -157,9 +157,13 @@ __global__ void mean3_kernel(const float* __restrict__ y0, const float* __restri
 // Two chained GEMMs of `rows` rows can hand their intermediate tensor over as operand planes (gemm_planes.hip) when both weights carry
 // planes of one fp16 format -- two fp16 planes (or one) fill exactly the bytes (half the bytes) of the fp32 tensor they replace, so
 // they live in its buffer -- and the problem is at the scale where the planes kernel is the dispatcher's choice anyway.
-// (rows: the GEMM pair's own rows.  From 24 streams on -- where the main passes run on planes anyway -- the shorter passes of the same step, the
+// (rows: the GEMM pair's own rows.  Round 5, after the LDS-DMA forms: from 10 streams on (12 / 16 / 20 streams +6 / +5 / +9 % frames/s, 10 streams +1.4 % and the
+// synchronous step 4.5 % shorter, 8 streams slower: profiles/r05_planes_min_streams.txt).  From that stream count on -- where the main passes run on planes anyway -- the shorter passes of the same step, the
 // quantizer downsampler's 88 / 47 rows per stream, go the same way: 3008 x 2048 x 512 at 64 streams 72 -> 28 us, profiles/r05_planes_tune.log)
-static bool planes_rows_ok(long rows, int streams) { return rows >= 3072 || (streams >= 24 && rows >= 1024); }
+static bool planes_rows_ok(long rows, int streams) {
+    const int ms = debug_options().planes_min_streams;        // (A/B: the stream count from which the encoder's passes hand their operands over as planes)
+    return rows >= 128L * ms || (streams >= ms && rows >= 1024);
+}
 bool planes_edge(const Lin& producer, const Lin& consumer, long rows, int streams) {
     return planes_rows_ok(rows, streams) && producer.Wp && consumer.Wp && producer.pmode == consumer.pmode && (producer.pmode == PLANES_H3 || producer.pmode == PLANES_H1) &&
            consumer.K % 32 == 0;

@@ -16,7 +16,7 @@ SHAPES = ((170, 512, 128, True), (170, 128, 512, True), (170, 1024, 256, True), 
           (128, 3072, 512, True), (128, 512, 1536, True), (170, 256, 128, False), (170, 384, 256, False), (170, 512, 384, False))
 print("// {M, N, K, variant}: measured winner of tools/planes_tune.py (MI355X, H3 format), sorted by (N, K, M)")
 rows = []
-for B in (16, 24, 32, 40, 48, 64, 96, 128):
+for B in (12, 16, 20, 24, 32, 40, 48, 64, 96, 128):
     for (T, N, K, ap) in SHAPES:
         M = B * T
         if M < 1024:
