@@ -160,10 +160,14 @@ __global__ void mean3_kernel(const float* __restrict__ y0, const float* __restri
 // (rows: the GEMM pair's own rows.  Round 5, after the LDS-DMA forms: from 10 streams on (12 / 16 / 20 streams +6 / +5 / +9 % frames/s, 10 streams +1.4 % and the
 // synchronous step 4.5 % shorter, 8 streams slower: profiles/r05_planes_min_streams.txt).  From that stream count on -- where the main passes run on planes anyway -- the shorter passes of the same step, the
 // quantizer downsampler's 88 / 47 rows per stream, go the same way: 3008 x 2048 x 512 at 64 streams 72 -> 28 us, profiles/r05_planes_tune.log)
+// (streams < 0: a batch whose encoder runs on a CU partition beside a multi-launch AR chain -- fp16 AR at 12-32 streams --: there the kernels tuned on the
+// partition keep the better THROUGHPUT below 24 streams, 4745 against 4390 frames/s at 16, although the synchronous step is 15 % longer: r05_planes_min_streams.txt)
 static bool planes_rows_ok(long rows, int streams) {
-    const int ms = debug_options().planes_min_streams;        // (A/B: the stream count from which the encoder's passes hand their operands over as planes)
-    return rows >= 128L * ms || (streams >= ms && rows >= 1024);
+    const int ms = streams < 0 ? std::max(24, debug_options().planes_min_streams) : debug_options().planes_min_streams;
+    const int n = streams < 0 ? -streams : streams;
+    return rows >= 128L * ms || (n >= ms && rows >= 1024);
 }
+static int planes_streams(const sva_batch* b) { return b->enc_cus > 0 ? -b->B : b->B; }
 bool planes_edge(const Lin& producer, const Lin& consumer, long rows, int streams) {
     return planes_rows_ok(rows, streams) && producer.Wp && consumer.Wp && producer.pmode == consumer.pmode && (producer.pmode == PLANES_H3 || producer.pmode == PLANES_H1) &&
            consumer.K % 32 == 0;
@@ -188,7 +192,7 @@ int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs
     ConvGemm p2;
     // batch scale: the hidden tensor goes from pwconv1's GELU epilogue to pwconv2 as operand planes, in the scratch buffer's own memory
     const long rows = (long)b->B * T;
-    if (planes_edge(c.pw1, c.pw2, rows, b->B)) {
+    if (planes_edge(c.pw1, c.pw2, rows, planes_streams(b))) {
         SVA_CHECK(h2_bs == (long)T * 4 * C, "cnx_block: planes hand-over needs dense hidden rows");
         p1.Cp = reinterpret_cast<unsigned short*>(h2); p1.cp_pstride = h2_bs * b->B; p1.cp_rows = rows;
         p2.Ap = p1.Cp; p2.ap_pstride = p1.cp_pstride; p2.ap_rows = rows;
@@ -199,7 +203,7 @@ int cnx_block_t(sva_batch* b, const CNX& c, Act& x, int T, float* h1, long h1_bs
         p1.dw_wT = c.dwT; p1.dw_b = c.dwb; p1.ln_w = c.lnw; p1.ln_b = c.lnb; p1.ln_eps = 1e-6f;
         SVA_TRY(gemm_call(b, x.p, x.bstride, (long)(x.H - 6) * C, C, b->B, T, 1, 1, 1, C, c.pw1, h2, h2_bs, 0, 4 * C, p1));
     } else {
-        if (planes_input(c.pw1, rows, b->B) && h1_bs == (long)T * C) {        // LayerNorm output straight into operand planes, in h1's own memory
+        if (planes_input(c.pw1, rows, planes_streams(b)) && h1_bs == (long)T * C) {        // LayerNorm output straight into operand planes, in h1's own memory
             p1.Ap = reinterpret_cast<unsigned short*>(h1); p1.ap_pstride = h1_bs * b->B; p1.ap_rows = rows;
             SVA_TRY(launch_dwconv7_ln(x.p, x.bstride, (long)(x.H - 6) * C, b->B, T, C, c.dwT, c.dwb, c.lnw, c.lnb, 1e-6f, h1, h1_bs, b->stream,
                                       reinterpret_cast<unsigned short*>(h1), p1.ap_pstride, planes_count(c.pw1.pmode), rows));
@@ -455,7 +459,7 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows, int part) {
             ConvGemm pn;
             pn.rms_w = L.attn_norm; pn.rms_eps = 1e-5f;
             SVA_TRY(gemm_call(b, xr, xr_bs, xr_off, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D, pn));
-        } else if (planes_input(L.wqkv, (long)B * T2, B)) {        // RMSNorm output as operand planes (in tr_hn's own memory)
+        } else if (planes_input(L.wqkv, (long)B * T2, planes_streams(b))) {        // RMSNorm output as operand planes (in tr_hn's own memory)
             ConvGemm pn;
             pn.Ap = reinterpret_cast<unsigned short*>(b->tr_hn); pn.ap_pstride = (long)B * T2 * D; pn.ap_rows = (long)B * T2;
             SVA_TRY(launch_rmsnorm_rows(xr, xr_bs, xr_off, D, B, T2, D, L.attn_norm, 1e-5f, b->tr_hn, (long)T2 * D, 0, D, st,
@@ -466,7 +470,7 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows, int part) {
             SVA_TRY(gemm_call(b, b->tr_hn, (long)T2 * D, 0, D, B, T2, 1, 1, 1, D, L.wqkv, b->tr_qkv, (long)T2 * 3 * D, 0, 3 * D));
         }
         ConvGemm po;
-        if (planes_input(L.wo, (long)B * Tr, B) && enc_attention_can_write_planes(T2)) {          // attention output as operand planes (in tr_att's own memory)
+        if (planes_input(L.wo, (long)B * Tr, planes_streams(b)) && enc_attention_can_write_planes(T2)) {          // attention output as operand planes (in tr_att's own memory)
             po.Ap = reinterpret_cast<unsigned short*>(b->tr_att); po.ap_pstride = (long)B * T2 * D; po.ap_rows = (long)B * T2;
             SVA_TRY(launch_enc_attention(b->tr_qkv, e->rope_enc, B, T2, c.tr_heads, 64, b->tr_att, r0, st,
                                          reinterpret_cast<unsigned short*>(b->tr_att), po.ap_pstride, planes_count(L.wo.pmode), po.ap_rows));
@@ -481,7 +485,7 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows, int part) {
         ConvGemm pg;
         pg.w13 = 1;
         ConvGemm pd;
-        if (planes_edge(L.w13, L.w2, (long)B * Tr, B)) {          // SwiGLU output -> w2 as operand planes, in tr_g's memory
+        if (planes_edge(L.w13, L.w2, (long)B * Tr, planes_streams(b))) {          // SwiGLU output -> w2 as operand planes, in tr_g's memory
             pg.Cp = reinterpret_cast<unsigned short*>(b->tr_g); pg.cp_pstride = (long)B * T2 * I; pg.cp_rows = (long)B * T2;
             pd.Ap = pg.Cp; pd.ap_pstride = pg.cp_pstride; pd.ap_rows = pg.cp_rows;
         }
@@ -489,7 +493,7 @@ int enc_transformer(sva_batch* b, const Act& xin, int need_rows, int part) {
             pg.rms_w = L.ffn_norm; pg.rms_eps = 1e-5f;
             SVA_TRY(gemm_call(b, xw, xw_bs, (long)r0 * D, D, B, Tr, 1, 1, 1, D, L.w13, b->tr_g, (long)T2 * I, (long)r0 * I, I, pg));
         } else {
-            if (planes_input(L.w13, (long)B * Tr, B)) {
+            if (planes_input(L.w13, (long)B * Tr, planes_streams(b))) {
                 pg.Ap = reinterpret_cast<unsigned short*>(b->tr_hn); pg.ap_pstride = (long)B * T2 * D; pg.ap_rows = (long)B * T2;
                 SVA_TRY(launch_rmsnorm_rows(xw, xw_bs, (long)r0 * D, D, B, Tr, D, L.ffn_norm, 1e-5f, b->tr_hn, (long)T2 * D, (long)r0 * D, D, st,
                                             reinterpret_cast<unsigned short*>(b->tr_hn), pg.ap_pstride, planes_count(L.w13.pmode), pg.ap_rows));
