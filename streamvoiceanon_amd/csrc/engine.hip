@@ -172,7 +172,11 @@ static bool abatch_serves(int B, int ar_dtype, bool pipelined, int chunk) {
     // (round 5, after the planes-DMA kernel shortened the encoder stage: at 32 fp32 streams the one-launch kernel unpartitioned gives 6416 frames/s / sync p50
     // 9.5 ms against 5773 / 11.5 for the multi-launch chain on its 64-CU partition and 5638 / 9.2 unpartitioned; at 48 it loses, 5915 vs 7220 --
     // profiles/r05_partition_sweep.txt)
-    const int hi = chunk > 1 ? 32 : (ar_dtype == 1 ? 11 : 32);
+    // (end of round 5, with the encoder and the vocoder on the planes paths from 10 streams: the fp16 AR too -- 12 / 16 / 24 / 32 streams 3720 / 4780 / 5290 / 6440
+    // frames/s for the multi-launch chain on its partition against 4990 / 6110 / 7200 / 8330 for this kernel unpartitioned, the synchronous step 19-25 %
+    // shorter; at 36-44 streams the two tie or it loses (fp32 36: 5735 vs 6183, 40: 6032 vs 6026, 44: 6210 vs 6131; fp16 40: 6785 vs 7370) -- profiles/r05_abatch_policy.txt)
+    (void)chunk;
+    const int hi = 32;
     return B >= abatch_lo(ar_dtype, pipelined) && B <= hi;
 }
 

@@ -1591,9 +1591,10 @@ def test_prefill_attention_mfma_vs_fp64(M, pos0, half_kv):
     assert np.abs(o_mfma - want).max() < 2e-5 and np.abs(o_ref - want).max() < 2e-5
 
 
-@pytest.mark.parametrize("B", [8, 64])
+@pytest.mark.parametrize("B", [8, 16, 32, 64])
 def test_fp16_batched_decode_teacher_forced_logits(eng_fp16, weights0, B, record_property):
-    """The batched fp16 decode (more than 6 streams: gemm_f16w.hip, fp16 weights on the f16 pipes, fp16 KV) against the fp32 fixture:
+    """The batched fp16 decode (3 - 32 streams: the one-launch kernel ar_batch.hip on fp16 weights -- 12 - 32 since the end of round 5 --; beyond:
+    gemm_f16w.hip, fp16 weights on the f16 pipes; fp16 KV either way) against the fp32 fixture:
     teacher-forced top-32 slow and fast logits of every frame within the fp16 budget 2e-2, taken from the LAST slot of the batch."""
     g, outs, content, audio, slow, fast, _ = _stream_vs_golden(eng_fp16, weights0, "stream_s0", forced=True, n_streams=B, slot=B - 1, n_limit=14)
     worst = 0.0
