@@ -403,8 +403,9 @@ int launch_planes_m(const ConvGemmGroup& gg, int variant, hipStream_t st) {
 // fill / drain / epilogue are ~40 % of it.  This kernel changes the structure instead of the schedule:
 //   * both operands are planes (the producers split: weights at finalize, activations in the epilogue / output pass of whoever wrote
 //     them), so global -> LDS is a pure copy: `global_load_lds_dwordx4` (16 bytes per lane, one 1 KiB piece = 16 rows x 32 k of one
-//     plane per wave-instruction; the lane-linear LDS image IS the chunk-major piece layout of the header, the rows are picked by the
-//     per-lane SOURCE offsets).  No staging registers, no ds_write, no VALU in the K loop;
+//     plane per wave-instruction; lane quads take a row's four chunks so the wave reads its KiB front to back, the LDS image is row-major
+//     with the chunk XOR-swizzled per row group -- see the lane-order comment in the kernel; the rows are picked by the per-lane SOURCE
+//     offsets).  No staging registers, no ds_write, no VALU in the K loop;
 //   * a ring of NST LDS stages, requests NST - 1 K steps ahead, COUNTED s_waitcnt vmcnt(N) (never 0 in steady state) + one raw
 //     s_barrier per K step: the DMA stays in flight across barriers (cdna_hip_programming.md, "Pipelining across barriers").  The
 //     loads are inline asm, invisible to hipcc's wait-count pass, and the K loop holds no other VMEM instruction;
@@ -414,9 +415,11 @@ int launch_planes_m(const ConvGemmGroup& gg, int variant, hipStream_t st) {
 //     operand -- so a lane holds FOUR CONSECUTIVE OUTPUT COLUMNS of one row (D[n][m]: n = 4 (lane >> 4) + r, m = lane & 15): bias /
 //     GELU / gamma / residual / SwiGLU (its w1 | w3 column groups are two accumulators of the same lane) and the split into output
 //     planes happen in registers, stores are 16 bytes (fp32) or 8 bytes per plane per lane.
-// Tile BM x 128 on 8 waves (two per SIMD): BM = 256 -> 4 x 2 waves of 64 x 64, three 48 KiB stages; BM = 128 -> 2 x 4 waves of
-// 64 x 32, four 32 KiB stages (the shapes with few column tiles).  One workgroup per CU; the grid is min(tiles, CUs of the stream);
-// XCD x owns a contiguous band of the (n-fastest) tile sequence, so the row panel a band shares is fetched into one L2.
+// Tile BM x 128 on 8 multiplying waves (two per SIMD): BM = 256 -> 4 x 2 waves of 64 x 64, three 48 KiB stages; BM = 128 -> 2 x 4 waves of
+// 64 x 32, four (or two: then two workgroups per CU) 32 KiB stages.  LW = 2 adds two LOADER waves that issue every request (see LW in the
+// kernel); CONV adds conv taps over the A planes, groups of three problems and narrow tiles (the HiFiGAN ResBlock convs).  The grid is
+// min(tiles, CUs of the stream x workgroups per CU); XCD x owns a contiguous band of the (n-fastest) tile sequence, so the row panel a band
+// shares is fetched into one L2.
 // ---------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ const char* uni_ptr(const char* p) {
@@ -794,7 +797,7 @@ int launch_planes_dma_t(const ConvGemmGroup& gg, hipStream_t st) {
     return 0;
 }
 
-// variants 8 .. 10 of launch_planes_gemm
+// variants 9 .. 14 of launch_planes_gemm (9 / 10: one / two workgroups per CU; 11 / 12: loader waves, 128 x 128 / 256 x 128; 13 / 14: the conv form's narrow tiles)
 bool planes_dma_supported(const ConvGemm& g, bool conv = false) {
     return planes_gemm_supported(g) && g.Ap && !g.a_silu && g.N % (conv ? 64 : 128) == 0 && (!conv || !g.w13) && g.ksplit <= 1 && (!g.w13 || g.N % 32 == 0) &&
            (!g.C || (g.ldc % 4 == 0 && g.c_off % 4 == 0 && g.c_bstride % 4 == 0)) && (!g.res || (g.ldr % 4 == 0 && g.r_off % 4 == 0 && g.r_bstride % 4 == 0));

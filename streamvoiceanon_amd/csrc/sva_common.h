@@ -28,7 +28,7 @@ void set_error(const std::string& msg);
 //                     (downsampler + transformer + BSQ), 4 AR, 8 vocoder (tools/pipe_skip.sh)
 //   planes_dbg=mask   TIMING DIAGNOSTIC (results are garbage): leave parts of the planes GEMM out -- 1 global loads of its K loop, 2 LDS stores, 4 MFMAs,
 //                     8 epilogue (tools/planes_probe.py)
-//   planes_dma=0      the planes GEMM never takes its persistent LDS-DMA form (variants 8 / 9): round 4's register-staged tiles (A/B)
+//   planes_dma=0      the planes GEMM never takes its persistent LDS-DMA form (variants 9 .. 14): round 4's register-staged tiles (A/B)
 //   voc_dma=0|1       the HiFiGAN levels' ResBlock convs on operand planes (C >= 64: the LDS-DMA planes kernel's conv form, C = 16 / 32: voc_conv_kernel;
 //                     activations between them as planes): never / at every batch size (default: from 10 code frames per step over the batch; parity tests force it at small batches)
 //   planes_min_streams=N  stream count from which the encoder's passes hand their operands over as planes (default 10; A/B)
@@ -192,9 +192,10 @@ int launch_pipe_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
 int planes_count(int mode);
 bool planes_gemm_supported(const ConvGemm& g);
 int launch_planes_gemm(const ConvGemmGroup& gg, int variant, hipStream_t st);
-// variants 9 / 10 of it: the persistent LDS-DMA-fed form (128 x 128 tiles, one / two workgroups per CU; A as planes, N % 128 == 0; a group's tiles form one sequence)
+// variants 9 .. 12 of it: the persistent LDS-DMA-fed form (9 / 10: 128 x 128 tiles, one / two workgroups per CU; 11 / 12: two loader waves beside the eight
+// multiplying ones, 128 x 128 / 256 x 128 tiles; A as planes, N % 128 == 0; a group's tiles form one sequence)
 bool planes_dma_gemm_supported(const ConvGemm& g);
-// its conv form (taps over A planes, a group's tiles as one sequence, SiLU'd output planes; variants 9 / 10 and the narrow tiles 13 / 14): N % 64 == 0
+// its conv form (taps over A planes, a group's tiles as one sequence, SiLU'd output planes; variants 9 / 10 / 11 and the narrow tiles 13 / 14): N % 64 == 0
 bool planes_dma_conv_supported(const ConvGemm& g);
 void planes_dma_set_cu_limit(int cus);        // CUs its grid may count on (0 = the device's); the engine sets it around launches on CU-masked streams
 // Narrow HiFiGAN levels (C = 16 / 32): one ResBlock conv stage of the three branches as a halo-resident conv over ROW-MAJOR operand planes
