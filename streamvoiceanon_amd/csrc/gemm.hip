@@ -918,6 +918,10 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
     {
         const auto& tab = static_table();
         auto it = tab.find({g.M, g.N, g.taps * g.Cin, g.taps, (int)key_flags, g.stride});
+        // a decode-sized row count between two tabulated ones (40 or 44 streams: the table holds 36 and 48) takes the choice of the next larger one within
+        // 1.5 x -- every kernel handles partial row tiles, and the heuristic's pick there measured 20 % slower (AR stage 4.7 ms at 40 / 44 streams, 3.8 at 48)
+        if (it == tab.end() && g.M >= 8 && g.M <= 512)
+            for (int m = g.M + 1; m <= g.M + g.M / 2 && it == tab.end(); ++m) it = tab.find({m, g.N, g.taps * g.Cin, g.taps, (int)key_flags, g.stride});
         if (it != tab.end()) {
             // the table is keyed by shape only; the pipelined / split kernels also need aligned operands (a seam such as sva_op_conv can
             // present a tuned shape with other strides): keep the tuned choice only if its kernel accepts THIS problem
