@@ -719,9 +719,9 @@ def main():
             tab = batch.gemm_profile_table()
             pipes = {"f32_mfma": [0.0, 0.0, 0], "bf16_split": [0.0, 0.0, 0], "f16_weights": [0.0, 0.0, 0], "planes_bf16x3": [0.0, 0.0, 0],
                      "planes_f16x2": [0.0, 0.0, 0], "planes_f16x1": [0.0, 0.0, 0], "planes_dma_f16x2": [0.0, 0.0, 0], "planes_dma_f16x1": [0.0, 0.0, 0]}       # flops, us, launches
-            KIND_PIPE = {4: "bf16_split", 5: "f16_weights", 6: "planes_bf16x3", 7: "planes_f16x2", 8: "planes_f16x1", 9: "planes_dma_f16x2", 10: "planes_dma_f16x1"}
+            KIND_PIPE = {4: "bf16_split", 5: "f16_weights", 7: "planes_f16x2", 8: "planes_f16x1", 9: "planes_dma_f16x2", 10: "planes_dma_f16x1"}
             for M_, N_, K_, taps_, mode_, us in tab:
-                # 0 small-M, 1 tiled, 2 pipelined: v_mfma_f32_16x16x4_f32; 4: six bf16 part products split in the K loop; 5: fp16 weights x (hi + lo)
+                # 0 small-M, 1 tiled, 2 pipelined, 6 weight-streaming (gemm_stream.hip): v_mfma_f32_16x16x4_f32; 4: six bf16 part products split in the K loop; 5: fp16 weights x (hi + lo)
                 # fp16 activations; 7 / 8: pre-split operand planes (gemm_planes.hip), register-staged tiles: fp16 x 2 (three products), fp16 x 1 (one);
                 # 9 / 10: the same formats through the persistent LDS-DMA kernel (both operands as planes: the encoder's big GEMMs)
                 kind = (int(mode_) >> 8) - 1

@@ -309,6 +309,11 @@ int sva_test_sampler(int device, int variant, int rows, int V, const float* logi
 /* microbenchmark of the conv-GEMM dispatcher: conv over [B][(taps-1)*dil + T][Cin] -> [B][T][N]; mode bits:
  * 1 GELU, 2 gamma+residual, 4 SiLU-on-load, 8 SwiGLU (w13); returns avg microseconds per launch in out_us[0] */
 int sva_bench_gemm(int device, int B, int T, int N, int Cin, int taps, int dil, int mode, int iters, float* out_us);
+/* One dispatch choice of the same kernel family on device-resident random data with `nrot` rotating weight copies (cold weights); kind -1 = the
+   dispatcher, 0 / 1 / 2 / 4 / 6 = small-M / tiled / pipelined / split-bf16 / weight-streaming kernel with parameters (a, b, c) as in
+   csrc/testhooks.hip.  out[0] = us per launch eager, out[1] = replayed as one graph, out[2] = max |C - C_dispatcher|, out[3] = max |C_dispatcher|. */
+int sva_bench_gemm_choice(int device, int B, int T, int N, int Cin, int taps, int dil, int mode, int kind, int a, int b, int c, int nrot, int iters,
+                          float* out);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,7 @@ constexpr int EDIT_CAP = 4096;           // previous tokens per head / suppresse
 
 struct Lin {
     float* W = nullptr;
+    float* Wk = nullptr;         // the same values in the fragment-major packing of gemm_stream.hip (K % 16 == 0)
     void* Wh = nullptr;          // fp16 copy in the same [N][K] layout (AR layers of an ar_dtype = 1 engine)
     float* b = nullptr;
     int N = 0, K = 0;

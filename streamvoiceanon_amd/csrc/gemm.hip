@@ -691,7 +691,8 @@ static int launch_t(const ConvGemm& g, hipStream_t st) {
 
 // One dispatch decision: kind 0 = small-M K-split kernel (a = rows/16 per workgroup, b = K-split waves, c = 16-column
 // tiles per wave); kind 1 = LDS-tiled kernel (a: 0 = 64x64, 1 = 128x128, 2 = 128x32, 3 = 256x16, 4 = 128x64, 5 = 64x128,
-// 6 = 256x64, 7 = 256x128 on 8 waves; 4..7 are reached through the autotuner only).
+// 6 = 256x64, 7 = 256x128 on 8 waves; 4..7 are reached through the autotuner only); kind 6 = weight-streaming kernel (gemm_stream.hip:
+// a = 16-row tiles, b = K-split waves, c = 16-column tiles per workgroup; reads the fragment-major weight copy when the problem carries one).
 struct Choice { int kind, a, b, c; int z = 1; };      // z: grid-level K split of the small-M kernel
 static thread_local int t_planes_mode = -1;              // set by launch_choice when the planes kernel took a kind-4 choice
 static thread_local int t_last_kind = -1;                // kernel family of this thread's latest dispatch (bench.py: per-pipe roofline)
@@ -757,6 +758,10 @@ static int launch_choice(const ConvGemm& g, hipStream_t st, const Choice& ch) {
         }
         SVA_CHECK(!g.Ap && !g.Cp, "conv_gemm: operand planes need the planes kernel");
         return launch_split_gemm(gg, ch.a, st);
+    }
+    if (ch.kind == 6) {                 // weight-streaming kernel (gemm_stream.hip): a = row tiles, b = K-split waves, c = column tiles per workgroup
+        SVA_CHECK(!t_group && stream_gemm_supported(g), "conv_gemm: the weight-streaming kernel takes single problems");
+        return launch_stream_gemm(g, g.Wk ? g.Wk : g.W, ch.a, ch.c, ch.b, g.Wk ? 2 : 0, 0, st);
     }
     if (ch.kind == 2) {                 // LDS-DMA ring kernel (gemm_pipe.hip), a = tile variant
         ConvGemmGroup gg;
@@ -926,7 +931,9 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
             // the table is keyed by shape only; the pipelined / split kernels also need aligned operands (a seam such as sva_op_conv can
             // present a tuned shape with other strides): keep the tuned choice only if its kernel accepts THIS problem
             const Choice& tc = it->second;
-            const bool ok = (tc.kind == 2) ? (c_vec && pipe_gemm_supported(g)) : (tc.kind == 4) ? (c_vec && split_gemm_supported(g)) : (tc.kind == 1 ? c_vec || tc.a == 0 : true);
+            const bool ok = (tc.kind == 2) ? (c_vec && pipe_gemm_supported(g)) : (tc.kind == 4) ? (c_vec && split_gemm_supported(g)) :
+                            (tc.kind == 6) ? (group_n == 1 && stream_gemm_supported(g) && (g.M + 16 * tc.a - 1) / (16 * tc.a) * (long)((g.N + 16 * tc.c - 1) / (16 * tc.c)) < 65536) :
+                            (tc.kind == 1 ? c_vec || tc.a == 0 : true);
             if (ok) ch = tc;
         }
     }
@@ -1019,6 +1026,16 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
                     if (g.N <= 64) cand.push_back(Choice{1, 2, 0, 0});
                     if (g.N <= 16 && !g.w13) cand.push_back(Choice{1, 3, 0, 0});
                 }
+                if (group_n == 1 && stream_gemm_supported(g) && g.M <= 512 && !g.dw_wT && g.N >= 16) {
+                    // weight-streaming kernel: (row tiles, column tiles, K-split waves) per workgroup
+                    const int mt_total = (g.M + 15) / 16;
+                    const int cfgs[15][3] = {{1, 1, 4}, {1, 1, 8}, {1, 1, 16}, {2, 1, 4}, {2, 1, 8}, {2, 1, 16}, {4, 1, 4}, {4, 1, 8},
+                                             {1, 2, 4}, {1, 2, 8}, {1, 2, 16}, {2, 2, 4}, {2, 2, 8}, {4, 2, 4}, {4, 2, 8}};
+                    for (const auto& cf : cfgs) {
+                        if (cf[0] > mt_total || (g.w13 && cf[1] != 2) || (cf[1] == 2 && g.N % 32 != 0)) continue;
+                        cand.push_back(Choice{6, cf[0], cf[2], cf[1]});
+                    }
+                }
                 if (c_vec && pipe_gemm_supported(g) && g.M >= 32 && g.N >= 32)
                     for (int v = 0; v <= 6; ++v) {
                         if (v == 4 && (g.M < 128 || g.N < 128)) continue;
@@ -1095,6 +1112,13 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
     if (kind == 4) {
         SVA_CHECK(split_gemm_supported(g) && a >= 0 && a <= 4 && g.N % 4 == 0 && g.ldc % 4 == 0, "conv_gemm_choice: the split-bf16 kernel needs Cin % 32 == 0 and 16-byte aligned C rows");
         SVA_TRY_RC(launch_choice(g, st, Choice{4, a, 0, 0}));
+        SVA_HIP(hipGetLastError());
+        return 0;
+    }
+    if (kind == 7) {                    // the weight-streaming kernel (gemm_stream.hip): a = row tiles, b = K-split waves, c = column tiles
+        SVA_CHECK(stream_gemm_supported(g) && (a == 1 || a == 2 || a == 4) && (c == 1 || c == 2) && (b == 4 || b == 8 || (b == 16 && a <= 2)) && !(g.w13 && c != 2),
+                  "conv_gemm_choice: bad weight-streaming configuration");
+        SVA_TRY_RC(launch_choice(g, st, Choice{6, a, b, c}));
         SVA_HIP(hipGetLastError());
         return 0;
     }

@@ -127,6 +127,21 @@ struct Packer {
         l.b = nullptr;
         return 0;
     }
+    // fragment-major copy of an uploaded [N][K] matrix for the weight-streaming GEMM (gemm_stream.hip): tile t of 16 rows, block kb of 16 k,
+    // lane l = (row & 15) + 16 * (k4): four consecutive k -- what lane l feeds to the four MFMA steps of the block; rows beyond N are zeros
+    int frag(Lin& l, const std::vector<float>& w) {
+        if (l.K % 16 != 0 || l.N < 16) return 0;
+        const long nkb = l.K / 16, nt16 = (l.N + 15) / 16;
+        std::vector<float> p((size_t)nt16 * nkb * 256, 0.f);
+        for (long t = 0; t < nt16; ++t)
+            for (long kb = 0; kb < nkb; ++kb)
+                for (int ln = 0; ln < 64; ++ln) {
+                    const long n = t * 16 + (ln & 15);
+                    if (n >= l.N) continue;
+                    memcpy(&p[((t * nkb + kb) * 64 + ln) * 4], &w[(size_t)n * l.K + kb * 16 + 4 * (ln >> 4)], 4 * sizeof(float));
+                }
+        return upload(e->allocs, &l.Wk, p);
+    }
     // nn.Linear [N, K]
     int linear(const std::string& prefix, Lin& l, int N, int K) {
         HostTensor w;
@@ -134,6 +149,7 @@ struct Packer {
         SVA_CHECK(w.numel() == (long)N * K, ("bad shape " + prefix).c_str());
         l.N = N; l.K = K;
         SVA_TRY(upload(e->allocs, &l.W, w.data));
+        SVA_TRY(frag(l, w.data));
         return bias_of(prefix, l);
     }
     // nn.Conv1d weight [Cout, Cin, k] -> [Cout][k][Cin]
@@ -147,6 +163,7 @@ struct Packer {
                 for (int j = 0; j < k; ++j) p[((size_t)o * k + j) * Cin + i] = w.data[((size_t)o * Cin + i) * k + j];
         l.N = Cout; l.K = k * Cin;
         SVA_TRY(upload(e->allocs, &l.W, p));
+        SVA_TRY(frag(l, p));
         return bias_of(prefix, l);
     }
     // nn.ConvTranspose1d weight [Cin, Cout, k], stride s, k == 2s (FishTransConvNet, firefly.py:114-138):
@@ -169,6 +186,7 @@ struct Packer {
                     }
         l.N = s * Cout; l.K = taps * Cin;
         SVA_TRY(upload(e->allocs, &l.W, p));
+        SVA_TRY(frag(l, p));
         const HostTensor* b = find(prefix + ".bias");
         SVA_CHECK(b && b->numel() == Cout, ("missing bias " + prefix).c_str());
         std::vector<float> bb((size_t)s * Cout);
@@ -218,6 +236,7 @@ struct Packer {
             else { float* f = nullptr; SVA_TRY(upload(e->allocs, &f, mp)); *mega_w13 = f; }
         }
         if (e->cfg.ar_dtype == 1 && mega_w13) SVA_TRY(upload_half(&l.Wh, out));      // the batched chain's interleaved layout in fp16
+        SVA_TRY(frag(l, out));
         return upload(e->allocs, &l.W, out);
     }
     // fp16 copy of an already uploaded [N][K] matrix's host values (ar_dtype = 1) or the fp32 device pointer itself

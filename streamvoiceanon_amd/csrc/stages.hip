@@ -19,7 +19,7 @@ int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda,
     ConvGemm g = proto;
     g.A = A; g.a_bstride = a_bstride; g.a_off = a_off; g.lda = lda;
     g.T = T; g.M = nb * T; g.stride = stride; g.dil = dil; g.taps = taps; g.Cin = Cin;
-    g.W = w.W; g.Wh = w.Wh; g.N = w.N; g.bias = w.b;
+    g.W = w.W; g.Wk = w.Wk; g.Wh = w.Wh; g.N = w.N; g.bias = w.b;
     g.Wp = w.Wp; g.wp_pstride = (long)w.N * w.K; g.wp_inv = w.wp_inv; g.pmode = w.pmode; g.ovf = b->d_mm_ovf;
     g.cu_limit = b->enc_cus;        // (the encoder / vocoder streams' CU mask when the batch runs its AR chain on a partition of its own)
     g.C = C; g.c_bstride = c_bstride; g.c_off = c_off; g.ldc = ldc;
@@ -73,7 +73,7 @@ int conv_desc(sva_batch* b, const Act& in, int T_out, int dil, int taps, const L
     SVA_CHECK(w.K == taps * in.C, "conv_desc: weight K mismatch");
     g.A = in.p; g.a_bstride = in.bstride; g.a_off = (long)(in.H - padL) * in.C; g.lda = in.C;
     g.T = T_out; g.M = b->B * T_out; g.stride = 1; g.dil = dil; g.taps = taps; g.Cin = in.C;
-    g.W = w.W; g.N = w.N; g.bias = w.b;
+    g.W = w.W; g.Wk = w.Wk; g.N = w.N; g.bias = w.b;
     g.Wp = w.Wp; g.wp_pstride = (long)w.N * w.K; g.wp_inv = w.wp_inv; g.pmode = w.pmode; g.ovf = b->d_mm_ovf;
     g.C = out.p; g.c_bstride = out.bstride; g.c_off = (long)out.H * out.C; g.ldc = out.C;
     return 0;

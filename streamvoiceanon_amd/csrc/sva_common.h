@@ -101,6 +101,7 @@ struct ConvGemm {
     int M = 0;                  // B * T
     int stride = 1, dil = 1, taps = 1, Cin = 0;
     const float* W = nullptr;   // [N][taps*Cin], K contiguous
+    const float* Wk = nullptr;  // optional fragment-major packing of W ([N / 16][K / 16][64 lanes][4]: gemm_stream.hip reads one contiguous KiB per wave-instruction)
     const void* Wh = nullptr;   // optional fp16 copy of W (ar_dtype = 1 AR layers): decode-sized problems stream it instead (gemm_f16w.hip)
     int N = 0;
     const float* bias = nullptr;    // [N]
@@ -236,8 +237,13 @@ int make_weight_planes(const float* dW, int N, int K, float max_abs, int mode, u
 bool f16w_gemm_supported(const ConvGemm& g);
 bool f16w_gemm_validated_compiler();      // built with the compiler the kernel's workarounds were validated with
 int launch_f16w_gemm(const ConvGemm& g, hipStream_t st);
+// gemm_stream.hip: weight-streaming f32-MFMA kernel for few rows -- every operand fragment of a wave requested up front, whole K per workgroup.
+// mt in {1, 2, 4} x nt in {1, 2} 16-row / 16-column tiles per workgroup, kw in {4, 8, 16} K-split waves; wmode bit 0 = non-temporal weight loads,
+// bit 1 = Wsrc is the fragment-major packing of g.W ([N / 16][K / 16][64][4]); probe != 0: timing diagnostics
+bool stream_gemm_supported(const ConvGemm& g);
+int launch_stream_gemm(const ConvGemm& g, const float* Wsrc, int mt, int nt, int kw, int wmode, int probe, hipStream_t st);
 int launch_conv_gemm(const ConvGemm& g, hipStream_t st);
-int conv_gemm_last_kind();          // kernel family the calling thread's latest launch_conv_gemm[_group] picked: 0 small-M, 1 tiled, 2 pipelined (f32 MFMA), 4 split-bf16, 5 fp16 weights (f16 MFMA), 7 / 8 planes H3 / H1, 9 / 10 their LDS-DMA form
+int conv_gemm_last_kind();          // kernel family the calling thread's latest launch_conv_gemm[_group] picked: 0 small-M, 1 tiled, 2 pipelined, 6 weight-streaming (f32 MFMA), 4 split-bf16, 5 fp16 weights (f16 MFMA), 7 / 8 planes H3 / H1, 9 / 10 their LDS-DMA form
 int launch_conv_gemm_group(const ConvGemm* gs, int n, hipStream_t st);
 // true when launch_conv_gemm would route this (M, N) problem to the K-split small-M kernel, which can normalise its A rows
 bool conv_gemm_can_fuse_rms(int M, int N);

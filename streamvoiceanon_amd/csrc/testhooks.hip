@@ -3,6 +3,7 @@
 #include "kernels.h"
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -213,6 +214,140 @@ extern "C" int sva_bench_gemm(int device, int B, int T, int N, int Cin, int taps
     SVA_HIP(hipEventElapsedTime(&ms, e0, e1));
     out_us[0] = ms * 1e3f / iters;
     (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dR);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
+    return 0;
+}
+
+// One dispatch choice of the conv-GEMM family timed on device-resident random data, `nrot` weight copies rotated launch by launch (large nrot:
+// every launch streams its weights from HBM, as inside a step that touches 0.8 GB of weights; 1: the weights stay in L2 / MALL).
+//   kind -1 = the dispatcher; 0 = small-M kernel (a = rows / 16, b = K-split waves, c = column tiles + 16 * grid-level K split); 1 tiled (a);
+//   2 = pipelined (a); 4 = split-bf16 (a); 6 = weight-streaming kernel (gemm_stream.hip: a = mt + 16 * nt, b = kw, c = wmode + 16 * probe)
+//   mode bits: 1 GELU, 2 residual + gamma, 4 SiLU on load, 8 SwiGLU (w13), 16 fused RMSNorm of the rows
+//   out[0] = microseconds per launch, eager back-to-back; out[1] = the same launches replayed as one hipGraph; out[2] = max |C - C_dispatcher|;
+//   out[3] = max |C_dispatcher|
+extern "C" int sva_bench_gemm_choice(int device, int B, int T, int N, int Cin, int taps, int dil, int mode, int kind, int a, int b, int c, int nrot,
+                                     int iters, float* out) {
+    SVA_HIP(hipSetDevice(device));
+    SVA_CHECK(nrot >= 1 && iters >= 1 && out, "bench_gemm_choice: arguments");
+    const int H = (taps - 1) * dil;
+    const long rows = H + T;
+    const long K = (long)taps * Cin;
+    const int Nout = (mode & 8) ? N / 2 : N;
+    const bool packed = kind == 6 && ((c & 15) & 2);
+    float *dA, *dB, *dC, *dC2, *dR, *dG;
+    std::vector<float*> dW(nrot, nullptr), dWp(nrot, nullptr);
+    SVA_HIP(hipMalloc(&dA, sizeof(float) * (size_t)B * rows * Cin));
+    SVA_HIP(hipMalloc(&dB, sizeof(float) * N));
+    SVA_HIP(hipMalloc(&dG, sizeof(float) * Cin));
+    SVA_HIP(hipMalloc(&dC, sizeof(float) * (size_t)B * T * Nout));
+    SVA_HIP(hipMalloc(&dC2, sizeof(float) * (size_t)B * T * Nout));
+    SVA_HIP(hipMalloc(&dR, sizeof(float) * (size_t)B * T * Nout));
+    std::vector<float> hA((size_t)B * rows * Cin), hW((size_t)N * K), hB(N), hG(Cin), hR((size_t)B * T * Nout);
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+    for (auto& v : hA) v = rnd();
+    for (auto& v : hW) v = rnd() * 0.05f;
+    for (auto& v : hB) v = rnd() * 0.1f;
+    for (auto& v : hG) v = 1.f + 0.1f * rnd();
+    for (auto& v : hR) v = rnd();
+    SVA_HIP(hipMemcpy(dA, hA.data(), sizeof(float) * hA.size(), hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(dB, hB.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(dG, hG.data(), sizeof(float) * Cin, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(dR, hR.data(), sizeof(float) * hR.size(), hipMemcpyHostToDevice));
+    std::vector<float> hWp;
+    if (packed) {           // fragment-major: [N / 16][K / 16][lane = (n & 15) + 16 * (k4)][4]
+        const long nkb = K / 16, nt16 = (N + 15) / 16;
+        hWp.assign((size_t)nt16 * nkb * 256, 0.f);
+        for (long t = 0; t < nt16; ++t)
+            for (long kb = 0; kb < nkb; ++kb)
+                for (int l = 0; l < 64; ++l) {
+                    const long n = t * 16 + (l & 15);
+                    if (n >= N) continue;
+                    for (int e = 0; e < 4; ++e) hWp[((t * nkb + kb) * 64 + l) * 4 + e] = hW[(size_t)n * K + kb * 16 + 4 * (l >> 4) + e];
+                }
+    }
+    for (int r = 0; r < nrot; ++r) {
+        SVA_HIP(hipMalloc(&dW[r], sizeof(float) * hW.size()));
+        SVA_HIP(hipMemcpy(dW[r], hW.data(), sizeof(float) * hW.size(), hipMemcpyHostToDevice));
+        if (packed) {
+            SVA_HIP(hipMalloc(&dWp[r], sizeof(float) * hWp.size()));
+            SVA_HIP(hipMemcpy(dWp[r], hWp.data(), sizeof(float) * hWp.size(), hipMemcpyHostToDevice));
+        }
+    }
+    ConvGemm g;
+    g.A = dA; g.a_bstride = rows * Cin; g.a_off = 0; g.lda = Cin; g.T = T; g.M = B * T; g.Cin = Cin; g.taps = taps; g.dil = dil;
+    g.W = dW[0]; g.N = N; g.bias = (mode & 8) ? nullptr : dB; g.C = dC; g.c_bstride = (long)T * Nout; g.ldc = Nout;
+    if (mode & 1) g.act = ACT_GELU;
+    if (mode & 2) { g.res = dR; g.r_bstride = (long)T * Nout; g.ldr = Nout; g.gamma = dB; }
+    if (mode & 4) g.a_silu = 1;
+    if (mode & 8) g.w13 = 1;
+    if (mode & 16) g.rms_w = dG;
+    hipStream_t st;
+    SVA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    SVA_TRY(conv_gemm_prepare_stream(st));
+    auto run = [&](int r) -> int {
+        ConvGemm q = g;
+        q.W = dW[r];
+        if (kind < 0) return launch_conv_gemm(q, st);
+        if (kind == 6) return launch_stream_gemm(q, packed ? dWp[r] : dW[r], a & 15, a >> 4, b, c & 15, c >> 4, st);
+        if (kind == 0 && (c >> 4) > 1) return launch_conv_gemm_choice_z(q, st, a, b, c & 15, c >> 4);
+        return launch_conv_gemm_choice(q, st, kind, a, b, c & 15);
+    };
+    // reference result: the dispatcher's own choice
+    {
+        ConvGemm q = g;
+        q.C = dC2;
+        SVA_TRY(launch_conv_gemm(q, st));
+    }
+    for (int i = 0; i < 3; ++i) SVA_TRY(run(i % nrot));
+    SVA_HIP(hipStreamSynchronize(st));
+    {
+        std::vector<float> c1((size_t)B * T * Nout), c2(c1.size());
+        SVA_HIP(hipMemcpy(c1.data(), dC, sizeof(float) * c1.size(), hipMemcpyDeviceToHost));
+        SVA_HIP(hipMemcpy(c2.data(), dC2, sizeof(float) * c2.size(), hipMemcpyDeviceToHost));
+        float md = 0.f, mx = 0.f;
+        for (size_t i = 0; i < c1.size(); ++i) { md = std::max(md, std::fabs(c1[i] - c2[i])); mx = std::max(mx, std::fabs(c2[i])); }
+        out[2] = md; out[3] = mx;
+    }
+    hipEvent_t e0, e1;
+    SVA_HIP(hipEventCreate(&e0));
+    SVA_HIP(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        SVA_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) SVA_TRY(run(i % nrot));
+        SVA_HIP(hipEventRecord(e1, st));
+        SVA_HIP(hipStreamSynchronize(st));
+        float ms = 0;
+        SVA_HIP(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+    }
+    out[0] = best * 1e3f / iters;
+    // the same chain as one graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    SVA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (int i = 0; i < iters && !rc; ++i) rc = run(i % nrot);
+    SVA_HIP(hipStreamEndCapture(st, &graph));
+    if (rc) return rc;
+    SVA_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    SVA_HIP(hipGraphLaunch(exec, st));
+    SVA_HIP(hipStreamSynchronize(st));
+    best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        SVA_HIP(hipEventRecord(e0, st));
+        SVA_HIP(hipGraphLaunch(exec, st));
+        SVA_HIP(hipEventRecord(e1, st));
+        SVA_HIP(hipStreamSynchronize(st));
+        float ms = 0;
+        SVA_HIP(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+    }
+    out[1] = best * 1e3f / iters;
+    (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+    for (int r = 0; r < nrot; ++r) { (void)hipFree(dW[r]); if (dWp[r]) (void)hipFree(dWp[r]); }
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dG); (void)hipFree(dC); (void)hipFree(dC2); (void)hipFree(dR);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
     return 0;
 }

@@ -100,6 +100,7 @@ def load_library():
     lib.sva_get_gemm_profile_table.argtypes = [vp, vp, C.c_long]
     lib.sva_get_gemm_profile_table.restype = C.c_long
     lib.sva_bench_gemm.argtypes = [i32] * 9 + [f32p]
+    lib.sva_bench_gemm_choice.argtypes = [i32] * 14 + [f32p]
     lib.sva_test_gemm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp]
     lib.sva_test_gemm_choice.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32]
     lib.sva_set_sampler_edits.argtypes = [vp, vp, i32, C.c_float, vp, i32]
@@ -120,7 +121,7 @@ EXPORTED_SYMBOLS = [
     "sva_dev_alloc", "sva_dev_free", "sva_dev_upload", "sva_dev_download", "sva_op_conv", "sva_op_affine", "sva_op_unary", "sva_op_colstats",
     "sva_op_cam_context", "sva_op_mul", "sva_op_add", "sva_op_conv2d", "sva_op_cf_to_rows", "sva_op_fbank_power", "sva_op_stft_mag", "sva_op_attention",
     "sva_op_geglu", "sva_op_l2norm", "sva_ops_capture_begin", "sva_ops_capture_end", "sva_ops_graph_launch", "sva_ops_graph_free",
-    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_test_gemm_planes", "sva_test_prefill_attention", "sva_set_sampler_edits", "sva_bench_gemm", "sva_test_sampler", "sva_host_launch_cost",
+    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_test_gemm_planes", "sva_test_prefill_attention", "sva_set_sampler_edits", "sva_bench_gemm", "sva_bench_gemm_choice", "sva_test_sampler", "sva_host_launch_cost",
 ]
 
 
@@ -596,6 +597,14 @@ def test_sampler(logits, noise, variant, temperature=0.7, top_p=0.7, iters=0, de
     _check(lib.sva_test_sampler(device, int(variant), rows, V, _ptr(L), _ptr(Q), float(temperature), float(top_p), _ptr(out), int(iters),
                                 us if iters > 0 else None), "sva_test_sampler")
     return (out, float(us[0])) if iters > 0 else out
+
+
+def bench_gemm_choice(B, T, N, Cin, kind, a=0, b=0, c=0, taps=1, dil=1, mode=0, nrot=1, iters=50, device=0):
+    """one dispatch choice (csrc/testhooks.hip: sva_bench_gemm_choice) -> (us eager, us as a graph, max |C - C_dispatcher|, max |C_dispatcher|)"""
+    lib = load_library()
+    out = (C.c_float * 4)()
+    _check(lib.sva_bench_gemm_choice(device, B, T, N, Cin, taps, dil, mode, kind, a, b, c, nrot, iters, out), "sva_bench_gemm_choice")
+    return float(out[0]), float(out[1]), float(out[2]), float(out[3])
 
 
 def bench_gemm(B, T, N, Cin, taps=1, dil=1, mode=0, iters=50, device=0):

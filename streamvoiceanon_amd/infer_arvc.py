@@ -265,9 +265,10 @@ class InferenceWrapper:
         ref = np.concatenate([np.asarray(r.detach().cpu().numpy() if hasattr(r, "detach") else r, dtype=np.float32).reshape(-1)
                               for r in ref_list])            # :411 / :415 torch.cat(ref_wav_list, dim=-1)
         if spk_emb_collate_type == "avg" and len(ref_list) > 1:
-            # reference quirk (vi): the 'avg' branch falls through to an undefined variable (:389-424) -- only 'concat_mel' works upstream
-            raise NotImplementedError("spk_emb_collate_type='avg' with several references raises NameError in the reference "
-                                      "(evaluations/infer_arvc.py:389-424); use 'concat_mel'")
+            # reference quirk (vi): THIS function's 'avg' branch falls through to an undefined variable (:389-424) -- only 'concat_mel' works
+            # for the streaming prompt upstream.  The offline infer() has its own, working 'avg' branch (:284-307): see infer / _avg_embeddings
+            raise NotImplementedError("spk_emb_collate_type='avg' with several references raises NameError in the reference's streaming "
+                                      "calculate_prompt (evaluations/infer_arvc.py:389-424); use 'concat_mel' (offline infer() supports 'avg')")
         if style_vectors is None or timbre_latents is None:
             from . import audio_io
 
@@ -296,6 +297,25 @@ class InferenceWrapper:
             ref_audio_codes = self.wav2target_fn(ref)                       # :431-434
             ref_content_codes = self.encode_content(ref)                    # :436-439
         return ref_audio_codes, ref_content_codes, style_vectors, timbre_latents, ref
+
+    def _avg_embeddings(self, refs, style_vectors=None, timbre_latents=None):
+        """infer's 'avg' collation (:284-303): per reference resample to 16 kHz -> calculate_style_vec / calculate_timbre_latent,
+        then torch.mean over the stack (fp32, reference order)."""
+        import torch
+        from . import audio_io
+
+        sv, tl = [], []
+        for w in refs:
+            w16 = audio_io.resample(np.asarray(w, np.float32).reshape(-1), self.sr, self.RESAMPLE_FREQ)
+            if style_vectors is None:
+                sv.append(torch.as_tensor(np.asarray(self.calculate_style_vec(w16), np.float32)).reshape(1, -1))
+            if timbre_latents is None:
+                tl.append(torch.as_tensor(np.asarray(self.calculate_timbre_latent(w16), np.float32)).reshape(1, 32, -1))
+        if style_vectors is None:
+            style_vectors = torch.mean(torch.stack(sv, dim=0), dim=0).numpy()
+        if timbre_latents is None:
+            timbre_latents = torch.mean(torch.stack(tl, dim=0), dim=0).numpy()
+        return style_vectors, timbre_latents
 
     def apply_noise_mixing(self, tensor, alpha, gauss=None):
         """:228-232 -- alpha*x + (1-alpha)*(randn*std + mean), global mean / unbiased std."""
@@ -399,9 +419,15 @@ class InferenceWrapper:
         src, src_path = self._load_src(src)
         if prompt is None:
             refs = self.load_and_crop_references(*self.process_ref_paths(ref_path, ref_crop_lengths))
-            prompt = self.calculate_prompt(refs, alpha=alpha, spk_emb_collate_type=spk_emb_collate_type,
-                                           style_vectors=sampling_kwargs.pop("style_vectors", None),
-                                           timbre_latents=sampling_kwargs.pop("timbre_latents", None))
+            style_vectors = sampling_kwargs.pop("style_vectors", None)
+            timbre_latents = sampling_kwargs.pop("timbre_latents", None)
+            if spk_emb_collate_type == "avg" and len(refs) > 1 and (style_vectors is None or timbre_latents is None):
+                # :284-307 -- the embeddings of every reference on its own, averaged; the two code streams still come from the
+                # concatenated audio (:305-306, 326-339).  (Only this offline branch works upstream: the streaming calculate_prompt's
+                # 'avg' branch, :389-424, reads an undefined variable, and stays refused there.)
+                style_vectors, timbre_latents = self._avg_embeddings(refs, style_vectors, timbre_latents)
+            prompt = self.calculate_prompt(refs, alpha=alpha, spk_emb_collate_type="concat_mel" if spk_emb_collate_type == "avg" else spk_emb_collate_type,
+                                           style_vectors=style_vectors, timbre_latents=timbre_latents)
         ref_audio_codes, ref_content_codes, style_vectors, timbre_latents = [
             np.asarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x) for x in prompt[:4]]
         src_codes = self.encode_content(src)

@@ -46,27 +46,57 @@ def gather_results(local, world: int, rank: int, dst: int = 0, force: bool = Fal
     return torch.cat(bufs, dim=0)
 
 
-def gather_ragged(items, world: int, rank: int, dst: int = 0, force: bool = False, pad_value=0):
+_DTYPES = ("int16", "int32", "int64", "float32", "float16", "uint8", "int8", "float64", "bfloat16")
+
+
+def gather_ragged(items, world: int, rank: int, dst: int = 0, force: bool = False, pad_value=0, device=None):
     """Gather per-utterance results of UNEQUAL length -- `items`: this rank's list of tensors [..., T_i] (same leading dims and dtype,
     time last; e.g. int16 / int32 codes [8, T_i] of utterances of different durations, which is what LPT sharding by length produces,
-    and ranks may hold different NUMBERS of utterances) -- to `dst`.  Two fixed-shape collectives instead of a gather_object (device
-    tensors stay on the device, RCCL-friendly): all ranks agree on (max count, max T) with one all_reduce(MAX), every rank sends
-    [n_max, ..., T_max] padded with `pad_value` plus its lengths [n_max] (-1 = no utterance); `dst` cuts the padding off again.
-    Returns the list of tensors in rank-major order on `dst` (sharding.unshard maps it back to utterance order), None elsewhere."""
+    and ranks may hold different NUMBERS of utterances, ZERO included: fewer utterances than ranks) -- to `dst`.  Fixed-shape
+    collectives instead of a gather_object (device tensors stay on the device, RCCL-friendly): one all_reduce(MAX) makes every rank
+    agree on (max count, max T, leading dims, dtype) -- a rank without utterances learns the layout from it --, one all_reduce(MIN)
+    of a consistency flag makes a mismatch raise on EVERY rank before any data moves (no rank is left waiting in a collective), then
+    every rank sends [n_max, ..., T_max] padded with `pad_value` plus its lengths [n_max] (-1 = no utterance); `dst` cuts the padding
+    off again.  `device`: where the collectives' tensors live on a rank with no items (default: the current CUDA device under the
+    NCCL / RCCL backend, else CPU).  Returns the list of tensors in rank-major order on `dst` (sharding.unshard maps it back to
+    utterance order), None elsewhere."""
     import torch
     import torch.distributed as dist
 
     if (world == 1 and not force) or not dist.is_initialized():
         return list(items)
-    assert len(items) > 0 or world > 1
-    dev = items[0].device if items else torch.device("cpu")
-    dims = torch.tensor([len(items), max((int(t.shape[-1]) for t in items), default=0)], dtype=torch.int64, device=dev)
-    dist.all_reduce(dims, op=dist.ReduceOp.MAX)
-    n_max, t_max = int(dims[0]), int(dims[1])
-    lead = tuple(items[0].shape[:-1]) if items else None
-    if lead is None:          # a rank without utterances still takes part: learn the leading dims from the root's view (all ranks share them)
-        raise ValueError("gather_ragged: every rank must hold at least one utterance (shard_utterances gives each rank one when n >= world)")
-    dtype = items[0].dtype
+    if items:
+        dev = items[0].device
+    elif device is not None:
+        dev = torch.device(device)
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    # meta = [count, T_max, n_lead, lead dims (<= 4, stored + 1), dtype code + 1]; zeros where this rank does not know
+    meta = [len(items), max((int(t.shape[-1]) for t in items), default=0), 0, 0, 0, 0, 0, 0]
+    own_ok = 1
+    if items:
+        lead = tuple(int(x) for x in items[0].shape[:-1])
+        name = str(items[0].dtype).replace("torch.", "")
+        own_ok = int(len(lead) <= 4 and name in _DTYPES and all(tuple(t.shape[:-1]) == lead and t.dtype == items[0].dtype for t in items))
+        if own_ok:
+            meta[2] = len(lead) + 1
+            for i, x in enumerate(lead):
+                meta[3 + i] = x + 1
+            meta[7] = _DTYPES.index(name) + 1
+    mt = torch.tensor(meta, dtype=torch.int64, device=dev)
+    dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+    agreed = [int(x) for x in mt.tolist()]
+    if items and own_ok and (agreed[2:] != meta[2:]):
+        own_ok = 0                                   # another rank holds other leading dims / another dtype
+    ok = torch.tensor([own_ok], dtype=torch.int64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        raise ValueError("gather_ragged: ranks disagree on the leading dims / dtype of their items (or an item list is inconsistent)")
+    n_max, t_max = agreed[0], agreed[1]
+    if n_max == 0:                                   # nobody holds anything
+        return [] if rank == dst else None
+    lead = tuple(x - 1 for x in agreed[3:3 + agreed[2] - 1])
+    dtype = getattr(torch, _DTYPES[agreed[7] - 1])
     pad = torch.full((n_max,) + lead + (t_max,), pad_value, dtype=dtype, device=dev)
     lens = torch.full((n_max,), -1, dtype=torch.int64, device=dev)
     for i, t in enumerate(items):

@@ -851,7 +851,9 @@ def test_every_gemm_dispatch_choice_vs_fp64():
         tol = 2e-6 * np.sqrt(K) * 4 + 1e-5
         ring = [(3, v, 0, 0) for v in range(7)]            # kind 3: the LDS-DMA ring kernel (gemm_pipe.hip), all tile variants
         split = [(4, v, 0, 0) for v in range(5)]           # kind 4: fp32 as six bf16 part products (gemm_split.hip), all tile variants
-        for ch in skinny + tiled + ring + split:
+        # kind 7: the weight-streaming kernel (gemm_stream.hip) on the row-major weights, (row tiles, K-split waves, column tiles)
+        stream = [(7, mt, kw, nt) for nt in (1, 2) for mt in (1, 2, 4) for kw in (4, 8, 16) if not (mt == 4 and kw == 16) and not (nt == 2 and N % 32)]
+        for ch in skinny + tiled + ring + split + stream:
             if ch[0] in (0, 2) and (((ch[3] & 15) == 2 and N % 32) or ((ch[3] & 15) == 4 and N % 64)):
                 continue
             if ch[0] == 1 and ((ch[1] in (1, 4, 6, 7) and M < 128) or (ch[1] in (1, 5, 7) and N < 128)):
@@ -861,6 +863,32 @@ def test_every_gemm_dispatch_choice_vs_fp64():
             out = E.test_gemm_choice(A, W, ch, bias=bias)
             err = np.abs(out - ref).max()
             assert err <= tol * np.abs(ref).max(), (M, N, K, ch, err)
+
+
+def test_stream_gemm_packed_weights_and_epilogues_vs_dispatcher():
+    """gemm_stream.hip through its product form -- the fragment-major weight copy -- with every prologue / epilogue it serves (fused RMSNorm,
+    SiLU on load, bias, GELU, gamma + residual, SwiGLU, conv taps over shifted rows), ragged rows / columns (N = 1000: a partial column tile),
+    K from 2 blocks per wave to the looping form (K = 5376: more blocks per wave than its registers hold), every workgroup shape: against the
+    dispatcher's tuned choice on the same operands (itself pinned to fp64 above) within fp32 summation-order noise."""
+    from streamvoiceanon_amd import engine as E
+
+    cases = [(64, 1, 4608, 768, 1, 1, 8 | 16), (64, 1, 2304, 768, 1, 1, 16), (64, 1, 768, 2304, 1, 1, 2), (33, 1, 1000, 768, 1, 1, 16),
+             (1, 170, 384, 1536, 1, 1, 2), (1, 170, 1536, 384, 1, 1, 1), (1, 128, 3072, 512, 1, 1, 8), (1, 47, 512, 2048, 1, 1, 2),
+             (1, 32, 256, 256, 11, 1, 4), (2, 40, 128, 128, 7, 3, 4), (1, 4, 512, 512, 13, 1, 0), (3, 5, 96, 48, 1, 1, 0)]
+    worst = 0.0
+    for (B, T, N, Cin, taps, dil, mode) in cases:
+        mt_total = (B * T + 15) // 16
+        for nt in (1, 2):
+            if ((mode & 8) and nt != 2) or (nt == 2 and N % 32):
+                continue
+            for mt in (1, 2, 4):
+                for kw in (4, 8, 16):
+                    if mt > mt_total or (mt == 4 and kw == 16):
+                        continue
+                    _, _, err, mx = E.bench_gemm_choice(B, T, N, Cin, 6, a=mt + 16 * nt, b=kw, c=2, taps=taps, dil=dil, mode=mode, nrot=2, iters=2)
+                    worst = max(worst, err / mx)
+                    assert err <= 4e-6 * mx + 1e-6, (B, T, N, Cin, taps, dil, mode, mt, nt, kw, err, mx)
+    print("stream GEMM vs dispatcher: worst relative difference %.2e" % worst)
 
 
 def test_config5_anonymisation_prompt_and_chunk4(weights0):

@@ -167,6 +167,44 @@ def test_offline_generate_matches_reference(weights0):
     np.testing.assert_allclose(wav[0, 0, -2048:].numpy(), g["pcm_last"], atol=1e-5)
 
 
+def test_offline_avg_collate_matches_reference(weights0):
+    """The reference's offline infer(spk_emb_collate_type="avg") with two references (evaluations/infer_arvc.py:284-307; captured by
+    tools/make_golden.py offline_avg): per-reference style / timbre embeddings averaged, code streams from the concatenated audio.  The
+    oracle's restatements replay every stage: embeddings (prompt_oracle), both prompt code streams, the source codes, generate, PCM."""
+    from oracle import prompt_oracle as PO
+    from streamvoiceanon_amd import audio_io, specs
+
+    g = load_golden("offline_avg_s0")
+    useed = int(g["audio_seed"])
+    W = {k: torch.from_numpy(sw.generate(int(g["weight_seed"]), k, shp)) for k, shp in specs.prompt_encoder_specs().items()}
+    refs = [synth_utterance(int(s), int(n)) for s, n in zip(g["ref_seeds"], g["ref_samples"])]
+    sv, tl = [], []
+    for r in refs:
+        r16 = torch.from_numpy(audio_io.resample(r, 44100, 16000))[None]
+        sv.append(PO.style_vector(r16, W))
+        tl.append(PO.timbre_latents(r16, W))
+    style = torch.mean(torch.stack(sv, dim=0), dim=0)
+    timbre = torch.mean(torch.stack(tl, dim=0), dim=0)
+    np.testing.assert_allclose(style.numpy(), g["style"], atol=1e-5)
+    np.testing.assert_allclose(timbre.numpy(), g["timbre"], atol=1e-5)
+    ref = torch.from_numpy(np.concatenate(refs))[None]
+    ac = O.firefly_encode(ref, weights0)
+    np.testing.assert_array_equal(ac.numpy(), g["ref_audio_codes"])
+    R = ref.shape[1] // 2048                           # (the second reference is not a whole number of frames: causal, the tail is dropped)
+    cc = O.encode_window(ref[:, :R * 2048], weights0)[0, 0]
+    np.testing.assert_array_equal(cc.numpy(), g["ref_content_codes"].reshape(-1))
+    src = torch.from_numpy(synth_utterance(useed, int(g["src_samples"])))[None]
+    sc = O.encode_window(src, weights0)[0, 0]
+    np.testing.assert_array_equal(sc.numpy(), g["src_content_codes"].reshape(-1))
+    ar = O.DualAR(weights0)
+    codes = ar.generate(torch.from_numpy(g["ref_content_codes"].reshape(-1)), torch.from_numpy(g["ref_audio_codes"][0]).long(), sc,
+                        torch.from_numpy(g["style"][0]), torch.from_numpy(g["timbre"][0]), int(g["delay"]),
+                        noise_fn=lambda s: tuple(torch.from_numpy(a) for a in frame_noise(useed, s)))
+    np.testing.assert_array_equal(codes.numpy(), g["codes"])
+    wav = O.vocode_window(codes.long(), weights0)
+    np.testing.assert_allclose(wav[0, 0, -2048:].numpy(), g["pcm_last"], atol=1e-5)
+
+
 def test_prompt_codes_match_reference(weights0):
     """calculate_prompt of the reference (firefly.encode + speech_tokenizer.encode of the prompt wav), SURVEY.md §8f N1."""
     g = load_golden("prompt_s0")

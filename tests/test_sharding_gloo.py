@@ -100,6 +100,86 @@ def test_two_rank_ragged_gather_equals_single_process():
         np.testing.assert_array_equal(got[u], _ragged_work(u, n).numpy())
 
 
+def _ragged_empty_main(rank, world, port, lengths, bad_rank, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from streamvoiceanon_amd.sharding import gather_ragged, shard_utterances, unshard
+
+    shards = shard_utterances(list(range(len(lengths))), world, lengths=lengths)
+    mine = [_ragged_work(u, lengths[u]) for u in shards[rank]]
+    if rank == bad_rank:
+        mine = [t.to(torch.int64) for t in mine]           # one rank with another dtype: EVERY rank must raise, nobody may hang
+    try:
+        got = gather_ragged(mine, world, rank)
+        raised = False
+    except ValueError:
+        got, raised = None, True
+    flag = torch.tensor([int(raised)])
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        perm = unshard(shards)
+        q.put(([got[i].numpy() for i in perm] if got is not None else None, [len(s_) for s_ in shards], int(flag.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world(target, world, args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_ragged_gather_with_empty_ranks_and_consistent_errors():
+    """fewer utterances than ranks (world 4, 2 utterances: two ranks hold NOTHING and still take part in the collectives, learning
+    the layout from the all_reduce), and a dtype mismatch on one rank raises ValueError on every rank instead of leaving the others blocked."""
+    lengths = [37, 12]
+    got, counts, n_raised = _run_world(_ragged_empty_main, 4, (lengths, -1))
+    assert sorted(counts) == [0, 0, 1, 1] and n_raised == 0
+    for u, n in enumerate(lengths):
+        np.testing.assert_array_equal(got[u], _ragged_work(u, n).numpy())
+    got, counts, n_raised = _run_world(_ragged_empty_main, 4, ([20, 30, 40, 50, 60], 2))
+    assert got is None and n_raised == 4
+
+
+def _bench_rank_logic_main(rank, world, port, n_utts, frames, q):
+    """bench.py's rank logic for configs[3] / [4] on gloo: shard the utterance ids, produce each utterance's [8, T] codes, gather, unshard"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from streamvoiceanon_amd.sharding import gather_ragged, gather_results, shard_utterances, unshard
+
+    shards = shard_utterances(list(range(n_utts)), world)
+    local = torch.stack([_ragged_work(u, frames) for u in shards[rank]])
+    out = gather_results(local, world, rank)
+    rag = gather_ragged([_ragged_work(u, frames) for u in shards[rank]], world, rank)
+    if rank == 0:
+        perm = unshard(shards)
+        assert out.shape[0] == n_utts == world * local.shape[0]                 # gathered_utterances == N x B
+        ok = all(torch.equal(out[perm[u]], _ragged_work(u, frames)) and torch.equal(rag[perm[u]], _ragged_work(u, frames)) for u in range(n_utts))
+        q.put((ok, [len(s_) for s_ in shards]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_bench_rank_logic_512_and_256_utterances():
+    """BASELINE configs[3] / [4] at their full utterance counts on 8 ranks (gloo): shard_utterances -> per-rank results -> gather ->
+    unshard returns every utterance's own result in utterance order, 64 / 32 utterances per rank."""
+    for n_utts, per in ((512, 64), (256, 32)):
+        ok, counts = _run_world(_bench_rank_logic_main, 8, (n_utts, 5))
+        assert ok and counts == [per] * 8
+
+
 def test_shard_utterances_lpt():
     sys.path.insert(0, ROOT)
     from streamvoiceanon_amd.sharding import shard_utterances

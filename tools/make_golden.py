@@ -14,6 +14,7 @@ Fixture contents (SURVEY.md §8c "Golden vectors to capture"):
   stream_long_reprefill.npz  672-chunk stream at the reference's default max_seq_frames = 768 (first re-prefill at chunk ~ 646)
   stream_chunk4.npz    chunk = 4 stream (config-5 shape), delay 2
   offline_s0.npz       offline ARVCWrapper.generate codes for a short source
+  offline_avg_s0.npz   the reference's offline infer() with spk_emb_collate_type="avg" and two references
   melfb.npz            mel filterbank checksums
   sampler_edits.npz    logits_to_probs with previous_tokens / repetition_penalty / suppress_tokens: probabilities per case
 """
@@ -263,6 +264,84 @@ def offline_fixture(w, feed, wseed, useed, pseed, src_frames=12, prompt_frames=4
     print("offline fixture", codes.shape)
 
 
+def offline_avg_fixture(w, feed, wseed=0, useed=1010, ref_seeds=(7910, 7911), src_frames=12, ref_frames=(22, 17), delay=2):
+    """The reference's offline infer() with spk_emb_collate_type="avg" and TWO references (evaluations/infer_arvc.py:261-380, the
+    branch :284-307): its own control flow end to end -- per-reference calculate_style_vec / calculate_timbre_latent through the
+    reference's CAM++ and SpeakerEncoder modules (synthetic weights, as in prompt_encoder_fixture), torch.mean over the stack, both code
+    streams from the concatenated audio, generate, code2wav.  Third-party calls it makes are served by the harness: librosa.load
+    returns the synthetic utterance named by the "path", torchaudio.functional.resample is streamvoiceanon_amd.audio_io.resample (a
+    stated deviation from soxr / torchaudio's kernel: the fixture pins the reference's FLOW, the resampler is the build's own),
+    kaldi.fbank / MelSpectrogram are oracle/prompt_oracle.py's restatements."""
+    import evaluations.infer_arvc as ria
+    import modules.dual_ar_stream as das
+    from modules.bicodec_speaker_encoder.speaker_encoder import SpeakerEncoder
+    from modules.campplus.DTDNN import CAMPPlus
+    from oracle import prompt_oracle as PO
+    from streamvoiceanon_amd import audio_io, specs
+
+    class Mel(torch.nn.Module):
+        hop_length = 320
+
+        def forward(self, wav):
+            return torch.stack([PO.mel_spectrogram_16k(x) for x in wav])
+
+    W = {k: torch.from_numpy(sw.generate(wseed, k, shp)) for k, shp in specs.prompt_encoder_specs().items()}
+    cam = CAMPPlus(feat_dim=80, embedding_size=192).eval()
+    cam.load_state_dict({k[6:]: v for k, v in W.items() if k.startswith("style.")}, strict=False)
+    spk = SpeakerEncoder(mel_fn=Mel(), input_dim=128, out_dim=1024, latent_dim=128, token_num=32, fsq_levels=[4] * 6, fsq_num_quantizers=1).eval()
+    missing, unexpected = spk.load_state_dict({k[7:]: v for k, v in W.items() if k.startswith("timbre.")}, strict=False)
+    assert not unexpected
+    audio = {"src": synth_utterance(useed, src_frames * 2048)}
+    for i, (rs, rf) in enumerate(zip(ref_seeds, ref_frames)):
+        audio[f"ref{i}"] = synth_utterance(rs, rf * 2048 + 777 * i)            # (the second one not a whole number of frames)
+    saved = dict(load=getattr(sys.modules["librosa"], "load", None), resample=sys.modules["torchaudio"].functional.resample,
+                 fbank=getattr(ria.kaldi, "fbank", None), dec=das.decode_one_token_ar, gen=w.model.generate)
+    inst = {k: w.__dict__.pop(k) for k in ("calculate_style_vec", "calculate_timbre_latent") if k in w.__dict__}      # the class's own methods run
+    sys.modules["librosa"].load = ria.librosa.load = lambda path, sr=None: (audio[str(path)].copy(), sr)
+    sys.modules["torchaudio"].functional.resample = lambda x, orig_freq=None, new_freq=None: torch.from_numpy(
+        np.stack([audio_io.resample(r, orig_freq, new_freq) for r in x.numpy()]))
+    ria.kaldi.fbank = lambda wav, num_mel_bins=80, dither=0, sample_frequency=16000: PO.kaldi_fbank(wav)
+    w.style_encoder, w.timbre_encoder = cam, spk
+    cap, step = {}, dict(i=0)
+
+    def patched(*a, **k):
+        ns, nf = frame_noise(useed, step["i"])
+        step["i"] += 1
+        feed.q = [ns] + [nf[j] for j in range(8)]
+        feed.live = True
+        r = saved["dec"](*a, **k)
+        feed.live = False
+        return r
+
+    def gen(**k):
+        cap.update({n: k[n].clone() for n in ("style_vectors", "timbre_latents", "ref_content_codes", "ref_audio_codes", "src_content_codes")})
+        cap["codes"] = saved["gen"](**k)
+        return cap["codes"]
+
+    das.decode_one_token_ar = patched
+    w.model.generate = gen
+    try:
+        wav = w.infer("src", ["ref0", "ref1"], delay=delay, alpha=1.0, spk_emb_collate_type="avg", save_result=False)
+    finally:
+        das.decode_one_token_ar = saved["dec"]
+        w.model.generate = saved["gen"]
+        sys.modules["torchaudio"].functional.resample = saved["resample"]
+        ria.kaldi.fbank = saved["fbank"]
+        if saved["load"] is None:
+            del sys.modules["librosa"].load
+        else:
+            sys.modules["librosa"].load = saved["load"]
+        w.__dict__.update(inst)
+        del w.style_encoder, w.timbre_encoder
+    np.savez_compressed(os.path.join(OUT, f"offline_avg_s{wseed}.npz"), weight_seed=wseed, audio_seed=useed, ref_seeds=np.array(ref_seeds),
+                        src_samples=audio["src"].shape[0], ref_samples=np.array([audio["ref0"].shape[0], audio["ref1"].shape[0]]), delay=delay,
+                        style=cap["style_vectors"].numpy(), timbre=cap["timbre_latents"].numpy(),
+                        ref_content_codes=cap["ref_content_codes"].numpy(), ref_audio_codes=cap["ref_audio_codes"].numpy().astype(np.int32),
+                        src_content_codes=cap["src_content_codes"].numpy(), codes=cap["codes"].numpy(),
+                        pcm_sum=float(np.asarray(wav, np.float64).sum()), pcm_last=np.asarray(wav, np.float32).reshape(-1)[-2048:])
+    print("offline avg fixture", tuple(cap["codes"].shape), "style", tuple(cap["style_vectors"].shape), "timbre", tuple(cap["timbre_latents"].shape))
+
+
 def prompt_fixture(w, wseed, useed, frames=48):
     """calculate_prompt (evaluations/infer_arvc.py:382-441) with the CAM++ / SparkTTS encoders stubbed by the harness:
     pins firefly.encode (wav2target_fn, :168-171) and speech_tokenizer.encode of the PROMPT."""
@@ -365,6 +444,9 @@ def main():
     if only == "stream_long":
         long_reprefill_fixture(rh.build_wrapper(seed=0), feed)
         return
+    if only == "offline_avg":
+        offline_avg_fixture(rh.build_wrapper(seed=0), feed)
+        return
     if only in (None, "prompt_encoders"):
         prompt_encoder_fixture(0)
         if only:
@@ -387,6 +469,7 @@ def main():
             offline_fixture(w, feed, 0, useed=1003, pseed=2003)
             encoder_long_fixture(w)
             prompt_fixture(w, 0, useed=1004)
+            offline_avg_fixture(w, feed)
             long_reprefill_fixture(w, feed)
 
 
