@@ -941,7 +941,7 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
     // generated offline from a logged tuning run) or the heuristic -- never from wall-clock measurements of this process, so two
     // processes, ranks or runs sum in the same order.  SVA_DEBUG=autotune=1 re-enables the timed search (tools/make_tune_table.py uses it).
     static const bool tune = debug_options().autotune != 0;
-    if (tune) {
+    if (tune && !g.Ap && !g.Cp) {          // (a problem whose operands are planes has one kernel family: its variant comes from planes_table.inc)
         // Shape-keyed autotune: the first eager launch of a problem shape times the candidate kernels / configurations on
         // the real operands with the output redirected to scratch, and keeps a candidate only if it beats the heuristic
         // by > 7 %.  Launches inside a stream capture (and shapes first seen there) use the heuristic.
@@ -1116,7 +1116,7 @@ int launch_conv_gemm_choice(const ConvGemm& g, hipStream_t st, int kind, int a, 
         return 0;
     }
     if (kind == 7) {                    // the weight-streaming kernel (gemm_stream.hip): a = row tiles, b = K-split waves, c = column tiles
-        SVA_CHECK(stream_gemm_supported(g) && (a == 1 || a == 2 || a == 4) && (c == 1 || c == 2) && (b == 4 || b == 8 || (b == 16 && a <= 2)) && !(g.w13 && c != 2),
+        SVA_CHECK(stream_gemm_supported(g) && (a == 1 || a == 2 || a == 4) && (c == 1 || c == 2) && (b == 4 || b == 8 || (b == 16 && a * c <= 2)) && !(g.w13 && c != 2),
                   "conv_gemm_choice: bad weight-streaming configuration");
         SVA_TRY_RC(launch_choice(g, st, Choice{6, a, b, c}));
         SVA_HIP(hipGetLastError());

@@ -601,6 +601,43 @@ def test_offline_generate_vs_reference_golden(eng, weights0):
     b.close()
 
 
+def test_offline_infer_avg_collate_vs_reference_golden(weights0, record_property):
+    """InferenceWrapper.infer(spk_emb_collate_type="avg") with two references, end to end on the device, against
+    the reference's own offline infer() (evaluations/infer_arvc.py:261-380, branch :284-307; tests/golden/offline_avg_s0.npz): the
+    averaged style / timbre embeddings (each reference through the device CAM++ / SparkTTS encoders on its own), then -- codes being
+    internal to infer() -- the converted waveform, which matches only if both prompt code streams, the source codes and every sampled
+    audio code match (device RNG keyed by the utterance seed = the fixture's noise)."""
+    from streamvoiceanon_amd import specs, synth_weights as sw
+    from streamvoiceanon_amd.infer_arvc import InferenceWrapper
+    from streamvoiceanon_amd.synth_audio import synth_utterance
+
+    g = load_golden("offline_avg_s0")
+    useed = int(g["audio_seed"])
+    W = dict(weights0)
+    W.update({k: torch.from_numpy(v) for k, v in sw.generate_all(int(g["weight_seed"]), specs.prompt_encoder_specs()).items()})
+    refs = [synth_utterance(int(s_), int(n)) for s_, n in zip(g["ref_seeds"], g["ref_samples"])]
+    src = synth_utterance(useed, int(g["src_samples"]))
+    w = InferenceWrapper(weights=W)
+    try:
+        style, timbre = w._avg_embeddings(refs)
+        assert np.abs(np.asarray(style) - g["style"]).max() <= 2e-4 * max(1.0, np.abs(g["style"]).max())
+        bad_rows = int((np.abs(np.asarray(timbre)[0] - g["timbre"][0]).max(axis=1) > 1e-4).sum())
+        rec = dict(test="offline_avg_timbre", latent_rows=32, rows_off_by_a_flipped_level=bad_rows)
+        record_property("fsq_flips", rec)
+        print("FSQ boundary flips (avg timbre):", rec)
+        assert bad_rows <= 1
+        with pytest.raises(NotImplementedError):          # the STREAMING calculate_prompt's 'avg' branch is broken upstream (:389-424) and stays refused
+            w.calculate_prompt(refs, spk_emb_collate_type="avg")
+        kw = {} if bad_rows == 0 else dict(timbre_latents=g["timbre"])        # a flipped FSQ level is an encoder-boundary effect: the flow is then checked on the fixture's latents
+        wav = w.infer(src, refs, delay=int(g["delay"]), alpha=1.0, spk_emb_collate_type="avg", save_result=False, noise_seed=useed, **kw)
+    finally:
+        w.close()
+    wav = np.asarray(wav, np.float32).reshape(-1)
+    assert wav.shape[0] == g["codes"].shape[-1] * 2048
+    np.testing.assert_allclose(wav[-2048:], g["pcm_last"], atol=PCM_TOL)
+    assert abs(float(wav.astype(np.float64).sum()) - float(g["pcm_sum"])) < 5e-2
+
+
 def test_offline_generate_sampling_kwargs_frame0_defaults(eng, weights0):
     """generate(**sampling_kwargs): the prefill's decode ignores them (dual_ar_stream.py:722 -> temperature = top_p = 0.7),
     every later frame uses them (:742-748); unsupported sampler arguments are refused, not dropped."""
@@ -852,7 +889,7 @@ def test_every_gemm_dispatch_choice_vs_fp64():
         ring = [(3, v, 0, 0) for v in range(7)]            # kind 3: the LDS-DMA ring kernel (gemm_pipe.hip), all tile variants
         split = [(4, v, 0, 0) for v in range(5)]           # kind 4: fp32 as six bf16 part products (gemm_split.hip), all tile variants
         # kind 7: the weight-streaming kernel (gemm_stream.hip) on the row-major weights, (row tiles, K-split waves, column tiles)
-        stream = [(7, mt, kw, nt) for nt in (1, 2) for mt in (1, 2, 4) for kw in (4, 8, 16) if not (mt == 4 and kw == 16) and not (nt == 2 and N % 32)]
+        stream = [(7, mt, kw, nt) for nt in (1, 2) for mt in (1, 2, 4) for kw in (4, 8, 16) if not (mt * nt > 2 and kw == 16) and not (nt == 2 and N % 32)]
         for ch in skinny + tiled + ring + split + stream:
             if ch[0] in (0, 2) and (((ch[3] & 15) == 2 and N % 32) or ((ch[3] & 15) == 4 and N % 64)):
                 continue
@@ -883,7 +920,7 @@ def test_stream_gemm_packed_weights_and_epilogues_vs_dispatcher():
                 continue
             for mt in (1, 2, 4):
                 for kw in (4, 8, 16):
-                    if mt > mt_total or (mt == 4 and kw == 16):
+                    if mt > mt_total or (mt * nt > 2 and kw == 16):
                         continue
                     _, _, err, mx = E.bench_gemm_choice(B, T, N, Cin, 6, a=mt + 16 * nt, b=kw, c=2, taps=taps, dil=dil, mode=mode, nrot=2, iters=2)
                     worst = max(worst, err / mx)
@@ -2051,6 +2088,60 @@ def test_mm_modes_batch64_vs_reference_golden(weights0, mm_mode):
     sums = np.array([float(o.astype(np.float64).sum()) for o in outs])
     np.testing.assert_allclose(sums, g["pcm_sum"][:len(outs)], atol=5e-2)
     assert checked >= 1
+
+
+def test_batch64_two_distinct_reference_utterances(weights0):
+    """at 64 streams the slots carry DIFFERENT utterances whose expected codes were captured from the reference --
+    even slots the `stream_s0` utterance, odd slots the `stream_reprefill` utterance (its first 12 chunks: before either stream's first
+    re-prefill the reference's outputs do not depend on max_seq_frames) -- each with its own prompt, noise and audio.  Every slot must
+    reproduce ITS fixture's content codes and audio codes through the batch-scale kernels (planes_dma_kernel incl. its conv form,
+    voc_conv_kernel, the batched decode chain): a stream-indexing fault that is symmetric in the slot cannot pass, and PCM is checked
+    where the fixtures hold it."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import frame_noise, synth_prompt, synth_utterance
+
+    gs = [load_golden("stream_s0"), load_golden("stream_reprefill")]
+    B, n_chunks, delay = 64, 12, 2
+    for g in gs:
+        assert int(g["chunk"]) == 1 and int(g["delay"]) == delay and (33 + 2 * int(g["prompt_frames"]) + 2 * (n_chunks - delay)) // 2 < int(g["max_seq_frames"])
+    e = E.Engine(weights0)
+    try:
+        b = E.Batch(e, n_streams=B, chunk_frames=1, delay=delay, max_seq_frames=768, buffer_frames=32)
+        seeds = [int(g["audio_seed"]) for g in gs]
+        for s_ in range(B):
+            g = gs[s_ & 1]
+            ac, cc, style, timbre = synth_prompt(int(g["prompt_seed"]), int(g["prompt_frames"]))
+            b.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=seeds[s_ & 1])
+        b.begin()
+        srcs = [synth_utterance(seeds[k], 2048 * int(gs[k]["n_chunks"])) for k in range(2)]
+        content, audio, outs, frame = [], [], [], 0
+        for i in range(n_chunks):
+            nz = []
+            for k in range(2):
+                ns, nf = frame_noise(seeds[k], frame)
+                nz.append(np.concatenate([ns, nf.reshape(-1)]))
+            noise = np.stack([nz[s_ & 1] for s_ in range(B)])[:, None]
+            x = np.stack([srcs[s_ & 1][i * 2048:(i + 1) * 2048] for s_ in range(B)])
+            outs.append(b.step(x, noise=noise))
+            content.append(b.tap("content_codes", (B, 1), np.int32)[:, 0].copy())
+            if i >= delay:
+                audio.append(b.tap("audio_codes", (B, 8, 1), np.int32)[:, :, 0].copy())
+                frame += 1
+        b.close()
+    finally:
+        e.close()
+    content = np.stack(content, axis=1)             # [B, n_chunks]
+    audio = np.stack(audio, axis=2)                 # [B, 8, n_chunks - delay]
+    for s_ in range(B):
+        g = gs[s_ & 1]
+        np.testing.assert_array_equal(content[s_], g["content_codes"][:n_chunks], err_msg=f"slot {s_}")
+        np.testing.assert_array_equal(audio[s_], g["audio_codes"][:, :n_chunks - delay], err_msg=f"slot {s_}")
+        sums = np.array([float(o[s_].astype(np.float64).sum()) for o in outs])
+        np.testing.assert_allclose(sums, g["pcm_sum"][:n_chunks], atol=5e-2)
+        for k, idx in enumerate(g["pcm_full_idx"]):
+            if int(idx) < n_chunks:
+                np.testing.assert_allclose(outs[int(idx)][s_], g["pcm_full"][k], atol=PCM_TOL)
+    assert not np.array_equal(audio[0], audio[1])       # the two utterances really differ
 
 
 # fp16-operand vocoder against the fp32 reference fixture.  SURVEY 8c guessed 1e-3 for "the fp16 path"; the reference's OWN formulation
