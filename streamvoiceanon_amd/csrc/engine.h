@@ -144,6 +144,7 @@ struct sva_engine {
     hipStream_t ops_stream = nullptr;      // stream of the prompt-path primitives (prompt_ops.hip: created on first use), capturable
     hipEvent_t mega_ev = nullptr;          // created by sva_engine_finalize, destroyed with the engine
     bool mega_ev_valid = false;
+    int persistent_batches = 0;            // live batches that decode with a persistent kernel (under mega_mu): a lone one skips the chain's event record per frame
     const void* mega_last = nullptr;       // (cleared when that batch is destroyed)
     std::mutex mega_mu;                    // batches of one engine may be driven by different host threads
     bool finalized = false;
@@ -232,6 +233,7 @@ struct sva_batch {
     // batched persistent decode kernel (ar_batch.hip): every stream of the batch in ONE launch per frame
     int enc_cus = 0;                       // CUs of the encoder / vocoder streams' mask when the batch is CU-partitioned (0: the whole device)
     bool use_abatch = false;
+    bool counted_persistent = false;       // this batch is counted in sva_engine::persistent_batches
     int abatch_G = 0;                      // workgroups of its launch (all co-resident: checked at batch creation)
     unsigned long long* d_ab_gran = nullptr;      // hand-off granules, arrays at ab_offs (ar_batch_granule_words)
     size_t ab_offs[11] = {};

@@ -50,6 +50,7 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "voc_dma_variant") o.voc_dma_variant = atoi(v.c_str());
             else if (k == "planes_lw") o.planes_lw = atoi(v.c_str());
             else if (k == "planes_min_streams") o.planes_min_streams = atoi(v.c_str());
+            else if (k == "ar_graph") o.ar_graph = atoi(v.c_str());
             else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());
@@ -611,6 +612,11 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
     SVA_HIP(hipHostMalloc((void**)&b->hp_out, sizeof(float) * (size_t)B * 2048 * chunk));
     for (int i = 0; i < 5; ++i) SVA_HIP(hipEventCreate(&b->ev[i]));
     b->ev_ok = true;
+    if (b->use_mega || b->use_abatch) {        // counted BEFORE the synchronisation below: launches another batch enqueued without a chain record are complete behind it
+        std::lock_guard<std::mutex> lk(e->mega_mu);
+        e->persistent_batches += 1;
+        b->counted_persistent = true;
+    }
     SVA_HIP(hipDeviceSynchronize());
     return 0;
 }
@@ -622,6 +628,7 @@ extern "C" void sva_batch_destroy(sva_batch* b) {
     {   // (a later batch may be allocated at this address: the chain's "same batch, no wait" test must not match it)
         std::lock_guard<std::mutex> lk(b->e->mega_mu);
         if (b->e->mega_last == b) b->e->mega_last = nullptr;
+        if (b->counted_persistent) { b->e->persistent_batches -= 1; b->counted_persistent = false; }
     }
     if (b->main_stream) (void)hipStreamSynchronize(b->main_stream);
     for (int i = 0; i < 2; ++i) if (b->aux[i]) (void)hipStreamSynchronize(b->aux[i]);
@@ -1054,6 +1061,9 @@ int steady_pipelined(sva_batch* b) {
     const sva_config& c = b->e->cfg;
     const int B = b->B, chunk = b->p.chunk_frames, n = 2048 * chunk, ncb = c.num_codebooks;
     hipStream_t se = b->main_stream, sa = b->sa, sv = b->sv;
+    // the stage-boundary events of sva_get_timings mean nothing under overlap and every event record is a barrier packet on its queue (~8 us of
+    // the AR chain's period each: profiles/r06_ar_chain_events.txt) -- only the pipe trace keeps them
+    const bool stage_ev = b->trace_n > 0;
     if (!b->pipe_dirty) {            // entering the pipelined regime: the side streams must see all serial work so far
         hipEvent_t ev = next_event(b);
         SVA_HIP(hipEventRecord(ev, se));
@@ -1088,7 +1098,7 @@ int steady_pipelined(sva_batch* b) {
         hipStream_t sx = b->aux[0];
         if (b->pipe_evD2C && !b->enc_merged) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evD2C, 0));
         b->stream = se;
-        SVA_HIP(hipEventRecord(b->ev[0], se));
+        if (stage_ev) SVA_HIP(hipEventRecord(b->ev[0], se));
         SVA_TRY(mark(0, se));
         if (b->enc_merged) {
             // ONE front-end chain on the main stream (the new frames ride in the head-pass launches); the side stream only carries
@@ -1156,7 +1166,7 @@ int steady_pipelined(sva_batch* b) {
             });
             b->stream = se;
             if (trc) return trc;
-            SVA_HIP(hipEventRecord(b->ev[1], sx));
+            if (stage_ev) SVA_HIP(hipEventRecord(b->ev[1], sx));
             SVA_TRY(mark(4, sx));
         } else {
         SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
@@ -1195,7 +1205,7 @@ int steady_pipelined(sva_batch* b) {
         if (trc) return trc;
         hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, sx, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
                            b->d_ncontent, b->d_step_content, B, (int*)nullptr);
-        SVA_HIP(hipEventRecord(b->ev[1], sx));
+        if (stage_ev) SVA_HIP(hipEventRecord(b->ev[1], sx));
         SVA_TRY(mark(4, sx));
         }
         evE = next_event(b);
@@ -1205,12 +1215,12 @@ int steady_pipelined(sva_batch* b) {
         if (b->pipe_evA[par]) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evA[par], 0));
         if (b->pipe_evR) { SVA_HIP(hipStreamWaitEvent(se, b->pipe_evR, 0)); b->pipe_evR = nullptr; }
         b->stream = se;
-        SVA_HIP(hipEventRecord(b->ev[0], se));
+        if (stage_ev) SVA_HIP(hipEventRecord(b->ev[0], se));
         SVA_TRY(launch_ring_write(b->ring, b->d_step, B, b->N, b->step_src ? b->step_src : b->d_chunk, n, se));
         SVA_TRY(b->enc_incremental ? encode_incremental(b, b->d_step, n, 1) : encode(b, b->d_step, n, 1));
         hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, se, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
                            b->d_ncontent, b->d_step_content, B, b->d_step);
-        SVA_HIP(hipEventRecord(b->ev[1], se));
+        if (stage_ev) SVA_HIP(hipEventRecord(b->ev[1], se));
         evE = next_event(b);
         SVA_HIP(hipEventRecord(evE, se));
     }
@@ -1221,7 +1231,7 @@ int steady_pipelined(sva_batch* b) {
     SVA_TRY(mark(5, sa));
     int rc = 0;
     if (debug_options().pipe_skip & 4) {
-    } else if (b->pipe_graph_mode) {
+    } else if (b->pipe_graph_mode && (debug_options().ar_graph >= 0 ? debug_options().ar_graph != 0 : true)) {
         // The AR stage is ~210 launches on ONE stream whose arguments never change (positions, frame counters, noise keys
         // and teacher-forcing flags live in device memory; the code buffer alternates, hence one graph per parity): replaying
         // it as a hipGraph takes those launches off the enqueueing thread, whose launch rate is otherwise as tight a bound
@@ -1252,7 +1262,7 @@ int steady_pipelined(sva_batch* b) {
         for (int ci = 0; ci < chunk && !rc; ++ci) rc = ar_decode_frame(b, ci);
     }
     if (rc) { b->stream = se; return rc; }
-    SVA_HIP(hipEventRecord(b->ev[2], sa));
+    if (stage_ev) SVA_HIP(hipEventRecord(b->ev[2], sa));
     SVA_TRY(mark(6, sa));
     hipEvent_t evA = next_event(b);
     SVA_HIP(hipEventRecord(evA, sa));
@@ -1274,7 +1284,7 @@ int steady_pipelined(sva_batch* b) {
     b->voc_codes = nullptr; b->voc_codes_event = nullptr;
     b->stream = se;
     if (rc) return rc;
-    SVA_HIP(hipEventRecord(b->ev[3], sv));
+    if (stage_ev) SVA_HIP(hipEventRecord(b->ev[3], sv));
     SVA_TRY(mark(8, sv));
     b->trace_steps += 1;
     b->pipe_dirty = true;

@@ -656,6 +656,10 @@ PersistentChain::PersistentChain(sva_batch* b_, hipStream_t st_, bool active_) :
     if (!active) return;
     lk.lock();
     sva_engine* e = b->e;
+    // The only batch of its engine that decodes persistently has nobody to be ordered against: no wait, no event record (a record is a barrier
+    // packet on the AR queue every frame).  A second such batch synchronises the device when it is created (engine.hip), so launches that were
+    // enqueued without a record are complete before the chain is needed.
+    if (e->persistent_batches <= 1) { active = false; lk.unlock(); return; }
     if (e->mega_ev_valid && e->mega_last != b && hipStreamWaitEvent(st, e->mega_ev, 0) != hipSuccess) {
         set_error("PersistentChain: hipStreamWaitEvent failed");
         rc = 1;
