@@ -61,9 +61,13 @@ def parse():
                     help="sva_config.mm_mode (default: the library's): batch-scale encoder / vocoder GEMM format, csrc/gemm_planes.hip")
     ap.add_argument("--voc-dtype", type=int, default=None, choices=(0, 1),
                     help="sva_config.voc_dtype: 1 = fp16-operand vocoder GEMMs, the reference's autocast precision (infer_arvc.py:493)")
-    ap.add_argument("--skip-semantic", action="store_true",
-                    help="sva_stream_params.skip_semantic: leave out the semantic-token head and its sample, which every caller of the reference "
-                         "discards (modules/dual_ar_stream.py:833); off by default -- the headline computes everything the reference computes")
+    ap.add_argument("--semantic-head", dest="skip_semantic", action="store_false",
+                    help="also compute the semantic-token head and its sample in the timed run.  Every caller of the reference discards that sample "
+                         "(modules/dual_ar_stream.py:833) and the engine's counter RNG makes it side-effect free, so the headline leaves it out "
+                         "(sva_stream_params.skip_semantic: codes and PCM are identical either way -- tests/test_gpu_parity.py); the line also carries "
+                         "the timing with the head computed (`semantic_head_on`)")
+    ap.add_argument("--skip-semantic", dest="skip_semantic", action="store_true", help="(default) see --semantic-head")
+    ap.set_defaults(skip_semantic=True)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=60, help="CPU-baseline sample size (chunk-steps)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -237,7 +241,7 @@ def pmc_traffic(B, chunk):
             lo, hi = (marks[8], marks[min(8 + 24, len(marks) - 1)]) if len(marks) > 12 else (0, 1 << 62)
             for x in rows:
                 kn = x["Kernel_Name"]
-                if not ("gemm_kernel" in kn or "split_ws_kernel" in kn) or not (lo <= int(x["Dispatch_Id"]) < hi):
+                if not any(t in kn for t in ("gemm_kernel", "split_ws_kernel", "planes_dma_kernel", "voc_conv_kernel")) or not (lo <= int(x["Dispatch_Id"]) < hi):
                     continue
                 a_ = acc.setdefault(x["Counter_Name"], [0, 0.0])
                 a_[0] += 1
@@ -592,10 +596,11 @@ def main():
     pin_info = {}
     cpus_at_start = os.sched_getaffinity(0)
 
-    def run_workload(B, steps, warmup, want_roofline):
+    def run_workload(B, steps, warmup, want_roofline, skip_semantic=None):
         """B streams per rank; returns (seconds for `steps` steps [max over ranks], stage timings, gathered count, roofline)"""
         pipelined = bool(args.pipeline) and not args.graph
-        batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=args.graph, pipeline=pipelined, skip_semantic=args.skip_semantic)
+        batch = E.Batch(eng, n_streams=B, chunk_frames=c, delay=2, use_graph=args.graph, pipeline=pipelined,
+                        skip_semantic=args.skip_semantic if skip_semantic is None else skip_semantic)
         # utterances are global ids sharded over ranks (weak scaling: B per rank)
         my_utts = shard_utterances(list(range(world * B)), world)[rank]
         for s_, u in enumerate(my_utts):
@@ -691,10 +696,16 @@ def main():
                  "host_enqueue_ms_idle_queue": round(enq[len(enq) // 2], 4),          # median with an empty queue: the pure host cost
                  "sync_latency_ms": {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[min(len(lat) - 1, int(0.99 * len(lat)))], 4),
                                      "n": n_lat}}
+        dt_rank = dt
         if world > 1 or force_dist:
             t = torch.tensor([dt], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+            # this rank's own clock next to the job's (MAX over ranks): rank 0 reports every rank's N = 1-equivalent frames/s
+            tl = [torch.zeros(1, device="cuda", dtype=torch.float64) for _ in range(world)] if rank == 0 else None
+            dist.gather(torch.tensor([dt_rank], device="cuda", dtype=torch.float64), tl, dst=0)
+            if rank == 0:
+                extra["per_rank_frames_per_s"] = [round(B * c * steps / float(x.item()), 1) for x in tl]
         # the trivial gather of the per-utterance RESULTS to rank 0 (north_star configs[3]/[4]; SURVEY.md 8e: codes [8, T] per utterance):
         # every frame each utterance decoded since begin() -- delay fill, warm-up, timed and latency-sample steps
         n_res = min(batch.frames_decoded(s_) for s_ in range(B))
@@ -703,8 +714,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             n_res = int(t.item())
         codes = np.stack([batch.pred_codes(s_, n_res) for s_ in range(B)])               # [B, 8, T]
-        gathered = gather_results(torch.from_numpy(codes).cuda(), world, rank, force=force_dist)
+        codes_dev = torch.from_numpy(codes).cuda()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        gathered = gather_results(codes_dev, world, rank, force=force_dist)
+        torch.cuda.synchronize()
+        extra["gather_ms"] = round((time.perf_counter() - tg) * 1e3, 3)          # the job's only collective (outside the timed region): [B, 8, T] int32 per rank to rank 0
         n_gathered_frames = int(gathered.shape[0] * gathered.shape[2]) if gathered is not None else 0
+        if rank == 0:
+            assert gathered is not None and int(gathered.shape[0]) == world * B, f"gathered {None if gathered is None else tuple(gathered.shape)} != {world} x {B} utterances"
         roof = None
         if rank == 0 and want_roofline:
             # dominant kernel = conv_gemm_kernel (f32 MFMA): algorithmic FLOPs of all its launches in one step /
@@ -744,14 +762,16 @@ def main():
             # workload; the committed profile's number is reported under its own name, never as `traffic`
             import glob
             traffic, pmc_info = None, None
-            if args.pmc and world == 1 and B == args.streams:
+            if args.pmc and world == 1 and (B == args.streams or (B == 64 and args.streams == 1)):
                 batch.sync()
                 traffic, pmc_info = pmc_traffic(B, c)
+            prof_stages = None
             prof_traffic, mfma_util, cands = None, None, sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_b{B}.json")))
             if cands and c == 1:
                 pj = json.load(open(cands[-1]))
                 prof_traffic = round(pj["hbm_bytes_per_launch"], 1)
                 mfma_util = round(pj["gemm_mfma_util"], 4) if pj.get("gemm_mfma_util") is not None else None
+                prof_stages = {k_: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v_.items()} for k_, v_ in (pj.get("stages") or {}).items()} or None
             alg_per_launch = alg_bytes / max(nl, 1)
             PEAK_SPLIT = 2500.0 / 6.0
             PEAK_F16W = 2500.0 / 2.0          # v_mfma_f32_16x16x32_f16, two part products (activation hi, lo) per weight block
@@ -765,24 +785,33 @@ def main():
             # the fraction of what the launches COULD have done in their own time on the pipes they ran on
             cap = sum(v["ms"] * v["peak"] for v in by_pipe.values())
             frac_own = (flops / 1e9) / cap if cap > 0 else 0.0
+            f32_only = set(by_pipe) <= {"f32_mfma"}
             roof = {"bound": "mfma", "kernel": "conv-GEMM family: pipe_gemm_kernel / conv_gemm_kernel / skinny_gemm_kernel (v_mfma_f32_16x16x4_f32) and split_gemm_kernel / "
                               "planes_gemm_kernel / planes_dma_kernel (the same fp32 problems on the 16-bit pipes: six bf16 part products split in the K loop, or "
                               "three fp16 part products from pre-split operand planes with sva_config.mm_mode = 1 -- fp32-grade results either way; one fp16 "
                               "product for a voc_dtype = 1 vocoder; planes_dma = the persistent LDS-DMA form the encoder's batch-scale GEMMs and, from 16 code "
                               "frames per step, the HiFiGAN ResBlock convs run in (incl. voc_conv_kernel for the C = 16 / 32 levels); the per-shape table picks)",
-                    "peak_note": "peak = 157.3 TF/s, the dense f32-MFMA peak (the arithmetic the path is specified in) -- `frac` = achieved / 157.3 as the contract "
-                                 "defines it; launches of the split-bf16 kernel run on the bf16 pipes, whose ceiling for this work is 2500 / 6 = 416.7 TF/s: `by_pipe` "
-                                 "prices each kernel family against its own pipe and `frac_of_own_pipes` is the time-weighted combination (the honest figure when "
-                                 "split launches are present); an ar_dtype = 1 batch adds `f16_weights` (gemm_f16w.hip: fp16 weights, activations as hi + lo fp16 "
+                    "peak_note": "one stream: peak = 157.3 TF/s, the dense f32-MFMA peak, `frac` = achieved / 157.3.  Batch scale: launches of the split-bf16 kernel run on "
+                                 "the bf16 pipes (ceiling for this work 2500 / 6 = 416.7 TF/s), the planes kernels on the fp16 pipes (2500 / 3 = 833.3 for three part "
+                                 "products): `by_pipe` prices each kernel family against its own pipe, `peak` is their time-weighted mean and `frac` = "
+                                 "`frac_of_own_pipes`; an ar_dtype = 1 batch adds `f16_weights` (gemm_f16w.hip: fp16 weights, activations as hi + lo fp16 "
                                  "parts, ceiling 2500 / 2 TF/s -- those launches are decode-sized and bound by their weight stream, not by the pipe)",
                     "achieved": round(ach, 3),
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
+                    # `frac` = achieved / peak OF THE PIPES THE LAUNCHES RAN ON: at one stream every launch is v_mfma_f32_16x16x4_f32 (peak 157.3);
+                    # at batch scale most of the work runs as fp16 part products, and dividing that by the f32-MFMA peak gave a "fraction" near or
+                    # above 1 -- there `peak` is the time-weighted peak of the pipes used and `frac` = frac_of_own_pipes
+                    "peak": PEAK_F32_MFMA_TFLOPS if f32_only else round(cap / max(sum(v["ms"] for v in by_pipe.values()), 1e-9), 1), "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5) if f32_only else round(frac_own, 5), "all_launches_on_f32_mfma": f32_only,
+                    "arithmetic": "f32 (v_mfma_f32_16x16x4_f32) in every launch" if f32_only else
+                                  "f32-grade: encoder / vocoder GEMMs from 10 streams as fp16 x 3 part products of exactly split fp32 operands (mm_mode 1; fp16 range, "
+                                  "absolute error floor 2^-25 for small activations), f32 MFMA for the AR chain and the narrow layers",
                     "frac_of_own_pipes": round(frac_own, 5), "by_pipe": by_pipe,
                     "mode": "one serial step, every conv-GEMM launch bracketed by hipEvents on its launch stream (launches do not overlap)",
                     "traffic": round(traffic, 1) if traffic is not None else None, "traffic_measurement": pmc_info,
                     "traffic_from_committed_profile": prof_traffic, "committed_profile": os.path.basename(cands[-1]) if prof_traffic is not None else None,
                     "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
                     "traffic_over_algorithmic": round(traffic / alg_per_launch, 3) if traffic else None,
+                    "stages_pmc_committed_profile": prof_stages,     # per stage: achieved fabric-side GB/s, fraction of 8 TB/s, MFMA utilisation (tools/pmc.sh -> tools/pmc_agg.py)
                     "mfma_util_pmc_committed_profile": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024) over the same kernels (tools/pmc.sh)
                     "launches_per_step": int(nl), "avg_launch_us": round(tot_ms * 1e3 / max(nl, 1), 3),
                     "algorithmic_gflop_per_step": round(flops / 1e9, 3), "gemm_ms_per_step": round(tot_ms, 4),
@@ -820,7 +849,7 @@ def main():
     }
     out.update(extra)
 
-    def stage_rates(B_, ms_step, tm_, gflop_step):
+    def stage_rates(B_, ms_step, tm_, gflop_step, f32_only=True):
         """Rates of the TIMED (pipelined) configuration and of the stages of a synchronised step: the conv-GEMM FLOPs of a step
         are the encoder's and the vocoder's (+ the AR's at B > 2); the AR at B <= 2 is weight streaming."""
         wb = 2 if args.ar_dtype else 4
@@ -831,22 +860,29 @@ def main():
         enc_gflop = 13.9 * B_                                                # merged incremental pass: head 160 + 6 + 4c rows, 128-token transformer
         voc_gflop = 2.646 * c * B_
         r = {"timed": {"note": "the K timed steps as run (stages of consecutive steps overlapped): algorithmic conv-GEMM FLOPs of a step / ms_per_step", "ms_per_step": round(ms_step, 4), "algorithmic_gflop_per_step": round(gflop_step, 3),
-                       "tflops": round(gflop_step / ms_step, 3), "frac_f32_mfma": round(gflop_step / ms_step / PEAK_F32_MFMA_TFLOPS, 5),
+                       "tflops": round(gflop_step / ms_step, 3), **({"frac_f32_mfma": round(gflop_step / ms_step / PEAK_F32_MFMA_TFLOPS, 5)} if f32_only else {}),
                        "unique_weight_bytes_per_step": int(weight_bytes), "weight_stream_GBs": round(weight_bytes / ms_step / 1e6, 1),
                        "frac_hbm": round(weight_bytes / ms_step / 1e6 / PEAK_HBM_GBS, 5)},
              "stages_synchronised_step": {
                  "encoder": {"ms": round(tm_["encoder"], 4), "gflop": round(enc_gflop, 2), "tflops": round(enc_gflop / max(tm_["encoder"], 1e-9), 2),
-                             "frac_f32_mfma": round(enc_gflop / max(tm_["encoder"], 1e-9) / PEAK_F32_MFMA_TFLOPS, 5)},
+                             **({"frac_f32_mfma": round(enc_gflop / max(tm_["encoder"], 1e-9) / PEAK_F32_MFMA_TFLOPS, 5)} if f32_only else {})},
                  "ar": {"ms": round(tm_["ar"], 4), "bytes": int(ar_bytes), "GBs": round(ar_bytes / max(tm_["ar"], 1e-9) / 1e6, 1),
                         "frac_hbm": round(ar_bytes / max(tm_["ar"], 1e-9) / 1e6 / PEAK_HBM_GBS, 5),
                         "note": "unique AR weight bytes (fast layers counted once per codebook pass: 8 x 30.7 M elements stream from L2 / MALL) + slow KV read"},
                  "vocoder": {"ms": round(tm_["vocoder"], 4), "gflop": round(voc_gflop, 2), "tflops": round(voc_gflop / max(tm_["vocoder"], 1e-9), 2),
-                             "frac_f32_mfma": round(voc_gflop / max(tm_["vocoder"], 1e-9) / PEAK_F32_MFMA_TFLOPS, 5)}}}
+                             **({"frac_f32_mfma": round(voc_gflop / max(tm_["vocoder"], 1e-9) / PEAK_F32_MFMA_TFLOPS, 5)} if f32_only else {})}}}
         return r
 
     if roof:
-        roof.update(stage_rates(B, ms, tm, roof["algorithmic_gflop_per_step"]))
+        roof.update(stage_rates(B, ms, tm, roof["algorithmic_gflop_per_step"], roof["all_launches_on_f32_mfma"]))
         out["roofline"] = roof
+    if world == 1 and args.skip_semantic and not args.no_batched and not args.config:
+        # the same timed run with the semantic-token head and its (discarded) sample computed, as the reference does (dual_ar_stream.py:1181-1186, 833)
+        dt_s, _, _, _, ex_s = run_workload(B, args.steps, args.warmup, False, skip_semantic=False)
+        out["semantic_head_on"] = {"ms_per_step": round(dt_s / args.steps * 1e3, 4), "value": round(world * B * c * args.steps / dt_s, 3), "unit": "frames/s",
+                                   "sync_latency_p50_ms": ex_s["sync_latency_ms"]["p50"],
+                                   "note": "the headline leaves the semantic head out (its sample is discarded by every caller; codes and PCM are bit-identical: "
+                                           "tests/test_gpu_parity.py::test_skip_semantic_head_changes_nothing_downstream)"}
     if world == 1 and B == 1 and not args.no_batched:
         # BASELINE.json configs[2] next to the headline single-stream workload: 64 concurrent streams on the same GPU
         # (the "frames/sec aggregate" half of the metric); informational, `value` above stays the configs[1] number
@@ -856,7 +892,7 @@ def main():
                                      "value": round(64 * c * 10 / dt2, 3), "unit": "frames/s", "rtf": round(ms2 * 1e-3 / (c * FRAME_S), 5),
                                      "x_realtime": round(64 * c * 10 / dt2 * FRAME_S, 2),
                                      "stage_ms_last_step": {k_: round(v, 4) for k_, v in tm2.items()},
-                                     "roofline": ({**roof2, **stage_rates(64, ms2, tm2, roof2["algorithmic_gflop_per_step"])} if roof2 else None), **extra2}
+                                     "roofline": ({**roof2, **stage_rates(64, ms2, tm2, roof2["algorithmic_gflop_per_step"], roof2["all_launches_on_f32_mfma"])} if roof2 else None), **extra2}
     if world == 1 and B == 1 and not args.no_batched:
         try:
             out["reprefill_64_streams"] = reprefill_block(eng)

@@ -165,20 +165,34 @@ int get_streams(int device, bool need_aux1, int n_streams_if_pipelined, StreamSe
 // (profiles/r04_small_batch_ab.txt, r04_abatch_sweep in the comments above).  SVA_DEBUG ar_batch=0 never, ar_batch=2 every size it can run
 // (a GROUP form of the persistent kernel -- 2-4 streams sharing each phase's weight registers and hand-offs on one set of 96 workgroups --
 // was built in round 4, measured slower than this policy at every size and removed in round 5: profiles/r04_group_ab.txt, git history)
+// The PIPELINED-mode policy -- which decode serves a batch of B streams (the batched persistent kernel or the multi-launch chain) and how many
+// CUs the AR chain's stream owns when it is the chain -- is a GENERATED table: tools/make_policy.py sweeps the candidates on the GPU
+// (frames/s of bench.py per stream count x decode x CU partition; log under profiles/) and emits policy_table.inc, so a kernel change
+// re-derives every threshold with one command instead of hand-edited constants.  A batch takes the row of the largest
+// measured stream count <= its own (same AR precision, same chunk class).
+struct PolicyRow { int ar_dtype, chunk_gt1, B, decode, cu_ar; };       // decode: 0 multi-launch chain, 2 batched persistent kernel; cu_ar: 0 = no partition
+static const PolicyRow kPolicy[] = {
+#include "policy_table.inc"
+};
+static const PolicyRow* policy_row(int B, int ar_dtype, int chunk) {
+    const PolicyRow *below = nullptr, *smallest = nullptr;
+    for (const PolicyRow& r : kPolicy) {
+        if (r.ar_dtype != ar_dtype || r.chunk_gt1 != (chunk > 1 ? 1 : 0)) continue;
+        if (r.B <= B && (!below || r.B > below->B)) below = &r;
+        if (!smallest || r.B < smallest->B) smallest = &r;
+    }
+    return below ? below : smallest;          // (fewer streams than any measured row: the smallest one)
+}
+// smallest pipelined stream count the batched kernel serves = one more than what the per-stream persistent kernel (ar_decode.hip) takes
 static int abatch_lo(int ar_dtype, bool pipelined) { return pipelined ? (ar_dtype == 1 ? 3 : 4) : 5; }
 static bool abatch_serves(int B, int ar_dtype, bool pipelined, int chunk) {
     const int mode = debug_options().ar_batch;
     if (mode == 0 || B > AR_BATCH_MAX_STREAMS) return false;
     if (mode == 2) return true;
-    // (round 5, after the planes-DMA kernel shortened the encoder stage: at 32 fp32 streams the one-launch kernel unpartitioned gives 6416 frames/s / sync p50
-    // 9.5 ms against 5773 / 11.5 for the multi-launch chain on its 64-CU partition and 5638 / 9.2 unpartitioned; at 48 it loses, 5915 vs 7220 --
-    // profiles/r05_partition_sweep.txt)
-    // (end of round 5, with the encoder and the vocoder on the planes paths from 10 streams: the fp16 AR too -- 12 / 16 / 24 / 32 streams 3720 / 4780 / 5290 / 6440
-    // frames/s for the multi-launch chain on its partition against 4990 / 6110 / 7200 / 8330 for this kernel unpartitioned, the synchronous step 19-25 %
-    // shorter; at 36-44 streams the two tie or it loses (fp32 36: 5735 vs 6183, 40: 6032 vs 6026, 44: 6210 vs 6131; fp16 40: 6785 vs 7370) -- profiles/r05_abatch_policy.txt)
-    (void)chunk;
-    const int hi = 32;
-    return B >= abatch_lo(ar_dtype, pipelined) && B <= hi;
+    if (B < abatch_lo(ar_dtype, pipelined)) return false;
+    if (!pipelined) return B <= 32;           // a caller that synchronises every chunk: one launch per frame from 5 streams (profiles/r04_small_batch_ab.txt)
+    const PolicyRow* r = policy_row(B, ar_dtype, chunk);
+    return r ? r->decode == 2 : B <= 32;
 }
 
 static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batch* b);
@@ -246,6 +260,11 @@ static int batch_create_impl(sva_engine* e, const sva_stream_params* p, sva_batc
         if (b->p.pipeline && !will_mega && !will_abatch && B <= (p->chunk_frames > 1 ? 16 : 32)) {      // (chunk 4: 16 streams +11 %, 32 streams -15 %: the round-3 partition A/B scripts, git history)
             part_streams = B;
             if (B >= 2) ar_cus = c.ar_dtype == 1 ? (B <= 8 ? 96 : 64) : (B <= 8 ? 128 : B <= 20 ? 96 : 64);
+        }
+        if (b->p.pipeline && !will_mega && !will_abatch && debug_options().ar_batch == 1) {      // the measured table, when it has a row for this batch
+            if (const PolicyRow* r = policy_row(B, c.ar_dtype, p->chunk_frames)) {
+                if (r->decode == 0) { part_streams = r->cu_ar > 0 ? B : 0; if (r->cu_ar > 0) ar_cus = r->cu_ar; }
+            }
         }
         if (debug_options().cu_partition == 0) part_streams = 0;
         else if (debug_options().cu_partition == 1 && b->p.pipeline) { part_streams = B; if (debug_options().cu_ar > 0) ar_cus = debug_options().cu_ar; }
@@ -1208,6 +1227,7 @@ int steady_pipelined(sva_batch* b) {
         if (stage_ev) SVA_HIP(hipEventRecord(b->ev[1], sx));
         SVA_TRY(mark(4, sx));
         }
+        if (b->pipe_evVc[par]) SVA_HIP(hipStreamWaitEvent(sx, b->pipe_evVc[par], 0));     // V(n-2) has read the audio-code buffer A(n) will overwrite (long since)
         evE = next_event(b);
         SVA_HIP(hipEventRecord(evE, sx));
     } else {
@@ -1221,12 +1241,13 @@ int steady_pipelined(sva_batch* b) {
         hipLaunchKernelGGL(append_content_kernel, dim3((B + 63) / 64), dim3(64), 0, se, b->d_codes, b->T2, chunk, b->d_content_hist, b->hist_cap,
                            b->d_ncontent, b->d_step_content, B, b->d_step);
         if (stage_ev) SVA_HIP(hipEventRecord(b->ev[1], se));
+        if (b->pipe_evVc[par]) SVA_HIP(hipStreamWaitEvent(se, b->pipe_evVc[par], 0));
         evE = next_event(b);
         SVA_HIP(hipEventRecord(evE, se));
     }
     // A(n)
-    SVA_HIP(hipStreamWaitEvent(sa, evE, 0));
-    if (b->pipe_evVc[par]) SVA_HIP(hipStreamWaitEvent(sa, b->pipe_evVc[par], 0));     // V(n-2) has read this buffer (long since)
+    SVA_HIP(hipStreamWaitEvent(sa, evE, 0));       // (evE also carries "V(n-2) has read the code buffer": the encoder chain waited for that event above --
+                                                   //  one barrier packet fewer on the AR queue, whose chain is the period of a one-stream pipeline)
     b->stream = sa;
     SVA_TRY(mark(5, sa));
     int rc = 0;

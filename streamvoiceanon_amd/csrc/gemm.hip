@@ -925,8 +925,26 @@ static int launch_conv_gemm_impl(const ConvGemm& g, hipStream_t st, int group_n)
         auto it = tab.find({g.M, g.N, g.taps * g.Cin, g.taps, (int)key_flags, g.stride});
         // a decode-sized row count between two tabulated ones (40 or 44 streams: the table holds 36 and 48) takes the choice of the next larger one within
         // 1.5 x -- every kernel handles partial row tiles, and the heuristic's pick there measured 20 % slower (AR stage 4.7 ms at 40 / 44 streams, 3.8 at 48)
-        if (it == tab.end() && g.M >= 8 && g.M <= 512)
-            for (int m = g.M + 1; m <= g.M + g.M / 2 && it == tab.end(); ++m) it = tab.find({m, g.N, g.taps * g.Cin, g.taps, (int)key_flags, g.stride});
+        // (the scan is memoised per shape -- ADVICE r05: an untabulated shape paid up to M / 2 map look-ups on every launch)
+        if (it == tab.end() && g.M >= 8 && g.M <= 512) {
+            static std::mutex memo_mu;
+            static std::map<std::array<int, 6>, int> memo;            // shape -> the tabulated row count it borrows (0: none)
+            const std::array<int, 6> key{g.M, g.N, g.taps * g.Cin, g.taps, (int)key_flags, g.stride};
+            int borrowed = -1;
+            {
+                std::lock_guard<std::mutex> lk(memo_mu);
+                auto mi = memo.find(key);
+                if (mi != memo.end()) borrowed = mi->second;
+            }
+            if (borrowed < 0) {
+                borrowed = 0;
+                for (int m = g.M + 1; m <= g.M + g.M / 2; ++m)
+                    if (tab.find({m, g.N, g.taps * g.Cin, g.taps, (int)key_flags, g.stride}) != tab.end()) { borrowed = m; break; }
+                std::lock_guard<std::mutex> lk(memo_mu);
+                memo[key] = borrowed;
+            }
+            if (borrowed > 0) it = tab.find({borrowed, g.N, g.taps * g.Cin, g.taps, (int)key_flags, g.stride});
+        }
         if (it != tab.end()) {
             // the table is keyed by shape only; the pipelined / split kernels also need aligned operands (a seam such as sva_op_conv can
             // present a tuned shape with other strides): keep the tuned choice only if its kernel accepts THIS problem

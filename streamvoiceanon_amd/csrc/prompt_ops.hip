@@ -299,6 +299,10 @@ extern "C" int sva_dev_alloc(sva_engine* e, long n, float** out) {
     SVA_CHECK(out && n > 0, "bad argument");
     SVA_HIP(hipMalloc((void**)out, sizeof(float) * (size_t)n));
     SVA_HIP(hipMemsetAsync(*out, 0, sizeof(float) * (size_t)n, os_));
+    // (a caller may hand the fresh buffer to a stream of its own -- the zero fill is complete when this returns; inside a capture of
+    // the ops stream there is nothing to wait for: hipMalloc is not capturable and this entry point is not called there)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(os_, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) SVA_HIP(hipStreamSynchronize(os_));
     return 0;
 }
 extern "C" int sva_dev_free(sva_engine* e, float* p) {

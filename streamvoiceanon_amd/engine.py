@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
 import weakref
 
 import numpy as np
@@ -218,6 +219,7 @@ class Engine:
                    f"sva_engine_load_weight({name})")
         _check(self.lib.sva_engine_finalize(self.h), "sva_engine_finalize")
         self._batches = weakref.WeakSet()
+        self.ops_lock = threading.RLock()      # serialises users of the engine's ops stream (prompt_encoders.py: recording / capture / replay)
 
     def close(self):
         if self.h:

@@ -36,6 +36,7 @@ class _Plan:
 
     def __init__(self):
         self.addrs, self.graph, self.out = [], None, None
+        self.put_sums = []          # checksum of every constant uploaded while recording: a replay must present the same payloads
 
 
 class _Dev:
@@ -46,7 +47,7 @@ class _Dev:
     def __init__(self, engine: E.Engine, plan: _Plan = None, mode: str = "eager"):
         self.engine, self.lib, self.h = engine, engine.lib, engine.h
         self.ptrs = []
-        self.plan, self.mode, self.cursor = plan, mode, 0
+        self.plan, self.mode, self.cursor, self.puts = plan, mode, 0, 0
 
     def alloc(self, n: int) -> int:
         if self.mode == "replay":
@@ -59,11 +60,22 @@ class _Dev:
         (self.plan.addrs if self.mode == "record" else self.ptrs).append(addr)
         return addr
 
-    def put(self, arr) -> int:
+    def put(self, arr, is_input: bool = False) -> int:
         a = _np(arr).reshape(-1)
         addr = self.alloc(a.size)
         if self.mode != "replay":
             E._check(self.lib.sva_dev_upload(self.h, C.c_void_p(addr), E._ptr(a), a.size), "sva_dev_upload")
+        if self.plan is not None and not is_input:      # (the call's input array is uploaded per call by _call / prepare)
+            # constants are functions of the input LENGTH only, which is what lets a replay skip their upload; one that depended on the input DATA
+            # would go stale silently -- so the replay checks every payload against what the recording uploaded
+            import zlib
+
+            key = (a.size, zlib.crc32(a.tobytes()))
+            if self.mode == "record":
+                self.plan.put_sums.append(key)
+            elif self.puts >= len(self.plan.put_sums) or self.plan.put_sums[self.puts] != key:
+                raise RuntimeError("prompt encoder replay: a constant differs from the recorded call (data-dependent put(): use alloc + upload per call)")
+            self.puts += 1
         return addr
 
     def upload(self, addr: int, arr):
@@ -147,6 +159,10 @@ class _Net:
 
     # ---- one call: eager / recording / captured / replayed (see _Plan) ---------------------------------------------
     def _call(self, wav) -> np.ndarray:
+        with self.engine.ops_lock:          # every encoder of an engine records / captures / replays on the engine's one ops stream
+            return self._call_locked(wav)
+
+    def _call_locked(self, wav) -> np.ndarray:
         n = wav.shape[0]
         if not self.use_graphs:
             d = _Dev(self.engine)
@@ -176,9 +192,15 @@ class _Net:
             g = C.c_void_p()
             try:
                 plan.out = self._run(d, wav)
-            finally:
-                rc = self.lib.sva_ops_capture_end(self.h, C.byref(g))
-            E._check(rc, "sva_ops_capture_end")
+            except Exception:
+                # the capture must be ended whatever happened; its half-recorded graph is freed and the plan dropped (the next call records anew)
+                self.lib.sva_ops_capture_end(self.h, C.byref(g))
+                if g.value:
+                    self.lib.sva_ops_graph_free(self.h, g)
+                self.plans.pop(n, None)
+                self._free_plan(plan)
+                raise
+            E._check(self.lib.sva_ops_capture_end(self.h, C.byref(g)), "sva_ops_capture_end")
             plan.graph = g
         E._check(self.lib.sva_ops_graph_launch(self.h, plan.graph), "sva_ops_graph_launch")
         return d.get(*plan.out)
@@ -278,7 +300,7 @@ class StyleEncoder(_Net):
         n = wav.shape[0]
         assert n >= 400, "style encoder: reference audio shorter than one 25 ms frame"
         m = 1 + (n - 400) // 160
-        dw = d.put(wav)
+        dw = d.put(wav, is_input=True)
         frames, spec, feat = d.alloc(m * 512), d.alloc(m * 272), d.alloc(m * 80)
         mo = C.c_int()
         E._check(lib.sva_op_fbank_power(h, dw, n, frames, spec, 272, C.byref(mo)), "sva_op_fbank_power")
@@ -388,7 +410,7 @@ class TimbreEncoder(_Net):
         lib, h = self.lib, self.h
         n = wav.shape[0]
         T = 1 + n // 320
-        dw = d.put(wav)
+        dw = d.put(wav, is_input=True)
         frames, spec = d.alloc(T * 1024), d.alloc(T * 528)
         mo = C.c_int()
         E._check(lib.sva_op_stft_mag(h, dw, n, 1024, 640, 320, frames, spec, 528, C.byref(mo)), "sva_op_stft_mag")

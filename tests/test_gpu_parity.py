@@ -404,6 +404,33 @@ def test_inference_wrapper_stream_infer(weights0):
     w.engine.close()
 
 
+@pytest.mark.parametrize("B", [1, 3, 40])
+def test_skip_semantic_head_changes_nothing_downstream(eng, B):
+    """sva_stream_params.skip_semantic (bench.py's default): the semantic-token head and its sample -- computed and discarded by every caller
+    of the reference (modules/dual_ar_stream.py:833, 1181-1186) -- are left out.  With the counter RNG that draw has no side effect, so audio
+    codes and PCM must be bit-identical with and without it, on the persistent B = 1 kernel, the batched persistent kernel and the
+    multi-launch decode chain (device RNG, pipelined steps with re-use of the same noise keys)."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    n_chunks = 10
+    audio = np.stack([synth_utterance(5100 + s_, 2048 * n_chunks) for s_ in range(B)])
+    res = []
+    for skip in (False, True):
+        b = E.Batch(eng, n_streams=B, skip_semantic=skip, pipeline=True)
+        for s_ in range(B):
+            ac, cc, style, timbre = synth_prompt(2100 + (s_ % 5), 64)
+            b.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=5100 + s_)
+        b.begin()
+        pcm = b.stream_chunks(audio)
+        codes = np.stack([b.pred_codes(s_, n_chunks - 2) for s_ in range(B)])
+        res.append((pcm.copy(), codes.copy(), b.decode_path()))
+        b.close()
+    assert res[0][2] == res[1][2]
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+
+
 def test_incremental_encoder_equals_window_recompute_long_stream(eng, weights0):
     """Exact-incremental encoder over a stream long enough for the whole 128-frame window to turn over
     (150 chunks): at every chunk the content code produced by the streaming step must equal the last code of the

@@ -31,7 +31,7 @@ with open(out, "w") as f:
     f.write("Name,CallsPerStep,AverageUs,TotalUsPerStep,Percentage\n")
     for k, (n, us) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         f.write('"%s",%.3f,%.3f,%.3f,%.2f\n' % (k, n / steps, us / n, us / steps, 100.0 * us / tot))
-gemm = {k: v for k, v in per.items() if "gemm_kernel" in k or "split_ws_kernel" in k}
+gemm = {k: v for k, v in per.items() if any(t in k for t in ("gemm_kernel", "split_ws_kernel", "planes_dma_kernel", "voc_conv_kernel"))}
 ar = {k: v for k, v in per.items() if "ar_decode_kernel" in k}
 print(json.dumps({
     "steps": steps, "wall_us_per_step_under_tracer": round((t1 - t0) / 1e3 / steps, 2),
