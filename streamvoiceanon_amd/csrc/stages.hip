@@ -814,6 +814,10 @@ int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const lon
             hg.X = b->hidden; hg.ldx = D; hg.M = B; hg.W = e->ar_output.W; hg.N = c.ar_vocab; hg.K = D; hg.norm_w = e->ar_norm;
             hg.eps = 1e-5f; hg.Y = b->slow_logits; hg.ldy = c.ar_vocab;
             SVA_TRY(launch_gemv(hg, st));
+        } else if (conv_gemm_can_fuse_rms(B, c.ar_vocab)) {        // the norm folded into the head's GEMM (a launch less per head: round 6)
+            ConvGemm pn;
+            pn.rms_w = e->ar_norm; pn.rms_eps = 1e-5f;
+            SVA_TRY(gemm_call(b, b->hidden, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_output, b->slow_logits, (long)B * c.ar_vocab, 0, c.ar_vocab, pn));
         } else {
             SVA_TRY(launch_rmsnorm_rows(b->hidden, (long)B * D, 0, D, 1, B, D, e->ar_norm, 1e-5f, b->ahn, (long)B * D, 0, D, st));
             SVA_TRY(gemm_call(b, b->ahn, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_output, b->slow_logits, (long)B * c.ar_vocab, 0, c.ar_vocab));
@@ -832,6 +836,10 @@ int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const lon
             fg.X = b->xf; fg.ldx = D; fg.M = B; fg.W = e->ar_fast_output.W; fg.N = cbs; fg.K = D; fg.norm_w = e->ar_fast_norm; fg.eps = 1e-5f;
             fg.Y = lg; fg.ldy = ncb * cbs;
             SVA_TRY(launch_gemv(fg, st));
+        } else if (conv_gemm_can_fuse_rms(B, cbs)) {
+            ConvGemm pn;
+            pn.rms_w = e->ar_fast_norm; pn.rms_eps = 1e-5f;
+            SVA_TRY(gemm_call(b, b->xf, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_fast_output, lg, (long)B * ncb * cbs, 0, ncb * cbs, pn));
         } else {
             SVA_TRY(launch_rmsnorm_rows(b->xf, (long)B * D, 0, D, 1, B, D, e->ar_fast_norm, 1e-5f, b->ahn, (long)B * D, 0, D, st));
             SVA_TRY(gemm_call(b, b->ahn, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_fast_output, lg, (long)B * ncb * cbs, 0, ncb * cbs));
