@@ -293,6 +293,9 @@ int sva_test_gemm_planes(int device, int M, int N, int K, const float* A, const 
  * out_ref: the per-row kernel, out_mfma: the flash-style MFMA kernel; us[2] their launch times when iters > 0. */
 int sva_test_prefill_attention(int device, int M, int H, int pos0, int S, const float* q, const float* keys, const float* vals,
                                int half_kv, float* out_ref, float* out_mfma, int iters, float* us);
+/* the same rows through the decode frame's paired attention kernel (rows 2 i, 2 i + 1 share one pass over the slot's K / V; M even) */
+int sva_test_pair_attention(int device, int M, int H, int pos0, int S, const float* q, const float* keys, const float* vals,
+                               int half_kv, float* out_ref, float* out_mfma, int iters, float* us);
 
 /* host cost (microseconds) of enqueueing one kernel from the calling thread, measured over `iters` launches of a one-element
  * kernel into an idle stream.  A synchronous single-stream step is ~170 launches (a pipelined one: four graph launches + the persistent

@@ -51,6 +51,8 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "planes_lw") o.planes_lw = atoi(v.c_str());
             else if (k == "planes_min_streams") o.planes_min_streams = atoi(v.c_str());
             else if (k == "ar_graph") o.ar_graph = atoi(v.c_str());
+            else if (k == "ar_pairs") o.ar_pairs = atoi(v.c_str());
+            else if (k == "head_fuse") o.head_fuse = atoi(v.c_str());
             else if (k == "voc_fused_mask") o.voc_fused_mask = atoi(v.c_str());
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());

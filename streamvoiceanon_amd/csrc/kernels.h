@@ -57,6 +57,10 @@ int launch_ar_fast_attention(const float* qkv, int M, int H, const int* slot, co
 template <typename KV>
 int launch_ar_attention(const float* qkv, int M, int H, int hd, const int* slot, const int* pos, const KV* cache,
                         long slot_stride, int S, float* out, hipStream_t st, float* partial = nullptr, int splits = 1);
+// rows (2 s, 2 s + 1) = positions (p, p + 1) of one slot for every s: one workgroup per (head, stream) reads the slot's K / V rows once for both
+template <typename KV>
+int launch_ar_attention_pairs(const float* qkv, int M, int H, int hd, const int* slot, const int* pos, const KV* cache, long slot_stride, int S, float* out,
+                              hipStream_t st);
 // The same attention for M rows at CONSECUTIVE positions pos0 .. pos0 + M - 1 of ONE slot (prefill / re-prefill / offline generate):
 // flash-style MFMA kernel, one 16-row query tile per workgroup, its four waves splitting the key blocks.
 template <typename KV>

@@ -841,6 +841,118 @@ int launch_ar_attention(const float* qkv, int M, int H, int hd, const int* slot,
     SVA_HIP(hipGetLastError());
     return 0;
 }
+// The decode frame's slow layers present every stream's TWO new rows (cached audio embedding, content token: positions p, p + 1 of one slot,
+// rows 2 s and 2 s + 1).  One workgroup per (head, stream) serves both from ONE pass over the slot's K / V rows -- the per-row kernel above read
+// them twice (PMC, 64 streams: 289 MB per launch against 118 MB of cached keys and values).  Each row's arithmetic -- the thread that owns a
+// key, the order of every sum -- is the per-row kernel's, so the results are bit-identical to it.
+template <typename KV>
+__global__ __launch_bounds__(256) void ar_attention_pair_kernel(const float* __restrict__ qkv, int H, const int* __restrict__ slot,
+                                                                const int* __restrict__ pos, const KV* __restrict__ cache,
+                                                                long slot_stride, int S, float* __restrict__ out) {
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sc0 = smem;                // [S] scores / probabilities of row 0
+    float* sc1 = sc0 + S;             // [S] ... of row 1
+    float* red = sc1 + S;             // [16]
+    float* part = red + 16;           // [2][16][64] partial P.V sums
+    const int h = blockIdx.x, m0 = 2 * blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int D = H * HD;
+    const int L0 = pos[m0] + 1, L1 = pos[m0 + 1] + 1;          // L1 = L0 + 1 (the launcher's contract; the loops below only need L1 >= L0)
+    const KV* kc = cache + (long)slot[m0] * slot_stride + (long)h * S * HD;
+    const KV* vc = kc + (long)H * S * HD;
+    const int part4 = tid & 3;
+    float q0[16], q1[16];
+    {
+        const float* qr = qkv + (long)m0 * 3 * D + h * HD + part4 * 16;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { q0[d] = qr[d]; q1[d] = qr[3 * D + d]; }
+    }
+    float mx0 = -INFINITY, mx1 = -INFINITY;
+    for (int j0 = 0; j0 < L1; j0 += 64) {
+        const int j = j0 + (tid >> 2);
+        float a0 = 0.f, a1 = 0.f;
+        if (j < L1) {
+            const KV* kr = kc + (long)j * HD + part4 * 16;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                // Two explicit v_fmac_f32 per key element.  Written as fmaf() pairs the compiler packs them into a chain of v_pk_fma_f32 whose
+                // odd terms read the key through op_sel:[0,1,0] (low lane <- high register of the loaded pair); on MI355X that form returned
+                // wrong low-lane sums in lanes 48..63 of a wave in ~1 % of the (head, stream) workgroups of a loaded 64-stream decode -- never
+                // in an isolated launch -- while the same chain without the op_sel read, and this form, are exact.
+                const float kv = from_kv(kr[d]);
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(a0) : "v"(q0[d]), "v"(kv));
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(a1) : "v"(q1[d]), "v"(kv));
+            }
+        }
+        a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64);
+        a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64);
+        a0 *= 0.125f; a1 *= 0.125f;
+        if (j < L0) {
+            if (part4 == 0) sc0[j] = a0;
+            mx0 = fmaxf(mx0, a0);
+        }
+        if (j < L1) {
+            if (part4 == 0) sc1[j] = a1;
+            mx1 = fmaxf(mx1, a1);
+        }
+    }
+    mx0 = wave_max(mx0); mx1 = wave_max(mx1);
+    if (lane == 0) { red[wave] = mx0; red[8 + wave] = mx1; }
+    __syncthreads();
+    mx0 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx1 = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
+    float sum0 = 0.f, sum1 = 0.f;
+    for (int j = tid; j < L1; j += 256) {
+        if (j < L0) { const float e = expf(sc0[j] - mx0); sc0[j] = e; sum0 += e; }
+        const float e1 = expf(sc1[j] - mx1); sc1[j] = e1; sum1 += e1;
+    }
+    sum0 = wave_sum(sum0); sum1 = wave_sum(sum1);
+    if (lane == 0) { red[4 + wave] = sum0; red[12 + wave] = sum1; }
+    __syncthreads();
+    sum0 = red[4] + red[5] + red[6] + red[7];
+    sum1 = red[12] + red[13] + red[14] + red[15];
+    const int c4 = tid & 15, jg = tid >> 4;
+    float4 u4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = jg; j < L1; j += 16) {
+        const KV* vr = vc + (long)j * HD + c4 * 4;
+        const float v0 = from_kv(vr[0]), v1 = from_kv(vr[1]), v2 = from_kv(vr[2]), v3 = from_kv(vr[3]);
+        if (j < L0) {
+            const float pj = sc0[j];
+            u4.x = fmaf(pj, v0, u4.x); u4.y = fmaf(pj, v1, u4.y); u4.z = fmaf(pj, v2, u4.z); u4.w = fmaf(pj, v3, u4.w);
+        }
+        const float pk = sc1[j];
+        w4.x = fmaf(pk, v0, w4.x); w4.y = fmaf(pk, v1, w4.y); w4.z = fmaf(pk, v2, w4.z); w4.w = fmaf(pk, v3, w4.w);
+    }
+    *reinterpret_cast<float4*>(&part[jg * HD + c4 * 4]) = u4;
+    *reinterpret_cast<float4*>(&part[16 * HD + jg * HD + c4 * 4]) = w4;
+    __syncthreads();
+    if (tid < 2 * HD) {
+        const int r = tid >> 6, t = tid & 63;
+        float o = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) o += part[r * 16 * HD + g2 * HD + t];
+        out[(long)(m0 + r) * D + h * HD + t] = o / (r ? sum1 : sum0);
+    }
+}
+// rows (2 s, 2 s + 1) = positions (p, p + 1) of slot s for every s (M even): the decode frame's slow layers (stages.hip)
+template <typename KV>
+int launch_ar_attention_pairs(const float* qkv, int M, int H, int hd, const int* slot, const int* pos, const KV* cache, long slot_stride, int S, float* out,
+                              hipStream_t st) {
+    SVA_CHECK(hd == 64 && M % 2 == 0, "ar_attention_pairs: head_dim 64, an even number of rows");
+    const size_t smem = ((size_t)2 * S + 16 + 2 * 16 * 64) * sizeof(float);
+    static DeviceOnce attr;
+    if (attr.needed() && smem > 48 * 1024) {
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_attention_pair_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        SVA_HIP(hipFuncSetAttribute((const void*)ar_attention_pair_kernel<__half>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr.done();
+    }
+    hipLaunchKernelGGL((ar_attention_pair_kernel<KV>), dim3(H, M / 2), dim3(256), smem, st, qkv, H, slot, pos, cache, slot_stride, S, out);
+    SVA_HIP(hipGetLastError());
+    return 0;
+}
+template int launch_ar_attention_pairs<float>(const float*, int, int, int, const int*, const int*, const float*, long, int, float*, hipStream_t);
+template int launch_ar_attention_pairs<__half>(const float*, int, int, int, const int*, const int*, const __half*, long, int, float*, hipStream_t);
 template int launch_ar_attention<float>(const float*, int, int, int, const int*, const int*, const float*, long, int, float*, hipStream_t, float*, int);
 template int launch_ar_attention<__half>(const float*, int, int, int, const int*, const int*, const __half*, long, int, float*, hipStream_t, float*, int);
 

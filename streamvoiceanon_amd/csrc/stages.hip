@@ -11,9 +11,6 @@
 using namespace sva;
 
 namespace sva {
-
-
-
 int gemm_call(sva_batch* b, const float* A, long a_bstride, long a_off, int lda, int nb, int T, int stride, int dil,
               int taps, int Cin, const Lin& w, float* C, long c_bstride, long c_off, int ldc, ConvGemm proto) {
     ConvGemm g = proto;
@@ -527,7 +524,7 @@ int encode(sva_batch* b, const int* step_ptr, int n_chunk, int add) {
 // the streaming pass when it entered the window and kept in d2c, which slides by c tokens per chunk.  The 8-layer
 // transformer + BSQ always run on all T2 tokens.  Same values as the window pass up to fp32 summation order.
 int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add, bool transformer_too) {
-    const int D = b->e->cfg.tr_dim, c = b->p.chunk_frames;
+    const int c = b->p.chunk_frames;
     hipStream_t st = b->stream;
     SVA_TRY(launch_shift_history(b->d_shift_d2c, 1, b->B, st, 16));                   // steady tokens slide down by c
     if (b->enc_merged) {
@@ -553,6 +550,7 @@ int encode_incremental(sva_batch* b, const int* step_ptr, int n_chunk, int add, 
 
 // ---- A: slow / fast transformer passes ------------------------------------------------------------
 // rows [M, dim] in b->ax, slot/pos arrays on device; KV written at pos, attention over 0..pos
+// run_slot == -2: the rows are the decode frame's pairs (2 s, 2 s + 1) = positions (p, p + 1) of slot s: one attention workgroup per pair and head;
 // run_slot >= 0: the rows sit at CONSECUTIVE positions run_pos0 .. run_pos0 + M - 1 of that one slot (prompt prefill, re-prefill,
 // offline generate) -- their attention runs as the flash-style MFMA kernel instead of one workgroup per (head, row)
 int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int* d_slot, const int* d_pos, const float* rope,
@@ -614,10 +612,12 @@ int ar_layers_pass(sva_batch* b, std::vector<TrLayer>& layers, int M, const int*
             __half* ch = reinterpret_cast<__half*>(kv) + (long)l * kv_layer;
             SVA_TRY(launch_rope_kvwrite<__half>(b->aqkv, M, H, 64, d_slot, d_pos, rope, ch, kv_slot, S, st));
             if (run_slot >= 0 && M >= 96) SVA_TRY(launch_ar_prefill_attention<__half>(b->aqkv, M, H, 64, run_slot, run_pos0, ch, kv_slot, S, b->aatt, st));
+            else if (run_slot == -2 && M % 2 == 0 && debug_options().ar_pairs) SVA_TRY(launch_ar_attention_pairs<__half>(b->aqkv, M, H, 64, d_slot, d_pos, ch, kv_slot, S, b->aatt, st));
             else SVA_TRY(launch_ar_attention<__half>(b->aqkv, M, H, 64, d_slot, d_pos, ch, kv_slot, S, b->aatt, st));
         } else {
             SVA_TRY(launch_rope_kvwrite<float>(b->aqkv, M, H, 64, d_slot, d_pos, rope, cache, kv_slot, S, st));
             if (run_slot >= 0 && M >= 96) SVA_TRY(launch_ar_prefill_attention<float>(b->aqkv, M, H, 64, run_slot, run_pos0, cache, kv_slot, S, b->aatt, st));
+            else if (run_slot == -2 && M % 2 == 0 && debug_options().ar_pairs) SVA_TRY(launch_ar_attention_pairs<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
             else SVA_TRY(launch_ar_attention<float>(b->aqkv, M, H, 64, d_slot, d_pos, cache, kv_slot, S, b->aatt, st));
         }
         ConvGemm po;
@@ -699,7 +699,7 @@ int ar_decode_frame(sva_batch* b, int ci) {
     hipLaunchKernelGGL(ar_prepare_step_kernel, dim3(B), dim3(256), 0, st, b->cached_audio_emb, e->content_emb, b->d_codes, b->T2,
                        code_off, b->d_last_pos, D, b->ax, b->d_slot, b->d_pos, b->d_step_content, chunk, ci);
     SVA_TRY(ar_layers_pass(b, e->ar_layers, 2 * B, b->d_slot, b->d_pos, e->rope_ar, (float*)b->kv_slow, b->kv_slow_layer,
-                           b->kv_slow_slot, c.max_seq_len, b->ax));
+                           b->kv_slow_slot, c.max_seq_len, b->ax, -2));         // (-2: ar_prepare_step_kernel's row pairs)
     return ar_frame_tail(b, ci, (long)2 * D, (long)D, b->d_codes, b->T2, code_off, 2);
 }
 
@@ -814,7 +814,7 @@ int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const lon
             hg.X = b->hidden; hg.ldx = D; hg.M = B; hg.W = e->ar_output.W; hg.N = c.ar_vocab; hg.K = D; hg.norm_w = e->ar_norm;
             hg.eps = 1e-5f; hg.Y = b->slow_logits; hg.ldy = c.ar_vocab;
             SVA_TRY(launch_gemv(hg, st));
-        } else if (conv_gemm_can_fuse_rms(B, c.ar_vocab)) {        // the norm folded into the head's GEMM (a launch less per head: round 6)
+        } else if (conv_gemm_can_fuse_rms(B, c.ar_vocab) && debug_options().head_fuse) {        // the norm folded into the head's GEMM (a launch less per head: round 6)
             ConvGemm pn;
             pn.rms_w = e->ar_norm; pn.rms_eps = 1e-5f;
             SVA_TRY(gemm_call(b, b->hidden, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_output, b->slow_logits, (long)B * c.ar_vocab, 0, c.ar_vocab, pn));
@@ -836,7 +836,7 @@ int ar_frame_tail(sva_batch* b, int ci, long hid_stride, long hid_off, const lon
             fg.X = b->xf; fg.ldx = D; fg.M = B; fg.W = e->ar_fast_output.W; fg.N = cbs; fg.K = D; fg.norm_w = e->ar_fast_norm; fg.eps = 1e-5f;
             fg.Y = lg; fg.ldy = ncb * cbs;
             SVA_TRY(launch_gemv(fg, st));
-        } else if (conv_gemm_can_fuse_rms(B, cbs)) {
+        } else if (conv_gemm_can_fuse_rms(B, cbs) && debug_options().head_fuse) {
             ConvGemm pn;
             pn.rms_w = e->ar_fast_norm; pn.rms_eps = 1e-5f;
             SVA_TRY(gemm_call(b, b->xf, (long)B * D, 0, D, 1, B, 1, 1, 1, D, e->ar_fast_output, lg, (long)B * ncb * cbs, 0, ncb * cbs, pn));

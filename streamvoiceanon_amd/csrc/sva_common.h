@@ -33,6 +33,8 @@ void set_error(const std::string& msg);
 //                     activations between them as planes): never / at every batch size (default: from 10 code frames per step over the batch; parity tests force it at small batches)
 //   ar_graph=0|1      the AR stage of the pipelined mode enqueued kernel by kernel / replayed as a graph (default: a graph unless the stage is ONE
 //                     persistent launch -- a one-node graph only adds its replay cost; A/B)
+//   ar_pairs=0        the decode frame's slow attention per row instead of per (stream, head) pair of rows (A/B, parity)
+//   head_fuse=0       the heads' RMSNorm as a launch of its own instead of the head GEMM's prologue (A/B)
 //   planes_min_streams=N  stream count from which the encoder's passes hand their operands over as planes (default 10; A/B)
 //   planes_lw=0       the planes GEMM's loader-wave forms (variants 11 / 12 of the table) fall back to variant 10 (A/B)
 //   voc_dma_variant=9|10|11|13|14  tile configuration of those convs where 128 x 128 tiles fill the chip (A/B)
@@ -41,7 +43,7 @@ void set_error(const std::string& msg);
 //   f16_weights=0|2   ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B) / on gemm_f16w.hip even when
 //                     the library was built with a compiler the kernel was not validated with
 struct DebugOptions {
-    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1, planes_dma = 1, voc_dma = -1, voc_dma_variant = 11, planes_lw = 1, planes_min_streams = 10, ar_graph = -1;
+    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1, planes_dma = 1, voc_dma = -1, voc_dma_variant = 11, planes_lw = 1, planes_min_streams = 10, ar_graph = -1, ar_pairs = 1, head_fuse = 1;
     std::string tune_dump;
 };
 const DebugOptions& debug_options();

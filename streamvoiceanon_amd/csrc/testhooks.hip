@@ -170,6 +170,76 @@ extern "C" int sva_test_prefill_attention(int device, int M, int H, int pos0, in
     return 0;
 }
 
+// The same rows through the decode frame's PAIRED attention kernel (rows 2 i, 2 i + 1 = consecutive positions of one slot; M even): out_mfma = its result
+extern "C" int sva_test_pair_attention(int device, int M, int H, int pos0, int S, const float* q, const float* keys, const float* vals,
+                                          int half_kv, float* out_ref, float* out_mfma, int iters, float* us) {
+    SVA_HIP(hipSetDevice(device));
+    const int D = H * 64, L = pos0 + M;
+    SVA_CHECK(L <= S, "sva_test_pair_attention: pos0 + M must fit the cache");
+    std::vector<float> qkv((size_t)M * 3 * D, 0.f);
+    for (int m = 0; m < M; ++m) memcpy(&qkv[(size_t)m * 3 * D], q + (size_t)m * D, sizeof(float) * D);
+    const size_t cache_elems = (size_t)2 * H * S * 64;
+    std::vector<float> cf(cache_elems, 0.f);
+    for (int j = 0; j < L; ++j)
+        for (int h = 0; h < H; ++h)
+            for (int dd = 0; dd < 64; ++dd) {
+                cf[((size_t)h * S + j) * 64 + dd] = keys[(size_t)j * D + h * 64 + dd];
+                cf[(size_t)H * S * 64 + ((size_t)h * S + j) * 64 + dd] = vals[(size_t)j * D + h * 64 + dd];
+            }
+    std::vector<int> slot(M, 0), pos(M);
+    for (int m = 0; m < M; ++m) pos[m] = pos0 + m;
+    float *dq, *dc, *do1, *do2;
+    int *ds, *dp;
+    void* dch = nullptr;
+    SVA_HIP(hipMalloc(&dq, sizeof(float) * qkv.size()));
+    SVA_HIP(hipMalloc(&dc, sizeof(float) * cache_elems));
+    SVA_HIP(hipMalloc(&do1, sizeof(float) * (size_t)M * D));
+    SVA_HIP(hipMalloc(&do2, sizeof(float) * (size_t)M * D));
+    SVA_HIP(hipMalloc(&ds, sizeof(int) * M));
+    SVA_HIP(hipMalloc(&dp, sizeof(int) * M));
+    SVA_HIP(hipMemcpy(dq, qkv.data(), sizeof(float) * qkv.size(), hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(dc, cf.data(), sizeof(float) * cache_elems, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(ds, slot.data(), sizeof(int) * M, hipMemcpyHostToDevice));
+    SVA_HIP(hipMemcpy(dp, pos.data(), sizeof(int) * M, hipMemcpyHostToDevice));
+    if (half_kv) {
+        std::vector<uint16_t> ch(cache_elems);
+        for (size_t i = 0; i < cache_elems; ++i) { const _Float16 hv = (_Float16)cf[i]; memcpy(&ch[i], &hv, 2); }
+        SVA_HIP(hipMalloc(&dch, 2 * cache_elems));
+        SVA_HIP(hipMemcpy(dch, ch.data(), 2 * cache_elems, hipMemcpyHostToDevice));
+    }
+    const long slot_stride = (long)cache_elems;
+    auto run = [&](int which) -> int {
+        if (half_kv) {
+            const __half* c16 = reinterpret_cast<const __half*>(dch);
+            return which ? launch_ar_attention_pairs<__half>(dq, M, H, 64, ds, dp, c16, slot_stride, S, do2, 0)
+                         : launch_ar_attention<__half>(dq, M, H, 64, ds, dp, c16, slot_stride, S, do1, 0);
+        }
+        return which ? launch_ar_attention_pairs<float>(dq, M, H, 64, ds, dp, dc, slot_stride, S, do2, 0)
+                     : launch_ar_attention<float>(dq, M, H, 64, ds, dp, dc, slot_stride, S, do1, 0);
+    };
+    for (int which = 0; which < 2; ++which) {
+        if (run(which)) return -1;
+        SVA_HIP(hipDeviceSynchronize());
+        if (iters > 0 && us) {
+            hipEvent_t e0, e1;
+            SVA_HIP(hipEventCreate(&e0)); SVA_HIP(hipEventCreate(&e1));
+            SVA_HIP(hipEventRecord(e0, 0));
+            for (int i = 0; i < iters; ++i) if (run(which)) return -1;
+            SVA_HIP(hipEventRecord(e1, 0));
+            SVA_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            SVA_HIP(hipEventElapsedTime(&ms, e0, e1));
+            us[which] = ms * 1000.f / iters;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+    }
+    SVA_HIP(hipMemcpy(out_ref, do1, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToHost));
+    SVA_HIP(hipMemcpy(out_mfma, do2, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToHost));
+    (void)hipFree(dq); (void)hipFree(dc); (void)hipFree(do1); (void)hipFree(do2); (void)hipFree(ds); (void)hipFree(dp);
+    if (dch) (void)hipFree(dch);
+    return 0;
+}
+
 // microbenchmark of the conv-GEMM dispatcher on device-resident random data:
 //   out_us[0] = average microseconds per launch over `iters` back-to-back launches (hipEvents)
 // mode bits: 1 = GELU epilogue, 2 = residual + gamma, 4 = silu-on-load, 8 = w13

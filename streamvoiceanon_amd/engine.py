@@ -106,6 +106,7 @@ def load_library():
     lib.sva_test_gemm_choice.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32]
     lib.sva_set_sampler_edits.argtypes = [vp, vp, i32, C.c_float, vp, i32]
     lib.sva_test_prefill_attention.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]
+    lib.sva_test_pair_attention.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]
     lib.sva_test_gemm_f16w.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp]
     lib.sva_test_gemm_planes.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.sva_host_launch_cost.argtypes = [i32, i32, f32p]
@@ -122,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "sva_dev_alloc", "sva_dev_free", "sva_dev_upload", "sva_dev_download", "sva_op_conv", "sva_op_affine", "sva_op_unary", "sva_op_colstats",
     "sva_op_cam_context", "sva_op_mul", "sva_op_add", "sva_op_conv2d", "sva_op_cf_to_rows", "sva_op_fbank_power", "sva_op_stft_mag", "sva_op_attention",
     "sva_op_geglu", "sva_op_l2norm", "sva_ops_capture_begin", "sva_ops_capture_end", "sva_ops_graph_launch", "sva_ops_graph_free",
-    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_test_gemm_planes", "sva_test_prefill_attention", "sva_set_sampler_edits", "sva_bench_gemm", "sva_bench_gemm_choice", "sva_test_sampler", "sva_host_launch_cost",
+    "sva_get_gemm_stats", "sva_get_gemm_bytes", "sva_stream_codes", "sva_profile_gemm", "sva_get_gemm_profile", "sva_get_gemm_profile_table", "sva_test_gemm", "sva_test_gemm_choice", "sva_test_gemm_f16w", "sva_test_gemm_planes", "sva_test_prefill_attention", "sva_test_pair_attention", "sva_set_sampler_edits", "sva_bench_gemm", "sva_bench_gemm_choice", "sva_test_sampler", "sva_host_launch_cost",
 ]
 
 
@@ -535,6 +536,21 @@ def test_prefill_attention(q, keys, vals, pos0=0, S=2048, half_kv=False, iters=0
     us = np.zeros(2, np.float32)
     _check(lib.sva_test_prefill_attention(device, M, D // 64, int(pos0), int(S), _ptr(q), _ptr(keys), _ptr(vals), int(bool(half_kv)), _ptr(o1), _ptr(o2),
                                           int(iters), _ptr(us)), "sva_test_prefill_attention")
+    return o1, o2, (float(us[0]), float(us[1]))
+
+
+def test_pair_attention(q, keys, vals, pos0=0, S=2048, half_kv=False, iters=0, device=0):
+    """as test_prefill_attention, the second output from the decode frame's PAIRED kernel (rows 2 i, 2 i + 1 = consecutive positions; M even)"""
+    lib = load_library()
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    keys = np.ascontiguousarray(keys, dtype=np.float32)
+    vals = np.ascontiguousarray(vals, dtype=np.float32)
+    M, D = q.shape
+    assert M % 2 == 0 and keys.shape == (pos0 + M, D) and vals.shape == keys.shape and D % 64 == 0
+    o1, o2 = np.empty((M, D), np.float32), np.empty((M, D), np.float32)
+    us = np.zeros(2, np.float32)
+    _check(lib.sva_test_pair_attention(device, M, D // 64, int(pos0), int(S), _ptr(q), _ptr(keys), _ptr(vals), int(bool(half_kv)), _ptr(o1), _ptr(o2),
+                                       int(iters), _ptr(us)), "sva_test_pair_attention")
     return o1, o2, (float(us[0]), float(us[1]))
 
 

@@ -1417,6 +1417,24 @@ def test_stream_infer_one_call_equals_chunk_by_chunk(weights0):
     w.engine.close()
 
 
+@pytest.mark.parametrize("half_kv", [False, True])
+def test_paired_decode_attention_equals_per_row_kernel(half_kv):
+    """The decode frame's slow layers serve the two new rows of a stream (positions p, p + 1) from ONE pass over the slot's K / V rows
+    (ar_attention_pair_kernel): bit-identical to the per-row kernel for short, medium and long contexts, fp32 and fp16 caches."""
+    from streamvoiceanon_amd import engine as E
+
+    rng = np.random.default_rng(31)
+    H = 12
+    for pos0, M in ((0, 2), (1, 6), (61, 8), (250, 64), (700, 16), (1531, 128), (2040, 8)):
+        q = rng.standard_normal((M, H * 64)).astype(np.float32)
+        k = rng.standard_normal((pos0 + M, H * 64)).astype(np.float32)
+        v = rng.standard_normal((pos0 + M, H * 64)).astype(np.float32)
+        ref, pair, _ = E.test_pair_attention(q, k, v, pos0=pos0, half_kv=half_kv)
+        np.testing.assert_array_equal(pair, ref, err_msg=f"pos0 {pos0} M {M}")
+        ref2, pair2, _ = E.test_pair_attention(q, k, v, pos0=pos0, half_kv=half_kv)
+        np.testing.assert_array_equal(pair2, pair)
+
+
 def test_config3_64_streams_10s_properties(eng):
     """BASELINE.json configs[2] at full size: 64 concurrent 10 s utterances (216 chunks, prompt R = 107) through the pipelined
     one-call path.  Size-independent properties: slots fed the same utterance / prompt / seed agree bit for bit wherever they
