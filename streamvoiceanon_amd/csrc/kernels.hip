@@ -876,10 +876,11 @@ __global__ __launch_bounds__(256) void ar_attention_pair_kernel(const float* __r
             const KV* kr = kc + (long)j * HD + part4 * 16;
 #pragma unroll
             for (int d = 0; d < 16; ++d) {
-                // Two explicit v_fmac_f32 per key element.  Written as fmaf() pairs the compiler packs them into a chain of v_pk_fma_f32 whose
-                // odd terms read the key through op_sel:[0,1,0] (low lane <- high register of the loaded pair); on MI355X that form returned
-                // wrong low-lane sums in lanes 48..63 of a wave in ~1 % of the (head, stream) workgroups of a loaded 64-stream decode -- never
-                // in an isolated launch -- while the same chain without the op_sel read, and this form, are exact.
+                // Two explicit v_fmac_f32 per key element.  Written as fmaf() pairs, the compiler packs the two rows into one chain of v_pk_fma_f32
+                // whose odd terms read the key through op_sel:[0,1,0]; builds of THIS kernel with that chain (compiler-made or hand-written) returned
+                // wrong low-lane sums in lanes 48..63 of a wave for ~1 % of the (head, stream) workgroups of a loaded 64-stream decode -- never in an
+                // isolated launch, and not in a stand-alone probe of the instruction form (tools/probes/pk_opsel_probe.hip) -- while the packed chain
+                // without the op_sel read and this form are exact in the same place (the in-situ bisection).
                 const float kv = from_kv(kr[d]);
                 asm("v_fmac_f32 %0, %1, %2" : "+v"(a0) : "v"(q0[d]), "v"(kv));
                 asm("v_fmac_f32 %0, %1, %2" : "+v"(a1) : "v"(q1[d]), "v"(kv));
