@@ -257,10 +257,10 @@ def _assert_forced_logits(g, slow, fast, tol, first=0):
     return worst
 
 
-@pytest.mark.parametrize("B,path", [(8, 2), (12, 2), (24, 2), (128, 0)])
+@pytest.mark.parametrize("B,path", [(8, 2), (12, 2), (24, 2), (64, 0), (128, 0)])
 def test_batched_decode_teacher_forced_logits_vs_reference(eng, weights0, B, path, record_property):
     """The hard AR gate THROUGH the kernels that serve batches: ar_batch.hip (one persistent launch per frame, the default decode at
-    5-24 synchronous fp32 streams; path 2) and the multi-launch decode at 128 streams (path 0).  Every slot carries the fixture
+    5-24 synchronous fp32 streams; path 2) and the multi-launch decode at 64 / 128 streams (path 0: the weight-streaming GEMMs and the paired decode attention of round 6).  Every slot carries the fixture
     utterance; with the codes teacher-forced, the top-32 slow and fast logits of every frame are within 2e-3 of the REFERENCE's
     (tests/golden/stream_s0.npz), taken from the last slot; a free run of the same batch reproduces the reference's codes."""
     n_limit = 24 if B <= 24 else 10
