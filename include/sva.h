@@ -206,7 +206,9 @@ long sva_get_gemm_profile_table(sva_batch* b, double* out, long max_rows);
  * (streamvoiceanon_amd/prompt_encoders.py) owns the activation buffers and the topology, these entry points do the arithmetic
  * on device arrays (channel-last rows [T][C], row strides in floats; every pointer below is a DEVICE pointer from sva_dev_alloc
  * unless it says host).  All of them run on ONE engine-owned stream, in call order (sva_dev_upload / _download are ordered with them and
- * return when their copy is done). */
+ * return when their copy is done).  That stream is non-blocking: nothing here is ordered with the caller's own streams, the legacy default stream or
+ * a batch's streams -- a buffer produced elsewhere must be complete (sva_sync / hipStreamSynchronize of its producer) before it is passed in, and a
+ * result consumed elsewhere must be fetched with sva_dev_download (which waits) or after a hipDeviceSynchronize. */
 int sva_dev_alloc(sva_engine* e, long n_floats, float** out);            /* zero-initialised */
 int sva_dev_free(sva_engine* e, float* p);
 int sva_dev_upload(sva_engine* e, float* dst, const float* host_src, long n_floats);
