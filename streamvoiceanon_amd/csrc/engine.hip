@@ -57,6 +57,7 @@ static void parse_debug(DebugOptions& o, const char* env) {
             else if (k == "autotune") o.autotune = atoi(v.c_str());
             else if (k == "tune_log") o.tune_log = atoi(v.c_str());
             else if (k == "tune_table") o.tune_table = atoi(v.c_str());
+            else if (k == "tune_kinds") o.tune_kinds = atoi(v.c_str());
             else if (k == "f16_weights") o.f16_weights = atoi(v.c_str());
             else if (k == "cu_partition") o.cu_partition = atoi(v.c_str());
             else if (k == "cu_ar") o.cu_ar = atoi(v.c_str());

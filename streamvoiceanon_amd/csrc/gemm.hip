@@ -365,7 +365,11 @@ __global__ __launch_bounds__(64 * KW) void skinny_gemm_kernel(const ConvGemmGrou
                 if (SILU) { a[i].x = silu_f(a[i].x); a[i].y = silu_f(a[i].y); a[i].z = silu_f(a[i].z); a[i].w = silu_f(a[i].w); }
                 a[i].x *= keep; a[i].y *= keep; a[i].z *= keep; a[i].w *= keep;
                 if (RMS) {
-                    ssq[i] += (a[i].x * a[i].x + a[i].y * a[i].y) + (a[i].z * a[i].z + a[i].w * a[i].w);
+                    // explicit sequential fmas: under -ffp-contract the pairwise form was fused differently per unrolled row tile (gemm_stream.hip), so a row's statistic depended on its position
+                    ssq[i] = __builtin_fmaf(a[i].x, a[i].x, ssq[i]);
+                    ssq[i] = __builtin_fmaf(a[i].y, a[i].y, ssq[i]);
+                    ssq[i] = __builtin_fmaf(a[i].z, a[i].z, ssq[i]);
+                    ssq[i] = __builtin_fmaf(a[i].w, a[i].w, ssq[i]);
                     a[i].x *= nv[d].x; a[i].y *= nv[d].y; a[i].z *= nv[d].z; a[i].w *= nv[d].w;
                 }
             }
@@ -850,7 +854,7 @@ static const std::map<std::array<int, 6>, Choice>& static_table() {
         std::map<std::array<int, 6>, Choice> t;
         if (!debug_options().tune_table) return t;
         for (const TuneRow& r : kTuneTable) {
-            if (r.kind < 0) continue;
+            if (r.kind < 0 || !((debug_options().tune_kinds >> r.kind) & 1)) continue;
             Choice c{r.kind, r.a, r.b, r.c};
             c.z = r.z;
             t[{r.key[0], r.key[1], r.key[2], r.key[3], r.key[4], r.key[5]}] = c;

@@ -116,7 +116,11 @@ __global__ __launch_bounds__(256) void pipe_gemm_kernel(const ConvGemmGroup gg) 
                 const float4 nw = *reinterpret_cast<const float4*>(nws + kc + kb * 16 + 4 * fk);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    ssq[i] += (af[i].x * af[i].x + af[i].y * af[i].y) + (af[i].z * af[i].z + af[i].w * af[i].w);
+                    // explicit sequential fmas: under -ffp-contract the pairwise form was fused differently per unrolled row tile (gemm_stream.hip), so a row's statistic depended on its position
+                    ssq[i] = __builtin_fmaf(af[i].x, af[i].x, ssq[i]);
+                    ssq[i] = __builtin_fmaf(af[i].y, af[i].y, ssq[i]);
+                    ssq[i] = __builtin_fmaf(af[i].z, af[i].z, ssq[i]);
+                    ssq[i] = __builtin_fmaf(af[i].w, af[i].w, ssq[i]);
                     af[i].x *= nw.x; af[i].y *= nw.y; af[i].z *= nw.z; af[i].w *= nw.w;
                 }
             }

@@ -47,6 +47,8 @@ struct StreamArgs {
 // LOOP: some wave holds more than KB blocks (a consumed block's registers are re-requested at once, clamped indices instead of a branch)
 template <int MT, int NT, int KW, int KB, int AOP, bool WP, int PROBE, bool LOOP>
 __global__ __launch_bounds__(64 * KW) void stream_gemm_kernel(const StreamArgs g) {
+    // no implicit contraction in this kernel: every row tile's arithmetic must round the same way (a row's result must not depend on its position)
+#pragma clang fp contract(off)
     if constexpr (PROBE == 1) return;
     constexpr bool SILU = AOP == 1, RMS = AOP == 2;
     extern __shared__ __attribute__((aligned(16))) float red[];      // [KW][MT*NT][64] f32x4 (+ [KW][MT][16] row sums of squares)
@@ -177,7 +179,12 @@ __global__ __launch_bounds__(64 * KW) void stream_gemm_kernel(const StreamArgs g
                 for (int i = 0; i < MT; ++i) {
                     if constexpr (SILU) { a[i].x = silu_s(a[i].x); a[i].y = silu_s(a[i].y); a[i].z = silu_s(a[i].z); a[i].w = silu_s(a[i].w); }
                     if constexpr (RMS) {
-                        ssq[i] += (a[i].x * a[i].x + a[i].y * a[i].y) + (a[i].z * a[i].z + a[i].w * a[i].w);
+                        // explicit, sequential fmas: left to -ffp-contract the sum of squares was fused differently per unrolled row tile (fma(x, x, y * y)
+                        // here, two products and an add there), which made a row's statistic -- and every logit after it -- depend on the row's position
+                        ssq[i] = __builtin_fmaf(a[i].x, a[i].x, ssq[i]);
+                        ssq[i] = __builtin_fmaf(a[i].y, a[i].y, ssq[i]);
+                        ssq[i] = __builtin_fmaf(a[i].z, a[i].z, ssq[i]);
+                        ssq[i] = __builtin_fmaf(a[i].w, a[i].w, ssq[i]);
                         a[i] *= nw;
                     }
                 }

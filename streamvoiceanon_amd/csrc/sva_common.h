@@ -21,7 +21,7 @@ void set_error(const std::string& msg);
 //   ar_batch_wgs=N   workgroups of its launch (default: one per 16-column tile of the widest phase, capped by what is resident)
 //   voc_fused_mask=M which narrow HiFiGAN levels run as the fused kernel (bit 0: C = 16, bit 1: C = 32; parity tests)
 //   autotune=1, tune_log=1, tune_table=0, tune_dump=PATH   timed search / its log / ignore the compiled-in table / dump the choices
-//                    (tools/make_tune_table.py)
+//                    (tools/make_tune_table.py); tune_kinds=MASK: only table rows whose kernel kind has its bit set are honoured (bisection)
 //   cu_partition=0|1  force the disjoint CU masks of the pipelined mode (AR 96 | encoder + vocoder 160) off / on (default: by stream count)
 //   cu_ar=N           with cu_partition=1: CUs of the AR stream's mask (default: by batch size; A/B only: the round-3 partition A/B scripts, git history)
 //   pipe_skip=mask    TIMING DIAGNOSTIC (results are garbage): leave out a chain of the pipelined step -- 1 encoder front, 2 side chain
@@ -43,7 +43,7 @@ void set_error(const std::string& msg);
 //   f16_weights=0|2   ar_dtype = 1 batched decode on the fp32 copy of the rounded weights instead of gemm_f16w.hip (A/B) / on gemm_f16w.hip even when
 //                     the library was built with a compiler the kernel was not validated with
 struct DebugOptions {
-    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1, planes_dma = 1, voc_dma = -1, voc_dma_variant = 11, planes_lw = 1, planes_min_streams = 10, ar_graph = -1, ar_pairs = 1, head_fuse = 1;
+    int ar_timing = 0, pipe_trace = 0, concurrency = 1, ar_persistent = 1, ar_batch = 1, ar_batch_wgs = 0, voc_fused_mask = -1, autotune = 0, tune_log = 0, tune_table = 1, f16_weights = 1, cu_partition = -1, cu_ar = 0, pipe_skip = 0, planes_dbg = 0, reprefill = 1, planes_dma = 1, voc_dma = -1, voc_dma_variant = 11, planes_lw = 1, planes_min_streams = 10, ar_graph = -1, ar_pairs = 1, head_fuse = 1, tune_kinds = -1;
     std::string tune_dump;
 };
 const DebugOptions& debug_options();

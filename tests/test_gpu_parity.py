@@ -1435,6 +1435,36 @@ def test_paired_decode_attention_equals_per_row_kernel(half_kv):
         np.testing.assert_array_equal(pair2, pair)
 
 
+@pytest.mark.parametrize("B", [12, 32, 40, 64])
+def test_twin_slots_agree_in_every_intermediate_state(eng, B):
+    """A row's result must not depend on its position in the batch -- checked on the decode's INTERMEDIATE state, which is far more sensitive than code
+    equality: slots s and s + B/2 carry the same prompt / utterance / seed; the pre-norm hidden state, the fast logits, the sampled codes and the PCM of
+    every step agree bit for bit (batched persistent decode at 12 / 32 synchronous streams, multi-launch decode at 40 / 64).  Round 6: the fused RMSNorm
+    statistic of the weight-streaming GEMM was contracted differently per unrolled row tile (fma(x, x, y * y) in one, two products and an add in another),
+    so twin hidden states differed in the last bit from the first frame on and a sampled code flipped about once per 10 000 slot-frames."""
+    from streamvoiceanon_amd import engine as E
+    from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
+
+    half, steps, c = B // 2, 8, eng.cfg
+    utts = [synth_utterance(3100 + u, 2048 * steps) for u in range(half)]
+    prompts = [synth_prompt(3200 + u, 107) for u in range(half)]
+    b = E.Batch(eng, n_streams=B, skip_semantic=True)
+    for s_ in range(B):
+        ac, cc, style, timbre = prompts[s_ % half]
+        b.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=700 + s_ % half)
+    b.begin()
+    assert b.decode_path() == (2 if B <= 32 else 0)
+    x = np.stack([utts[s_ % half] for s_ in range(B)])
+    for i in range(steps):
+        out = b.step(x[:, i * 2048:(i + 1) * 2048])
+        np.testing.assert_array_equal(out[:half], out[half:], err_msg=f"pcm, step {i}")
+        for name, shp, dt in (("hidden", (B, c.ar_dim), np.float32), ("fast_logits", (B, c.num_codebooks * c.codebook_size), np.float32),
+                              ("sampled_codes", (B, c.num_codebooks), np.int32), ("content_codes", (B, 1), np.int32)):
+            t = b.tap(name, shp, dt)
+            np.testing.assert_array_equal(t[:half], t[half:], err_msg=f"{name}, step {i}")
+    b.close()
+
+
 def test_config3_64_streams_10s_properties(eng):
     """BASELINE.json configs[2] at full size: 64 concurrent 10 s utterances (216 chunks, prompt R = 107) through the pipelined
     one-call path.  Size-independent properties: slots fed the same utterance / prompt / seed agree bit for bit wherever they
