@@ -153,10 +153,14 @@ template <> struct WReg<float> {
 __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        _Float16 h = (_Float16)v[i];
+        // the value itself is pinned first: where it is a product (RMSNorm weight x activation) some unrolled copies otherwise round it straight to fp16
+        // (v_fma_mixlo_f16: one rounding) and others through fp32 (v_mul + v_cvt: two), and a row's hi / lo pair depended on the row tile it sat in
+        float xv = v[i];
+        asm("" : "+v"(xv));
+        _Float16 h = (_Float16)xv;
         asm("" : "+v"(h));
         hi[i] = h;
-        lo[i] = (_Float16)(v[i] - (float)h);
+        lo[i] = (_Float16)(xv - (float)h);
     }
 }
 

@@ -31,10 +31,14 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, f16x8& 
         // differently -- the hi operand of the MFMA from the fp32-rounded product (v_cvt_pk_f16_f32), lo against v_fma_mixlo_f16 of
         // the EXACT product -- and the two roundings of hi disagree by one fp16 ulp about once per 2^13 elements (measured: single
         // elements 2^-12 off).  With one hi, lo = v - hi is consistent whichever way v is evaluated.
-        _Float16 h = (_Float16)v[i];
+        // the value itself is pinned first: where it is a product (RMSNorm weight x activation) some unrolled copies otherwise round it straight to fp16
+        // (v_fma_mixlo_f16: one rounding) and others through fp32 (v_mul + v_cvt: two), and a row's hi / lo pair depended on the row tile it sat in
+        float xv = v[i];
+        asm("" : "+v"(xv));
+        _Float16 h = (_Float16)xv;
         asm("" : "+v"(h));
         hi[i] = h;
-        lo[i] = (_Float16)(v[i] - (float)h);
+        lo[i] = (_Float16)(xv - (float)h);
     }
 }
 

@@ -1435,25 +1435,20 @@ def test_paired_decode_attention_equals_per_row_kernel(half_kv):
         np.testing.assert_array_equal(pair2, pair)
 
 
-@pytest.mark.parametrize("B", [12, 32, 40, 64])
-def test_twin_slots_agree_in_every_intermediate_state(eng, B):
-    """A row's result must not depend on its position in the batch -- checked on the decode's INTERMEDIATE state, which is far more sensitive than code
-    equality: slots s and s + B/2 carry the same prompt / utterance / seed; the pre-norm hidden state, the fast logits, the sampled codes and the PCM of
-    every step agree bit for bit (batched persistent decode at 12 / 32 synchronous streams, multi-launch decode at 40 / 64).  Round 6: the fused RMSNorm
-    statistic of the weight-streaming GEMM was contracted differently per unrolled row tile (fma(x, x, y * y) in one, two products and an add in another),
-    so twin hidden states differed in the last bit from the first frame on and a sampled code flipped about once per 10 000 slot-frames."""
+def _twin_states(engine, B, expect_path=None):
     from streamvoiceanon_amd import engine as E
     from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance
 
-    half, steps, c = B // 2, 8, eng.cfg
+    half, steps, c = B // 2, 8, engine.cfg
     utts = [synth_utterance(3100 + u, 2048 * steps) for u in range(half)]
     prompts = [synth_prompt(3200 + u, 107) for u in range(half)]
-    b = E.Batch(eng, n_streams=B, skip_semantic=True)
+    b = E.Batch(engine, n_streams=B, skip_semantic=True)
     for s_ in range(B):
         ac, cc, style, timbre = prompts[s_ % half]
         b.prefill_prompt(s_, cc, ac, style, timbre, noise_seed=700 + s_ % half)
     b.begin()
-    assert b.decode_path() == (2 if B <= 32 else 0)
+    if expect_path is not None:
+        assert b.decode_path() == expect_path
     x = np.stack([utts[s_ % half] for s_ in range(B)])
     for i in range(steps):
         out = b.step(x[:, i * 2048:(i + 1) * 2048])
@@ -1463,6 +1458,22 @@ def test_twin_slots_agree_in_every_intermediate_state(eng, B):
             t = b.tap(name, shp, dt)
             np.testing.assert_array_equal(t[:half], t[half:], err_msg=f"{name}, step {i}")
     b.close()
+
+
+@pytest.mark.parametrize("B", [12, 64])
+def test_twin_slots_agree_in_every_intermediate_state_fp16_ar(eng_fp16, B):
+    """as below on the fp16 decode (ar_batch.hip on fp16 weights at 12 streams, gemm_f16w.hip + fp16 KV at 64)"""
+    _twin_states(eng_fp16, B)
+
+
+@pytest.mark.parametrize("B", [12, 32, 40, 64])
+def test_twin_slots_agree_in_every_intermediate_state(eng, B):
+    """A row's result must not depend on its position in the batch -- checked on the decode's INTERMEDIATE state, which is far more sensitive than code
+    equality: slots s and s + B/2 carry the same prompt / utterance / seed; the pre-norm hidden state, the fast logits, the sampled codes and the PCM of
+    every step agree bit for bit (batched persistent decode at 12 / 32 synchronous streams, multi-launch decode at 40 / 64).  Round 6: the fused RMSNorm
+    statistic of the weight-streaming GEMM was contracted differently per unrolled row tile (fma(x, x, y * y) in one, two products and an add in another),
+    so twin hidden states differed in the last bit from the first frame on and a sampled code flipped about once per 10 000 slot-frames."""
+    _twin_states(eng, B, 2 if B <= 32 else 0)
 
 
 def test_config3_64_streams_10s_properties(eng):
