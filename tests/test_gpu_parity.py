@@ -1457,6 +1457,12 @@ def _twin_states(engine, B, expect_path=None):
                               ("sampled_codes", (B, c.num_codebooks), np.int32), ("content_codes", (B, 1), np.int32)):
             t = b.tap(name, shp, dt)
             np.testing.assert_array_equal(t[:half], t[half:], err_msg=f"{name}, step {i}")
+        for name in ("mel", "feat", "z", "u", "voc_z"):          # the encoder's and the vocoder's intermediate tensors (whole-batch buffers of unknown-here extent)
+            big = np.empty(64 << 20, np.uint8)
+            n = b.lib.sva_get_tap(b.h, name.encode(), E._ptr(big), big.nbytes)
+            assert n > 0 and n % B == 0, (name, n)
+            t = big[:n].reshape(B, n // B)
+            np.testing.assert_array_equal(t[:half], t[half:], err_msg=f"{name}, step {i}")
     b.close()
 
 
