@@ -3,7 +3,8 @@ slot s and slot s + B/2 must agree bit for bit (PCM and codes) whatever the batc
 attention's first build (wrong only in a loaded launch, never in isolation).  Covers the decode paths the policy table selects:
 batched persistent kernel, multi-launch chain with and without a CU partition, fp32 / fp16 AR, chunk 1 / 4, skip_semantic on / off.
 
-    python tools/soak_slots.py [chunks]         (on the GPU box; default 120 chunks per configuration)
+    python tools/soak_slots.py [chunks] [ragged]   (on the GPU box; default 120 chunks per configuration; "ragged": prompt lengths 60 .. 195 frames across the pairs, so
+                                                    the streams of a batch sit at different KV positions and re-prefill on different steps)
 """
 import sys
 import time
@@ -15,6 +16,7 @@ from streamvoiceanon_amd import engine as E, specs, synth_weights as sw         
 from streamvoiceanon_amd.synth_audio import synth_prompt, synth_utterance       # noqa: E402
 
 n_chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+ragged = len(sys.argv) > 2 and sys.argv[2] == "ragged"
 W = {k: sw.generate(0, k, shp) for k, shp in specs.all_specs().items()}
 W = {k: v for k, v in W.items() if v is not None}
 R = 107
@@ -25,7 +27,7 @@ for ar_dtype, voc_dtype in ((0, 0), (1, 1)):
         half = B // 2
         steps = max(8, n_chunks // chunk)
         utts = [synth_utterance(1000 + u, 2048 * chunk * steps) for u in range(half)]
-        prompts = [synth_prompt(2000 + u, R) for u in range(half)]
+        prompts = [synth_prompt(2000 + u, 60 + 9 * (u % 16) if ragged else R) for u in range(half)]
         b = E.Batch(eng, n_streams=B, chunk_frames=chunk, pipeline=True, skip_semantic=skip)
         for s in range(B):
             ac, cc, style, timbre = prompts[s % half]
