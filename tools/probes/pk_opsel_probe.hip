@@ -63,6 +63,59 @@ __global__ __launch_bounds__(256) void probe_kernel(const float* __restrict__ ke
     if (keep == 12345.678f) sink[0] = keep;
 }
 
+// FORM 2 / 3: the same two chains inside the paired attention kernel's score loop as it was when it failed (scores of two query rows per key, quad exchange through
+// ds_bpermute, the score stored to LDS by one lane of the quad under a narrowed EXEC, keys [0, L0) for row 0 and [0, L0 + 1) for row 1); the reference scores
+// go through the same exchange from plain v_fmac_f32 chains; compared after the barrier.  FORM 2: odd terms through op_sel:[0,1,0]; FORM 3: through a copied pair.
+template <int FORM>
+__global__ __launch_bounds__(256) void probe_loop_kernel(const float* __restrict__ keys, const float* __restrict__ q, int L0, long region, unsigned* bad) {
+    extern __shared__ float lds[];
+    float* sc0 = lds; float* sc1 = sc0 + 2048; float* rf0 = sc1 + 2048; float* rf1 = rf0 + 2048;
+    const int tid = threadIdx.x, part4 = tid & 3, L1 = L0 + 1;
+    float q0[16], q1[16];
+    const float* qr = q + (size_t)blockIdx.x * 128 + part4 * 16;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) { q0[d] = qr[d]; q1[d] = qr[64 + d]; }
+    const float* kc = keys + (size_t)blockIdx.x * region;
+    for (int j0 = 0; j0 < L1; j0 += 64) {
+        const int j = j0 + (tid >> 2);
+        float a0 = 0.f, a1 = 0.f, r0 = 0.f, r1 = 0.f;
+        if (j < L1) {
+            const float* kr = kc + (size_t)j * 64 + part4 * 16;
+            f2 acc = {0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < 16; d += 2) {
+                const f2 kk = {kr[d], kr[d + 1]};
+                const f2 qa = {q1[d], q0[d]}, qb = {q1[d + 1], q0[d + 1]};
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(qa), "v"(kk));
+                if constexpr (FORM == 2) {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(qb), "v"(kk));
+                } else {
+                    f2 kb = {kk.y, kk.y};
+                    asm("" : "+v"(kb));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(qb), "v"(kb));
+                }
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(r0) : "v"(q0[d]), "v"(kk.x));
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(r1) : "v"(q1[d]), "v"(kk.x));
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(r0) : "v"(q0[d + 1]), "v"(kk.y));
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(r1) : "v"(q1[d + 1]), "v"(kk.y));
+            }
+            a1 = acc.x; a0 = acc.y;
+        }
+        a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64);
+        a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64);
+        r0 += __shfl_xor(r0, 1, 64); r1 += __shfl_xor(r1, 1, 64);
+        r0 += __shfl_xor(r0, 2, 64); r1 += __shfl_xor(r1, 2, 64);
+        if (j < L0) { if (part4 == 0) { sc0[j] = a0 * 0.125f; rf0[j] = r0 * 0.125f; } }
+        if (j < L1) { if (part4 == 0) { sc1[j] = a1 * 0.125f; rf1[j] = r1 * 0.125f; } }
+    }
+    __syncthreads();
+    for (int j = tid; j < L1; j += 256) {
+        const int quarter = ((j & 63) >> 2) >> 2;          // the 16-lane quarter of the wave whose lanes computed key j (4 lanes per key)
+        if (j < L0 && __float_as_uint(sc0[j]) != __float_as_uint(rf0[j])) atomicAdd(bad + 4 + quarter, 1u);
+        if (__float_as_uint(sc1[j]) != __float_as_uint(rf1[j])) atomicAdd(bad + quarter, 1u);
+    }
+}
+
 int main() {
     const int blocks = 768, L = 1024;
     const long region = 2048L * 64;                       // floats per workgroup: 512 KiB
@@ -92,6 +145,23 @@ int main() {
                form == 0 ? "odd terms through op_sel:[0,1,0]" : "odd terms through a copied pair", reps, blocks, L);
         printf("   low result lane : %u %u %u %u   high result lane: %u %u %u %u   (of %.3g checks each)\n", tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6],
                tot[7], checks);
+    }
+    for (int form = 2; form < 4; ++form) {
+        unsigned tot[8] = {0};
+        const int reps = 200;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipMemset(bad, 0, 32));
+            const int L0 = 255 + 7 * (r % 97);
+            if (form == 2) hipLaunchKernelGGL(probe_loop_kernel<2>, dim3(blocks), dim3(256), 4 * 2048 * sizeof(float), 0, keys, q, L0, region, bad);
+            else hipLaunchKernelGGL(probe_loop_kernel<3>, dim3(blocks), dim3(256), 4 * 2048 * sizeof(float), 0, keys, q, L0, region, bad);
+            CK(hipDeviceSynchronize());
+            unsigned h[8];
+            CK(hipMemcpy(h, bad, 32, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 8; ++i) tot[i] += h[i];
+        }
+        printf("form %d (the paired attention score loop, %s): %d launches x %d workgroups, 255 .. 927 keys; keys whose score differs from the v_fmac chain, by the 16-lane quarter that computed them --\n",
+               form, form == 2 ? "odd terms through op_sel:[0,1,0]" : "odd terms through a copied pair", reps, blocks);
+        printf("   row 1 (low result lane): %u %u %u %u   row 0 (high result lane): %u %u %u %u\n", tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], tot[7]);
     }
     return 0;
 }
